@@ -1,0 +1,224 @@
+/*
+ * wgebra_hip.h -- C ABI of libwgebra_hip.so: the MI355X (gfx950) backend behind the wgebra operator
+ * surface (Gemm / Gemv / Reduce / OpAssign on wgcore GpuTensor / GpuTensorView).
+ *
+ * It replaces exactly the slab of the reference that sits under that surface:
+ *   wgpu::Buffer storage          (wgcore tensor.rs:117-122,150-154)      -> wg_buf_*      (hipMalloc / hipHostMalloc)
+ *   CommandEncoder/ComputePass +
+ *   Queue::submit + Device::poll  (wgcore kernel.rs:15-27,125-146;
+ *                                  tensor.rs:300-325)                      -> wg_ctx_*      (one in-order hipStream_t)
+ *   ViewShape uniform buffers     (wgcore shapes.rs:9-21,107-116)          -> wg_view_shape passed BY VALUE as kernel args
+ *   the 10 WGSL entry points      (wgebra linalg/{gemm,gemv,reduce,
+ *                                  op_assign}.wgsl)                        -> wg_gemm / wg_gemv / wg_reduce / wg_op_assign
+ *   GpuTimestamps                 (wgcore timestamps.rs:9-248)             -> wg_timestamps_* (hipEvent pairs)
+ *
+ * Conventions
+ *   - Plain C: opaque handles, plain pointers and sizes, `int` status returns (0 == WG_OK). No C++/torch types.
+ *   - All tensors are COLUMN-MAJOR; a view is (buffer, wg_view_shape); element (i,j,t) lives at element index
+ *     t*stride_mat + offset + i + j*stride of the buffer (shape.wgsl:45-47,60-62). Units: ELEMENTS of the dtype.
+ *   - A context owns one in-order stream: operators enqueue asynchronously w.r.t. the host, in call order,
+ *     exactly like dispatches recorded into one ComputePass; wg_ctx_sync / wg_buf_read block.
+ *   - A context is not thread-safe; distinct contexts are independent (one per GPU for multi-GPU).
+ *   - Errors: where the reference panics (assert_eq!) the call returns a status and records a message with the
+ *     reference's text (wg_last_error_string); where the reference silently skips a dispatch (zero-sized buffer
+ *     or grid, kernel.rs:111-123,144) the call returns WG_OK and launches nothing.
+ *   - Where the reference would read or write out of bounds (its shaders run with bounds checks disabled,
+ *     wgcore utils.rs:11-19) the call returns WG_ERR_OUT_OF_BOUNDS / WG_ERR_PRECONDITION instead.
+ */
+#ifndef WGEBRA_HIP_H
+#define WGEBRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGEBRA_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------------------------------ */
+/* status codes                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+typedef enum wg_status {
+    WG_OK = 0,
+    WG_ERR_DIM_MISMATCH = 1,  /* reference: assert_eq!(.., "Gemm: dimension mismatch.") & friends -> panic   */
+    WG_ERR_PRECONDITION = 2,  /* vec4 alignment (rows/stride/stride_mat/offset % 4), GemvFast rows%4 (gemv.rs:122) */
+    WG_ERR_INVALID_ARG = 3,   /* null handle, unknown enum value, foreign-context buffer                      */
+    WG_ERR_OUT_OF_BOUNDS = 4, /* the view addresses elements past the end of its buffer                       */
+    WG_ERR_HIP = 5,           /* a HIP runtime call failed; message carries hipGetErrorString                 */
+    WG_ERR_UNSUPPORTED = 6,   /* dtype/variant combination not implemented                                    */
+    WG_ERR_NO_DEVICE = 7      /* no gfx950 device visible (GpuInstance::new() -> Err, gpu.rs:24-58)           */
+} wg_status;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* enums: same names and ORDER as the Rust enums                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+typedef enum wg_dtype { WG_F32 = 0, WG_F16 = 1 } wg_dtype; /* reference kernels are f32 only; F16 is this build's extension */
+
+typedef enum wg_gemm_variant { /* wgebra gemm.rs:26-35 */
+    WG_GEMM = 0, WG_GEMM_FAST = 1, WG_GEMM_TR = 2, WG_GEMM_TR_FAST = 3
+} wg_gemm_variant;
+
+typedef enum wg_gemv_variant { /* wgebra gemv.rs:25-34 */
+    WG_GEMV = 0, WG_GEMV_FAST = 1, WG_GEMV_TR = 2, WG_GEMV_TR_FAST = 3
+} wg_gemv_variant;
+
+typedef enum wg_reduce_op { /* wgebra reduce.rs:13-27 */
+    WG_REDUCE_MIN = 0, WG_REDUCE_MAX = 1, WG_REDUCE_SUM = 2, WG_REDUCE_PROD = 3, WG_REDUCE_SQNORM = 4
+} wg_reduce_op;
+
+typedef enum wg_op_assign_variant { /* wgebra op_assign.rs:12-26 */
+    WG_OP_ADD = 0, WG_OP_SUB = 1, WG_OP_MUL = 2, WG_OP_DIV = 3, WG_OP_COPY = 4
+} wg_op_assign_variant;
+
+/* wgpu::BufferUsages bit values (the flags TensorBuilder takes, tensor.rs:65-112). Only MAP_READ / MAP_WRITE
+ * change behaviour here: a MAP_* buffer is pinned host memory (the "staging" tensor of gemm.rs:163-168). */
+enum {
+    WG_USAGE_MAP_READ = 1u << 0, WG_USAGE_MAP_WRITE = 1u << 1, WG_USAGE_COPY_SRC = 1u << 2,
+    WG_USAGE_COPY_DST = 1u << 3, WG_USAGE_INDEX = 1u << 4, WG_USAGE_VERTEX = 1u << 5,
+    WG_USAGE_UNIFORM = 1u << 6, WG_USAGE_STORAGE = 1u << 7, WG_USAGE_INDIRECT = 1u << 8,
+    WG_USAGE_QUERY_RESOLVE = 1u << 9
+};
+
+/* ------------------------------------------------------------------------------------------------ */
+/* wg_view_shape: byte-identical to wgcore::shapes::ViewShape (#[repr(C)], 24 B; shapes.rs:9-21)    */
+/*                and to WGSL `Shape` (shape.wgsl:10-33).                                            */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct wg_view_shape {
+    uint32_t size[3];    /* rows, cols, mats */
+    uint32_t stride;     /* elements between two columns */
+    uint32_t stride_mat; /* elements between two matrices */
+    uint32_t offset;     /* index of the first element of the view in the buffer */
+} wg_view_shape;
+
+typedef struct wg_ctx wg_ctx;               /* GpuInstance (gpu.rs:7-12) + the encoder/pass/queue it feeds */
+typedef struct wg_buf wg_buf;               /* wgpu::Buffer */
+typedef struct wg_cmdbuf wg_cmdbuf;         /* wgpu::CommandBuffer (a recorded, replayable hipGraphExec) */
+typedef struct wg_timestamps wg_timestamps; /* wgcore::timestamps::GpuTimestamps */
+
+/* ------------------------------------------------------------------------------------------------ */
+/* library / device                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+int wg_abi_version(void);
+/* Thread-local message of the last failing call on this thread ("" if none). Never NULL. */
+const char *wg_last_error_string(void);
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+int wg_device_count(void);
+
+/* GpuInstance::new() (gpu.rs:24-58): bind `device`, create the in-order stream. */
+int wg_ctx_create(int device, wg_ctx **out);
+/* Same, but enqueue on an existing hipStream_t (e.g. the stream another runtime owns). Not destroyed with the ctx. */
+int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out);
+int wg_ctx_destroy(wg_ctx *ctx);
+/* queue.submit(..) + device.poll(PollType::wait()) (tensor.rs:304-312): block until all enqueued work is done. */
+int wg_ctx_sync(wg_ctx *ctx);
+int wg_ctx_device(const wg_ctx *ctx);
+void *wg_ctx_stream(const wg_ctx *ctx); /* the hipStream_t, for interop */
+/* Device facts the bench prints next to every roofline: name (<=255 chars), CU count, clock MHz, HBM bytes. */
+int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int *clock_mhz, uint64_t *hbm_bytes);
+/* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. */
+int wg_ctx_reserve_workspace(wg_ctx *ctx, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* buffers  (TensorBuilder::build / build_init / build_bytes, tensor.rs:115-186)                     */
+/* ------------------------------------------------------------------------------------------------ */
+/* Uninitialised buffer of `bytes` bytes (0 is legal: an empty tensor). */
+int wg_buf_create(wg_ctx *ctx, size_t bytes, uint32_t usage, wg_buf **out);
+/* create_buffer_init: allocate and upload synchronously (tensor.rs:149-161). */
+int wg_buf_create_init(wg_ctx *ctx, const void *data, size_t bytes, uint32_t usage, wg_buf **out);
+/* Non-owning wrapper around device memory someone else allocated (e.g. a torch tensor's data_ptr()). */
+int wg_buf_wrap(wg_ctx *ctx, void *device_ptr, size_t bytes, wg_buf **out);
+int wg_buf_destroy(wg_buf *buf); /* Drop for GpuTensor / Buffer */
+size_t wg_buf_size(const wg_buf *buf);
+void *wg_buf_device_ptr(const wg_buf *buf);
+/* Queue::write_buffer: stream-ordered host->device copy of `bytes` at byte `offset`. Host memory may be pageable. */
+int wg_buf_write(wg_ctx *ctx, wg_buf *dst, size_t offset, const void *data, size_t bytes);
+/* GpuTensor::read / read_to (tensor.rs:300-384): device->host, BLOCKS until the data is in `dst`. */
+int wg_buf_read(wg_ctx *ctx, const wg_buf *src, size_t offset, void *dst, size_t bytes);
+/* CommandEncoder::copy_buffer_to_buffer (tensor.rs:227-264): stream-ordered device copy. */
+int wg_buf_copy(wg_ctx *ctx, const wg_buf *src, size_t src_offset, wg_buf *dst, size_t dst_offset, size_t bytes);
+int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* operators                                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+/*
+ * Gemm::dispatch_generic (wgebra gemm.rs:65-127): out = m1 * m2 (WG_GEMM, WG_GEMM_FAST) or m1^T * m2
+ * (WG_GEMM_TR, WG_GEMM_TR_FAST), batched over size[2]; `out` is overwritten.
+ *   DIM_MISMATCH  : the five assert_eq! of gemm.rs:91-95.
+ *   PRECONDITION  : rows/stride/stride_mat/offset of any view, or K or N, not a multiple of 4 (the vec4 view of
+ *                   shape.wgsl:64-66 makes the reference's result undefined there).
+ *   *_FAST        : the reference requires K % 256 == 0 and reads out of bounds otherwise (gemm.wgsl:40,162);
+ *                   here every K % 4 == 0 is accepted and all four variants run the same tuned kernel.
+ * dtype WG_F16 (extension): f16 operands, f32 accumulation, result rounded once (RNE) to f16.
+ */
+int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype,
+            wg_buf *out, wg_view_shape out_shape,
+            const wg_buf *m1, wg_view_shape m1_shape,
+            const wg_buf *m2, wg_view_shape m2_shape);
+
+/*
+ * Gemv::dispatch_generic (wgebra gemv.rs:64-137): out[:,y,z] = m[:,:,z] * v[:,y,z] (or m^T), for every RHS
+ * column y < out.size[1] and matrix z < out.size[2]; `out` is overwritten.
+ *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).
+ *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122), vec4 alignment.
+ *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
+ */
+int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
+            wg_buf *out, wg_view_shape out_shape,
+            const wg_buf *m, wg_view_shape m_shape,
+            const wg_buf *v, wg_view_shape v_shape);
+
+/*
+ * Reduce::dispatch (wgebra reduce.rs:100-113): result[0] = reduce(op, value[offset .. offset+size[0])).
+ * `result` is the GpuScalar's buffer (>= 4 bytes). The summation ORDER is the reference's (128 strided lanes,
+ * then the 64..1 tree; reduce.wgsl:68-87), so Min/Max/Sum/Prod are bit-identical to it; n == 0 gives the init
+ * value (0, 1, +3.4e38, -3.4e38).
+ */
+int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
+              const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
+
+/*
+ * Extension (BASELINE config 4): one launch for many vectors. Column c of matrix t of the
+ * column-major view is reduced exactly as wg_reduce would reduce the vector view at
+ * offset + c*stride + t*stride_mat; results[c + t*size[1]] (f32 each).
+ */
+int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
+                      const wg_buf *values, wg_view_shape values_shape, wg_buf *results);
+
+/*
+ * OpAssign::dispatch (wgebra op_assign.rs:71-95): a[i] = a[i] (op) b[i], i < a.size[0]; WG_OP_COPY: a[i] = b[i].
+ * Scalar indexing offset+i (shape.wgsl:36-38). DIM_MISMATCH: a.size[0] != b.size[0] (op_assign.rs:82-86).
+ * IEEE-correct + - * / : bit-identical to the reference's CPU check.
+ */
+int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype,
+                 wg_buf *a, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* record / replay: CommandEncoder -> finish() -> CommandBuffer -> Queue::submit, as a hipGraph      */
+/* ------------------------------------------------------------------------------------------------ */
+/* Start recording: operator and copy calls are captured instead of executed (no sync/read/create while recording). */
+int wg_encoder_begin(wg_ctx *ctx);
+/* encoder.finish(): stop recording and instantiate the replayable command buffer. */
+int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out);
+/* queue.submit(Some(cmdbuf)): enqueue one replay on the context's stream. May be submitted many times. */
+int wg_queue_submit(wg_ctx *ctx, wg_cmdbuf *cmdbuf);
+int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* GpuTimestamps (wgcore timestamps.rs): begin/end-of-pass timestamps on the context's stream        */
+/* ------------------------------------------------------------------------------------------------ */
+int wg_timestamps_create(wg_ctx *ctx, uint32_t capacity, wg_timestamps **out); /* GpuTimestamps::new */
+int wg_timestamps_destroy(wg_timestamps *ts);
+int wg_timestamps_clear(wg_timestamps *ts);
+/* Record the next timestamp at the current point of the stream; *index (optional) receives its slot. */
+int wg_timestamps_write(wg_ctx *ctx, wg_timestamps *ts, uint32_t *index);
+uint32_t wg_timestamps_len(const wg_timestamps *ts);
+/* wait_for_results_ms (timestamps.rs:226-230): block, then out_ms[i] = time of slot i relative to slot 0. */
+int wg_timestamps_wait_for_results_ms(wg_timestamps *ts, double *out_ms, uint32_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGEBRA_HIP_H */

@@ -1,0 +1,320 @@
+"""GPU parity tests proper: HIP kernels (through the C ABI) vs the oracle and the committed golden vectors.
+Sizes here are ones the oracle finishes in seconds; BASELINE-size runs live in test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+
+import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _wg():
+    import wgmath_amd as wg
+    return wg
+
+
+def _wo():
+    from oracle import wgsl_oracle as wo
+    return wo
+
+
+S_STORAGE = 128 | 4 | 8  # STORAGE | COPY_SRC | COPY_DST
+
+
+def upload(gpu, shape, flat, dtype=np.float32):
+    wg = _wg()
+    return wg.TensorBuilder.tensor(shape, S_STORAGE).build_init(gpu.device(), np.asarray(flat, dtype), dtype)
+
+
+def run_pass(gpu, fn):
+    enc = gpu.device().create_command_encoder()
+    with enc.compute_pass("test", None) as p:
+        fn(p)
+    gpu.queue().submit([enc.finish()])
+
+
+# --------------------------------------------------------------------------------------------------------
+# golden vectors
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["gemm_u01_64x256x32x2", "gemm_pm1_64x256x32x2"])
+def test_gemm_golden(gpu, name):
+    wg = _wg()
+    g = U.golden(name)
+    M, K, N, mats = (int(x) for x in g["dims"])
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    for variant in wg.GemmVariant:
+        tr = variant in (wg.GemmVariant.GemmTr, wg.GemmVariant.GemmTrFast)
+        key = "tr" if tr else "nn"
+        m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), g[f"m1_{key}"])
+        m2 = upload(gpu, (K, N, mats), g[f"m2_{key}"])
+        out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float32))
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+        got = out.read(gpu.device())
+        U.assert_close_f64(got, g[f"truth_{key}"], K, g[f"sabs_{key}"], f"{name} {variant!r} vs f64")
+        U.assert_close_oracle(got, g[f"out_v{int(variant)}"], K, g[f"sabs_{key}"], f"{name} {variant!r} vs golden")
+
+
+@pytest.mark.parametrize("name", ["gemv_u01_128x256x3x2", "gemv_pm1_128x256x3x2"])
+def test_gemv_golden(gpu, name):
+    wg = _wg()
+    g = U.golden(name)
+    R, C, nrhs, mats = (int(x) for x in g["dims"])
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    m = upload(gpu, (R, C, mats), g["m"])
+    for variant in wg.GemvVariant:
+        tr = variant in (wg.GemvVariant.GemvTr, wg.GemvVariant.GemvTrFast)
+        key = "tr" if tr else "nn"
+        vlen, olen = (R, C) if tr else (C, R)
+        v = upload(gpu, (vlen, nrhs, mats), g[f"v_{key}"])
+        out = upload(gpu, (olen, nrhs, mats), np.full(olen * nrhs * mats, np.nan, np.float32))
+        run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, out, m, v, variant))
+        got = out.read(gpu.device())
+        U.assert_close_f64(got, g[f"truth_{key}"], vlen, g[f"sabs_{key}"], f"{name} {variant!r} vs f64")
+        U.assert_close_oracle(got, g[f"out_v{int(variant)}"], vlen, g[f"sabs_{key}"], f"{name} {variant!r} vs golden")
+
+
+def test_reduce_golden_bit_exact(gpu):
+    wg = _wg()
+    g = U.golden("reduce")
+    shapes = wg.ViewShapeBuffers()
+    for n in (0, 1, 127, 128, 129, 345, 65536, "prod4096"):
+        x = g[f"x_{n}"]
+        vec = upload(gpu, (max(x.size, 1),), x if x.size else np.zeros(1, np.float32))
+        for op in wg.ReduceOp:
+            res = upload(gpu, (), np.array([np.nan], np.float32))
+            red = wg.Reduce.new(gpu.device(), op)
+            view = vec.as_view().rows(0, x.size) if x.size else vec.rows(0, 0)
+            run_pass(gpu, lambda p: red.dispatch(gpu.device(), shapes, p, view, res))
+            got = res.read(gpu.device())
+            U.assert_bits_equal(got, g[f"expected_{n}"][int(op):int(op) + 1], f"reduce n={n} {op!r}")
+
+
+def test_reduce_batched_and_unaligned(gpu, oracle_c):
+    wg, wo = _wg(), _wo()
+    g = U.golden("reduce")
+    shapes = wg.ViewShapeBuffers()
+    xb = g["xb"]
+    mat = upload(gpu, (1000, 96), xb)
+    for op in wg.ReduceOp:
+        red = wg.Reduce.new(gpu.device(), op)
+        res = upload(gpu, (96,), np.full(96, np.nan, np.float32))
+        run_pass(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, mat, res))
+        U.assert_bits_equal(res.read(gpu.device()), g[f"expected_batched_{int(op)}"], f"batched reduce {op!r}")
+        # unaligned vector base (offset 3, length 777): the scalar twin must give the same bits as the oracle
+        res1 = upload(gpu, (), np.array([np.nan], np.float32))
+        view = wg.GpuTensorView(wg.ViewShape((777, 1, 1), 1, 1, 3), mat, 1)
+        run_pass(gpu, lambda p: red.dispatch(gpu.device(), shapes, p, view, res1))
+        exp = oracle_c.reduce(int(op), xb, wo.Shape(777, 1, 1, 1, 1, 3))
+        U.assert_bits_equal(res1.read(gpu.device()), np.array([exp], np.float32), f"unaligned reduce {op!r}")
+        # odd stride (not a multiple of 4) -> every column unaligned -> scalar twin, batched
+        v2 = wg.GpuTensorView(wg.ViewShape((333, 50, 1), 1001, 1, 2), mat, 2)
+        res2 = upload(gpu, (50,), np.full(50, np.nan, np.float32))
+        run_pass(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, v2, res2))
+        exp2 = oracle_c.reduce_batched(int(op), xb, wo.Shape(333, 50, 1, 1001, 1, 2))
+        U.assert_bits_equal(res2.read(gpu.device()), exp2, f"odd-stride batched reduce {op!r}")
+
+
+# --------------------------------------------------------------------------------------------------------
+# shape sweeps vs the oracle on the same seeded inputs
+# --------------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [
+    # M,   K,   N, mats
+    (4, 4, 4, 1), (8, 4, 12, 1), (36, 20, 28, 1), (256, 256, 128, 1), (260, 264, 132, 1), (512, 48, 260, 2),
+    (128, 1024, 64, 1), (1024, 16, 512, 1), (252, 1000, 124, 3),
+]
+
+
+@pytest.mark.parametrize("M,K,N,mats", GEMM_SHAPES)
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_shapes(gpu, oracle_c, M, K, N, mats, tr):
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M * 1000003 + K * 1009 + N * 7 + mats + int(tr))
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    s1 = wo.Shape(K, M, mats) if tr else wo.Shape(M, K, mats)
+    s2, so = wo.Shape(K, N, mats), wo.Shape(M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    orc = np.zeros(M * N * mats, np.float32)
+    oracle_c.gemm(int(variant), orc, so, a, s1, b, s2)
+    m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a)
+    m2 = upload(gpu, (K, N, mats), b)
+    out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float32))
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+    got = out.read(gpu.device())
+    A, B = wo.view(a, s1), wo.view(b, s2)
+    for t in range(mats):
+        amk = A[:, :, t].T if tr else A[:, :, t]
+        truth, sabs = wo.gemm_f64(amk, B[:, :, t])
+        g_t = wo.view(got, so)[:, :, t]
+        U.assert_close_f64(g_t, truth, K, sabs, f"gemm {M}x{K}x{N} mat {t} tr={tr} vs f64")
+        U.assert_close_oracle(g_t, wo.view(orc, so)[:, :, t], K, sabs, "vs oracle")
+
+
+def test_gemm_identity_asymmetric(gpu):
+    """A = I with an asymmetric B catches a transposed/permuted C write (guide: 'always A=I-check with asymmetric B')."""
+    wg = _wg()
+    M = K = 384
+    N = 136
+    eye = np.eye(M, K, dtype=np.float32)
+    B = (np.arange(K * N, dtype=np.float32).reshape(K, N) % 1021) + np.arange(N, dtype=np.float32)[None, :] * 0.5
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    for variant in (wg.GemmVariant.Gemm, wg.GemmVariant.GemmTr):
+        m1, m2 = upload(gpu, (M, K), eye), upload(gpu, (K, N), B)
+        out = upload(gpu, (M, N), np.zeros(M * N, np.float32))
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+        got = out.read(gpu.device()).reshape(M, N, order="F")
+        assert np.array_equal(got, B.astype(np.float32)), variant
+
+
+def test_gemm_strided_views(gpu, oracle_c):
+    """Views built by GpuMatrix::columns / rows / GpuCubeView::matrix (tensor.rs:466-626): non-default stride/offset."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(77)
+    PR, PC = 96, 80  # parents
+    pa = (rng.random(PR * PC * 2, dtype=np.float32) - 0.5).astype(np.float32)
+    pb = (rng.random(PR * PC * 2, dtype=np.float32) - 0.5).astype(np.float32)
+    po0 = (rng.random(PR * PC * 2, dtype=np.float32)).astype(np.float32)
+    ta, tb, to = upload(gpu, (PR, PC, 2), pa), upload(gpu, (PR, PC, 2), pb), upload(gpu, (PR, PC, 2), po0)
+    # m1 = rows 8..72 (64) x cols 4..36 (32) of matrix 1 of ta; m2 = rows 0..32 x cols 8..28 (20) of matrix 1 of tb
+    a_view = ta.as_view().matrix(1).columns(4, 32).rows(8, 64)
+    b_view = tb.as_view().matrix(1).columns(8, 20).rows(0, 32)
+    o_view = to.as_view().matrix(0).columns(12, 20).rows(16, 64)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, o_view, a_view, b_view))
+    got = to.read(gpu.device())
+    orc = po0.copy()
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    oracle_c.gemm(0, orc, sh(o_view), pa, sh(a_view), pb, sh(b_view))
+    A, B = wo.view(pa, sh(a_view))[:, :, 0], wo.view(pb, sh(b_view))[:, :, 0]
+    truth, sabs = wo.gemm_f64(A, B)
+    U.assert_close_f64(wo.view(got, sh(o_view))[:, :, 0], truth, 32, sabs, "strided gemm vs f64")
+    # everything outside the output view is untouched
+    mask = np.ones(po0.size, bool)
+    s = sh(o_view).resolved()
+    idx = s.offset + np.arange(s.nrows)[:, None] + np.arange(s.ncols)[None, :] * s.stride
+    mask[idx.ravel()] = False
+    assert np.array_equal(got[mask], po0[mask])
+    U.assert_close_oracle(wo.view(got, sh(o_view))[:, :, 0], wo.view(orc, sh(o_view))[:, :, 0], 32, sabs, "strided gemm vs oracle")
+
+
+GEMV_SHAPES = [
+    # R,    C, nrhs, mats
+    (4, 4, 1, 1), (8, 260, 1, 1), (260, 8, 1, 1), (1024, 1024, 1, 1), (512, 4096, 2, 1), (4096, 512, 3, 2),
+    (252, 1000, 5, 1), (128, 65536, 1, 1), (65536, 128, 1, 1), (2048, 2048, 4, 1),
+]
+
+
+@pytest.mark.parametrize("R,C,nrhs,mats", GEMV_SHAPES)
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemv_shapes(gpu, oracle_c, R, C, nrhs, mats, tr):
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(R * 7919 + C * 31 + nrhs * 5 + mats + int(tr))
+    m = (rng.random(R * C * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    vlen, olen = (R, C) if tr else (C, R)
+    v = (rng.random(vlen * nrhs * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    o0 = rng.random(olen * nrhs * mats, dtype=np.float32)
+    sm, sv, so = wo.Shape(R, C, mats), wo.Shape(vlen, nrhs, mats), wo.Shape(olen, nrhs, mats)
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    orc = o0.copy()
+    oracle_c.gemv(int(variant), orc, so, m, sm, v, sv)
+    tm, tv, to = upload(gpu, (R, C, mats), m), upload(gpu, (vlen, nrhs, mats), v), upload(gpu, (olen, nrhs, mats), o0)
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, to, tm, tv, variant))
+    got = to.read(gpu.device())
+    A, X = wo.view(m, sm), wo.view(v, sv)
+    for t in range(mats):
+        amk = A[:, :, t].T if tr else A[:, :, t]
+        truth, sabs = wo.gemm_f64(amk, X[:, :, t])
+        U.assert_close_f64(wo.view(got, so)[:, :, t], truth, vlen, sabs, f"gemv {R}x{C} rhs={nrhs} mat {t} tr={tr} vs f64")
+        U.assert_close_oracle(wo.view(got, so)[:, :, t], wo.view(orc, so)[:, :, t], vlen, sabs, "vs oracle")
+
+
+@pytest.mark.parametrize("n,off_a,off_b", [(1, 0, 0), (3, 1, 1), (1757, 0, 0), (1757, 3, 3), (1757, 1, 2), (100003, 5, 9), (1 << 20, 0, 4)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_op_assign_offsets(gpu, n, off_a, off_b, dtype):
+    wg = _wg()
+    rng = np.random.default_rng(n + off_a * 17 + off_b)
+    pa = (rng.random(n + 16, dtype=np.float32) * 4 - 2).astype(dtype)
+    pb = (rng.random(n + 16, dtype=np.float32) * 4 - 2).astype(dtype)
+    shapes = wg.ViewShapeBuffers()
+    for op in wg.OpAssignVariant:
+        ta, tb = upload(gpu, (n + 16,), pa, dtype), upload(gpu, (n + 16,), pb, dtype)
+        oa = wg.OpAssign.new(gpu.device(), op)
+        va, vb = ta.rows(off_a, n), tb.rows(off_b, n)
+        run_pass(gpu, lambda p: oa.dispatch(gpu.device(), shapes, p, va, vb))
+        got = ta.read(gpu.device())
+        exp = pa.copy()
+        x, y = pa[off_a:off_a + n].astype(np.float32), pb[off_b:off_b + n].astype(np.float32)
+        with np.errstate(all="ignore"):
+            r = {0: x + y, 1: x - y, 2: x * y, 3: x / y, 4: y}[int(op)]
+        exp[off_a:off_a + n] = r.astype(dtype)
+        U.assert_bits_equal(got, exp, f"op_assign {op!r} n={n} offsets ({off_a},{off_b}) {np.dtype(dtype).name}")
+
+
+# --------------------------------------------------------------------------------------------------------
+# error behaviour (what the reference turns into a panic / a silent skip)
+# --------------------------------------------------------------------------------------------------------
+def test_errors_and_skips(gpu):
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    z = lambda *shape: upload(gpu, shape, np.zeros(int(np.prod(shape)), np.float32))
+    gemm, gemv = wg.Gemm.from_device(dev), wg.Gemv.from_device(dev)
+    enc = dev.create_command_encoder()
+    p = enc.compute_pass("errors", None)
+    with pytest.raises(wg.DimensionMismatch, match="Gemm: dimension mismatch."):
+        gemm.dispatch(dev, shapes, p, z(8, 8), z(8, 12), z(8, 8))
+    with pytest.raises(AssertionError):  # DimensionMismatch is an AssertionError, like a Rust assert_eq! panic
+        gemm.dispatch_tr(dev, shapes, p, z(8, 8), z(8, 12), z(8, 8))
+    with pytest.raises(wg.DimensionMismatch, match="Gemv: dimension mismatch."):
+        gemv.dispatch(dev, shapes, p, z(8), z(8, 12), z(8))
+    with pytest.raises(wg.DimensionMismatch, match="Op-assign: dimension mismatch."):
+        wg.OpAssign.new(dev, wg.OpAssignVariant.Add).dispatch(dev, shapes, p, z(8), z(12))
+    with pytest.raises(wg.PreconditionFailed):  # gemv.rs:122
+        gemv.dispatch_generic(dev, shapes, p, z(6), z(6, 8), z(8), wg.GemvVariant.GemvFast)
+    with pytest.raises(wg.PreconditionFailed):  # not vec4-aligned
+        gemm.dispatch(dev, shapes, p, z(6, 8), z(6, 8), z(8, 8))
+    with pytest.raises(wg.WgError, match="addresses"):  # view larger than its buffer
+        big = z(8, 8)
+        gemm.dispatch(dev, shapes, p, wg.GpuTensorView(wg.ViewShape((16, 16, 1), 16, 256, 0), big, 2), z(16, 16), z(16, 16))
+    # GemvTrFast with rows % 128 != 0 silently runs GemvTr (gemv.rs:99-104)
+    m, v, o = upload(gpu, (8, 12), np.ones(96, np.float32)), upload(gpu, (8,), np.ones(8, np.float32)), z(12)
+    gemv.dispatch_generic(dev, shapes, p, o, m, v, wg.GemvVariant.GemvTrFast)
+    # zero-sized tensors: silently skipped (kernel.rs:111-123)
+    gemm.dispatch(dev, shapes, p, z(0, 0), z(0, 0), z(0, 0))
+    wg.OpAssign.new(dev, wg.OpAssignVariant.Add).dispatch(dev, shapes, p, z(0), z(0))
+    p.end()
+    gpu.queue().submit([enc.finish()])
+    assert np.array_equal(o.read(dev), np.full(12, 8, np.float32))
+
+
+# --------------------------------------------------------------------------------------------------------
+# runtime: record/replay, timestamps, staging copies
+# --------------------------------------------------------------------------------------------------------
+def test_record_replay_and_timestamps(gpu):
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    n = 4096
+    a = upload(gpu, (n,), np.zeros(n, np.float32))
+    b = upload(gpu, (n,), np.ones(n, np.float32))
+    add = wg.OpAssign.new(dev, wg.OpAssignVariant.Add)
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p:
+        add.dispatch(dev, shapes, p, a, b)
+        add.dispatch(dev, shapes, p, a, b)
+    cb = enc.finish()
+    assert np.array_equal(a.read(dev), np.zeros(n, np.float32))  # nothing ran while recording
+    for _ in range(5):
+        gpu.queue().submit([cb])
+    assert np.array_equal(a.read(dev), np.full(n, 10, np.float32))
+
+    ts = wg.GpuTimestamps.new(dev, 8)
+    enc = dev.create_command_encoder()
+    with enc.compute_pass("timed", ts) as p:
+        for _ in range(10):
+            add.dispatch(dev, shapes, p, a, b)
+    ts.resolve(enc)
+    gpu.queue().submit([enc.finish()])
+    t = ts.wait_for_results_ms()
+    assert len(t) == 2 and t[0] == 0.0 and 0.0 < t[1] < 1000.0
+    assert np.array_equal(a.slow_read(gpu), np.full(n, 20, np.float32))

@@ -1,0 +1,118 @@
+"""ctypes binding of libwgebra_hip.so (include/wgebra_hip.h).  No fallback: if the HIP library is missing or an
+entry point is absent, importing this module raises -- the product path never routes around the GPU kernels."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libwgebra_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "wgebra_hip.h")
+
+# status codes (wg_status)
+WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_OF_BOUNDS, WG_ERR_HIP, \
+    WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE = range(8)
+WG_F32, WG_F16 = 0, 1
+
+
+class ViewShapeC(ctypes.Structure):
+    """wg_view_shape == wgcore::shapes::ViewShape (#[repr(C)], 24 bytes; shapes.rs:9-21)."""
+    _fields_ = [("size", ctypes.c_uint32 * 3), ("stride", ctypes.c_uint32), ("stride_mat", ctypes.c_uint32),
+                ("offset", ctypes.c_uint32)]
+
+
+assert ctypes.sizeof(ViewShapeC) == 24
+
+
+class WgError(RuntimeError):
+    """A non-OK wg_status.  `.status` is the code, the message is wg_last_error_string()."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+class DimensionMismatch(WgError, AssertionError):
+    """What the reference raises as a panic from assert_eq!(..., "... dimension mismatch.")."""
+
+
+class PreconditionFailed(WgError, AssertionError):
+    pass
+
+
+class NoDevice(WgError):
+    pass
+
+
+def declared_symbols(header_path: str = HEADER_PATH) -> list[str]:
+    """Every function the public header declares (used by the ABI-completeness test)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wg_[a-z0-9_]+)\s*\(", text)))
+
+
+def _load() -> ctypes.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C wgmath_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, cp, ci, u32, u64, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
+    pvp = ctypes.POINTER(vp)
+    S = ViewShapeC
+    sig = {
+        "wg_abi_version": (ci, []),
+        "wg_last_error_string": (cp, []),
+        "wg_device_count": (ci, []),
+        "wg_ctx_create": (ci, [ci, pvp]),
+        "wg_ctx_create_on_stream": (ci, [ci, vp, pvp]),
+        "wg_ctx_destroy": (ci, [vp]),
+        "wg_ctx_sync": (ci, [vp]),
+        "wg_ctx_device": (ci, [vp]),
+        "wg_ctx_stream": (vp, [vp]),
+        "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
+        "wg_ctx_reserve_workspace": (ci, [vp, sz]),
+        "wg_buf_create": (ci, [vp, sz, u32, pvp]),
+        "wg_buf_create_init": (ci, [vp, vp, sz, u32, pvp]),
+        "wg_buf_wrap": (ci, [vp, vp, sz, pvp]),
+        "wg_buf_destroy": (ci, [vp]),
+        "wg_buf_size": (sz, [vp]),
+        "wg_buf_device_ptr": (vp, [vp]),
+        "wg_buf_write": (ci, [vp, vp, sz, vp, sz]),
+        "wg_buf_read": (ci, [vp, vp, sz, vp, sz]),
+        "wg_buf_copy": (ci, [vp, vp, sz, vp, sz, sz]),
+        "wg_buf_fill_zero": (ci, [vp, vp]),
+        "wg_gemm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_gemv": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
+        "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
+        "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
+        "wg_encoder_begin": (ci, [vp]),
+        "wg_encoder_finish": (ci, [vp, pvp]),
+        "wg_queue_submit": (ci, [vp, vp]),
+        "wg_cmdbuf_destroy": (ci, [vp]),
+        "wg_timestamps_create": (ci, [vp, u32, pvp]),
+        "wg_timestamps_destroy": (ci, [vp]),
+        "wg_timestamps_clear": (ci, [vp]),
+        "wg_timestamps_write": (ci, [vp, vp, ctypes.POINTER(u32)]),
+        "wg_timestamps_len": (u32, [vp]),
+        "wg_timestamps_wait_for_results_ms": (ci, [vp, ctypes.POINTER(ctypes.c_double), u32]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    lib._wg_signatures = sig
+    return lib
+
+
+lib = _load()
+
+_EXC = {WG_ERR_DIM_MISMATCH: DimensionMismatch, WG_ERR_PRECONDITION: PreconditionFailed, WG_ERR_NO_DEVICE: NoDevice}
+
+
+def check(status: int) -> None:
+    if status != WG_OK:
+        msg = lib.wg_last_error_string().decode("utf-8", "replace")
+        raise _EXC.get(status, WgError)(status, msg or f"wg_status {status}")

@@ -1,0 +1,186 @@
+// Operator front-end of the C ABI: the host-side half of Gemm/Gemv/Reduce/OpAssign::dispatch.
+// Mirrors, check for check, wgebra gemm.rs:75-126, gemv.rs:74-136, reduce.rs:100-113, op_assign.rs:79-94 and the
+// silent-skip rules of wgcore kernel.rs:111-123,144; adds the bounds/alignment checks the reference leaves to UB.
+#include "wg_internal.hpp"
+
+namespace {
+
+struct View {
+    uint32_t rows, cols, mats, stride, stride_mat, offset;
+};
+inline View mk(const wg_view_shape &s) { return { s.size[0], s.size[1], s.size[2], s.stride, s.stride_mat, s.offset }; }
+
+// Largest element index the view touches + 1 (0 for an empty view).
+inline uint64_t extent(const View &v) {
+    if (v.rows == 0 || v.cols == 0 || v.mats == 0) return 0;
+    return (uint64_t)(v.mats - 1) * v.stride_mat + v.offset + (uint64_t)(v.rows - 1) + (uint64_t)(v.cols - 1) * v.stride + 1;
+}
+
+int check_bounds(const char *op, const char *name, const View &v, const wg_buf *b, wg_dtype dt) {
+    const uint64_t need = extent(v), have = b->bytes / wg_dtype_size(dt);
+    if (need > have)
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "%s: view `%s` addresses %llu elements but its buffer holds %llu", op, name,
+                            (unsigned long long)need, (unsigned long long)have);
+    return WG_OK;
+}
+
+// The kernels bind every buffer as array<vec4<f32>> (gemm.wgsl:9-14, gemv.wgsl:9-14) and convert shapes with
+// with_vec4_elts (shape.wgsl:64-66): rows, stride, stride_mat and offset must be multiples of 4 for that to address
+// the same elements. (stride only matters with > 1 column, stride_mat with > 1 matrix: GpuMatrix::column sets
+// stride = 1 and GpuCubeView::matrix sets stride_mat = 1, tensor.rs:474,574-584.)
+int check_vec4(const char *op, const char *name, const View &v) {
+    if (v.rows % 4 || v.offset % 4 || (v.cols > 1 && v.stride % 4) || (v.mats > 1 && v.stride_mat % 4))
+        return wg_set_error(WG_ERR_PRECONDITION,
+                            "%s: view `%s` {size:[%u,%u,%u], stride:%u, stride_mat:%u, offset:%u} is not vec4-aligned "
+                            "(rows, stride, stride_mat, offset must be multiples of 4: shape.wgsl:64-66)",
+                            op, name, v.rows, v.cols, v.mats, v.stride, v.stride_mat, v.offset);
+    return WG_OK;
+}
+
+int check_common(const char *op, const wg_ctx *ctx, wg_dtype dtype, const wg_buf *const *bufs, int n) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "%s: ctx is NULL", op);
+    if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "%s: unknown dtype %d", op, (int)dtype);
+    for (int i = 0; i < n; ++i) {
+        if (!bufs[i]) return wg_set_error(WG_ERR_INVALID_ARG, "%s: buffer argument %d is NULL", op, i);
+        if (bufs[i]->ctx->device != ctx->device)
+            return wg_set_error(WG_ERR_INVALID_ARG, "%s: buffer argument %d lives on device %d, the context on device %d", op, i,
+                                bufs[i]->ctx->device, ctx->device);
+    }
+    return WG_OK;
+}
+
+inline const void *elem_ptr(const wg_buf *b, uint64_t elem, wg_dtype dt) { return (const char *)b->ptr + elem * wg_dtype_size(dt); }
+
+} // namespace
+
+extern "C" {
+
+int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m1,
+            wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape) {
+    const wg_buf *bufs[3] = { out, m1, m2 };
+    if (int rc = check_common("Gemm", ctx, dtype, bufs, 3)) return rc;
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
+    const bool tr = variant == WG_GEMM_TR || variant == WG_GEMM_TR_FAST;
+    const View o = mk(out_shape), a = mk(m1_shape), b = mk(m2_shape);
+
+    // gemm.rs:81-96
+    const uint32_t m_rows = tr ? a.cols : a.rows, m_cols = tr ? a.rows : a.cols;
+    if (m_cols != b.rows || m_rows != o.rows || o.cols != b.cols || o.mats != a.mats || o.mats != b.mats)
+        return wg_set_error(WG_ERR_DIM_MISMATCH,
+                            "Gemm: dimension mismatch. (out [%u,%u,%u], m1 [%u,%u,%u]%s, m2 [%u,%u,%u])", o.rows, o.cols, o.mats,
+                            a.rows, a.cols, a.mats, tr ? "^T" : "", b.rows, b.cols, b.mats);
+    // kernel.rs:111-123 (zero-sized binding) and :144 (zero-sized grid): silently skipped
+    if (out->bytes == 0 || m1->bytes == 0 || m2->bytes == 0) return WG_OK;
+    if (o.rows == 0 || o.mats == 0) return WG_OK;
+    if (o.cols == 0) return WG_OK; // the kernels' k-loop over m2 columns runs zero times
+
+    if (int rc = check_vec4("Gemm", "out", o)) return rc;
+    if (int rc = check_vec4("Gemm", "m1", a)) return rc;
+    if (int rc = check_vec4("Gemm", "m2", b)) return rc;
+    if (o.cols % 4 || m_cols % 4 || m_rows % 4)
+        return wg_set_error(WG_ERR_PRECONDITION, "Gemm: M=%u, N=%u, K=%u must be multiples of 4 (4x4 blocks, gemm.wgsl:87,94)",
+                            m_rows, o.cols, m_cols);
+    if (int rc = check_bounds("Gemm", "out", o, out, dtype)) return rc;
+    if (int rc = check_bounds("Gemm", "m1", a, m1, dtype)) return rc;
+    if (int rc = check_bounds("Gemm", "m2", b, m2, dtype)) return rc;
+
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
+    wgk_mat B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };
+    void *C = (void *)elem_ptr(out, o.offset, dtype);
+    if (dtype == WG_F32) return wgk_gemm_f32(ctx, tr, m_rows, o.cols, m_cols, o.mats, (float *)C, o.stride, o.stride_mat, A, B);
+    return wgk_gemm_f16(ctx, tr, m_rows, o.cols, m_cols, o.mats, (__half *)C, o.stride, o.stride_mat, A, B);
+}
+
+int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m,
+            wg_view_shape m_shape, const wg_buf *v, wg_view_shape v_shape) {
+    const wg_buf *bufs[3] = { out, m, v };
+    if (int rc = check_common("Gemv", ctx, dtype, bufs, 3)) return rc;
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemv: unknown variant %d", (int)variant);
+    const bool tr = variant == WG_GEMV_TR || variant == WG_GEMV_TR_FAST;
+    const View o = mk(out_shape), mm = mk(m_shape), vv = mk(v_shape);
+
+    // gemv.rs:79-91 -- the reference checks exactly these two
+    const uint32_t m_rows = tr ? mm.cols : mm.rows, m_cols = tr ? mm.rows : mm.cols;
+    if (m_cols != vv.rows || m_rows != o.rows)
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "Gemv: dimension mismatch. (out [%u,%u,%u], m [%u,%u,%u]%s, v [%u,%u,%u])", o.rows,
+                            o.cols, o.mats, mm.rows, mm.cols, mm.mats, tr ? "^T" : "", vv.rows, vv.cols, vv.mats);
+    // gemv.rs:99-104: GemvTrFast silently becomes GemvTr when m.rows % 128 != 0 (same kernel here either way)
+    if (variant == WG_GEMV_TR_FAST && mm.rows % 128u != 0) variant = WG_GEMV_TR;
+    // gemv.rs:122: assert_eq!(out_nrows % 4, 0) on the fast paths
+    if ((variant == WG_GEMV_FAST || variant == WG_GEMV_TR_FAST) && o.rows % 4u != 0)
+        return wg_set_error(WG_ERR_PRECONDITION, "Gemv: assertion `left == right` failed (out_nrows %% 4 == 0, gemv.rs:122): out has %u rows",
+                            o.rows);
+    if (out->bytes == 0 || m->bytes == 0 || v->bytes == 0) return WG_OK;
+    if (o.rows == 0 || o.cols == 0 || o.mats == 0) return WG_OK;
+
+    // The grid is [.., out_ncols, out_nmats] and indexes m with z, v with (y, z) (gemv.wgsl:40,46,62): the views
+    // that are actually addressed take their column / matrix counts from `out`.
+    const View m_eff = { mm.rows, mm.cols, o.mats, mm.stride, mm.stride_mat, mm.offset };
+    const View v_eff = { vv.rows, o.cols, o.mats, vv.stride, vv.stride_mat, vv.offset };
+    if (int rc = check_vec4("Gemv", "out", o)) return rc;
+    if (int rc = check_vec4("Gemv", "m", m_eff)) return rc;
+    if (int rc = check_vec4("Gemv", "v", v_eff)) return rc;
+    if (m_cols % 4 || m_rows % 4)
+        return wg_set_error(WG_ERR_PRECONDITION, "Gemv: matrix dimensions %u x %u must be multiples of 4 (gemv.wgsl:73,76)", mm.rows, mm.cols);
+    if (int rc = check_bounds("Gemv", "out", o, out, dtype)) return rc;
+    if (int rc = check_bounds("Gemv", "m", m_eff, m, dtype)) return rc;
+    if (int rc = check_bounds("Gemv", "v", v_eff, v, dtype)) return rc;
+
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    wgk_mat M = { elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat };
+    wgk_mat V = { elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat };
+    return wgk_gemv(ctx, tr, dtype, o.rows, m_cols, o.cols, o.mats, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, V);
+}
+
+int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *value, wg_view_shape value_shape, wg_buf *result) {
+    const wg_buf *bufs[2] = { value, result };
+    if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;
+    if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
+    if (value->bytes == 0 || result->bytes == 0) return WG_OK; // kernel.rs:111-123
+    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    // reduce.wgsl:71-72: input[offset + i], i < nrows; stride / ncols / nmats are ignored
+    const View vec = { value_shape.size[0], 1, 1, 1, 1, value_shape.offset };
+    if (int rc = check_bounds("Reduce", "value", vec, value, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_reduce(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, 1, 1, 0, 0, (float *)result->ptr);
+}
+
+int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *values, wg_view_shape values_shape, wg_buf *results) {
+    const wg_buf *bufs[2] = { values, results };
+    if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;
+    if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
+    const View v = mk(values_shape);
+    const uint64_t nvec = (uint64_t)v.cols * v.mats;
+    if (nvec == 0 || results->bytes == 0) return WG_OK;
+    if (results->bytes / sizeof(float) < nvec)
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: results buffer holds %zu f32 but %llu vectors are reduced",
+                            results->bytes / sizeof(float), (unsigned long long)nvec);
+    if (values->bytes == 0 && v.rows != 0) return WG_OK;
+    if (int rc = check_bounds("Reduce", "values", v, values, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_reduce(ctx, (int)op, dtype, elem_ptr(values, v.offset, dtype), v.rows, v.cols, v.mats, v.stride, v.stride_mat,
+                      (float *)results->ptr);
+}
+
+int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype, wg_buf *a, wg_view_shape a_shape, const wg_buf *b,
+                 wg_view_shape b_shape) {
+    const wg_buf *bufs[2] = { a, b };
+    if (int rc = check_common("OpAssign", ctx, dtype, bufs, 2)) return rc;
+    if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "OpAssign: unknown variant %d", (int)op);
+    // op_assign.rs:82-86
+    if (a_shape.size[0] != b_shape.size[0])
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "Op-assign: dimension mismatch. (a has %u rows, b has %u)", a_shape.size[0],
+                            b_shape.size[0]);
+    if (a->bytes == 0 || b->bytes == 0) return WG_OK; // kernel.rs:111-123
+    const uint32_t n = a_shape.size[0];
+    if (n == 0) return WG_OK; // kernel.rs:144
+    // op_assign.wgsl:43-45: a[offset_a + i], b[offset_b + i]
+    const View va = { n, 1, 1, 1, 1, a_shape.offset }, vb = { n, 1, 1, 1, 1, b_shape.offset };
+    if (int rc = check_bounds("OpAssign", "a", va, a, dtype)) return rc;
+    if (int rc = check_bounds("OpAssign", "b", vb, b, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_op_assign(ctx, (int)op, dtype, (void *)elem_ptr(a, va.offset, dtype), elem_ptr(b, vb.offset, dtype), n);
+}
+
+} // extern "C"

@@ -1,0 +1,287 @@
+// Gemv: out[:,y,z] = m[:,:,z] * v[:,y,z]  or  m[:,:,z]^T * v[:,y,z]      (wgebra gemv.wgsl:28-155)
+//
+// HBM-bound: the matrix (4*R*C bytes) is streamed exactly once; v / out are noise. Column-major storage decides
+// the two shapes:
+//
+//  N  (out = m v):  a column is contiguous over rows, so lane l owns rows 4l..4l+3 (one float4) and a wave sweeps
+//     columns: every load is 16 B/lane, 1 KiB contiguous per wave. A 256-thread workgroup covers 256 rows; its 4
+//     waves take disjoint column ranges and are summed through LDS. Because R/256 row blocks cannot fill 256 CUs
+//     (config 4: R = 4096 -> 16), the column range is additionally split over grid.y ("split-K"); each split
+//     writes a partial and a tiny second kernel sums the partials in a FIXED order (deterministic; no atomics).
+//     v is fetched 64 columns at a time with one coalesced load per wave and broadcast with v_readlane.
+//
+//  T  (out = m^T v): a column is one dot product with v. Each wave owns 4 adjacent columns and sweeps rows with
+//     float4 loads (v's float4 is loaded once and reused for the 4 columns), then a wave-shuffle butterfly
+//     reduces the 64 lanes; the 4 results are stored as one float4. Rows are split over grid.y when there are too
+//     few columns to fill the chip.
+//
+// The reference's four variants differ only in how invocations are laid out (naive: one thread per 4 rows; fast: a
+// 32-lane workgroup + LDS tree per 4 rows) and in their summation order; all four map to these two kernels. GEMV
+// parity is tolerance-based: the order here is "per-lane sequential, then butterfly", which satisfies the
+// same error bound as both WGSL orders.
+#include "wg_internal.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kMaxRhs = 4; // RHS columns handled per pass over the matrix (m is read once for all of them)
+
+__device__ __forceinline__ float4 ld_stream(const float4 *p) { return wg_ld_nt(p); }
+__device__ __forceinline__ float readlane_f(float x, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+__device__ __forceinline__ void fma4(float4 &acc, float4 a, float s) {
+    acc.x = fmaf(a.x, s, acc.x);
+    acc.y = fmaf(a.y, s, acc.y);
+    acc.z = fmaf(a.z, s, acc.z);
+    acc.w = fmaf(a.w, s, acc.w);
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
+    return x;
+}
+
+struct GemvArgs {
+    const float *m; uint32_t ldm; uint64_t m_batch;
+    const float *v; uint32_t ldv; uint64_t v_batch;
+    float *dst;      // out, or the partials buffer when nsplit > 1
+    uint32_t ld_dst; // elements between RHS columns of dst
+    uint64_t dst_batch;
+    uint64_t dst_split; // elements between splits (partials only)
+    uint32_t rows_out;  // length of out
+    uint32_t k;         // contraction length
+    uint32_t nrhs;      // total RHS columns
+    uint32_t k_per_split;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// N: dst[r] = sum_c m[r, c] v[c],  r in this block's 256 rows, c in this split's column range
+// grid = (row blocks, splits, nmats * rhs groups)
+// ------------------------------------------------------------------------------------------------------
+template <int NRHS>
+__global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
+    __shared__ float4 part[kWaves][NRHS][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rhs_groups = (a.nrhs + kMaxRhs - 1) / kMaxRhs;
+    const uint32_t z = blockIdx.z / rhs_groups, y0 = (blockIdx.z % rhs_groups) * kMaxRhs;
+    const uint32_t row = blockIdx.x * 256u + 4u * lane;
+    const bool row_ok = row < a.rows_out;
+
+    const uint32_t c_begin = blockIdx.y * a.k_per_split;
+    const uint32_t c_end = min(a.k, c_begin + a.k_per_split);
+    // this wave's contiguous share of the split's columns, in multiples of 4 columns
+    const uint32_t ncol4 = (c_end - c_begin + 3u) / 4u;
+    const uint32_t per_wave = ((ncol4 + kWaves - 1) / kWaves) * 4u;
+    const uint32_t w_begin = min(c_end, c_begin + wave * per_wave);
+    const uint32_t w_end = min(c_end, w_begin + per_wave);
+
+    const float *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
+    const float *vp = a.v + z * a.v_batch;
+
+    float4 acc[NRHS];
+#pragma unroll
+    for (int y = 0; y < NRHS; ++y) acc[y] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (uint32_t cb = w_begin; cb < w_end; cb += 64u) {
+        // one coalesced fetch of up to 64 v entries per RHS, broadcast below with v_readlane
+        float vv[NRHS];
+#pragma unroll
+        for (int y = 0; y < NRHS; ++y)
+            vv[y] = (cb + lane < w_end && y0 + y < a.nrhs) ? vp[(uint64_t)(y0 + y) * a.ldv + cb + lane] : 0.f;
+        const float4 *col = reinterpret_cast<const float4 *>(mp + (uint64_t)cb * a.ldm);
+        const uint64_t ld4 = a.ldm / 4u;
+        if (cb + 64u <= w_end) {
+#pragma unroll
+            for (int u8 = 0; u8 < 64; u8 += 8) {
+                float4 mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mv[u] = ld_stream(col + (uint64_t)(u8 + u) * ld4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv[u], readlane_f(vv[y], u8 + u));
+            }
+        } else {
+            const int rem = (int)(w_end - cb); // wave-uniform
+#pragma unroll 4
+            for (int u = 0; u < rem; ++u) {
+                float4 mv = ld_stream(col + (uint64_t)u * ld4);
+#pragma unroll
+                for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv, __shfl(vv[y], u, 64));
+            }
+        }
+    }
+
+#pragma unroll
+    for (int y = 0; y < NRHS; ++y) part[wave][y][lane] = acc[y];
+    __syncthreads();
+    if (wave == 0 && row_ok) {
+#pragma unroll
+        for (int y = 0; y < NRHS; ++y) {
+            if (y0 + y >= a.nrhs) break;
+            float4 s = part[0][y][lane];
+#pragma unroll
+            for (int w = 1; w < kWaves; ++w) {
+                float4 p = part[w][y][lane];
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+            float *d = a.dst + z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + row;
+            *reinterpret_cast<float4 *>(d) = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// T: dst[c] = sum_r m[r, c] v[r],  4 columns per wave, rows of this split
+// grid = (column groups of 16, splits, nmats * rhs groups)
+// ------------------------------------------------------------------------------------------------------
+template <int NRHS>
+__global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t rhs_groups = (a.nrhs + kMaxRhs - 1) / kMaxRhs;
+    const uint32_t z = blockIdx.z / rhs_groups, y0 = (blockIdx.z % rhs_groups) * kMaxRhs;
+    const uint32_t col0 = (blockIdx.x * kWaves + wave) * 4u;
+    if (col0 >= a.rows_out) return; // rows_out % 4 == 0: a wave's 4 columns are all in or all out
+
+    const uint32_t r_begin = blockIdx.y * a.k_per_split;
+    const uint32_t r_end = min(a.k, r_begin + a.k_per_split);
+
+    const float *mp = a.m + z * a.m_batch + (uint64_t)col0 * a.ldm;
+    const float *vp = a.v + z * a.v_batch;
+    const uint64_t ld4 = a.ldm / 4u;
+
+    float acc[4][NRHS];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int y = 0; y < NRHS; ++y) acc[c][y] = 0.f;
+
+    auto step = [&](uint32_t r) { // r: this lane's first row (multiple of 4), r < r_end
+        const float4 *m4 = reinterpret_cast<const float4 *>(mp + r);
+        float4 mv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mv[c] = ld_stream(m4 + c * ld4);
+#pragma unroll
+        for (int y = 0; y < NRHS; ++y) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y0 + y < a.nrhs) x = *reinterpret_cast<const float4 *>(vp + (uint64_t)(y0 + y) * a.ldv + r);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]);
+                acc[c][y] = fmaf(mv[c].y, x.y, acc[c][y]);
+                acc[c][y] = fmaf(mv[c].z, x.z, acc[c][y]);
+                acc[c][y] = fmaf(mv[c].w, x.w, acc[c][y]);
+            }
+        }
+    };
+
+    uint32_t r = r_begin + 4u * lane;
+    // two row-steps per trip: 8 matrix float4 + 2*NRHS vector float4 in flight per lane
+    for (; (uint64_t)r + 256u < r_end; r += 512u) {
+        step(r);
+        step(r + 256u);
+    }
+    for (; r < r_end; r += 256u) step(r);
+
+#pragma unroll
+    for (int y = 0; y < NRHS; ++y) {
+        if (y0 + y >= a.nrhs) break;
+        float4 s;
+        s.x = wave_sum(acc[0][y]);
+        s.y = wave_sum(acc[1][y]);
+        s.z = wave_sum(acc[2][y]);
+        s.w = wave_sum(acc[3][y]);
+        if (lane == 0) {
+            float *d = a.dst + z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + col0;
+            *reinterpret_cast<float4 *>(d) = s;
+        }
+    }
+}
+
+// out[r] = sum_{s < nsplit} partial[s][r], s ascending. partial layout: [z][s][y][rows_out] dense.
+__global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__restrict__ partial, uint32_t nsplit, uint32_t rows_out,
+                                                                 uint32_t nrhs, float *__restrict__ out, uint32_t ld_out,
+                                                                 uint64_t out_batch) {
+    const uint32_t r4 = blockIdx.x * kThreads + threadIdx.x; // float4 index within a column
+    if (r4 * 4u >= rows_out) return;
+    const uint32_t y = blockIdx.y, z = blockIdx.z;
+    const uint64_t split_stride = (uint64_t)nrhs * rows_out;
+    const float4 *p = reinterpret_cast<const float4 *>(partial + (uint64_t)z * nsplit * split_stride + (uint64_t)y * rows_out) + r4;
+    float4 s = p[0];
+    for (uint32_t i = 1; i < nsplit; ++i) {
+        float4 q = p[(uint64_t)i * (split_stride / 4u)];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    *reinterpret_cast<float4 *>(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4) = s;
+}
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); }
+
+} // namespace
+
+int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
+             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
+    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: only f32 is implemented (the reference kernel is f32: gemv.wgsl:9-14)");
+    if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
+    const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
+    if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/4) = %llu exceeds 65535", (unsigned long long)gz64);
+    const uint32_t gz = (uint32_t)gz64;
+
+    // blocks along the output, and how finely the contraction must be split to give every CU ~4 workgroups
+    const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
+    const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
+    const uint64_t blocks_xy = (uint64_t)gx * gz;
+    uint32_t want = blocks_xy >= (uint64_t)cus * 4u ? 1u : ceil_div((uint32_t)cus * 4u, (uint32_t)blocks_xy);
+    uint32_t max_split = k == 0 ? 1u : ceil_div(k, min_k_per_split);
+    uint32_t nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
+    if (nsplit > 65535u) nsplit = 65535u;
+    uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
+    nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
+
+    GemvArgs a;
+    a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = m.batch;
+    a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = v.batch;
+    a.rows_out = rows_out; a.k = k; a.nrhs = nrhs; a.k_per_split = k_per_split;
+    float *partial = nullptr;
+    if (nsplit > 1) {
+        size_t bytes = (size_t)nmats * nsplit * nrhs * rows_out * sizeof(float);
+        void *ws = nullptr;
+        if (int rc = wg_ctx_workspace(ctx, bytes, &ws)) return rc;
+        partial = (float *)ws;
+        a.dst = partial;
+        a.ld_dst = rows_out;
+        a.dst_split = (uint64_t)nrhs * rows_out;
+        a.dst_batch = (uint64_t)nsplit * nrhs * rows_out;
+    } else {
+        a.dst = (float *)out;
+        a.ld_dst = out_ld;
+        a.dst_split = 0;
+        a.dst_batch = out_batch;
+    }
+
+    const dim3 grid(gx, nsplit, gz), block(kThreads);
+    const int tile = nrhs >= 4 ? 4 : (nrhs >= 2 ? 2 : 1);
+    // kMaxRhs RHS columns per group; the kernel template is the per-pass register tile (a group of 3 uses tile 4)
+    if (trans) {
+        if (tile == 1) hipLaunchKernelGGL(gemv_t_kernel<1>, grid, block, 0, ctx->stream, a);
+        else if (tile == 2 && nrhs == 2) hipLaunchKernelGGL(gemv_t_kernel<2>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(gemv_t_kernel<4>, grid, block, 0, ctx->stream, a);
+    } else {
+        if (tile == 1) hipLaunchKernelGGL(gemv_n_kernel<1>, grid, block, 0, ctx->stream, a);
+        else if (tile == 2 && nrhs == 2) hipLaunchKernelGGL(gemv_n_kernel<2>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(gemv_n_kernel<4>, grid, block, 0, ctx->stream, a);
+    }
+    WG_HIP_TRY(hipGetLastError());
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, kThreads), nrhs, nmats), block, 0, ctx->stream, partial,
+                           nsplit, rows_out, nrhs, (float *)out, out_ld, out_batch);
+        WG_HIP_TRY(hipGetLastError());
+    }
+    return WG_OK;
+}

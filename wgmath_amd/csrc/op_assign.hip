@@ -1,0 +1,181 @@
+// OpAssign: a[i] = a[i] (op) b[i]   (wgebra op_assign.wgsl:40-47, op table op_assign.rs:28-38).
+//
+// HBM-bound streaming kernel: 12 bytes per f32 element (8 for Copy, which never reads `a`).
+// Layout: both views are contiguous runs of n elements starting at (buffer + offset).
+// The reference launches ceil(n/64) workgroups of 64 threads doing one 4-byte access each; here each lane moves
+// 16 bytes per access (float4 / 8 x half), UNROLL accesses in flight per lane, over a grid capped at a few
+// workgroups per CU (grid-stride), with a scalar head/tail so that any offset/length is accepted.
+// IEEE-correct + - * / (no fast-math, correctly rounded division): results are bit-identical to the CPU.
+#include "wg_internal.hpp"
+
+namespace {
+
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_DIV = 3, OP_COPY = 4 };
+
+template <int OP>
+__device__ __forceinline__ float apply(float a, float b) {
+    if constexpr (OP == OP_ADD) return __fadd_rn(a, b);
+    else if constexpr (OP == OP_SUB) return __fsub_rn(a, b);
+    else if constexpr (OP == OP_MUL) return __fmul_rn(a, b);
+    else if constexpr (OP == OP_DIV) return __fdiv_rn(a, b);
+    else return b;
+}
+
+template <int OP>
+__device__ __forceinline__ float4 apply4(float4 a, float4 b) {
+    return make_float4(apply<OP>(a.x, b.x), apply<OP>(a.y, b.y), apply<OP>(a.z, b.z), apply<OP>(a.w, b.w));
+}
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 4;
+
+// `a`/`b` point at the first element; [head, head + 4*n4) is the 16-byte aligned body, the <= 3 elements before
+// and after it are done by the first lanes of block 0.
+template <int OP>
+__global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const float *b0, uint32_t head, uint32_t n4, uint32_t n) {
+    if (blockIdx.x == 0) {
+        const uint32_t body_end = head + 4u * n4;
+        const uint32_t edge = head + (n - body_end);
+        if (threadIdx.x < edge) {
+            const uint32_t i = threadIdx.x < head ? threadIdx.x : body_end + (threadIdx.x - head);
+            float vb = b0[i], va = vb;
+            if constexpr (OP != OP_COPY) va = a0[i];
+            a0[i] = apply<OP>(va, vb);
+        }
+    }
+    float4 *a = reinterpret_cast<float4 *>(a0 + head);
+    const float4 *b = reinterpret_cast<const float4 *>(b0 + head);
+    const uint32_t stride = gridDim.x * kThreads;
+    uint32_t i = blockIdx.x * kThreads + threadIdx.x;
+    // main: kUnroll independent 16-byte accesses per lane per trip
+    for (; (uint64_t)i + (uint64_t)(kUnroll - 1) * stride < n4; i += kUnroll * stride) {
+        float4 va[kUnroll], vb[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            vb[u] = b[i + u * stride];
+            if constexpr (OP != OP_COPY) va[u] = a[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) a[i + u * stride] = apply4<OP>(va[u], vb[u]);
+    }
+    for (; i < n4; i += stride) {
+        float4 vb = b[i], va = vb;
+        if constexpr (OP != OP_COPY) va = a[i];
+        a[i] = apply4<OP>(va, vb);
+    }
+}
+
+// any alignment; also the head/tail of the vector path
+template <int OP>
+__global__ __launch_bounds__(kThreads) void op_assign_f32_scalar(float *a, const float *b, uint32_t n) {
+    const uint32_t stride = gridDim.x * kThreads;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        float vb = b[i], va = vb;
+        if constexpr (OP != OP_COPY) va = a[i];
+        a[i] = apply<OP>(va, vb);
+    }
+}
+
+// f16 (extension): computed in f32 and rounded once; for + - * / that equals the correctly rounded f16 result
+// (24 >= 2*11 + 2 significand bits, so the double rounding is innocuous).
+template <int OP>
+__device__ __forceinline__ __half apply_h(__half a, __half b) {
+    if constexpr (OP == OP_COPY) return b;
+    else return __float2half_rn(apply<OP>(__half2float(a), __half2float(b)));
+}
+
+struct alignas(16) half8 { __half h[8]; };
+
+template <int OP>
+__global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const __half *b0, uint32_t head, uint32_t n8, uint32_t n) {
+    if (blockIdx.x == 0) {
+        const uint32_t body_end = head + 8u * n8;
+        const uint32_t edge = head + (n - body_end);
+        if (threadIdx.x < edge) {
+            const uint32_t i = threadIdx.x < head ? threadIdx.x : body_end + (threadIdx.x - head);
+            __half vb = b0[i], va = vb;
+            if constexpr (OP != OP_COPY) va = a0[i];
+            a0[i] = apply_h<OP>(va, vb);
+        }
+    }
+    half8 *a = reinterpret_cast<half8 *>(a0 + head);
+    const half8 *b = reinterpret_cast<const half8 *>(b0 + head);
+    const uint32_t stride = gridDim.x * kThreads;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n8; i += stride) {
+        half8 vb = b[i], va = vb;
+        if constexpr (OP != OP_COPY) va = a[i];
+        half8 r;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r.h[k] = apply_h<OP>(va.h[k], vb.h[k]);
+        a[i] = r;
+    }
+}
+template <int OP>
+__global__ __launch_bounds__(kThreads) void op_assign_f16_scalar(__half *a, const __half *b, uint32_t n) {
+    const uint32_t stride = gridDim.x * kThreads;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
+        __half vb = b[i], va = vb;
+        if constexpr (OP != OP_COPY) va = a[i];
+        a[i] = apply_h<OP>(va, vb);
+    }
+}
+
+inline uint32_t grid_for(uint64_t work_items, int cus) {
+    uint64_t blocks = (work_items + kThreads - 1) / kThreads;
+    uint64_t cap = (uint64_t)(cus > 0 ? cus : 256) * 8; // ~8 workgroups of 4 waves per CU, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (uint32_t)blocks;
+}
+
+template <int OP>
+int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n) {
+    const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
+    if ((pa & 15) == (pb & 15)) {
+        // scalar head up to the 16-byte boundary, vector body, scalar tail
+        uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 4);
+        if (head > n) head = n;
+        uint32_t n4 = (n - head) / 4;
+        hipLaunchKernelGGL(op_assign_f32_vec<OP>, dim3(grid_for(n4, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
+                           head, n4, n);
+    } else {
+        hipLaunchKernelGGL(op_assign_f32_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n);
+    }
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+template <int OP>
+int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n) {
+    const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
+    if ((pa & 15) == (pb & 15) && (pa & 1) == 0) {
+        uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 2);
+        if (head > n) head = n;
+        uint32_t n8 = (n - head) / 8;
+        hipLaunchKernelGGL(op_assign_f16_vec<OP>, dim3(grid_for(n8, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
+                           head, n8, n);
+    } else {
+        hipLaunchKernelGGL(op_assign_f16_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n);
+    }
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+} // namespace
+
+int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, uint32_t n) {
+    if (n == 0) return WG_OK;
+#define WG_CASE(OPV)                                                                              \
+    case OPV:                                                                                     \
+        return dtype == WG_F32 ? launch_f32<OPV>(ctx, (float *)a, (const float *)b, n)            \
+                               : launch_f16<OPV>(ctx, (__half *)a, (const __half *)b, n);
+    switch (op) {
+        WG_CASE(OP_ADD)
+        WG_CASE(OP_SUB)
+        WG_CASE(OP_MUL)
+        WG_CASE(OP_DIV)
+        WG_CASE(OP_COPY)
+    }
+#undef WG_CASE
+    return wg_set_error(WG_ERR_INVALID_ARG, "OpAssign: unknown variant %d", op);
+}

@@ -1,0 +1,176 @@
+// Reduce: result = reduce(op, x[0..n))   (wgebra reduce.wgsl:68-96, op tables reduce.rs:30-58).
+//
+// The reference's order is fully specified: 128 lanes, lane t folds x[t], x[t+128], ... ascending into
+// ws[t] (starting from `init`), then a tree ws[t] = f(ws[t], ws[t+s]) for s = 64,32,...,1.  This kernel keeps
+// exactly that expression tree per vector -- so Min/Max/Sum/Prod are bit-identical to the reference order
+// (SqNorm too, with the product rounded separately: no FMA contraction) -- but maps it onto CDNA4 differently:
+//
+//   * the 128 virtual lanes of one vector live in 32 physical lanes x float4 (virtual lane t = 4*p + c): every
+//     load is a 16-byte-per-lane, 512-byte-contiguous row of the vector, kUnroll rows in flight per lane;
+//   * a wave64 therefore carries TWO vectors, a 256-thread workgroup EIGHT, and one launch covers every column
+//     of a matrix view (the reference needs one single-workgroup dispatch per vector: reduce.rs:110-112);
+//   * the tree's cross-lane steps (strides 64..4) are wave shuffles inside each 32-lane half, strides 2 and 1
+//     are in-register; no LDS, no barrier.
+// HBM-bound: 4 bytes per element read, 4 bytes per vector written.
+// Vectors whose base is not 16-byte aligned take the scalar twin (128 lanes x 4-byte loads, same tree).
+#include "wg_internal.hpp"
+
+namespace {
+
+enum { R_MIN = 0, R_MAX = 1, R_SUM = 2, R_PROD = 3, R_SQNORM = 4 };
+
+template <int OP>
+__device__ __forceinline__ float r_init() {
+    if constexpr (OP == R_MIN) return 3.4e38f;        // init_max_f32 (reduce.wgsl:40-42) -- not FLT_MAX
+    else if constexpr (OP == R_MAX) return -3.4e38f;  // init_min_f32 (reduce.wgsl:44-46)
+    else if constexpr (OP == R_PROD) return 1.0f;
+    else return 0.0f;
+}
+template <int OP>
+__device__ __forceinline__ float r_ws(float acc, float x) { // workspace_fn
+    if constexpr (OP == R_MIN) return fminf(acc, x);
+    else if constexpr (OP == R_MAX) return fmaxf(acc, x);
+    else if constexpr (OP == R_SUM) return __fadd_rn(acc, x);
+    else if constexpr (OP == R_PROD) return __fmul_rn(acc, x);
+    else return __fadd_rn(acc, __fmul_rn(x, x));
+}
+template <int OP>
+__device__ __forceinline__ float r_red(float a, float b) { // reduce_fn
+    if constexpr (OP == R_MIN) return fminf(a, b);
+    else if constexpr (OP == R_MAX) return fmaxf(a, b);
+    else if constexpr (OP == R_PROD) return __fmul_rn(a, b);
+    else return __fadd_rn(a, b); // Sum and SqNorm (reduce.rs:55)
+}
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = 8;
+
+__device__ __forceinline__ const float *vector_base(const float *base, uint32_t q, uint32_t ncols, uint32_t stride,
+                                                    uint32_t stride_mat) {
+    const uint32_t c = q % ncols, t = q / ncols;
+    return base + (uint64_t)c * stride + (uint64_t)t * stride_mat;
+}
+
+// 32 physical lanes x float4 per vector; requires every vector base 16-byte aligned.
+template <int OP>
+__global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict__ base, uint32_t n, uint32_t ncols,
+                                                         uint32_t nvec, uint32_t stride, uint32_t stride_mat,
+                                                         float *__restrict__ results) {
+    const uint32_t q = blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
+    const uint32_t p = threadIdx.x & 31;
+    if (q >= nvec) return; // whole 32-lane half leaves together; shuffles below never cross halves
+    const float *x = vector_base(base, q, ncols, stride, stride_mat);
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+
+    float acc[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
+    const uint32_t full_rows = n / 128u;
+    uint32_t r = 0;
+    for (; r + kUnroll <= full_rows; r += kUnroll) {
+        float4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = wg_ld_nt(&x4[(uint64_t)(r + u) * 32u + p]);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) { // rows in ascending order: the per-lane chain of reduce.wgsl:71-74
+            acc[0] = r_ws<OP>(acc[0], v[u].x);
+            acc[1] = r_ws<OP>(acc[1], v[u].y);
+            acc[2] = r_ws<OP>(acc[2], v[u].z);
+            acc[3] = r_ws<OP>(acc[3], v[u].w);
+        }
+    }
+    for (; r < full_rows; ++r) {
+        float4 v = x4[(uint64_t)r * 32u + p];
+        acc[0] = r_ws<OP>(acc[0], v.x);
+        acc[1] = r_ws<OP>(acc[1], v.y);
+        acc[2] = r_ws<OP>(acc[2], v.z);
+        acc[3] = r_ws<OP>(acc[3], v.w);
+    }
+    { // ragged last row: i = 128*full_rows + 4p + c < n
+        const uint32_t i0 = full_rows * 128u + 4u * p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (i0 + c < n) acc[c] = r_ws<OP>(acc[c], x[i0 + c]);
+    }
+    // tree, virtual strides 64,32,16,8,4 == physical 16,8,4,2,1 (lanes >= stride compute garbage nobody reads)
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = r_red<OP>(acc[c], __shfl_down(acc[c], s, 32));
+    }
+    // virtual strides 2 and 1 live inside lane 0
+    acc[0] = r_red<OP>(acc[0], acc[2]);
+    acc[1] = r_red<OP>(acc[1], acc[3]);
+    acc[0] = r_red<OP>(acc[0], acc[1]);
+    if (p == 0) results[q] = acc[0];
+}
+
+// 128 physical lanes per vector, any alignment; 2 vectors per workgroup.
+template <int OP>
+__global__ __launch_bounds__(kThreads) void reduce_rows1(const float *__restrict__ base, uint32_t n, uint32_t ncols,
+                                                         uint32_t nvec, uint32_t stride, uint32_t stride_mat,
+                                                         float *__restrict__ results) {
+    __shared__ float upper[2][64];
+    const uint32_t half = threadIdx.x >> 7; // which vector of the workgroup
+    const uint32_t t = threadIdx.x & 127;
+    const uint32_t q = blockIdx.x * 2 + half;
+    float acc = r_init<OP>();
+    if (q < nvec) {
+        const float *x = vector_base(base, q, ncols, stride, stride_mat);
+        uint32_t i = t;
+        for (; (uint64_t)i + 128u * (kUnroll - 1) < n; i += 128u * kUnroll) {
+            float v[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = x[i + 128u * u];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) acc = r_ws<OP>(acc, v[u]);
+        }
+        for (; i < n; i += 128u) {
+            acc = r_ws<OP>(acc, x[i]);
+            if (i + 128u < i) break;
+        }
+    }
+    // stride 64 crosses the two waves of a vector: through LDS
+    if (t >= 64) upper[half][t - 64] = acc;
+    __syncthreads();
+    if (t < 64) {
+        acc = r_red<OP>(acc, upper[half][t]);
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) acc = r_red<OP>(acc, __shfl_down(acc, s, 64));
+        if (t == 0 && q < nvec) results[q] = acc;
+    }
+}
+
+template <int OP>
+int launch(wg_ctx *ctx, const float *base, uint32_t n, uint32_t ncols, uint32_t nmats, uint32_t stride,
+           uint32_t stride_mat, float *results) {
+    const uint64_t nvec64 = (uint64_t)ncols * nmats;
+    if (nvec64 == 0) return WG_OK;
+    if (nvec64 > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: more than 2^31 vectors in one call");
+    const uint32_t nvec = (uint32_t)nvec64;
+    const bool aligned = ((uintptr_t)base % 16 == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
+    if (aligned) {
+        const uint32_t per_block = kThreads / 32;
+        hipLaunchKernelGGL(reduce_rows4<OP>, dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n,
+                           ncols, nvec, stride, stride_mat, results);
+    } else {
+        hipLaunchKernelGGL(reduce_rows1<OP>, dim3((nvec + 1) / 2), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride,
+                           stride_mat, results);
+    }
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+} // namespace
+
+int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
+               uint32_t stride, uint32_t stride_mat, float *results) {
+    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: only f32 is implemented (the reference kernel is f32: reduce.wgsl:5-8)");
+    const float *b = (const float *)base;
+    switch (op) {
+    case R_MIN: return launch<R_MIN>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
+    case R_MAX: return launch<R_MAX>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
+    case R_SUM: return launch<R_SUM>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
+    case R_PROD: return launch<R_PROD>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
+    case R_SQNORM: return launch<R_SQNORM>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
+    }
+    return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", op);
+}

@@ -1,0 +1,367 @@
+// Runtime half of the boundary: contexts (device + in-order stream), buffers, record/replay, timestamps.
+// Replaces wgcore's wgpu plumbing: gpu.rs:24-58 (GpuInstance), tensor.rs:115-186,227-264,300-384 (buffer
+// create/copy/read), kernel.rs:15-27 (compute pass), timestamps.rs (GpuTimestamps).
+#include "wg_internal.hpp"
+
+#include <cstring>
+#include <new>
+#include <string>
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+int wg_set_error(int status, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+void wg_clear_error() { g_last_error.clear(); }
+
+int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->workspace_bytes) {
+        if (ctx->recording)
+            return wg_set_error(WG_ERR_INVALID_ARG, "workspace of %zu bytes needed while recording: call wg_ctx_reserve_workspace first", bytes);
+        WG_HIP_TRY(hipSetDevice(ctx->device));
+        // in-order stream: earlier users of the old workspace must be done before it is freed
+        WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->workspace) WG_HIP_TRY(hipFree(ctx->workspace));
+        ctx->workspace = nullptr;
+        ctx->workspace_bytes = 0;
+        size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        WG_HIP_TRY(hipMalloc(&ctx->workspace, want));
+        ctx->workspace_bytes = want;
+    }
+    *out = ctx->workspace;
+    return WG_OK;
+}
+extern "C" {
+
+int wg_abi_version(void) { return WGEBRA_HIP_ABI_VERSION; }
+const char *wg_last_error_string(void) { return g_last_error.c_str(); }
+
+int wg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx **out) {
+    if (!out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = wg_device_count();
+    if (n <= 0) return wg_set_error(WG_ERR_NO_DEVICE, "Failed to initialize gpu adapter.: no HIP device visible");
+    if (device < 0 || device >= n) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create: device %d not in [0,%d)", device, n);
+    WG_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    WG_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return wg_set_error(WG_ERR_NO_DEVICE, "device %d is %s; this library ships gfx950 (MI355X) code objects only",
+                            device, prop.gcnArchName);
+    wg_ctx *ctx = new (std::nothrow) wg_ctx();
+    if (!ctx) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    ctx->device = device;
+    ctx->compute_units = prop.multiProcessorCount;
+    if (owns) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete ctx;
+            return wg_set_error(WG_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+    } else {
+        ctx->stream = stream;
+    }
+    ctx->owns_stream = owns;
+    *out = ctx;
+    return WG_OK;
+}
+
+int wg_ctx_create(int device, wg_ctx **out) { return ctx_create_common(device, nullptr, true, out); }
+int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out) {
+    return ctx_create_common(device, (hipStream_t)hip_stream, false, out);
+}
+
+int wg_ctx_destroy(wg_ctx *ctx) {
+    if (!ctx) return WG_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->workspace) (void)hipFree(ctx->workspace);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return WG_OK;
+}
+
+int wg_ctx_sync(wg_ctx *ctx) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_sync: ctx is NULL");
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_sync: cannot synchronise while recording");
+    WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return WG_OK;
+}
+int wg_ctx_device(const wg_ctx *ctx) { return ctx ? ctx->device : -1; }
+void *wg_ctx_stream(const wg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int *clock_mhz, uint64_t *hbm_bytes) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_device_info: ctx is NULL");
+    hipDeviceProp_t prop;
+    WG_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name256) snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return WG_OK;
+}
+
+int wg_ctx_reserve_workspace(wg_ctx *ctx, size_t bytes) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_reserve_workspace: ctx is NULL");
+    void *p;
+    return wg_ctx_workspace(ctx, bytes, &p);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------------------
+int wg_buf_create(wg_ctx *ctx, size_t bytes, uint32_t usage, wg_buf **out) {
+    if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_create: NULL argument");
+    *out = nullptr;
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_create: cannot allocate while recording");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    wg_buf *b = new (std::nothrow) wg_buf();
+    if (!b) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    b->ctx = ctx;
+    b->bytes = bytes;
+    b->usage = usage;
+    b->host_pinned = (usage & (WG_USAGE_MAP_READ | WG_USAGE_MAP_WRITE)) != 0;
+    if (bytes > 0) {
+        hipError_t e = b->host_pinned ? hipHostMalloc(&b->ptr, bytes, hipHostMallocDefault) : hipMalloc(&b->ptr, bytes);
+        if (e != hipSuccess) {
+            delete b;
+            return wg_set_error(WG_ERR_HIP, "allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    *out = b;
+    return WG_OK;
+}
+
+int wg_buf_create_init(wg_ctx *ctx, const void *data, size_t bytes, uint32_t usage, wg_buf **out) {
+    if (bytes > 0 && !data) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_create_init: data is NULL");
+    int rc = wg_buf_create(ctx, bytes, usage, out);
+    if (rc != WG_OK) return rc;
+    if (bytes > 0) {
+        // create_buffer_init is synchronous in the reference (mapped at creation): keep that contract.
+        hipError_t e = hipMemcpy((*out)->ptr, data, bytes, (*out)->host_pinned ? hipMemcpyHostToHost : hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            wg_buf_destroy(*out);
+            *out = nullptr;
+            return wg_set_error(WG_ERR_HIP, "upload of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        }
+    }
+    return WG_OK;
+}
+
+int wg_buf_wrap(wg_ctx *ctx, void *device_ptr, size_t bytes, wg_buf **out) {
+    if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_wrap: NULL argument");
+    if (bytes > 0 && !device_ptr) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_wrap: device_ptr is NULL");
+    wg_buf *b = new (std::nothrow) wg_buf();
+    if (!b) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    b->ctx = ctx;
+    b->ptr = device_ptr;
+    b->bytes = bytes;
+    b->usage = WG_USAGE_STORAGE | WG_USAGE_COPY_SRC | WG_USAGE_COPY_DST;
+    b->owned = false;
+    *out = b;
+    return WG_OK;
+}
+
+int wg_buf_destroy(wg_buf *buf) {
+    if (!buf) return WG_OK;
+    int rc = WG_OK;
+    if (buf->owned && buf->ptr) {
+        (void)hipSetDevice(buf->ctx->device);
+        // Pending stream work may still reference the memory (wgpu keeps a dropped buffer alive until the
+        // submission that uses it retires): retire it first.
+        (void)hipStreamSynchronize(buf->ctx->stream);
+        hipError_t e = buf->host_pinned ? hipHostFree(buf->ptr) : hipFree(buf->ptr);
+        if (e != hipSuccess) rc = wg_set_error(WG_ERR_HIP, "free failed: %s", hipGetErrorString(e));
+    }
+    delete buf;
+    return rc;
+}
+
+size_t wg_buf_size(const wg_buf *buf) { return buf ? buf->bytes : 0; }
+void *wg_buf_device_ptr(const wg_buf *buf) { return buf ? buf->ptr : nullptr; }
+
+static int check_range(const char *what, const wg_buf *b, size_t offset, size_t bytes) {
+    if (offset > b->bytes || bytes > b->bytes - offset)
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "%s: range [%zu, %zu) exceeds the buffer's %zu bytes", what, offset,
+                            offset + bytes, b->bytes);
+    return WG_OK;
+}
+
+int wg_buf_write(wg_ctx *ctx, wg_buf *dst, size_t offset, const void *data, size_t bytes) {
+    if (!ctx || !dst || (bytes && !data)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_write: NULL argument");
+    if (int rc = check_range("wg_buf_write", dst, offset, bytes)) return rc;
+    if (bytes == 0) return WG_OK;
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_write: host uploads cannot be recorded");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipMemcpyAsync((char *)dst->ptr + offset, data, bytes, hipMemcpyDefault, ctx->stream));
+    // Queue::write_buffer copies out of `data` before returning; pageable memcpyAsync already stages, but a
+    // pinned source would be read later -- make the contract unconditional.
+    WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return WG_OK;
+}
+
+int wg_buf_read(wg_ctx *ctx, const wg_buf *src, size_t offset, void *dst, size_t bytes) {
+    if (!ctx || !src || (bytes && !dst)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_read: NULL argument");
+    if (int rc = check_range("wg_buf_read", src, offset, bytes)) return rc;
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_read: cannot read back while recording");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    if (bytes) WG_HIP_TRY(hipMemcpyAsync(dst, (const char *)src->ptr + offset, bytes, hipMemcpyDefault, ctx->stream));
+    WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return WG_OK;
+}
+
+int wg_buf_copy(wg_ctx *ctx, const wg_buf *src, size_t src_offset, wg_buf *dst, size_t dst_offset, size_t bytes) {
+    if (!ctx || !src || !dst) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_copy: NULL argument");
+    if (int rc = check_range("wg_buf_copy(src)", src, src_offset, bytes)) return rc;
+    if (int rc = check_range("wg_buf_copy(dst)", dst, dst_offset, bytes)) return rc;
+    if (bytes == 0) return WG_OK;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipMemcpyAsync((char *)dst->ptr + dst_offset, (const char *)src->ptr + src_offset, bytes, hipMemcpyDefault,
+                              ctx->stream));
+    return WG_OK;
+}
+
+int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf) {
+    if (!ctx || !buf) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_fill_zero: NULL argument");
+    if (buf->bytes == 0) return WG_OK;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipMemsetAsync(buf->ptr, 0, buf->bytes, ctx->stream));
+    return WG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// record / replay
+// ---------------------------------------------------------------------------------------------------
+int wg_encoder_begin(wg_ctx *ctx) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_begin: ctx is NULL");
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_begin: already recording");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->recording = true;
+    return WG_OK;
+}
+
+int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out) {
+    if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: NULL argument");
+    *out = nullptr;
+    if (!ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: not recording");
+    ctx->recording = false;
+    hipGraph_t graph = nullptr;
+    WG_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return wg_set_error(WG_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    wg_cmdbuf *cb = new (std::nothrow) wg_cmdbuf();
+    if (!cb) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    cb->ctx = ctx;
+    cb->graph = graph;
+    cb->exec = exec;
+    *out = cb;
+    return WG_OK;
+}
+
+int wg_queue_submit(wg_ctx *ctx, wg_cmdbuf *cmdbuf) {
+    if (!ctx || !cmdbuf) return wg_set_error(WG_ERR_INVALID_ARG, "wg_queue_submit: NULL argument");
+    if (cmdbuf->ctx != ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_queue_submit: command buffer belongs to another context");
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_queue_submit: cannot submit while recording");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipGraphLaunch(cmdbuf->exec, ctx->stream));
+    return WG_OK;
+}
+
+int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf) {
+    if (!cmdbuf) return WG_OK;
+    (void)hipSetDevice(cmdbuf->ctx->device);
+    (void)hipStreamSynchronize(cmdbuf->ctx->stream);
+    if (cmdbuf->exec) (void)hipGraphExecDestroy(cmdbuf->exec);
+    if (cmdbuf->graph) (void)hipGraphDestroy(cmdbuf->graph);
+    delete cmdbuf;
+    return WG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// timestamps
+// ---------------------------------------------------------------------------------------------------
+int wg_timestamps_create(wg_ctx *ctx, uint32_t capacity, wg_timestamps **out) {
+    if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_create: NULL argument");
+    *out = nullptr;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    wg_timestamps *ts = new (std::nothrow) wg_timestamps();
+    if (!ts) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    ts->ctx = ctx;
+    ts->events.resize(capacity, nullptr);
+    for (uint32_t i = 0; i < capacity; ++i) {
+        hipError_t e = hipEventCreate(&ts->events[i]);
+        if (e != hipSuccess) {
+            wg_timestamps_destroy(ts);
+            return wg_set_error(WG_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+    }
+    *out = ts;
+    return WG_OK;
+}
+
+int wg_timestamps_destroy(wg_timestamps *ts) {
+    if (!ts) return WG_OK;
+    (void)hipSetDevice(ts->ctx->device);
+    for (hipEvent_t e : ts->events)
+        if (e) (void)hipEventDestroy(e);
+    delete ts;
+    return WG_OK;
+}
+
+int wg_timestamps_clear(wg_timestamps *ts) {
+    if (!ts) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_clear: NULL argument");
+    ts->len = 0;
+    return WG_OK;
+}
+
+int wg_timestamps_write(wg_ctx *ctx, wg_timestamps *ts, uint32_t *index) {
+    if (!ctx || !ts) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write: NULL argument");
+    if (ts->len >= ts->events.size())
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "wg_timestamps_write: capacity %zu exhausted", ts->events.size());
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write: not recordable");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipEventRecord(ts->events[ts->len], ctx->stream));
+    if (index) *index = ts->len;
+    ts->len++;
+    return WG_OK;
+}
+
+uint32_t wg_timestamps_len(const wg_timestamps *ts) { return ts ? ts->len : 0; }
+
+int wg_timestamps_wait_for_results_ms(wg_timestamps *ts, double *out_ms, uint32_t capacity) {
+    if (!ts || (capacity && !out_ms)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_wait_for_results_ms: NULL argument");
+    if (ts->len == 0) return WG_OK;
+    WG_HIP_TRY(hipSetDevice(ts->ctx->device));
+    WG_HIP_TRY(hipEventSynchronize(ts->events[ts->len - 1]));
+    uint32_t n = ts->len < capacity ? ts->len : capacity;
+    for (uint32_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        if (i > 0) WG_HIP_TRY(hipEventElapsedTime(&ms, ts->events[0], ts->events[i]));
+        out_ms[i] = (double)ms;
+    }
+    return WG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,92 @@
+// Internal declarations shared by the runtime, the operator front-end and the kernel launchers.
+// Nothing here is part of the ABI (include/wgebra_hip.h is).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "../../include/wgebra_hip.h"
+
+struct wg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = true;
+    bool recording = false;
+    void *workspace = nullptr; // scratch for split reductions (GEMV partials)
+    size_t workspace_bytes = 0;
+    int compute_units = 0;
+};
+
+struct wg_buf {
+    wg_ctx *ctx = nullptr;
+    void *ptr = nullptr; // device pointer (or pinned-host pointer for MAP_* buffers; device-accessible)
+    size_t bytes = 0;
+    uint32_t usage = 0;
+    bool owned = true;
+    bool host_pinned = false;
+};
+
+struct wg_cmdbuf {
+    wg_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+struct wg_timestamps {
+    wg_ctx *ctx = nullptr;
+    std::vector<hipEvent_t> events;
+    uint32_t len = 0;
+};
+
+// ---- error plumbing -------------------------------------------------------------------------------
+int wg_set_error(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void wg_clear_error();
+
+#define WG_HIP_TRY(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            return wg_set_error(WG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),   \
+                                __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// Grow-only scratch. Fails while recording if it would have to allocate.
+int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out);
+
+// 16-byte streaming load with the non-temporal hint (data read exactly once: keep it out of the way in L2/MALL)
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 wg_ld_nt(const float4 *p) {
+    wg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wg_f4 *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+static inline size_t wg_dtype_size(wg_dtype d) { return d == WG_F16 ? 2 : 4; }
+
+// ---- kernel launchers (one per .hip file). All enqueue on ctx->stream and return a wg_status. -----
+// Pointers are already offset to the first element of the view; ld* / batch strides in elements.
+
+struct wgk_mat {
+    const void *ptr; // first element of the view (matrix 0)
+    uint32_t ld;     // column stride (elements)
+    uint64_t batch;  // matrix stride (elements)
+};
+
+int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, uint32_t n);
+
+int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
+               uint32_t stride, uint32_t stride_mat, float *results);
+
+// out[rows_out, nrhs, nmats]; trans == false: out = m * v, m is (rows_out x k); trans: out = m^T v, m is (k x rows_out)
+int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
+             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v);
+
+// out (M x N) = op(m1) (M x K) * m2 (K x N); trans: m1 stored K x M
+int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
+                 float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);
+int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
+                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);

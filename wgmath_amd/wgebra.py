@@ -1,0 +1,155 @@
+"""Host-side mirror of wgebra's dense operator surface over the C ABI (include/wgebra_hip.h).
+
+  Gemm / GemmVariant         crates/wgebra/src/linalg/gemm.rs:9-127
+  Gemv / GemvVariant         crates/wgebra/src/linalg/gemv.rs:9-137
+  Reduce / ReduceOp          crates/wgebra/src/linalg/reduce.rs:13-113
+  OpAssign / OpAssignVariant crates/wgebra/src/linalg/op_assign.rs:12-95
+
+Signatures keep the reference's parameter order -- dispatch(device, shapes, pass, out, a, b[, variant]) -- so that a test
+written against the reference reads the same here.  `device` and `shapes` are accepted for signature compatibility; the
+work is enqueued on the stream behind `pass`.  Where the reference panics (assert_eq!), these raise an exception that
+is also an AssertionError, carrying the reference's message.
+"""
+from __future__ import annotations
+
+import enum
+
+import numpy as np
+
+from ._lib import check, lib
+from .wgcore import ComputePass, GpuTensor, GpuTensorView, ViewShapeBuffers, as_view, wg_dtype
+
+
+class GemmVariant(enum.IntEnum):  # gemm.rs:26-35
+    Gemm = 0
+    GemmFast = 1
+    GemmTr = 2
+    GemmTrFast = 3
+
+
+class GemvVariant(enum.IntEnum):  # gemv.rs:25-34
+    Gemv = 0
+    GemvFast = 1
+    GemvTr = 2
+    GemvTrFast = 3
+
+
+class ReduceOp(enum.IntEnum):  # reduce.rs:13-27
+    Min = 0
+    Max = 1
+    Sum = 2
+    Prod = 3
+    SqNorm = 4
+
+
+class OpAssignVariant(enum.IntEnum):  # op_assign.rs:12-26
+    Add = 0
+    Sub = 1
+    Mul = 2
+    Div = 3
+    Copy = 4
+
+
+def _common_dtype(*views: GpuTensorView):
+    dt = views[0].dtype
+    for v in views[1:]:
+        if v.dtype != dt:
+            raise TypeError(f"operands must share one element type, got {[str(x.dtype) for x in views]}")
+    return wg_dtype(dt)
+
+
+class Gemm:
+    """gemm.rs:9-21.  The four pipelines of the reference are one ahead-of-time compiled MFMA kernel family here, so
+    construction is free (no shader compilation)."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    @staticmethod
+    def from_device(device) -> "Gemm":
+        return Gemm(device)
+
+    def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m1, m2) -> None:
+        self.dispatch_generic(device, shapes, pass_, out, m1, m2, GemmVariant.Gemm)
+
+    def dispatch_tr(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m1, m2) -> None:
+        self.dispatch_generic(device, shapes, pass_, out, m1, m2, GemmVariant.GemmTr)
+
+    def dispatch_generic(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m1, m2, variant: GemmVariant) -> None:
+        out, m1, m2 = as_view(out, 3), as_view(m1, 3), as_view(m2, 3)
+        dt = _common_dtype(out, m1, m2)
+        check(lib.wg_gemm(pass_._ctx.handle, int(variant), dt,
+                          out.buffer()._h, out.shape().to_c(), m1.buffer()._h, m1.shape().to_c(),
+                          m2.buffer()._h, m2.shape().to_c()))
+
+
+class Gemv:
+    """gemv.rs:9-21."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    @staticmethod
+    def from_device(device) -> "Gemv":
+        return Gemv(device)
+
+    def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m, v) -> None:
+        self.dispatch_generic(device, shapes, pass_, out, m, v, GemvVariant.Gemv)
+
+    def dispatch_tr(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m, v) -> None:
+        self.dispatch_generic(device, shapes, pass_, out, m, v, GemvVariant.GemvTr)
+
+    def dispatch_generic(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m, v, variant: GemvVariant) -> None:
+        out, m, v = as_view(out, 3), as_view(m, 3), as_view(v, 3)
+        dt = _common_dtype(out, m, v)
+        check(lib.wg_gemv(pass_._ctx.handle, int(variant), dt,
+                          out.buffer()._h, out.shape().to_c(), m.buffer()._h, m.shape().to_c(),
+                          v.buffer()._h, v.shape().to_c()))
+
+
+class Reduce:
+    """reduce.rs:62-113: `Reduce::new(device, op)` then `dispatch(device, shapes, pass, value, result)`."""
+
+    def __init__(self, device, op: ReduceOp):
+        self.device = device
+        self.op = ReduceOp(op)
+
+    @staticmethod
+    def new(device, op: ReduceOp) -> "Reduce":
+        return Reduce(device, op)
+
+    def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, value, result: GpuTensor) -> None:
+        value = as_view(value, 1)
+        check(lib.wg_reduce(pass_._ctx.handle, int(self.op), wg_dtype(value.dtype), value.buffer()._h, value.shape().to_c(),
+                            result._h))
+
+    def dispatch_batched(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, values, results: GpuTensor) -> None:
+        """Extension (one launch for every column of a matrix/cube view): results[c + t*ncols], each equal to what
+        `dispatch` gives for that column."""
+        values = as_view(values, 3)
+        check(lib.wg_reduce_batched(pass_._ctx.handle, int(self.op), wg_dtype(values.dtype), values.buffer()._h,
+                                    values.shape().to_c(), results._h))
+
+    def eval_cpu(self, val: np.ndarray) -> np.float32:
+        """reduce.rs:116-124 (`#[doc(hidden)]` test helper): what nalgebra computes, in NumPy."""
+        val = np.asarray(val, np.float32)
+        return {ReduceOp.Min: val.min, ReduceOp.Max: val.max, ReduceOp.Prod: val.prod, ReduceOp.Sum: val.sum,
+                ReduceOp.SqNorm: lambda: (val * val).sum()}[self.op]()
+
+
+class OpAssign:
+    """op_assign.rs:43-95: `OpAssign::new(device, op)` then `dispatch(device, shapes, pass, in_out_a, in_b)`."""
+
+    def __init__(self, device, op: OpAssignVariant):
+        self.device = device
+        self.op = OpAssignVariant(op)
+
+    @staticmethod
+    def new(device, op: OpAssignVariant) -> "OpAssign":
+        return OpAssign(device, op)
+
+    def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, in_out_a, in_b) -> None:
+        a, b = as_view(in_out_a, 1), as_view(in_b, 1)
+        dt = _common_dtype(a, b)
+        check(lib.wg_op_assign(pass_._ctx.handle, int(self.op), dt, a.buffer()._h, a.shape().to_c(), b.buffer()._h,
+                               b.shape().to_c()))
