@@ -1,0 +1,446 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the wgebra dense hot path on MI355X, against its roofline, with the CPU port beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+one Gemm / Gemv / batched Reduce dispatch (for N > 1: the M-sharded Gemm of every rank + the RCCL all-gather of C).
+Rank 0 prints ONE JSON line (schema: see DESIGN.md "Measurement").
+
+Workloads (BASELINE.json `configs`):
+  gemm_f32_4096         f32 GEMM 4096^3           (configs[1])   MFMA-bound   TFLOP/s
+  gemm_f16_8192         f16 GEMM 8192^3           (configs[2])   MFMA-bound   TFLOP/s
+  gemv_f32_4096x65536   f32 GEMV 4096 x 65536     (configs[3])   HBM-bound    GB/s
+  gemvtr_f32_65536x4096 the transposed twin       (configs[3])   HBM-bound    GB/s
+  reduce_f32_4096x65536 4096 Sum-reductions of 65536 (configs[3]) HBM-bound   GB/s
+  gemm_f16_32768        f16 GEMM 32768^3, M-sharded over the ranks + all-gather (configs[4])
+With --gpus N > 1 every GEMM workload is M-sharded over the N ranks ("strong": the total problem is fixed).
+
+Only the cpu_baseline leg touches oracle/ (as the thing timed on the host cores, never as the product path).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# chip peaks: /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters" (dense, no sparsity)
+PEAK_HBM_GBS = 8000.0
+PEAK_MFMA_TFLOPS = {"f32": 157.3, "f16": 2500.0}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# synthetic data: seeded, U[-1,1) (full-range random operands: zero/constant fills flatter the clocks)
+# ------------------------------------------------------------------------------------------------------------
+def rand_block(seed: int, n: int, dtype) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return (rng.random(n, dtype=np.float32) * np.float32(2) - np.float32(1)).astype(dtype)
+
+
+def device_random(wg, gpu, shape, dtype, seed):
+    """A tensor of `shape` filled by tiling a 16 Mi-element seeded random block with device-side copies
+    (keeps host RNG time and PCIe traffic bounded for the multi-GiB configs; every element is still random data)."""
+    n = int(np.prod(shape))
+    block_n = min(n, 1 << 24)
+    S = wg.BufferUsages
+    t = wg.TensorBuilder.tensor(shape, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(gpu.device(), dtype)
+    blk = wg.TensorBuilder.vector(block_n, S.STORAGE | S.COPY_SRC).build_init(gpu.device(), rand_block(seed, block_n, dtype))
+    item = np.dtype(dtype).itemsize
+    from wgmath_amd._lib import check, lib
+    off = 0
+    while off < n:
+        m = min(block_n, n - off)
+        check(lib.wg_buf_copy(gpu._ctx.handle, blk._h, 0, t._h, off * item, m * item))
+        off += m
+    gpu.sync()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------
+class Workload:
+    name = ""
+    dtype = "f32"
+    metric = ""
+    unit = ""
+    bound = "hbm"
+    kernel = ""  # dominant kernel, for the rocprof cross-check
+
+    def setup(self, wg, gpu, rank, world): ...
+    def step(self): ...
+    def units_per_step(self) -> float: ...        # whole job (all ranks), in `unit`-numerator units (flops or bytes)
+    def algorithmic_per_launch(self) -> float: ...  # this rank's dominant kernel, per launch
+    def cpu_baseline(self, budget_s: float) -> dict: ...
+    def check(self) -> None: ...                  # cheap sanity check of the result (not timed)
+
+
+class GemmWorkload(Workload):
+    bound = "mfma"
+    metric = "gemm_tflops"
+    unit = "TFLOP/s"
+
+    def __init__(self, name, M, N, K, dtype):
+        self.name, self.M, self.N, self.K = name, M, N, K
+        self.dtype = dtype
+        self.np_dtype = np.float32 if dtype == "f32" else np.float16
+        self.kernel = "gemm_f32_kernel" if dtype == "f32" else "gemm_f16_kernel"
+
+    def setup(self, wg, gpu, rank, world):
+        self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
+        assert self.M % (4 * world) == 0, "M must split into vec4-aligned row blocks"
+        self.Mg = self.M // world  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
+        self.A = device_random(wg, gpu, (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
+        self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
+        self.gemm = wg.Gemm.from_device(gpu.device())
+        self.shapes = wg.ViewShapeBuffers()
+        self.torch_out = None
+        if world == 1:
+            S = wg.BufferUsages
+            self.C = wg.TensorBuilder.matrix(self.Mg, self.N, S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
+            self.C_view = self.C.as_embedded_view(3)
+        else:
+            import torch
+            tdt = torch.float32 if self.dtype == "f32" else torch.float16
+            # gathered result: a GpuCube [Mg, N, world] (stride_mat = Mg*N): rank g's row block is matrix g
+            self.torch_out = torch.empty((world, self.N, self.Mg), dtype=tdt, device=f"cuda:{gpu._ctx.device_index}")
+            self.C = wg.GpuTensor.wrap(gpu.device(), self.torch_out.data_ptr(), (self.Mg, self.N, world), self.np_dtype,
+                                       keepalive=self.torch_out)
+            self.C_view = self.C.as_view().matrix(rank)
+        self.enc = gpu.device().create_command_encoder()
+        self.pass_ = self.enc.compute_pass("bench", None)
+
+    def step(self):
+        self.gemm.dispatch(self.gpu.device(), self.shapes, self.pass_, self.C_view, self.A, self.B)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.torch_out, self.torch_out[self.rank])
+
+    def units_per_step(self):
+        return 2.0 * self.M * self.N * self.K
+
+    def algorithmic_per_launch(self):
+        return 2.0 * self.Mg * self.N * self.K
+
+    def check(self):
+        # sampled rows of C_g against f64 on the host
+        wg, gpu = self.wg, self.gpu
+        rows = np.unique(np.random.default_rng(1).integers(0, self.Mg, 8))
+        A = self.A.read(gpu.device()).reshape(self.Mg, self.K, order="F")[rows].astype(np.float64)
+        B = self.B.read(gpu.device()).reshape(self.K, self.N, order="F").astype(np.float64)
+        full = self.C.read(gpu.device())
+        Cg = (full.reshape(self.Mg, self.N, -1, order="F")[:, :, self.rank if self.world > 1 else 0])[rows].astype(np.float64)
+        truth, sabs = A @ B, np.abs(A) @ np.abs(B)
+        tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) if self.dtype == "f16" else 0)
+        err = np.abs(Cg - truth)
+        assert (err <= tol).all(), f"bench sanity check failed: worst err/tol {(err / tol).max():.3g}"
+
+    def cpu_baseline(self, budget_s):
+        if self.dtype != "f32":
+            return None  # the reference (and hence its port) has no f16 kernel
+        from oracle import wgsl_oracle as wo
+        C = wo.CLib()
+        M, N, K = self.M, self.N, self.K
+        a, b = rand_block(1, M * K, np.float32), rand_block(2, K * N, np.float32)
+        out = np.zeros(M * N, np.float32)
+        s1, s2, so = wo.Shape(M, K), wo.Shape(K, N), wo.Shape(M, N)
+        active_wgs = -(-(M // 4) // 64)  # gemm.wgsl:86: only invocations x < M/4 do work
+        flops_per_wg = 2.0 * 256 * N * K  # 64 invocations x 4 rows
+        t0 = time.perf_counter()
+        C.gemm(wo.GEMM, out, so, a, s1, b, s2, 0, 1)
+        t1 = time.perf_counter() - t0
+        n = int(max(1, min(active_wgs - 1, budget_s / max(t1, 1e-3) * C.num_threads() / 4)))
+        t0 = time.perf_counter()
+        C.gemm(wo.GEMM, out, so, a, s1, b, s2, 1, 1 + n)
+        dt = time.perf_counter() - t0
+        return {"value": flops_per_wg * n / dt / 1e12, "unit": "TFLOP/s", "cores": C.num_threads(), "kind": "port",
+                "sample": f"oracle/wgsl_oracle.c `gemm` (naive WGSL order), workgroups [1,{1 + n}) of {active_wgs} active "
+                          f"({256 * n} of {M} output rows x all {N} columns, K={K}) in {dt:.1f} s"}
+
+
+class GemvWorkload(Workload):
+    bound = "hbm"
+    metric = "gemv_gbs"
+    unit = "GB/s"
+
+    def __init__(self, name, R, C, trans):
+        self.name, self.R, self.C, self.trans = name, R, C, trans
+        self.kernel = "gemv_t_kernel" if trans else "gemv_n_kernel"
+
+    def setup(self, wg, gpu, rank, world):
+        self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
+        R, C = self.R, self.C
+        self.m = device_random(wg, gpu, (R, C), np.float32, 0xC000 + rank)
+        vlen, olen = (R, C) if self.trans else (C, R)
+        self.v = device_random(wg, gpu, (vlen,), np.float32, 0xD000)
+        S = wg.BufferUsages
+        self.out = wg.TensorBuilder.vector(olen, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+        self.gemv = wg.Gemv.from_device(gpu.device())
+        self.shapes = wg.ViewShapeBuffers()
+        self.enc = gpu.device().create_command_encoder()
+        self.pass_ = self.enc.compute_pass("bench", None)
+        self.variant = wg.GemvVariant.GemvTr if self.trans else wg.GemvVariant.Gemv
+
+    def step(self):
+        self.gemv.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.out, self.m, self.v, self.variant)
+
+    def _bytes(self):
+        return 4.0 * (self.R * self.C + self.R + self.C)  # matrix + vector + result
+
+    def units_per_step(self):
+        return self._bytes() * self.world  # every rank streams its own matrix (independent units, no collective)
+
+    def algorithmic_per_launch(self):
+        return self._bytes()
+
+    def check(self):
+        gpu = self.gpu
+        m = self.m.read(gpu.device()).reshape(self.R, self.C, order="F")
+        v = self.v.read(gpu.device()).astype(np.float64)
+        got = self.out.read(gpu.device()).astype(np.float64)
+        idx = np.unique(np.random.default_rng(2).integers(0, got.size, 64))
+        a = (m[:, idx].T if self.trans else m[idx, :]).astype(np.float64)
+        truth, sabs = a @ v, np.abs(a) @ np.abs(v)
+        tol = 2 * np.sqrt(v.size) * 2.0 ** -24 * sabs
+        assert (np.abs(got[idx] - truth) <= tol).all(), "bench sanity check failed (gemv)"
+
+    def cpu_baseline(self, budget_s):
+        from oracle import wgsl_oracle as wo
+        C = wo.CLib()
+        R, Cc = self.R, self.C
+        scale = 8  # 1/8 of the columns (or rows): same access pattern, bounded memory (128 MiB) and time
+        if self.trans:
+            Rs, Cs = R, Cc // scale
+        else:
+            Rs, Cs = R, Cc // scale
+        m = rand_block(3, Rs * Cs, np.float32)
+        vlen, olen = (Rs, Cs) if self.trans else (Cs, Rs)
+        v, out = rand_block(4, vlen, np.float32), np.zeros(olen, np.float32)
+        variant = wo.GEMV_TR if self.trans else wo.GEMV
+        C.gemv(variant, out, wo.Shape(olen), m, wo.Shape(Rs, Cs), v, wo.Shape(vlen))  # warm
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(budget_s, 10.0) or reps < 3:
+            C.gemv(variant, out, wo.Shape(olen), m, wo.Shape(Rs, Cs), v, wo.Shape(vlen))
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": 4.0 * (Rs * Cs + Rs + Cs) / dt / 1e9, "unit": "GB/s", "cores": C.num_threads(), "kind": "port",
+                "sample": f"oracle/wgsl_oracle.c `{'gemv_tr' if self.trans else 'gemv'}` on a {Rs}x{Cs} slice (1/{scale} of the matrix), "
+                          f"mean of {reps} runs, {dt * 1e3:.1f} ms each"}
+
+
+class ReduceWorkload(Workload):
+    bound = "hbm"
+    metric = "reduce_gbs"
+    unit = "GB/s"
+    kernel = "reduce_rows4"
+
+    def __init__(self, name, nvec, n):
+        self.name, self.nvec, self.n = name, nvec, n
+
+    def setup(self, wg, gpu, rank, world):
+        self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
+        # 4096 vectors of 65536, each contiguous: a 65536 x 4096 column-major matrix
+        self.x = device_random(wg, gpu, (self.n, self.nvec), np.float32, 0xE000 + rank)
+        S = wg.BufferUsages
+        self.res = wg.TensorBuilder.vector(self.nvec, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+        self.red = wg.Reduce.new(gpu.device(), wg.ReduceOp.Sum)
+        self.shapes = wg.ViewShapeBuffers()
+        self.enc = gpu.device().create_command_encoder()
+        self.pass_ = self.enc.compute_pass("bench", None)
+
+    def step(self):
+        self.red.dispatch_batched(self.gpu.device(), self.shapes, self.pass_, self.x, self.res)
+
+    def _bytes(self):
+        return 4.0 * (self.n * self.nvec + self.nvec)
+
+    def units_per_step(self):
+        return self._bytes() * self.world
+
+    def algorithmic_per_launch(self):
+        return self._bytes()
+
+    def check(self):
+        from oracle import wgsl_oracle as wo
+        gpu = self.gpu
+        x = self.x.read(gpu.device())
+        got = self.res.read(gpu.device())
+        for c in (0, 1, self.nvec // 2, self.nvec - 1):
+            exp = wo.reduce(wo.SUM, x, wo.Shape(self.n, 1, 1, 1, 1, c * self.n))
+            assert np.float32(exp).tobytes() == got[c:c + 1].tobytes(), "bench sanity check failed (reduce is not bit-exact)"
+
+    def cpu_baseline(self, budget_s):
+        from oracle import wgsl_oracle as wo
+        C = wo.CLib()
+        nv = self.nvec // 8
+        x = rand_block(5, self.n * nv, np.float32)
+        C.reduce_batched(wo.SUM, x, wo.Shape(self.n, nv))
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(budget_s, 10.0) or reps < 3:
+            C.reduce_batched(wo.SUM, x, wo.Shape(self.n, nv))
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": 4.0 * (self.n * nv + nv) / dt / 1e9, "unit": "GB/s", "cores": C.num_threads(), "kind": "port",
+                "sample": f"oracle/wgsl_oracle.c reduce (128-lane order) on {nv} of the {self.nvec} vectors, one OpenMP task per vector, "
+                          f"mean of {reps} runs, {dt * 1e3:.1f} ms each"}
+
+
+WORKLOADS = {
+    "gemm_f32_4096": lambda: GemmWorkload("gemm_f32_4096", 4096, 4096, 4096, "f32"),
+    "gemm_f16_8192": lambda: GemmWorkload("gemm_f16_8192", 8192, 8192, 8192, "f16"),
+    "gemm_f16_32768": lambda: GemmWorkload("gemm_f16_32768", 32768, 32768, 32768, "f16"),
+    "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
+    "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
+    "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
+    "reduce_f32_4096x65536": lambda: ReduceWorkload("reduce_f32_4096x65536", 4096, 65536),
+}
+DEFAULT_WORKLOAD = "gemm_f32_4096"
+SECONDARY = ["gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536"]
+
+
+def load_traffic(workload: str):
+    """HBM bytes per launch measured with rocprofv3 --pmc (separate passes), recorded under profiles/ (DESIGN.md)."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(workload)
+    except Exception:
+        return None
+
+
+def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget):
+    w = WORKLOADS[name]()
+    w.setup(wg, gpu, rank, world)
+    for _ in range(warmup):
+        w.step()
+    ts = wg.GpuTimestamps.new(gpu.device(), 2)
+    barrier()
+    gpu.sync()
+    t0 = time.perf_counter()
+    ts.write(gpu.device())
+    for _ in range(steps):
+        w.step()
+    ts.write(gpu.device())
+    gpu.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ev = ts.wait_for_results_ms()
+    kernel_ms = (ev[1] - ev[0]) / steps  # HIP events on the stream the kernels run on
+    w.check()
+    res = {"workload": w, "elapsed": elapsed, "kernel_ms": kernel_ms}
+    res["cpu"] = w.cpu_baseline(cpu_budget) if (with_cpu and rank == 0 and world == 1) else None
+    return res
+
+
+def summarize(w, elapsed, kernel_ms, steps, world):
+    scale = 1e12 if w.unit == "TFLOP/s" else 1e9
+    value = w.units_per_step() * steps / elapsed / scale
+    achieved = w.algorithmic_per_launch() / (kernel_ms * 1e-3) / scale
+    peak = PEAK_MFMA_TFLOPS[w.dtype] if w.bound == "mfma" else PEAK_HBM_GBS
+    roof = {"bound": w.bound, "kernel": w.kernel, "achieved": round(achieved, 3), "peak": peak, "unit": w.unit,
+            "frac": round(achieved / peak, 4), "kernel_ms": round(kernel_ms, 5), "traffic": load_traffic(w.name)}
+    return value, roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                     f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...`")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import wgmath_amd as wg
+
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # share torch's current stream so that the GEMM and the all-gather are ordered without extra events
+        gpu = wg.GpuInstance.new(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        gpu = wg.GpuInstance.new(local_rank)
+
+        def barrier():
+            gpu.sync()
+
+    info = gpu.adapter()
+    main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
+                            not args.no_cpu_baseline, args.cpu_budget)
+    elapsed = main_res["elapsed"]
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    w = main_res["workload"]
+    value, roof = summarize(w, elapsed, main_res["kernel_ms"], args.steps, world)
+
+    main_cpu = main_res["cpu"]
+    main_res = None  # release the headline workload's buffers before the secondary configs allocate theirs
+    w_name, w_metric, w_unit, w_dtype, w_is_gemm = w.name, w.metric, w.unit, w.dtype, isinstance(w, GemmWorkload)
+    w = None
+    others = []
+    if world == 1 and not args.no_secondary:
+        for name in SECONDARY:
+            if name == args.workload:
+                continue
+            try:
+                r = run_workload(wg, gpu, name, max(10, min(args.steps, 50)), min(args.warmup, 5), rank, world, barrier,
+                                 not args.no_cpu_baseline, min(args.cpu_budget, 6.0))
+                v, rf = summarize(r["workload"], r["elapsed"], r["kernel_ms"], max(10, min(args.steps, 50)), world)
+                others.append({"workload": name, "metric": r["workload"].metric, "value": round(v, 3), "unit": r["workload"].unit,
+                               "dtype": r["workload"].dtype, "roofline": rf, "cpu_baseline": r["cpu"]})
+            except Exception as e:  # a secondary config must never take the headline down with it
+                others.append({"workload": name, "error": f"{type(e).__name__}: {e}"})
+
+    if rank == 0:
+        line = {
+            "metric": w_metric, "value": round(value, 3), "unit": w_unit, "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "strong" if w_is_gemm else "weak", "vs_baseline": None, "dtype": w_dtype,
+            "data": "synthetic (seeded U[-1,1), resident in HBM before the timed region)",
+            "config": {"workload": w_name, "device": info["name"], "compute_units": info["compute_units"],
+                       "parallelism": f"m-shard x{world} + RCCL all-gather" if (world > 1 and w_is_gemm) else f"replicas x{world}"},
+            "roofline": roof, "cpu_baseline": main_cpu, "others": others,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol the header declares, fails loudly without a
+device, and the host-side mirror reproduces the reference's view arithmetic (wgcore tensor.rs / shapes.rs)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import wgmath_amd as wg
+from wgmath_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _lib.declared_symbols()
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, f"include/wgebra_hip.h declares symbols the library does not export: {missing}"
+    assert set(declared) == set(_lib.lib._wg_signatures), "the ctypes binding and the header disagree on the entry points"
+    assert _lib.lib.wg_abi_version() == 1
+
+
+def test_exported_symbols_are_plain_c():
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert set(_lib.declared_symbols()) <= names
+    leaked = [n for n in names if n.startswith("wg_") and n not in set(_lib.declared_symbols())]
+    assert not leaked, f"undeclared wg_* exports: {leaked}"
+
+
+def test_view_shape_is_24_bytes_repr_c():
+    # shapes.rs:9-21: #[repr(C)] { size: [u32; 3], stride: u32, stride_mat: u32, offset: u32 }
+    assert ctypes.sizeof(_lib.ViewShapeC) == 24
+    assert _lib.ViewShapeC.stride.offset == 12 and _lib.ViewShapeC.stride_mat.offset == 16 and _lib.ViewShapeC.offset.offset == 20
+
+
+def test_header_compiles_as_c_and_cpp(tmp_path):
+    src = tmp_path / "t.c"
+    src.write_text('#include "wgebra_hip.h"\nint main(void){ wg_view_shape s = {{1,1,1},1,1,0}; return (int)sizeof(s) - 24; }\n')
+    for cc, std in (("gcc", "-std=c99"), ("g++", "-std=c++11")):
+        exe = tmp_path / f"t_{cc}"
+        subprocess.run([cc, std, "-Wall", "-Werror", "-pedantic", "-x", "c" if cc == "gcc" else "c++", "-I", os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe)], check=True)
+        assert subprocess.run([str(exe)]).returncode == 0
+
+
+@pytest.mark.skipif(wg.GpuInstance.device_count() > 0, reason="a GPU is visible")
+def test_no_device_fails_loudly():
+    with pytest.raises(wg.NoDevice, match="Failed to initialize gpu adapter"):
+        wg.GpuInstance.new()
+    assert _lib.lib.wg_gemm(None, 0, 0, None, _lib.ViewShapeC(), None, _lib.ViewShapeC(), None, _lib.ViewShapeC()) == _lib.WG_ERR_INVALID_ARG
+    assert b"NULL" in _lib.lib.wg_last_error_string()
+
+
+def test_missing_library_is_an_import_error(tmp_path):
+    code = ("import importlib.util, sys; sys.path.insert(0, %r);"
+            "import wgmath_amd._lib as L" % ROOT)
+    env = dict(os.environ)
+    # point the loader at a directory without the .so by copying only _lib.py
+    pkg = tmp_path / "wgmath_amd"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "_lib.py").write_text(open(os.path.join(ROOT, "wgmath_amd", "_lib.py")).read())
+    r = subprocess.run(["python", "-c", "import sys; sys.path.insert(0, %r); import wgmath_amd._lib" % str(tmp_path)],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "There is no CPU fallback" in r.stderr
+
+
+def test_product_path_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "wgmath_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "wgsl_oracle" not in text and "from oracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+    for f in os.listdir(os.path.join(ROOT, "include")):
+        assert "oracle" not in open(os.path.join(ROOT, "include", f)).read().lower().replace("the oracle", "")
+
+
+# ---- host-side view arithmetic (no device memory needed: detached tensors) ---------------------------------------
+class _NoCtx:
+    handle = None
+
+
+def detached(shape, dtype=np.float32):
+    return wg.GpuTensor(_NoCtx(), 0, shape, np.dtype(dtype))
+
+
+def vs(view):
+    s = view.shape()
+    return (*s.size, s.stride, s.stride_mat, s.offset)
+
+
+def test_default_views_match_tensor_rs():
+    # tensor.rs:287-297,514-541 -- SURVEY Appendix A table
+    assert vs(detached((10,)).as_embedded_view(3)) == (10, 1, 1, 10, 10, 0)
+    assert vs(detached((6, 7)).as_embedded_view(3)) == (6, 7, 1, 6, 42, 0)
+    assert vs(detached((6, 7, 3)).as_view()) == (6, 7, 3, 6, 42, 0)
+    assert vs(wg.as_view(detached((6, 7)), 3)) == (6, 7, 1, 6, 42, 0)
+    with pytest.raises(AssertionError):
+        detached((6, 7)).as_embedded_view(1)
+    with pytest.raises(AssertionError):  # tensor.rs:520
+        detached((4, 4)).reshape([5, 5])
+    assert vs(detached((8, 8)).reshape([4, 4], stride=8, stride_mat=1)) == (4, 4, 1, 8, 1, 0)
+
+
+def test_matrix_and_vector_slicing_match_tensor_rs():
+    m = detached((12, 20))
+    assert vs(m.column(3)) == (12, 1, 1, 1, 1, 36)                      # tensor.rs:574-584
+    assert vs(m.columns(4, 8)) == (12, 8, 1, 12, 240, 48)               # tensor.rs:596-610
+    assert vs(m.rows(4, 8)) == (8, 20, 1, 12, 240, 4)                   # tensor.rs:612-626
+    assert vs(m.slice((2, 3), (4, 5))) == (4, 5, 1, 12, 240, 2 + 3 * 4)  # tensor.rs:587-594: offset uses the SLICE's nrows
+    v = detached((100,))
+    assert vs(v.rows(10, 20)) == (20, 1, 1, 100, 100, 10)               # tensor.rs:669-680
+    assert vs(v.rows(10, 20).rows(5, 5)) == (5, 1, 1, 100, 100, 15)     # tensor.rs:445-462
+    with pytest.raises(AssertionError, match="Rows slice range out of bounds"):
+        v.rows(10, 20).rows(18, 5)
+    c = detached((4, 6, 5))
+    assert vs(c.as_view().matrix(2)) == (4, 6, 1, 4, 1, 48)             # tensor.rs:466-480: stride_mat = 1
+    with pytest.raises(AssertionError):
+        c.as_view().matrix(5)
+    assert vs(c.as_view().matrix(1).columns(2, 3)) == (4, 3, 1, 4, 1, 24 + 8)   # tensor.rs:484-496
+    assert vs(c.as_view().matrix(1).columns(2, 3).rows(1, 2)) == (2, 3, 1, 4, 1, 33)  # tensor.rs:498-510
+
+
+def test_view_shape_f32_to_vec4_floor_division():
+    s = wg.ViewShape((10, 7, 2), 10, 70, 6)  # shapes.rs:25-38 floors (the WGSL twin ceils: shape.wgsl:64-66)
+    assert s.f32_to_vec4() == wg.ViewShape((2, 7, 2), 2, 17, 1)
+    assert s.f32_to_vec4(column_major=False) == wg.ViewShape((10, 1, 2), 2, 17, 1)
+
+
+def test_tensor_builder_len_and_asserts():
+    b = wg.TensorBuilder.matrix(3, 5, wg.BufferUsages.STORAGE)
+    assert b.len() == 15 and wg.TensorBuilder.scalar(wg.BufferUsages.STORAGE).len() == 1
+    assert int(wg.BufferUsages.MAP_READ | wg.BufferUsages.COPY_DST) == 9 and int(wg.BufferUsages.STORAGE) == 128
+    with pytest.raises(ValueError):
+        wg.TensorBuilder.vector(2 ** 32, wg.BufferUsages.STORAGE)
+
+
+def test_enums_keep_reference_order():
+    assert [v.name for v in wg.GemmVariant] == ["Gemm", "GemmFast", "GemmTr", "GemmTrFast"]          # gemm.rs:26-35
+    assert [v.name for v in wg.GemvVariant] == ["Gemv", "GemvFast", "GemvTr", "GemvTrFast"]          # gemv.rs:25-34
+    assert [v.name for v in wg.ReduceOp] == ["Min", "Max", "Sum", "Prod", "SqNorm"]                  # reduce.rs:13-27
+    assert [v.name for v in wg.OpAssignVariant] == ["Add", "Sub", "Mul", "Div", "Copy"]              # op_assign.rs:12-26
+    hdr = open(_lib.HEADER_PATH).read()
+    for name in ("WG_GEMM = 0, WG_GEMM_FAST = 1, WG_GEMM_TR = 2, WG_GEMM_TR_FAST = 3",
+                 "WG_REDUCE_MIN = 0, WG_REDUCE_MAX = 1, WG_REDUCE_SUM = 2, WG_REDUCE_PROD = 3, WG_REDUCE_SQNORM = 4",
+                 "WG_OP_ADD = 0, WG_OP_SUB = 1, WG_OP_MUL = 2, WG_OP_DIV = 3, WG_OP_COPY = 4"):
+        assert name in hdr
+
+
+def test_reduce_eval_cpu_matches_reference_helper():
+    x = np.random.default_rng(0).random(345, dtype=np.float32)
+    assert wg.Reduce(None, wg.ReduceOp.SqNorm).eval_cpu(x) == np.float32((x * x).sum())
+    assert wg.Reduce(None, wg.ReduceOp.Min).eval_cpu(x) == x.min()

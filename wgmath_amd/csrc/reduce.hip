@@ -32,7 +32,11 @@ __device__ __forceinline__ float r_ws(float acc, float x) { // workspace_fn
     else if constexpr (OP == R_MAX) return fmaxf(acc, x);
     else if constexpr (OP == R_SUM) return __fadd_rn(acc, x);
     else if constexpr (OP == R_PROD) return __fmul_rn(acc, x);
-    else return __fadd_rn(acc, __fmul_rn(x, x));
+    else {
+        float sq = __fmul_rn(x, x);
+        asm volatile("" : "+v"(sq)); // the product is rounded on its own (reduce_sqnorm_f32 as restated by the oracle): never an FMA
+        return __fadd_rn(acc, sq);
+    }
 }
 template <int OP>
 __device__ __forceinline__ float r_red(float a, float b) { // reduce_fn

@@ -111,7 +111,7 @@ int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int
     if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_device_info: ctx is NULL");
     hipDeviceProp_t prop;
     WG_HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
-    if (name256) snprintf(name256, 256, "%s (%s)", prop.name, prop.gcnArchName);
+    if (name256) snprintf(name256, 256, "%s (%s)", prop.name[0] ? prop.name : "AMD Instinct (name not reported)", prop.gcnArchName);
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
     if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
