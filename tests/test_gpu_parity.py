@@ -318,3 +318,70 @@ def test_record_replay_and_timestamps(gpu):
     t = ts.wait_for_results_ms()
     assert len(t) == 2 and t[0] == 0.0 and 0.0 < t[1] < 1000.0
     assert np.array_equal(a.slow_read(gpu), np.full(n, 20, np.float32))
+
+
+# --------------------------------------------------------------------------------------------------------
+# f16 Gemm (extension: no reference kernel -- contract defined in DESIGN.md: f16 in, f32 accumulate, one RNE rounding)
+# --------------------------------------------------------------------------------------------------------
+F16_SHAPES = [
+    # M,   K,   N, mats      (multiples of 256/64 -> MFMA fast path; anything else -> generic path)
+    (256, 64, 256, 1), (512, 128, 256, 1), (256, 192, 768, 2), (1024, 1024, 512, 1),
+    (36, 20, 28, 1), (260, 72, 132, 1), (256, 60, 256, 1), (64, 1024, 64, 3),
+]
+
+
+def f16_check(got, a64, b64, K, what):
+    truth = a64 @ b64
+    sabs = np.abs(a64) @ np.abs(b64)
+    tol = U.f32_gate(K, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25  # + half an f16 ulp (+ subnormal floor)
+    err = np.abs(np.asarray(got, np.float64) - truth)
+    assert (err <= tol).all(), f"{what}: worst err/tol = {(err / tol).max():.3g} at {np.unravel_index((err / tol).argmax(), err.shape)}"
+
+
+@pytest.mark.parametrize("M,K,N,mats", F16_SHAPES)
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f16_shapes(gpu, M, K, N, mats, tr):
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M * 31 + K * 17 + N + mats + int(tr))
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    s1 = wo.Shape(K, M, mats) if tr else wo.Shape(M, K, mats)
+    s2, so = wo.Shape(K, N, mats), wo.Shape(M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a, np.float16)
+    m2 = upload(gpu, (K, N, mats), b, np.float16)
+    out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float16), np.float16)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+    got = out.read(gpu.device())
+    assert got.dtype == np.float16
+    A, B = wo.view(a, s1), wo.view(b, s2)
+    for t in range(mats):
+        amk = (A[:, :, t].T if tr else A[:, :, t]).astype(np.float64)
+        f16_check(wo.view(got, so)[:, :, t], amk, B[:, :, t].astype(np.float64), K, f"f16 gemm {M}x{K}x{N} mat {t} tr={tr}")
+
+
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f16_identity_asymmetric(gpu, tr):
+    """A = I, asymmetric small-integer B (exact in f16): any row/column permutation or transposition in the tr-read,
+    the interleaved tile map or the epilogue shows up as a bit mismatch."""
+    wg = _wg()
+    M = K = 512
+    N = 256
+    eye = np.eye(M, K, dtype=np.float16)
+    B = ((np.arange(K)[:, None] * 7 + np.arange(N)[None, :] * 13) % 2039 - 1000).astype(np.float16)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    m1, m2 = upload(gpu, (M, K), eye, np.float16), upload(gpu, (K, N), B, np.float16)
+    out = upload(gpu, (M, N), np.zeros(M * N, np.float16), np.float16)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+    got = out.read(gpu.device()).reshape(M, N, order="F")
+    assert np.array_equal(got, B), f"mismatch at {np.argwhere(got != B)[:5]}"
+    # and a permutation matrix on the left (row p(i) of B lands in row i): catches M-side mapping errors the identity hides
+    perm = np.random.default_rng(3).permutation(M)
+    P = np.zeros((M, K), np.float16)
+    P[np.arange(M), perm] = 1
+    m1p = upload(gpu, (M, K), P.T if tr else P, np.float16)
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1p, m2, variant))
+    got = out.read(gpu.device()).reshape(M, N, order="F")
+    assert np.array_equal(got, B[perm]), f"mismatch at {np.argwhere(got != B[perm])[:5]}"

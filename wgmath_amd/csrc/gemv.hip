@@ -202,21 +202,36 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
     }
 }
 
-// out[r] = sum_{s < nsplit} partial[s][r], s ascending. partial layout: [z][s][y][rows_out] dense.
+// out[r] = sum_{s < nsplit} partial[s][r] in a FIXED order. partial layout: [z][s][y][rows_out] dense.
+// A workgroup covers 16 float4 rows x 16 "split lanes": lane j adds splits j, j+16, ... ascending, then the 16 lane sums
+// are added ascending through LDS -- enough parallelism that the pass costs a couple of microseconds, not 12.
 __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__restrict__ partial, uint32_t nsplit, uint32_t rows_out,
                                                                  uint32_t nrhs, float *__restrict__ out, uint32_t ld_out,
                                                                  uint64_t out_batch) {
-    const uint32_t r4 = blockIdx.x * kThreads + threadIdx.x; // float4 index within a column
-    if (r4 * 4u >= rows_out) return;
+    __shared__ float4 red[16][16];
+    const uint32_t rl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const uint32_t r4 = blockIdx.x * 16u + rl; // float4 index within a column
+    const bool ok = r4 * 4u < rows_out;
     const uint32_t y = blockIdx.y, z = blockIdx.z;
     const uint64_t split_stride = (uint64_t)nrhs * rows_out;
-    const float4 *p = reinterpret_cast<const float4 *>(partial + (uint64_t)z * nsplit * split_stride + (uint64_t)y * rows_out) + r4;
-    float4 s = p[0];
-    for (uint32_t i = 1; i < nsplit; ++i) {
-        float4 q = p[(uint64_t)i * (split_stride / 4u)];
-        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+        const float4 *p = reinterpret_cast<const float4 *>(partial + (uint64_t)z * nsplit * split_stride + (uint64_t)y * rows_out) + r4;
+        for (uint32_t i = sl; i < nsplit; i += 16u) {
+            float4 q = p[(uint64_t)i * (split_stride / 4u)];
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
     }
-    *reinterpret_cast<float4 *>(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4) = s;
+    red[sl][rl] = s;
+    __syncthreads();
+    if (sl == 0 && ok) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            float4 q = red[j][rl];
+            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+        }
+        *reinterpret_cast<float4 *>(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4) = s;
+    }
 }
 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); }
@@ -279,7 +294,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     }
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, kThreads), nrhs, nmats), block, 0, ctx->stream, partial,
+        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, 16u), nrhs, nmats), block, 0, ctx->stream, partial,
                            nsplit, rows_out, nrhs, (float *)out, out_ld, out_batch);
         WG_HIP_TRY(hipGetLastError());
     }
