@@ -7,7 +7,8 @@ import os
 import re
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libwgebra_hip.so")
+# WGEBRA_HIP_LIB selects another build of the SAME library (kernel A/B experiments); never a different backend.
+LIB_PATH = os.environ.get("WGEBRA_HIP_LIB") or os.path.join(_PKG, "libwgebra_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "wgebra_hip.h")
 
 # status codes (wg_status)

@@ -23,7 +23,13 @@
 // Shapes the fast path does not cover (M, N % 256, K % 64, misaligned views) take a small generic kernel.
 #include "wg_internal.hpp"
 
+#include <type_traits>
+
 namespace {
+
+#ifndef WG_ABLATE
+#define WG_ABLATE 0 // timing experiments only: 1 = no barrier, 2 = no DMA, 4 = no LDS reads (bitmask); results are garbage
+#endif
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef short short4_t __attribute__((ext_vector_type(4)));
@@ -52,17 +58,30 @@ struct GemmArgs {
 // K-step, serialising HBM latency with the MFMAs. Hidden from its scoreboard, the DMA stays in flight during the whole
 // K-step; the kernel waits for it itself (wait_dma) right before the barrier that publishes the stage.
 __device__ __forceinline__ void glds16(const _Float16 *gsrc, uint32_t lds_dst) {
+    if (WG_ABLATE & 2) return;
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
+                 : "v"(gsrc), "s"(lds_dst));
+}
+// Same DMA with the cheaper address form: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + immediate.
+template <int IMM>
+__device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_dst) {
+    if (WG_ABLATE & 2) return;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%c4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM));
 }
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ short4_t lds_tr(const char *p) {
+    if (WG_ABLATE & 4) { short4_t v = { (short)(uintptr_t)p, 1, 2, 3 }; return v; }
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WG_AS3 short4_t *)p);
 }
-__device__ __forceinline__ half8_t lds_h8(const char *p) { return *reinterpret_cast<const half8_t *>(p); }
+__device__ __forceinline__ half8_t lds_h8(const char *p) {
+    if (WG_ABLATE & 4) { half8_t v = { (_Float16)(float)(uintptr_t)p, 1, 2, 3, 4, 5, 6, 7 }; return v; }
+    return *reinterpret_cast<const half8_t *>(p);
+}
 __device__ __forceinline__ half8_t cat(short4_t lo, short4_t hi) {
     short8_t v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
     return __builtin_bit_cast(half8_t, v);
@@ -132,17 +151,52 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_f16_kernel(GemmArgs g) {
             a_src[par] = A + (uint64_t)(16u * wave + ((lane >> 2) & 3)) * g.lda + m0 + 128u * par + 32u * (lane >> 4) + 8u * (lane & 3);
     }
 
+    // 32-bit per-lane byte offsets relative to the tile's (wave-uniform) base pointers
+    uint32_t a_voff[8], b_voff[8]; // NN uses a_voff[0..3] (+256-byte immediate for odd pieces); TN/B: [par*4 + (q>>1)]
+    const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
+    if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+        for (int qh = 0; qh < 4; ++qh) {
+            const int chunk = (lane & 7) ^ (4 * par + (lane >> 4));
+            const uint32_t row = 64u * wave + 8u * par + 16u * qh + (lane >> 3);
+            b_voff[par * 4 + qh] = (row * g.ldb + 8u * chunk) * 2u;
+            if constexpr (TRANS_A) a_voff[par * 4 + qh] = (row * g.lda + 8u * chunk) * 2u;
+        }
+    if constexpr (!TRANS_A) {
+#pragma unroll
+        for (int qh = 0; qh < 4; ++qh)
+            a_voff[qh] = ((16u * wave + 4u * qh + ((lane >> 2) & 3)) * g.lda + 32u * (lane >> 4) + 8u * (lane & 3)) * 2u;
+    }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
-    auto stage = [&](int buf, uint32_t k0) {
+    // quarter `part` (0..3) of this wave's 16 DMA pieces of one stage: 2 of A + 2 of B
+    auto stage_part = [&](int buf, uint32_t k0, int part) {
         const uint32_t sa = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 8192);
         const uint32_t sb = sa + A_BYTES;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 2 * part; q < 2 * part + 2; ++q) {
             if constexpr (TRANS_A) glds16(a_src[q & 1] + (uint64_t)(16u * (q >> 1)) * g.lda + k0, sa + q * 1024);
             else glds16(a_src[q & 1] + (uint64_t)(k0 + 4u * (q >> 1)) * g.lda, sa + q * 1024);
+            glds16(b_src[q & 1] + (uint64_t)(16u * (q >> 1)) * g.ldb + k0, sb + q * 1024);
         }
+    };
+    auto stage = [&](int buf, uint32_t k0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) glds16(b_src[q & 1] + (uint64_t)(16u * (q >> 1)) * g.ldb + k0, sb + q * 1024);
+        for (int part = 0; part < 4; ++part) stage_part(buf, k0, part);
+    };
+    // point p (0..15) of a K-step issues ONE DMA piece: A piece p>>1 when p is even, B piece p>>1 when odd
+    auto stage_piece = [&](int buf, uint32_t k0, int p, int) {
+        const uint32_t sa = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 8192);
+        const int q = p >> 1;
+        if ((p & 1) == 0) {
+            if constexpr (TRANS_A) glds16s<0>(a_voff[(q & 1) * 4 + (q >> 1)], a_base + k0, sa + q * 1024);
+            // the instruction's immediate offset is added to the LDS address as well as to the global one: take it back out of M0
+            else if (q & 1) glds16s<256>(a_voff[q >> 1], a_base + (uint64_t)k0 * g.lda, sa + q * 1024 - 256);
+            else glds16s<0>(a_voff[q >> 1], a_base + (uint64_t)k0 * g.lda, sa + q * 1024);
+        } else {
+            glds16s<0>(b_voff[(q & 1) * 4 + (q >> 1)], b_base + k0, sa + A_BYTES + q * 1024);
+        }
     };
 
     // ---- per-lane LDS read offsets ----
@@ -176,42 +230,69 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_f16_kernel(GemmArgs g) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[T][tb][u][e] = 0.f;
 
-    auto compute = [&](int buf) {
+    // ---- hand-placed K-step schedule ----------------------------------------------------------------------------
+    // 64 "slots" per K-step, one per MFMA; __builtin_amdgcn_sched_barrier(0) between slots pins the ORDER, the compiler
+    // still inserts the (counted) lgkmcnt waits, so ds_read -> MFMA dependencies stay correct by construction.
+    //   slot (kk, j): MFMA #j of substep kk  (A fragment j>>2, B fragment j&3)
+    //                 + LDS read #j (j < 12) of substep kk+1's fragments into the other register set
+    //                 + (j & 3) == 3: one A and one B DMA piece of the NEXT stage
+    // so every LDS read / DMA issue sits in the shadow of a 32-cycle MFMA, a whole substep (16 MFMAs) ahead of its use.
+    short4_t a_lo[2][4], a_hi[2][4]; // NN: the two transpose reads of each A fragment
+    half8_t a_f[2][4];               // TN: A fragment by ds_read_b128
+    half8_t b_f[2][4];
+
+    auto read_op = [&](const char *s, int kk, int r, int set) { // r: 0..11 (NN) / 0..7 (TN)
+        if constexpr (TRANS_A) {
+            if (r < 4) a_f[set][r] = lds_h8(s + a_off[r & 1][kk] + (r >> 1) * 8192); // fragment r = (T = r>>1, tb = r&1)
+            else b_f[set][r - 4] = lds_h8(s + b_off[kk] + (r - 4) * 4096);
+        } else {
+            if (r < 2) { // A fragment 0 first, then all of B, then the rest of A: the first MFMA's operands arrive first
+                const char *p = s + a_off[0][0] + kk * 8192;
+                if (r == 0) a_lo[set][0] = lds_tr(p); else a_hi[set][0] = lds_tr(p + 2048);
+            } else if (r < 6) {
+                b_f[set][r - 2] = lds_h8(s + b_off[kk] + (r - 2) * 4096);
+            } else {
+                const int f = 1 + ((r - 6) >> 1); // fragment f = (T = f>>1, tb = f&1)
+                const char *p = s + a_off[f & 1][0] + kk * 8192 + (f >> 1) * 512;
+                if (((r - 6) & 1) == 0) a_lo[set][f] = lds_tr(p); else a_hi[set][f] = lds_tr(p + 2048);
+            }
+        }
+    };
+    constexpr int kReads = TRANS_A ? 8 : 12;
+
+    auto compute = [&](int buf, auto prefetch, uint32_t k_next) {
         const char *s = smem + buf * STAGE_BYTES;
 #pragma unroll
+        for (int r = 0; r < kReads; ++r) read_op(s, 0, r, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            half8_t bf[4], af[2][2];
+            const int cur = kk & 1, nxt = cur ^ 1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) bf[u] = lds_h8(s + b_off[kk] + u * 4096);
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb) {
-                    if constexpr (TRANS_A) {
-                        af[T][tb] = lds_h8(s + a_off[tb][kk] + T * 8192);
-                    } else {
-                        const char *p = s + a_off[tb][0] + kk * 8192 + T * 512;
-                        af[T][tb] = cat(lds_tr(p), lds_tr(p + 2048));
-                    }
+            for (int j = 0; j < 16; ++j) {
+                const int f = j >> 2, u = j & 3;
+                half8_t af;
+                if constexpr (TRANS_A) af = a_f[cur][f]; else af = cat(a_lo[cur][f], a_hi[cur][f]);
+                acc[f >> 1][f & 1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b_f[cur][u], acc[f >> 1][f & 1][u], 0, 0, 0);
+                if (kk < 3 && j < kReads) read_op(s, kk + 1, j, nxt);
+                if constexpr (decltype(prefetch)::value) {
+                    if ((j & 3) == 3) stage_piece(buf ^ 1, k_next, kk * 4 + (j >> 2) - 0, 0);
                 }
-#pragma unroll
-            for (int T = 0; T < 2; ++T)
-#pragma unroll
-                for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        acc[T][tb][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[T][tb], bf[u], acc[T][tb][u], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
     const uint32_t nk = g.K / BK;
     stage(0, 0);
-    for (uint32_t t = 0; t < nk; ++t) {
-        wait_dma();      // this wave's pieces of tile t have landed (issued a whole K-step ago)
-        __syncthreads(); // ... and everybody's; and everyone has left buffer (t+1)&1
-        if (t + 1 < nk) stage((t + 1) & 1, (t + 1) * BK);
-        compute(t & 1);
+    for (uint32_t t = 0; t + 1 < nk; ++t) {
+        wait_dma();      // this wave's pieces of tile t have landed (issued during the previous K-step)
+        if (!(WG_ABLATE & 1)) __syncthreads(); // ... and everybody's; and everyone has left buffer (t+1)&1
+        compute(t & 1, std::true_type{}, (t + 1) * BK);
     }
+    wait_dma();
+    __syncthreads();
+    compute((nk - 1) & 1, std::false_type{}, 0);
 
     // ---- epilogue: f32 -> f16 (RNE), 16-byte stores. C/D map of the 32x32 MFMA: register e -> row (e&3) + 8 (e>>2) + 4 hk ----
     // rows of tile (T, tb): m = 64 T + 16 gq + 8 hk + 4 (tb ^ (gq>>1)) + (e&3)  => the pair (tb = gq>>1, tb = 1 - (gq>>1)) is 8 consecutive rows
