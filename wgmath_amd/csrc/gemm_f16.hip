@@ -38,11 +38,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define WG_AS1 __attribute__((address_space(1)))
 #define WG_AS3 __attribute__((address_space(3)))
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int kThreads = 256;
-constexpr int A_BYTES = BM * BK * 2; // 32 KiB
-constexpr int B_BYTES = BN * BK * 2;
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+constexpr int BM = 256, BN = 256, BKH = 32; // K advances in half-steps of 32
+constexpr int HA_BYTES = BM * BKH * 2;      // 16 KiB
+constexpr int HB_BYTES = BN * BKH * 2;
+constexpr int HSTAGE_BYTES = HA_BYTES + HB_BYTES; // 32 KiB
+constexpr int NSLOT = 5;                    // 5 x 32 KiB = all 160 KiB of LDS
 
 struct GemmArgs {
     const _Float16 *a; uint32_t lda; uint64_t a_batch;
@@ -73,7 +73,10 @@ __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32
                  : "=&s"(keep)
                  : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM));
 }
-__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's DMA pieces are still in flight (they retire in issue order)
+template <int N>
+__device__ __forceinline__ void wait_dma_keep() { asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(N) : "memory"); }
 __device__ __forceinline__ short4_t lds_tr(const char *p) {
     if (WG_ABLATE & 4) { short4_t v = { (short)(uintptr_t)p, 1, 2, 3 }; return v; }
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WG_AS3 short4_t *)p);
@@ -105,13 +108,26 @@ __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, uint32_t
     }
 }
 
-template <bool TRANS_A>
-__global__ __launch_bounds__(kThreads, 1) void gemm_f16_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+// NWN = waves along N (2 or 4); always 2 waves along M.  NWN = 2: 4 waves, one per SIMD, 128x128 each (512 registers);
+// NWN = 4: 8 waves, two per SIMD, 128x64 each (<= 256 registers).
+//
+// Pipeline: the K loop advances in HALF-steps of 32 k. A half-stage (A 256x32 + B 32x256 = 32 KiB) lives in one of
+// NSLOT = 5 LDS slots (5 x 32 KiB = the whole 160 KiB). During half-step h every wave
+//   * runs its MFMAs on slot h%5 (fragments were read one substep earlier -- across the barrier for the first substep),
+//   * issues its share of the LDS-DMA of half-stage h+4 into slot (h-1)%5 (released by the barrier that opened h),
+//   * and ends with `s_waitcnt vmcnt(2 stages)` + barrier: half-stage h+2 has landed; it was issued 2-3 half-steps
+//     (2-3 thousand cycles) earlier, so the wait never sees L2/MALL latency, and no DMA is ever issued "just in time".
+template <bool TRANS_A, int NWN>
+__global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g) {
+    constexpr int NWAVES = 2 * NWN;
+    constexpr int NU = 8 / NWN;          // B fragments (32 columns each) per wave: 4 or 2
+    constexpr int WN_COLS = 32 * NU;     // columns per wave
+    constexpr int PCS = 16 / NWAVES;     // DMA pieces of A (and of B) per wave per half-stage: 4 or 2
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * HSTAGE_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int hk = lane >> 5;          // which 8 of the MFMA's 16 k this lane feeds
     const int i32 = lane & 31;         // MFMA row (A) / column (B) index
     const int g1 = (lane >> 4) & 1, cq = (lane >> 2) & 3, e4 = lane & 3;
@@ -124,181 +140,166 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_f16_kernel(GemmArgs g) {
     const _Float16 *B = g.b + z * g.b_batch;
     _Float16 *C = g.c + z * g.c_batch;
 
-    // ---- per-lane global source pointers for the DMA pieces (this wave stages pieces P = 8*wave + q, q < 8) ----
-    // B tile, [n][64 k] rows: piece P = rows 8P..8P+7, lane -> row 8P + (lane>>3), swizzled chunk lane&7
-    const _Float16 *b_src[2]; // q even / odd share everything but the row parity class used by the swizzle
-    {
-        // row = 8P + (lane>>3) = 64*wave + 8q + (lane>>3); (row>>1)&7 = (4q + (lane>>4)) & 7 = 4*(q&1) + (lane>>4)
-        for (int par = 0; par < 2; ++par) {
-            const int sw = 4 * par + (lane >> 4);
-            const int chunk = (lane & 7) ^ sw;
-            const uint32_t row = 64u * wave + 8u * par + (lane >> 3);
-            b_src[par] = B + (uint64_t)(n0 + row) * g.ldb + 8u * chunk;
-        }
-    }
-    const _Float16 *a_src[2];
-    if constexpr (TRANS_A) {
-        for (int par = 0; par < 2; ++par) {
-            const int sw = 4 * par + (lane >> 4);
-            const int chunk = (lane & 7) ^ sw;
-            const uint32_t row = 64u * wave + 8u * par + (lane >> 3);
-            a_src[par] = A + (uint64_t)(m0 + row) * g.lda + 8u * chunk;
-        }
-    } else {
-        // A tile, blocks [kq][mblk][4 k][32 m]: piece P = blocks 4P..4P+3 -> kq = P>>1, mblk = 4*(P&1) + (lane>>4),
-        // k row within block (lane>>2)&3, 16-byte piece lane&3.  k = 16*wave + 4*(q>>1) + j, m = 128*(q&1) + 32*(lane>>4) + 8*(lane&3)
-        for (int par = 0; par < 2; ++par)
-            a_src[par] = A + (uint64_t)(16u * wave + ((lane >> 2) & 3)) * g.lda + m0 + 128u * par + 32u * (lane >> 4) + 8u * (lane & 3);
-    }
-
-    // 32-bit per-lane byte offsets relative to the tile's (wave-uniform) base pointers
-    uint32_t a_voff[8], b_voff[8]; // NN uses a_voff[0..3] (+256-byte immediate for odd pieces); TN/B: [par*4 + (q>>1)]
+    // ---- DMA addressing: this wave stages pieces P = PCS*wave + q (q < PCS) of A and of B; 1 KiB per piece ----
+    // B half-tile (and op(A) for TN), [row][32 k] = 64-byte rows: piece P = rows 16P..16P+15, lane -> row 16P + (lane>>2),
+    //   position lane&3 holds logical 16-byte chunk (lane&3) ^ ((row>>2)&3) = (lane&3) ^ (lane>>4)
+    // A half-tile (NN), 256-byte blocks [kq][mblk][4 k][32 m]: piece P = blocks 4P..4P+3 -> kq = P>>1, mblk = 4*(P&1) + (lane>>4),
+    //   k row within the block (lane>>2)&3, 16-byte piece lane&3
+    uint32_t a_voff[PCS], b_voff[PCS]; // 32-bit per-lane byte offsets relative to wave-uniform base pointers
     const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
-#pragma unroll
-        for (int qh = 0; qh < 4; ++qh) {
-            const int chunk = (lane & 7) ^ (4 * par + (lane >> 4));
-            const uint32_t row = 64u * wave + 8u * par + 16u * qh + (lane >> 3);
-            b_voff[par * 4 + qh] = (row * g.ldb + 8u * chunk) * 2u;
-            if constexpr (TRANS_A) a_voff[par * 4 + qh] = (row * g.lda + 8u * chunk) * 2u;
-        }
-    if constexpr (!TRANS_A) {
-#pragma unroll
-        for (int qh = 0; qh < 4; ++qh)
-            a_voff[qh] = ((16u * wave + 4u * qh + ((lane >> 2) & 3)) * g.lda + 32u * (lane >> 4) + 8u * (lane & 3)) * 2u;
+    for (int q = 0; q < PCS; ++q) {
+        const uint32_t P = PCS * wave + q;
+        const int chunk = (lane & 3) ^ (lane >> 4);
+        const uint32_t row = 16u * P + (lane >> 2);
+        b_voff[q] = (row * g.ldb + 8u * chunk) * 2u;
+        if constexpr (TRANS_A) a_voff[q] = (row * g.lda + 8u * chunk) * 2u;
+        else a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + 128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3)) * 2u;
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
-    // quarter `part` (0..3) of this wave's 16 DMA pieces of one stage: 2 of A + 2 of B
-    auto stage_part = [&](int buf, uint32_t k0, int part) {
-        const uint32_t sa = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 8192);
-        const uint32_t sb = sa + A_BYTES;
-#pragma unroll
-        for (int q = 2 * part; q < 2 * part + 2; ++q) {
-            if constexpr (TRANS_A) glds16(a_src[q & 1] + (uint64_t)(16u * (q >> 1)) * g.lda + k0, sa + q * 1024);
-            else glds16(a_src[q & 1] + (uint64_t)(k0 + 4u * (q >> 1)) * g.lda, sa + q * 1024);
-            glds16(b_src[q & 1] + (uint64_t)(16u * (q >> 1)) * g.ldb + k0, sb + q * 1024);
-        }
-    };
-    auto stage = [&](int buf, uint32_t k0) {
-#pragma unroll
-        for (int part = 0; part < 4; ++part) stage_part(buf, k0, part);
-    };
-    // point p (0..15) of a K-step issues ONE DMA piece: A piece p>>1 when p is even, B piece p>>1 when odd
-    auto stage_piece = [&](int buf, uint32_t k0, int p, int) {
-        const uint32_t sa = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_BYTES + wave * 8192);
+    // point p (0 .. 2*PCS-1) of a half-step issues ONE DMA piece: A piece p>>1 when p is even, B piece p>>1 when odd
+    auto stage_piece = [&](uint32_t slot, uint32_t k0, int p) {
+        const uint32_t sa = __builtin_amdgcn_readfirstlane(lds_base + slot * HSTAGE_BYTES + wave * (PCS * 1024));
         const int q = p >> 1;
         if ((p & 1) == 0) {
-            if constexpr (TRANS_A) glds16s<0>(a_voff[(q & 1) * 4 + (q >> 1)], a_base + k0, sa + q * 1024);
-            // the instruction's immediate offset is added to the LDS address as well as to the global one: take it back out of M0
-            else if (q & 1) glds16s<256>(a_voff[q >> 1], a_base + (uint64_t)k0 * g.lda, sa + q * 1024 - 256);
-            else glds16s<0>(a_voff[q >> 1], a_base + (uint64_t)k0 * g.lda, sa + q * 1024);
+            if constexpr (TRANS_A) glds16s<0>(a_voff[q], a_base + k0, sa + q * 1024);
+            else glds16s<0>(a_voff[q], a_base + (uint64_t)k0 * g.lda, sa + q * 1024);
         } else {
-            glds16s<0>(b_voff[(q & 1) * 4 + (q >> 1)], b_base + k0, sa + A_BYTES + q * 1024);
+            glds16s<0>(b_voff[q], b_base + k0, sa + HA_BYTES + q * 1024);
         }
     };
 
-    // ---- per-lane LDS read offsets ----
-    // B fragment for N-tile u, k-substep kk: row n = 128 wn + 32 u + i32, chunk (2kk + hk) ^ ((i32>>1)&7)
-    uint32_t b_off[4];
+    // ---- per-lane LDS read offsets (within a slot) ----
+    // B fragment for N-tile u, substep kk (0/1): row n = WN_COLS*wn + 32 u + i32, chunk (2kk + hk) ^ ((i32>>2)&3)
+    uint32_t b_off[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) b_off[kk] = A_BYTES + (128u * wn + i32) * 128u + (((2 * kk + hk) ^ ((i32 >> 1) & 7)) * 16u);
+    for (int kk = 0; kk < 2; ++kk)
+        b_off[kk] = HA_BYTES + ((uint32_t)WN_COLS * wn + i32) * 64u + (((2 * kk + hk) ^ ((i32 >> 2) & 3)) * 16u);
     // A fragment.  MFMA row i32 = 16 g1 + 4 cq + e4 of tile (T, tb)  <->  m = 128 wm + 64 T + 32 g1 + 8 cq + 4 (tb ^ g1) + e4
-    uint32_t a_off[2][4]; // TN: [tb][kk] ; NN: [tb][0] only
+    uint32_t a_off[2][2]; // TN: [tb][kk] ; NN: [tb][0] only
     if constexpr (TRANS_A) {
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
             const uint32_t ml = 128u * wm + 32u * g1 + 8u * cq + 4u * (tb ^ g1) + e4;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) a_off[tb][kk] = ml * 128u + (((2 * kk + hk) ^ ((ml >> 1) & 7)) * 16u);
+            for (int kk = 0; kk < 2; ++kk) a_off[tb][kk] = ml * 64u + (((2 * kk + hk) ^ ((ml >> 2) & 3)) * 16u);
         }
     } else {
-        // transpose read: source lane p = lane&15 supplies 4 consecutive m at k row (p>>2): address is linear in p
+        // transpose read: source lane p = lane&15 supplies 4 consecutive m at k row (p>>2): the address is linear in p
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
             a_off[tb][0] = hk * 4096u + (4u * wm + g1) * 256u + (uint32_t)(lane & 15) * 16u + (tb ^ g1) * 8u;
     }
 
-    floatx16 acc[2][2][4]; // [T][tb][u]
+    floatx16 acc[2][2][NU]; // [T][tb][u]
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < NU; ++u)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[T][tb][u][e] = 0.f;
 
-    // ---- hand-placed K-step schedule ----------------------------------------------------------------------------
-    // 64 "slots" per K-step, one per MFMA; __builtin_amdgcn_sched_barrier(0) between slots pins the ORDER, the compiler
-    // still inserts the (counted) lgkmcnt waits, so ds_read -> MFMA dependencies stay correct by construction.
-    //   slot (kk, j): MFMA #j of substep kk  (A fragment j>>2, B fragment j&3)
-    //                 + LDS read #j (j < 12) of substep kk+1's fragments into the other register set
-    //                 + (j & 3) == 3: one A and one B DMA piece of the NEXT stage
-    // so every LDS read / DMA issue sits in the shadow of a 32-cycle MFMA, a whole substep (16 MFMAs) ahead of its use.
+    // ---- hand-placed schedule ---------------------------------------------------------------------------------------
+    // One "slot" per MFMA; __builtin_amdgcn_sched_barrier(0) between slots pins the ORDER, the compiler still inserts
+    // the (counted) lgkmcnt waits, so ds_read -> MFMA dependencies stay correct by construction.
+    //   slot (kk, j): MFMA #j of substep kk (A fragment j / NU, B fragment j % NU)
+    //                 + its share of the LDS reads of the NEXT substep's fragments (other register set; for kk = 1 that is
+    //                   substep 0 of the next half-stage, already published by the barrier that opened this half-step)
+    //                 + every 4th slot: one DMA piece of half-stage h+4
     short4_t a_lo[2][4], a_hi[2][4]; // NN: the two transpose reads of each A fragment
     half8_t a_f[2][4];               // TN: A fragment by ds_read_b128
-    half8_t b_f[2][4];
+    half8_t b_f[2][NU];
+    constexpr int kReads = (TRANS_A ? 4 : 8) + NU;
+    constexpr int kSlots = 4 * NU; // MFMAs per substep
+    static_assert(2 * kSlots == 8 * PCS, "one DMA point per 4 MFMA slots");
 
-    auto read_op = [&](const char *s, int kk, int r, int set) { // r: 0..11 (NN) / 0..7 (TN)
+    auto read_op = [&](const char *s, int kk, int r, int set) {
         if constexpr (TRANS_A) {
-            if (r < 4) a_f[set][r] = lds_h8(s + a_off[r & 1][kk] + (r >> 1) * 8192); // fragment r = (T = r>>1, tb = r&1)
-            else b_f[set][r - 4] = lds_h8(s + b_off[kk] + (r - 4) * 4096);
+            if (r == 0) a_f[set][0] = lds_h8(s + a_off[0][kk]);
+            else if (r <= NU) b_f[set][r - 1] = lds_h8(s + b_off[kk] + (r - 1) * 2048);
+            else { const int f = r - NU; a_f[set][f] = lds_h8(s + a_off[f & 1][kk] + (f >> 1) * 4096); } // f = (T = f>>1, tb = f&1)
         } else {
             if (r < 2) { // A fragment 0 first, then all of B, then the rest of A: the first MFMA's operands arrive first
                 const char *p = s + a_off[0][0] + kk * 8192;
                 if (r == 0) a_lo[set][0] = lds_tr(p); else a_hi[set][0] = lds_tr(p + 2048);
-            } else if (r < 6) {
-                b_f[set][r - 2] = lds_h8(s + b_off[kk] + (r - 2) * 4096);
+            } else if (r < 2 + NU) {
+                b_f[set][r - 2] = lds_h8(s + b_off[kk] + (r - 2) * 2048);
             } else {
-                const int f = 1 + ((r - 6) >> 1); // fragment f = (T = f>>1, tb = f&1)
+                const int f = 1 + ((r - 2 - NU) >> 1); // fragment f = (T = f>>1, tb = f&1)
                 const char *p = s + a_off[f & 1][0] + kk * 8192 + (f >> 1) * 512;
-                if (((r - 6) & 1) == 0) a_lo[set][f] = lds_tr(p); else a_hi[set][f] = lds_tr(p + 2048);
+                if (((r - 2 - NU) & 1) == 0) a_lo[set][f] = lds_tr(p); else a_hi[set][f] = lds_tr(p + 2048);
             }
         }
     };
-    constexpr int kReads = TRANS_A ? 8 : 12;
 
-    auto compute = [&](int buf, auto prefetch, uint32_t k_next) {
-        const char *s = smem + buf * STAGE_BYTES;
+    // one half-step on LDS slot `cur`; DMA (if any) goes to slot `dst`, next half-stage's first fragments come from `nxt`
+    auto half_step = [&](uint32_t cur, uint32_t nxt, uint32_t dst, uint32_t k_dma, auto do_dma, auto has_next) {
+        const char *s = smem + cur * HSTAGE_BYTES;
+        const char *sn = smem + nxt * HSTAGE_BYTES;
 #pragma unroll
-        for (int r = 0; r < kReads; ++r) read_op(s, 0, r, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int f = j >> 2, u = j & 3;
+            for (int j = 0; j < kSlots; ++j) {
+                const int f = j / NU, u = j % NU;
                 half8_t af;
-                if constexpr (TRANS_A) af = a_f[cur][f]; else af = cat(a_lo[cur][f], a_hi[cur][f]);
-                acc[f >> 1][f & 1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b_f[cur][u], acc[f >> 1][f & 1][u], 0, 0, 0);
-                if (kk < 3 && j < kReads) read_op(s, kk + 1, j, nxt);
-                if constexpr (decltype(prefetch)::value) {
-                    if ((j & 3) == 3) stage_piece(buf ^ 1, k_next, kk * 4 + (j >> 2) - 0, 0);
+                if constexpr (TRANS_A) af = a_f[kk][f]; else af = cat(a_lo[kk][f], a_hi[kk][f]);
+                acc[f >> 1][f & 1][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, b_f[kk][u], acc[f >> 1][f & 1][u], 0, 0, 0);
+                if (kk == 0) {
+#pragma unroll
+                    for (int r = j; r < kReads; r += kSlots) read_op(s, 1, r, 1);
+                } else if constexpr (decltype(has_next)::value) {
+#pragma unroll
+                    for (int r = j; r < kReads; r += kSlots) read_op(sn, 0, r, 0);
+                }
+                if constexpr (decltype(do_dma)::value) {
+                    if ((j & 3) == 3) stage_piece(dst, k_dma, (kk * kSlots + j) >> 2);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
+    auto next_slot = [](uint32_t s) { return s + 1 == NSLOT ? 0u : s + 1; };
 
-    const uint32_t nk = g.K / BK;
-    stage(0, 0);
-    for (uint32_t t = 0; t + 1 < nk; ++t) {
-        wait_dma();      // this wave's pieces of tile t have landed (issued during the previous K-step)
-        if (!(WG_ABLATE & 1)) __syncthreads(); // ... and everybody's; and everyone has left buffer (t+1)&1
-        compute(t & 1, std::true_type{}, (t + 1) * BK);
+    const uint32_t nh = g.K / BKH; // half-steps
+    // prologue: up to 4 half-stages in flight, everything landed before the first barrier (once per tile)
+    for (uint32_t h = 0; h < 4 && h < nh; ++h) {
+#pragma unroll
+        for (int p = 0; p < 2 * PCS; ++p) stage_piece(h, h * BKH, p);
     }
-    wait_dma();
+    wait_dma_all();
     __syncthreads();
-    compute((nk - 1) & 1, std::false_type{}, 0);
+#pragma unroll
+    for (int r = 0; r < kReads; ++r) read_op(smem, 0, r, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    uint32_t cur = 0, h = 0;
+    // steady state: half-stage h+4 exists
+    for (; h + 4 < nh; ++h) {
+        const uint32_t nxt = next_slot(cur);
+        const uint32_t dst = cur == 0 ? NSLOT - 1 : cur - 1; // slot of half-stage h-1 == slot of h+4
+        half_step(cur, nxt, dst, (h + 4) * BKH, std::true_type{}, std::true_type{});
+        wait_dma_keep<2 * 2 * PCS>(); // half-stages h+3 and h+4 may still be in flight; h+2 has landed
+        if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    }
+    // tail: nothing left to issue
+    for (; h + 1 < nh; ++h) {
+        const uint32_t nxt = next_slot(cur);
+        half_step(cur, nxt, 0, 0, std::false_type{}, std::true_type{});
+        wait_dma_all();
+        if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    }
+    half_step(cur, cur, 0, 0, std::false_type{}, std::false_type{});
 
     // ---- epilogue: f32 -> f16 (RNE), 16-byte stores. C/D map of the 32x32 MFMA: register e -> row (e&3) + 8 (e>>2) + 4 hk ----
     // rows of tile (T, tb): m = 64 T + 16 gq + 8 hk + 4 (tb ^ (gq>>1)) + (e&3)  => the pair (tb = gq>>1, tb = 1 - (gq>>1)) is 8 consecutive rows
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        _Float16 *cc = C + (uint64_t)(n0 + 128u * wn + 32u * u + i32) * g.ldc + m0 + 128u * wm + 8u * hk;
+    for (int u = 0; u < NU; ++u) {
+        _Float16 *cc = C + (uint64_t)(n0 + (uint32_t)WN_COLS * wn + 32u * u + i32) * g.ldc + m0 + 128u * wm + 8u * hk;
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -386,16 +387,20 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
-    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BK == 0) && K >= (uint32_t)BK && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
+    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok;
     if (fast) {
         g.tiles_m = M / BM;
         g.tiles_n = N / BN;
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-        const dim3 grid((uint32_t)tiles, nmats), block(kThreads);
-        if (trans) hipLaunchKernelGGL(gemm_f16_kernel<true>, grid, block, 0, ctx->stream, g);
-        else hipLaunchKernelGGL(gemm_f16_kernel<false>, grid, block, 0, ctx->stream, g);
+        const dim3 grid((uint32_t)tiles, nmats);
+#ifndef WG_F16_NWN
+#define WG_F16_NWN 2 // 2 = 4 waves, one per SIMD (measured 1198 TF at 8192^3, less LDS traffic); 4 = 8 waves, two per SIMD (1184 TF)
+#endif
+        const dim3 block(128 * WG_F16_NWN);
+        if (trans) hipLaunchKernelGGL((gemm_f16_kernel<true, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f16_kernel<false, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
     } else {
         g.tiles_m = (M + 63) / 64;
         g.tiles_n = (N + 63) / 64;
