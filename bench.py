@@ -101,75 +101,103 @@ class GemmWorkload(Workload):
         self.kernel = "gemm_f32_kernel" if dtype == "f32" else "gemm_f16_kernel"
 
     def setup(self, wg, gpu, rank, world):
+        from wgmath_amd.sharded import MShardPlan, ShardedGemm
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
-        assert self.M % (4 * world) == 0, "M must split into vec4-aligned row blocks"
-        self.Mg = self.M // world  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
+        # N-panels: the all-gather of panel i overlaps the GEMM of panel i+1 (only meaningful with > 1 rank)
+        npanels = 1 if world == 1 else max(1, min(8, self.N // 2048))
+        self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels)
+        self.Mg = plan.Mg  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
         self.A = device_random(wg, gpu, (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
         self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
         self.gemm = wg.Gemm.from_device(gpu.device())
         self.shapes = wg.ViewShapeBuffers()
         self.torch_out = None
+        S = wg.BufferUsages
         if world == 1:
-            S = wg.BufferUsages
-            self.C = wg.TensorBuilder.matrix(self.Mg, self.N, S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
-            self.C_view = self.C.as_embedded_view(3)
+            self.C = wg.TensorBuilder.vector(plan.gathered_elems(), S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
         else:
             import torch
             tdt = torch.float32 if self.dtype == "f32" else torch.float16
-            # gathered result: a GpuCube [Mg, N, world] (stride_mat = Mg*N): rank g's row block is matrix g
-            self.torch_out = torch.empty((world, self.N, self.Mg), dtype=tdt, device=f"cuda:{gpu._ctx.device_index}")
-            self.C = wg.GpuTensor.wrap(gpu.device(), self.torch_out.data_ptr(), (self.Mg, self.N, world), self.np_dtype,
+            # the gathered buffer [panel][rank][np*Mg]; per panel a GpuCube [Mg, np, world] (wgmath_amd/sharded.py)
+            self.torch_out = torch.empty(plan.gathered_elems(), dtype=tdt, device=f"cuda:{gpu._ctx.device_index}")
+            self.C = wg.GpuTensor.wrap(gpu.device(), self.torch_out.data_ptr(), (plan.gathered_elems(),), self.np_dtype,
                                        keepalive=self.torch_out)
-            self.C_view = self.C.as_view().matrix(rank)
         self.enc = gpu.device().create_command_encoder()
         self.pass_ = self.enc.compute_pass("bench", None)
+        a_view = self.A.as_embedded_view(3)
+
+        def local_gemm(out_shape, a_shape, b_shape):
+            self.gemm.dispatch(gpu.device(), self.shapes, self.pass_, wg.GpuTensorView(out_shape, self.C, 2), a_view,
+                               wg.GpuTensorView(b_shape, self.B, 2))
+
+        def all_gather(start, count, rk):
+            import torch.distributed as dist
+            out = self.torch_out[start:start + world * count]
+            return dist.all_gather_into_tensor(out, out[rk * count:(rk + 1) * count], async_op=True)
+
+        self.driver = ShardedGemm(plan, rank, local_gemm, all_gather, wait=lambda w: w.wait())
 
     def step(self):
-        self.gemm.dispatch(self.gpu.device(), self.shapes, self.pass_, self.C_view, self.A, self.B)
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(self.torch_out, self.torch_out[self.rank])
+        self.driver.step()
 
     def units_per_step(self):
         return 2.0 * self.M * self.N * self.K
 
     def algorithmic_per_launch(self):
-        return 2.0 * self.Mg * self.N * self.K
+        return 2.0 * self.Mg * self.plan.np_ * self.K  # one launch = one N-panel of this rank's row block
+
+    def launches_per_step(self):
+        return self.plan.npanels
 
     def check(self):
-        # sampled rows of C_g against f64 on the host
-        wg, gpu = self.wg, self.gpu
-        rows = np.unique(np.random.default_rng(1).integers(0, self.Mg, 8))
+        # sampled (row, column-block) entries of this rank's C_g against f64 on the host
+        gpu, pl = self.gpu, self.plan
+        rng = np.random.default_rng(1)
+        rows = np.unique(rng.integers(0, self.Mg, 6))
+        cols = np.unique(rng.integers(0, self.N, 24))
+        item = np.dtype(self.np_dtype).itemsize
+        from wgmath_amd._lib import check, lib
         A = self.A.read(gpu.device()).reshape(self.Mg, self.K, order="F")[rows].astype(np.float64)
-        B = self.B.read(gpu.device()).reshape(self.K, self.N, order="F").astype(np.float64)
-        full = self.C.read(gpu.device())
-        Cg = (full.reshape(self.Mg, self.N, -1, order="F")[:, :, self.rank if self.world > 1 else 0])[rows].astype(np.float64)
-        truth, sabs = A @ B, np.abs(A) @ np.abs(B)
-        tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) if self.dtype == "f16" else 0)
-        err = np.abs(Cg - truth)
+
+        def read_range(t, start, n):
+            out = np.empty(n, self.np_dtype)
+            check(lib.wg_buf_read(gpu._ctx.handle, t._h, start * item, out.ctypes.data, n * item))
+            return out
+
+        Bc = np.stack([read_range(self.B, c * self.K, self.K) for c in cols], axis=1).astype(np.float64)  # K x ncols
+        got = np.empty((rows.size, cols.size))
+        for jc, c in enumerate(cols):
+            p, j = divmod(int(c), pl.np_)
+            colbuf = read_range(self.C, (p * pl.world + self.rank) * pl.panel_elems + j * self.Mg, self.Mg)
+            got[:, jc] = colbuf[rows]
+        truth, sabs = A @ Bc, np.abs(A) @ np.abs(Bc)
+        tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
+        err = np.abs(got - truth)
         assert (err <= tol).all(), f"bench sanity check failed: worst err/tol {(err / tol).max():.3g}"
 
     def cpu_baseline(self, budget_s):
-        if self.dtype != "f32":
-            return None  # the reference (and hence its port) has no f16 kernel
+        # The reference's only GEMM is the f32 WGSL kernel; its CPU port is timed on a slice with the SAME K
+        # (for the f16 workloads this is still the f32 port: there is no reference f16 path to port).
         from oracle import wgsl_oracle as wo
         C = wo.CLib()
-        M, N, K = self.M, self.N, self.K
-        a, b = rand_block(1, M * K, np.float32), rand_block(2, K * N, np.float32)
-        out = np.zeros(M * N, np.float32)
-        s1, s2, so = wo.Shape(M, K), wo.Shape(K, N), wo.Shape(M, N)
-        active_wgs = -(-(M // 4) // 64)  # gemm.wgsl:86: only invocations x < M/4 do work
-        flops_per_wg = 2.0 * 256 * N * K  # 64 invocations x 4 rows
+        K = self.K
+        Ms = min(self.M, 8192)
+        Ns = min(self.N, 256 if K > 8192 else 1024)
+        a, b = rand_block(1, Ms * K, np.float32), rand_block(2, K * Ns, np.float32)
+        out = np.zeros(Ms * Ns, np.float32)
+        s1, s2, so = wo.Shape(Ms, K), wo.Shape(K, Ns), wo.Shape(Ms, Ns)
+        active_wgs = -(-(Ms // 4) // 64)  # gemm.wgsl:86: only invocations x < M/4 do work
+        flops_per_wg = 2.0 * min(256, Ms) * Ns * K  # 64 invocations x 4 rows
         t0 = time.perf_counter()
         C.gemm(wo.GEMM, out, so, a, s1, b, s2, 0, 1)
         t1 = time.perf_counter() - t0
-        n = int(max(1, min(active_wgs - 1, budget_s / max(t1, 1e-3) * C.num_threads() / 4)))
+        n = int(max(1, min(active_wgs, budget_s / max(t1, 1e-3))))
         t0 = time.perf_counter()
-        C.gemm(wo.GEMM, out, so, a, s1, b, s2, 1, 1 + n)
+        C.gemm(wo.GEMM, out, so, a, s1, b, s2, 0, n)
         dt = time.perf_counter() - t0
         return {"value": flops_per_wg * n / dt / 1e12, "unit": "TFLOP/s", "cores": C.num_threads(), "kind": "port",
-                "sample": f"oracle/wgsl_oracle.c `gemm` (naive WGSL order), workgroups [1,{1 + n}) of {active_wgs} active "
-                          f"({256 * n} of {M} output rows x all {N} columns, K={K}) in {dt:.1f} s"}
+                "sample": f"oracle/wgsl_oracle.c `gemm` (f32, naive WGSL order; the reference has no f16 kernel), {min(256, Ms) * n} rows x {Ns} "
+                          f"columns x K={K} of the {self.M}x{self.N}x{K} problem, {n} of {active_wgs} active workgroups, {dt:.1f} s"}
 
 
 class GemvWorkload(Workload):
@@ -308,8 +336,10 @@ WORKLOADS = {
     "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
     "reduce_f32_4096x65536": lambda: ReduceWorkload("reduce_f32_4096x65536", 4096, 65536),
 }
-DEFAULT_WORKLOAD = "gemm_f32_4096"
-SECONDARY = ["gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536"]
+# Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
+# driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
+DEFAULT_WORKLOAD = "gemm_f16_32768"
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536"]
 
 
 def load_traffic(workload: str):
@@ -338,7 +368,8 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     barrier()
     elapsed = time.perf_counter() - t0
     ev = ts.wait_for_results_ms()
-    kernel_ms = (ev[1] - ev[0]) / steps  # HIP events on the stream the kernels run on
+    launches = getattr(w, "launches_per_step", lambda: 1)()
+    kernel_ms = (ev[1] - ev[0]) / (steps * launches)  # HIP events on the stream the kernels run on
     if not os.environ.get("WG_BENCH_NO_CHECK"):
         w.check()
     res = {"workload": w, "elapsed": elapsed, "kernel_ms": kernel_ms}
@@ -359,8 +390,8 @@ def summarize(w, elapsed, kernel_ms, steps, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")

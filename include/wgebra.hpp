@@ -1,0 +1,298 @@
+// wgebra.hpp -- header-only C++17 mirror of the wgcore / wgebra surface the dense path uses, over the C ABI
+// (wgebra_hip.h).  Same type and method names, parameter order and error behaviour as the reference:
+//   wgcore::GpuInstance      crates/wgcore/src/gpu.rs:7-78
+//   wgcore::TensorBuilder / GpuTensor<T> / GpuTensorView<T>   crates/wgcore/src/tensor.rs:41-706
+//   wgcore::ViewShape / ViewShapeBuffers                      crates/wgcore/src/shapes.rs:9-117
+//   wgcore::CommandEncoder / ComputePass / Queue              crates/wgcore/src/kernel.rs:7-27 (+ wgpu)
+//   wgebra::Gemm / Gemv / Reduce / OpAssign (+ variant enums) crates/wgebra/src/linalg/{gemm,gemv,reduce,op_assign}.rs
+// Where the reference panics (assert_eq!), these throw wgcore::Panic (a std::logic_error) carrying the same message.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+#include "wgebra_hip.h"
+
+namespace wgcore {
+
+struct Panic : std::logic_error { int status; Panic(int s, const std::string &m) : std::logic_error(m), status(s) {} };
+struct Error : std::runtime_error { int status; Error(int s, const std::string &m) : std::runtime_error(m), status(s) {} };
+
+inline void check(int rc) {
+    if (rc == WG_OK) return;
+    std::string msg = wg_last_error_string();
+    if (rc == WG_ERR_DIM_MISMATCH || rc == WG_ERR_PRECONDITION) throw Panic(rc, msg);
+    throw Error(rc, msg);
+}
+
+// wgpu::BufferUsages
+struct BufferUsages {
+    enum : uint32_t { MAP_READ = 1, MAP_WRITE = 2, COPY_SRC = 4, COPY_DST = 8, INDEX = 16, VERTEX = 32, UNIFORM = 64,
+                      STORAGE = 128, INDIRECT = 256, QUERY_RESOLVE = 512 };
+};
+
+using ViewShape = wg_view_shape; // byte-identical (shapes.rs:9-21)
+
+// shapes.rs:45-117: a cache of uniform buffers in the reference; shapes are kernel arguments here, so it is empty and
+// exists for signature compatibility.
+struct ViewShapeBuffers { static ViewShapeBuffers create() { return {}; } };
+
+template <typename T> struct dtype_of;
+template <> struct dtype_of<float> { static constexpr wg_dtype value = WG_F32; };
+#if defined(__FLT16_MANT_DIG__)
+template <> struct dtype_of<_Float16> { static constexpr wg_dtype value = WG_F16; };
+#endif
+
+class Device {
+  public:
+    explicit Device(wg_ctx *c) : ctx_(c) {}
+    wg_ctx *raw() const { return ctx_; }
+  private:
+    wg_ctx *ctx_;
+};
+
+class CommandBuffer {
+  public:
+    CommandBuffer() = default;
+    explicit CommandBuffer(wg_cmdbuf *cb) : cb_(cb, [](wg_cmdbuf *p) { wg_cmdbuf_destroy(p); }) {}
+    wg_cmdbuf *raw() const { return cb_.get(); }
+  private:
+    std::shared_ptr<wg_cmdbuf> cb_;
+};
+
+class CommandEncoder;
+class ComputePass {
+  public:
+    explicit ComputePass(wg_ctx *c) : ctx_(c) {}
+    wg_ctx *ctx() const { return ctx_; }
+  private:
+    wg_ctx *ctx_;
+};
+
+// wgpu::CommandEncoder + CommandEncoderExt::compute_pass (kernel.rs:15-27). record == false: work is enqueued as encoded.
+class CommandEncoder {
+  public:
+    CommandEncoder(wg_ctx *c, bool record) : ctx_(c), record_(record) { if (record_) check(wg_encoder_begin(ctx_)); }
+    ComputePass compute_pass(const char * /*label*/, std::nullptr_t = nullptr) { return ComputePass(ctx_); }
+    CommandBuffer finish() {
+        if (!record_) return CommandBuffer();
+        wg_cmdbuf *cb = nullptr;
+        check(wg_encoder_finish(ctx_, &cb));
+        return CommandBuffer(cb);
+    }
+    wg_ctx *ctx() const { return ctx_; }
+  private:
+    wg_ctx *ctx_;
+    bool record_;
+};
+
+class Queue {
+  public:
+    explicit Queue(wg_ctx *c) : ctx_(c) {}
+    void submit(const CommandBuffer &cb) const { if (cb.raw()) check(wg_queue_submit(ctx_, cb.raw())); }
+  private:
+    wg_ctx *ctx_;
+};
+
+// gpu.rs:7-78
+class GpuInstance {
+  public:
+    static GpuInstance create(int device_index = 0) { // GpuInstance::new().await
+        wg_ctx *c = nullptr;
+        check(wg_ctx_create(device_index, &c));
+        return GpuInstance(c);
+    }
+    const Device &device() const { return device_; }
+    const Queue &queue() const { return queue_; }
+    CommandEncoder create_command_encoder(bool record = false) const { return CommandEncoder(ctx_.get(), record); }
+    void poll_wait() const { check(wg_ctx_sync(ctx_.get())); }
+  private:
+    explicit GpuInstance(wg_ctx *c) : ctx_(c, [](wg_ctx *p) { wg_ctx_destroy(p); }), device_(c), queue_(c) {}
+    std::shared_ptr<wg_ctx> ctx_;
+    Device device_;
+    Queue queue_;
+};
+
+template <typename T> class GpuTensor;
+
+// tensor.rs:415-542: (ViewShape, &Buffer), Copy
+template <typename T>
+class GpuTensorView {
+  public:
+    GpuTensorView(ViewShape s, wg_buf *b) : shape_(s), buf_(b) {}
+    ViewShape shape() const { return shape_; }
+    wg_buf *buffer() const { return buf_; }
+    uint32_t len() const { return shape_.size[0]; }
+    GpuTensorView rows(uint32_t first, uint32_t nrows) const { // tensor.rs:445-462 / 498-510
+        ViewShape s = shape_;
+        s.size[0] = nrows;
+        s.offset += first;
+        return GpuTensorView(s, buf_);
+    }
+    GpuTensorView columns(uint32_t first_col, uint32_t ncols) const { // tensor.rs:484-496
+        ViewShape s = shape_;
+        s.size[1] = ncols;
+        s.size[2] = 1;
+        s.offset += s.stride * first_col;
+        return GpuTensorView(s, buf_);
+    }
+    GpuTensorView matrix(uint32_t id) const { // tensor.rs:466-480 (stride_mat: 1, as in the reference)
+        if (id >= shape_.size[2]) throw Panic(WG_ERR_PRECONDITION, "assertion failed: matrix_id < nmats");
+        ViewShape s = shape_;
+        s.size[2] = 1;
+        s.offset += s.stride_mat * id;
+        s.stride_mat = 1;
+        return GpuTensorView(s, buf_);
+    }
+  private:
+    ViewShape shape_;
+    wg_buf *buf_;
+};
+
+// tensor.rs:192-400; DIM is a run-time property here (0..3)
+template <typename T>
+class GpuTensor {
+  public:
+    GpuTensor(wg_ctx *ctx, wg_buf *b, std::vector<uint32_t> shape)
+        : ctx_(ctx), buf_(b, [](wg_buf *p) { wg_buf_destroy(p); }), shape_(std::move(shape)) {}
+    uint64_t len() const { uint64_t n = 1; for (auto s : shape_) n *= s; return n; }
+    uint64_t bytes_len() const { return sizeof(T) * len(); }
+    const std::vector<uint32_t> &shape() const { return shape_; }
+    wg_buf *buffer() const { return buf_.get(); }
+
+    void copy_from(CommandEncoder &enc, const GpuTensor &src) const { // tensor.rs:227-233
+        if (len() != src.len()) throw Panic(WG_ERR_DIM_MISMATCH, "assertion `left == right` failed (copy_from: len)");
+        check(wg_buf_copy(enc.ctx(), src.buffer(), 0, buffer(), 0, bytes_len()));
+    }
+    std::vector<T> read(const Device &dev) const { // tensor.rs:375-384 (blocking)
+        std::vector<T> out(len());
+        check(wg_buf_read(dev.raw(), buffer(), 0, out.data(), bytes_len()));
+        return out;
+    }
+    // as_embedded_view::<_, 3>() (tensor.rs:287-297): column-major defaults
+    GpuTensorView<T> as_embedded_view() const {
+        ViewShape s{{1, 1, 1}, 1, 1, 0};
+        for (size_t i = 0; i < shape_.size() && i < 3; ++i) s.size[i] = shape_[i];
+        s.stride = shape_.empty() ? 1 : shape_[0];
+        s.stride_mat = (shape_.empty() ? 1 : shape_[0]) * (shape_.size() > 1 ? shape_[1] : 1);
+        return GpuTensorView<T>(s, buffer());
+    }
+    operator GpuTensorView<T>() const { return as_embedded_view(); } // From<&GpuTensor> (tensor.rs:403-409)
+  private:
+    wg_ctx *ctx_;
+    std::shared_ptr<wg_buf> buf_;
+    std::vector<uint32_t> shape_;
+};
+template <typename T> using GpuScalar = GpuTensor<T>;
+template <typename T> using GpuVector = GpuTensor<T>;
+template <typename T> using GpuMatrix = GpuTensor<T>;
+template <typename T> using GpuCube = GpuTensor<T>;
+
+// tensor.rs:65-187
+class TensorBuilder {
+  public:
+    static TensorBuilder scalar(uint32_t usage) { return TensorBuilder({}, usage); }
+    static TensorBuilder vector(uint32_t dim, uint32_t usage) { return TensorBuilder({dim}, usage); }
+    static TensorBuilder matrix(uint32_t nrows, uint32_t ncols, uint32_t usage) { return TensorBuilder({nrows, ncols}, usage); }
+    static TensorBuilder tensor(std::vector<uint32_t> shape, uint32_t usage) { return TensorBuilder(std::move(shape), usage); }
+    uint64_t len() const { uint64_t n = 1; for (auto s : shape_) n *= s; return n; }
+
+    template <typename T> GpuTensor<T> build(const Device &dev) const {
+        wg_buf *b = nullptr;
+        check(wg_buf_create(dev.raw(), sizeof(T) * len(), usage_, &b));
+        return GpuTensor<T>(dev.raw(), b, shape_);
+    }
+    template <typename T> GpuTensor<T> build_init(const Device &dev, const std::vector<T> &data) const {
+        if (data.size() < len()) // tensor.rs:176-182
+            throw Panic(WG_ERR_PRECONDITION, "Incorrect number of elements provided for initializing Tensor.Expected at least " +
+                                                 std::to_string(len()) + ", found " + std::to_string(data.size()));
+        wg_buf *b = nullptr;
+        check(wg_buf_create_init(dev.raw(), data.data(), sizeof(T) * len(), usage_, &b));
+        return GpuTensor<T>(dev.raw(), b, shape_);
+    }
+  private:
+    TensorBuilder(std::vector<uint32_t> shape, uint32_t usage) : shape_(std::move(shape)), usage_(usage) {}
+    std::vector<uint32_t> shape_;
+    uint32_t usage_;
+};
+
+} // namespace wgcore
+
+namespace wgebra {
+using namespace wgcore;
+
+enum class GemmVariant { Gemm = WG_GEMM, GemmFast = WG_GEMM_FAST, GemmTr = WG_GEMM_TR, GemmTrFast = WG_GEMM_TR_FAST };
+enum class GemvVariant { Gemv = WG_GEMV, GemvFast = WG_GEMV_FAST, GemvTr = WG_GEMV_TR, GemvTrFast = WG_GEMV_TR_FAST };
+enum class ReduceOp { Min = WG_REDUCE_MIN, Max = WG_REDUCE_MAX, Sum = WG_REDUCE_SUM, Prod = WG_REDUCE_PROD, SqNorm = WG_REDUCE_SQNORM };
+enum class OpAssignVariant { Add = WG_OP_ADD, Sub = WG_OP_SUB, Mul = WG_OP_MUL, Div = WG_OP_DIV, Copy = WG_OP_COPY };
+
+// gemm.rs:9-127
+struct Gemm {
+    static Gemm from_device(const Device &) { return {}; } // pipelines are ahead-of-time compiled: nothing to build
+    template <typename T>
+    void dispatch_generic(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> out, GpuTensorView<T> m1,
+                          GpuTensorView<T> m2, GemmVariant variant) const {
+        check(wg_gemm(pass.ctx(), (wg_gemm_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(), m1.buffer(), m1.shape(),
+                      m2.buffer(), m2.shape()));
+    }
+    template <typename T>
+    void dispatch(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m1, GpuTensorView<T> m2) const {
+        dispatch_generic(d, s, p, out, m1, m2, GemmVariant::Gemm);
+    }
+    template <typename T>
+    void dispatch_tr(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m1, GpuTensorView<T> m2) const {
+        dispatch_generic(d, s, p, out, m1, m2, GemmVariant::GemmTr);
+    }
+};
+
+// gemv.rs:9-137
+struct Gemv {
+    static Gemv from_device(const Device &) { return {}; }
+    template <typename T>
+    void dispatch_generic(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> out, GpuTensorView<T> m,
+                          GpuTensorView<T> v, GemvVariant variant) const {
+        check(wg_gemv(pass.ctx(), (wg_gemv_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(), m.buffer(), m.shape(),
+                      v.buffer(), v.shape()));
+    }
+    template <typename T>
+    void dispatch(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m, GpuTensorView<T> v) const {
+        dispatch_generic(d, s, p, out, m, v, GemvVariant::Gemv);
+    }
+    template <typename T>
+    void dispatch_tr(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m, GpuTensorView<T> v) const {
+        dispatch_generic(d, s, p, out, m, v, GemvVariant::GemvTr);
+    }
+};
+
+// reduce.rs:62-113
+struct Reduce {
+    ReduceOp op;
+    static Reduce create(const Device &, ReduceOp op) { return {op}; } // Reduce::new(device, op)
+    template <typename T>
+    void dispatch(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> value, const GpuScalar<T> &result) const {
+        check(wg_reduce(pass.ctx(), (wg_reduce_op)op, dtype_of<T>::value, value.buffer(), value.shape(), result.buffer()));
+    }
+    template <typename T> // extension: every column of a matrix/cube view in one launch
+    void dispatch_batched(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> values, const GpuVector<T> &results) const {
+        check(wg_reduce_batched(pass.ctx(), (wg_reduce_op)op, dtype_of<T>::value, values.buffer(), values.shape(), results.buffer()));
+    }
+};
+
+// op_assign.rs:43-95
+struct OpAssign {
+    OpAssignVariant op;
+    static OpAssign create(const Device &, OpAssignVariant op) { return {op}; } // OpAssign::new(device, op)
+    template <typename T>
+    void dispatch(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> in_out_a, GpuTensorView<T> in_b) const {
+        check(wg_op_assign(pass.ctx(), (wg_op_assign_variant)op, dtype_of<T>::value, in_out_a.buffer(), in_out_a.shape(), in_b.buffer(),
+                           in_b.shape()));
+    }
+};
+
+} // namespace wgebra

@@ -1,0 +1,116 @@
+"""M-sharded GEMM across the GPUs of one node: one process per GPU, RCCL all-gather over xGMI (torch.distributed "nccl").
+
+The reference has no multi-device path (one wgpu::Device + one Queue, crates/wgcore/src/gpu.rs:7-12); this is the
+north-star's addition, expressed in the reference's own tensor model:
+
+  * rank g owns A_g = A[g*Mg:(g+1)*Mg, :] as its OWN contiguous column-major tensor (Mg = M/P, a multiple of 4 so the vec4
+    precondition holds), B (K x N) is replicated, C_g = A_g * B needs no communication;
+  * row blocks of a column-major C are not contiguous, so the gathered result is not an M x N matrix but, per N-panel, a
+    GpuCube [Mg, np, P] (stride = Mg, stride_mat = np*Mg): matrix g of the cube is rank g's row block of that panel --
+    exactly what `GpuCubeView::matrix(g)` addresses (tensor.rs:466-480). The gathered buffer is laid out
+    [panel][rank][np*Mg] so that every panel's all-gather writes one contiguous range (in-place: each rank's GEMM writes
+    its own slot of the panel, then the collective fills the others).
+  * N is split into panels so that the all-gather of panel i (on RCCL's stream) overlaps the GEMM of panel i+1: xGMI is
+    point-to-point (7 links x ~153 GB/s per GPU; only P-1 of them reach participating peers), so an un-overlapped gather
+    would cost ~40 % of the 4-GPU compute time at 32768^3.
+
+`MShardPlan` is pure host arithmetic (tested on CPU); `ShardedGemm` drives one rank. The local GEMM and the collective are
+injected so that the same driver runs under gloo in the CPU tests and on the HIP kernels + RCCL in bench.py.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List
+
+from .wgcore import ViewShape
+
+
+@dataclass(frozen=True)
+class MShardPlan:
+    M: int
+    N: int
+    K: int
+    world: int
+    npanels: int = 1
+
+    def __post_init__(self):
+        if self.world < 1 or self.npanels < 1:
+            raise ValueError("world and npanels must be >= 1")
+        if self.M % (4 * self.world):
+            raise ValueError(f"M={self.M} must split into {self.world} row blocks that are multiples of 4 (vec4 views)")
+        if self.N % (4 * self.npanels):
+            raise ValueError(f"N={self.N} must split into {self.npanels} column panels that are multiples of 4")
+        if self.K % 4:
+            raise ValueError("K must be a multiple of 4")
+        if self.M * self.N >= 2 ** 32 or self.Mg * self.K >= 2 ** 32 or self.K * self.N >= 2 ** 32:
+            raise ValueError("tensors are indexed with u32 elements (shape.wgsl:10-33): each must have < 2^32 elements")
+
+    # -- sizes -------------------------------------------------------------------------------------------------
+    @property
+    def Mg(self) -> int:  # rows per rank
+        return self.M // self.world
+
+    @property
+    def np_(self) -> int:  # columns per panel
+        return self.N // self.npanels
+
+    @property
+    def panel_elems(self) -> int:  # one rank's slot of one panel
+        return self.Mg * self.np_
+
+    def gathered_elems(self) -> int:
+        return self.M * self.N
+
+    def a_rows(self, rank: int):
+        return rank * self.Mg, self.Mg
+
+    # -- views (units: elements), all in the reference's ViewShape model --------------------------------------------
+    def a_shape(self) -> ViewShape:  # this rank's A_g, its own dense tensor
+        return ViewShape((self.Mg, self.K, 1), self.Mg, self.Mg * self.K, 0)
+
+    def b_panel_shape(self, panel: int) -> ViewShape:  # B[:, panel columns] == GpuMatrix::columns (tensor.rs:596-610)
+        return ViewShape((self.K, self.np_, 1), self.K, self.K * self.N, panel * self.np_ * self.K)
+
+    def out_shape(self, panel: int, rank: int) -> ViewShape:  # where rank's GEMM of `panel` writes inside the gathered buffer
+        return ViewShape((self.Mg, self.np_, 1), self.Mg, self.panel_elems, (panel * self.world + rank) * self.panel_elems)
+
+    def panel_range(self, panel: int):  # contiguous element range of a panel in the gathered buffer (the all-gather's output)
+        start = panel * self.world * self.panel_elems
+        return start, self.world * self.panel_elems
+
+    def cube_shape(self, panel: int) -> ViewShape:  # the gathered panel as a GpuCube [Mg, np, P]
+        return ViewShape((self.Mg, self.np_, self.world), self.Mg, self.panel_elems, panel * self.world * self.panel_elems)
+
+    def element_index(self, row: int, col: int) -> int:
+        """Flat index of C[row, col] in the gathered buffer."""
+        g, i = divmod(row, self.Mg)
+        p, j = divmod(col, self.np_)
+        return (p * self.world + g) * self.panel_elems + j * self.Mg + i
+
+
+class ShardedGemm:
+    """One rank of the M-sharded GEMM.
+
+    local_gemm(out_shape, a_shape, b_shape)  enqueues C_g[:, panel] = A_g * B[:, panel] into the gathered buffer
+    all_gather(start, count_per_rank, rank)  starts the (possibly asynchronous) in-place all-gather of the contiguous
+                                             range [start, start + world*count_per_rank); returns a handle or None
+    wait(handle)                             blocks the compute stream on that collective
+    """
+
+    def __init__(self, plan: MShardPlan, rank: int, local_gemm: Callable, all_gather: Callable, wait: Callable = lambda h: None):
+        if not 0 <= rank < plan.world:
+            raise ValueError("rank out of range")
+        self.plan, self.rank = plan, rank
+        self._gemm, self._gather, self._wait = local_gemm, all_gather, wait
+
+    def step(self) -> None:
+        """All panels: GEMM of panel i, then start its all-gather; the collectives drain while later panels compute."""
+        pl = self.plan
+        handles: List = []
+        for p in range(pl.npanels):
+            self._gemm(pl.out_shape(p, self.rank), pl.a_shape(), pl.b_panel_shape(p))
+            if pl.world > 1:
+                start, _ = pl.panel_range(p)
+                handles.append(self._gather(start, pl.panel_elems, self.rank))
+        for h in handles:
+            self._wait(h)
