@@ -346,7 +346,7 @@ def load_traffic(workload: str):
     """HBM bytes per launch measured with rocprofv3 --pmc (separate passes), recorded under profiles/ (DESIGN.md)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(path)).get(workload)
+        return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
