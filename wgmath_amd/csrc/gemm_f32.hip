@@ -19,16 +19,23 @@
 //     are 16 consecutive rows of C, written as four float4 stores.
 //   * TN: m1 is K x M, so op(A)[m][k] is k contiguous like B: As[m][16 k] with the same swizzle, tiles are plain
 //     32-row blocks.
-// Pipeline: global -> registers (next k-tile, issued before the MFMAs) -> LDS (other buffer) -> one barrier per k-tile.
-// With 2 waves per SIMD the second workgroup's MFMAs cover the first one's barrier / LDS refill.
-// Edges: every global access is predicated at float4 granularity (rows/cols/K are multiples of 4 by the vec4
-// precondition), out-of-range operands are zero-filled, so any M, N, K % 4 == 0 is accepted.
+// Pipeline (interior tiles): LDS-DMA into a 3-slot ring, two k-tiles ahead, counted vmcnt, barrier in the middle of a run
+// of MFMAs, fragments of the next tile prefetched across it (gemm_f32_tile_dma below): 140 TFLOP/s at 4096^3 = 89 % of
+// peak, 93.5 % MFMA-cycle utilisation. With 2 workgroups per CU the partner wave on each SIMD covers what is left.
+// Edge tiles (gemm_f32_tile<.., true>): global -> registers -> LDS (double buffer), every global access predicated at
+// float4 granularity (rows/cols/K are multiples of 4 by the vec4 precondition), out-of-range operands zero-filled, so
+// any M, N, K % 4 == 0 is accepted.
 // Workgroup ids are remapped so that each XCD (private L2) works on a contiguous band of tiles.
 #include "wg_internal.hpp"
+
+#include <type_traits>
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+#ifndef WG_ABLATE
+#define WG_ABLATE 0 // timing experiments only (results are garbage): 2 = no global loads / LDS stores, 4 = no LDS reads
+#endif
 
 constexpr int BM = 256, BN = 128, BK = 16;
 constexpr int kThreads = 256;
@@ -41,6 +48,7 @@ struct GemmArgs {
     float *c; uint32_t ldc; uint64_t c_batch;
     uint32_t M, N, K;
     uint32_t tiles_m, tiles_n;
+    uint32_t dma_ok; // leading dimensions small enough for 32-bit byte offsets within a tile
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
@@ -55,24 +63,24 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
     return base + local;
 }
 
-template <bool TRANS_A>
-__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[2][A_TILE];
-    __shared__ __attribute__((aligned(16))) float Bs[2][B_TILE];
-
+// One k-tile (16 k) = 2 substeps of 8 k = 2 x 32 MFMAs per wave. The loop body is hand-placed in "slots" (one MFMA +
+// at most one other memory op) pinned with sched_barrier(0); the compiler still inserts every s_waitcnt, so the
+// dependencies stay correct by construction:
+//   substep 0: MFMAs on fragment set 0 | slots 0-5: LDS reads of substep 1's fragments -> set 1
+//                                      | slots 8-13: global loads of tile t+1 -> staging registers
+//   substep 1: MFMAs on fragment set 1 | slots 0-5: staging registers -> LDS buffer (t+1)&1
+//                                      | after slot 7: barrier (tile t+1 published; buffer t&1 may be refilled next round)
+//                                      | slots 8-13: LDS reads of tile t+1's substep-0 fragments -> set 0
+// so no LDS latency is exposed at a tile boundary and the barrier sits in the middle of a run of MFMAs.
+// EDGE = false: interior tiles, no predication (no branches in the loop).
+template <bool TRANS_A, bool EDGE>
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, float *Bs, const float *A, const float *B, float *C,
+                                              uint32_t m0, uint32_t n0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int i = lane & 31, h = lane >> 5;
-
-    const uint32_t tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
-    const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
-    const uint32_t m0 = tm * BM, n0 = tn * BN;
-    const uint32_t z = blockIdx.y;
-    const float *A = g.a + z * g.a_batch;
-    const float *B = g.b + z * g.b_batch;
-    float *C = g.c + z * g.c_batch;
 
     floatx16 acc[4][2];
 #pragma unroll
@@ -82,105 +90,118 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
-    float4 ra[4], rb[2];
-
-    auto load_tile = [&](uint32_t k0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+    wg_f4 ra[4], rb[2]; // staging registers of the next tile
+    // Interior tiles issue the loads from inline asm: hipcc otherwise sinks them from their slot down to the LDS stores that
+    // consume them and waits for each right there (measured: full memory latency exposed once per k-tile, -12 %). An asm load
+    // is invisible to the compiler's vmcnt bookkeeping, so wait_staged() is the explicit wait in front of the first store.
+    auto ldg = [&](wg_f4 &dst, const float *p, bool ok) {
+        if constexpr (EDGE) {
+            float4 v = ldg4(p, ok);
+            dst = wg_f4{ v.x, v.y, v.z, v.w };
+        } else {
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+        }
+    };
+    auto wait_staged = [&]() {
+        if constexpr (!EDGE)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(rb[0]), "+v"(rb[1])::"memory");
+    };
+    auto load_one = [&](uint32_t k0, int r) { // r: 0..3 -> A, 4..5 -> B
+        if (WG_ABLATE & 2) { if (r < 4) ra[r] = wg_f4{ 1, 2, 3, 4 }; else rb[r - 4] = wg_f4{ 1, 2, 3, 4 }; return; }
+        if (r < 4) {
             const int f = tid + kThreads * r;
             if constexpr (!TRANS_A) { // A[m][k] at a + k*lda + m : float4 along m
                 const uint32_t m = m0 + 4u * (f & 63), k = k0 + (f >> 6);
-                ra[r] = ldg4(A + (uint64_t)k * g.lda + m, m < g.M && k < g.K);
+                ldg(ra[r], A + (uint64_t)k * g.lda + m, m < g.M && k < g.K);
             } else { // op(A)[m][k] at a + m*lda + k : float4 along k
                 const uint32_t m = m0 + (f >> 2), k = k0 + 4u * (f & 3);
-                ra[r] = ldg4(A + (uint64_t)m * g.lda + k, m < g.M && k < g.K);
+                ldg(ra[r], A + (uint64_t)m * g.lda + k, m < g.M && k < g.K);
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int f = tid + kThreads * r;
+        } else {
+            const int f = tid + kThreads * (r - 4);
             const uint32_t n = n0 + (f >> 2), k = k0 + 4u * (f & 3);
-            rb[r] = ldg4(B + (uint64_t)n * g.ldb + k, n < g.N && k < g.K);
+            ldg(rb[r - 4], B + (uint64_t)n * g.ldb + k, n < g.N && k < g.K);
         }
     };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+    auto store_one = [&](int buf, int r) {
+        if (WG_ABLATE & 2) return;
+        if (r < 4) {
             const int f = tid + kThreads * r;
             if constexpr (!TRANS_A) {
-                *reinterpret_cast<float4 *>(&As[buf][(f >> 6) * BM + 4 * (f & 63)]) = ra[r];
+                *reinterpret_cast<wg_f4 *>(&As[buf * A_TILE + (f >> 6) * BM + 4 * (f & 63)]) = ra[r];
             } else {
                 const int mm = f >> 2, ch = f & 3;
-                *reinterpret_cast<float4 *>(&As[buf][mm * BK + 4 * (ch ^ ((mm >> 2) & 3))]) = ra[r];
+                *reinterpret_cast<wg_f4 *>(&As[buf * A_TILE + mm * BK + 4 * (ch ^ ((mm >> 2) & 3))]) = ra[r];
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int f = tid + kThreads * r;
+        } else {
+            const int f = tid + kThreads * (r - 4);
             const int nn = f >> 2, ch = f & 3;
-            *reinterpret_cast<float4 *>(&Bs[buf][nn * BK + 4 * (ch ^ ((nn >> 2) & 3))]) = rb[r];
+            *reinterpret_cast<wg_f4 *>(&Bs[buf * B_TILE + nn * BK + 4 * (ch ^ ((nn >> 2) & 3))]) = rb[r - 4];
         }
     };
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = 2 * ks + h; // this half-wave's 4 consecutive k within the 16-deep tile
-            float4 bf[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int nn = wn * 64 + 32 * u + i;
-                bf[u] = *reinterpret_cast<const float4 *>(&Bs[buf][nn * BK + 4 * (chunk ^ ((nn >> 2) & 3))]);
+    float4 af[2][4], bf[2][2]; // fragment sets (by substep parity)
+    auto read_one = [&](int buf, int ks, int r, int set) { // r: 0..3 -> A, 4..5 -> B
+        const int chunk = 2 * ks + h; // this half-wave's 4 consecutive k within the 16-deep tile
+        if (WG_ABLATE & 4) { if (r < 4) af[set][r] = make_float4(buf, ks, r, set); else bf[set][r - 4] = make_float4(buf, ks, r, set); return; }
+        if (r < 4) {
+            if constexpr (!TRANS_A) { // af[s]: rows 4i..4i+3 at k = 4*chunk + s
+                af[set][r] = *reinterpret_cast<const float4 *>(&As[buf * A_TILE + (4 * chunk + r) * BM + wm * 128 + 4 * i]);
+            } else { // af[t]: row 32t + i, k = 4*chunk .. +3
+                const int mm = wm * 128 + 32 * r + i;
+                af[set][r] = *reinterpret_cast<const float4 *>(&As[buf * A_TILE + mm * BK + 4 * (chunk ^ ((mm >> 2) & 3))]);
             }
-            if constexpr (!TRANS_A) {
-                float4 af[4]; // af[s]: rows 4i..4i+3 at k = 4*chunk + s
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    af[s] = *reinterpret_cast<const float4 *>(&As[buf][(4 * chunk + s) * BM + wm * 128 + 4 * i]);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(af[s], t), comp(bf[u], s), acc[t][u], 0, 0, 0);
-            } else {
-                float4 af[4]; // af[t]: row 32t + i, k = 4*chunk .. +3
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int mm = wm * 128 + 32 * t + i;
-                    af[t] = *reinterpret_cast<const float4 *>(&As[buf][mm * BK + 4 * (chunk ^ ((mm >> 2) & 3))]);
-                }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(af[t], s), comp(bf[u], s), acc[t][u], 0, 0, 0);
-            }
+        } else {
+            const int nn = wn * 64 + 32 * (r - 4) + i;
+            bf[set][r - 4] = *reinterpret_cast<const float4 *>(&Bs[buf * B_TILE + nn * BK + 4 * (chunk ^ ((nn >> 2) & 3))]);
         }
+    };
+    auto mfma_slot = [&](int set, int j) { // j: 0..31 -> (s, t, u); consecutive MFMAs hit different accumulators
+        const int sidx = j >> 3, t = (j >> 1) & 3, u = j & 1;
+        const float a = TRANS_A ? comp(af[set][t], sidx) : comp(af[set][sidx], t);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, comp(bf[set][u], sidx), acc[t][u], 0, 0, 0);
     };
 
     const uint32_t nk = (g.K + BK - 1) / BK;
-    if (nk > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
-    for (uint32_t kt = 0; kt < nk; ++kt) {
+    auto tile_body = [&](uint32_t kt, auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
         const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tile((kt + 1) * BK);
-        compute(buf);
-        if (more) store_tile(buf ^ 1);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { // substep 0
+            mfma_slot(0, j);
+            if (j < 6) read_one(buf, 1, j, 1);
+            if (NEXT && j >= 8 && j < 14) load_one((kt + 1) * BK, j - 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { // substep 1
+            mfma_slot(1, j);
+            if (NEXT && j == 0) wait_staged(); // issued >= 18 MFMA slots (>= 1100 cycles) ago
+            if (NEXT && j < 6) store_one(buf ^ 1, j);
+            if (NEXT && j == 7) __syncthreads();
+            if (NEXT && j >= 8 && j < 14) read_one(buf ^ 1, 0, j - 8, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (nk > 0) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) load_one(0, r);
+        wait_staged();
+#pragma unroll
+        for (int r = 0; r < 6; ++r) store_one(0, r);
         __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 6; ++r) read_one(0, 0, r, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (uint32_t kt = 0; kt + 1 < nk; ++kt) tile_body(kt, std::true_type{});
+        tile_body(nk - 1, std::false_type{});
     }
 
     // epilogue. C/D map of the 32x32 MFMA: lane l, register e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const uint32_t col = n0 + wn * 64 + 32 * u + i;
-        if (col >= g.N) continue;
+        if (EDGE && col >= g.N) continue;
         float *cc = C + (uint64_t)col * g.ldc;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) { // e >> 2
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t row = m0 + wm * 128 + 32 * gq + 16 * h + 4 * q;
-                    if (row < g.M)
+                    if (!EDGE || row < g.M)
                         *reinterpret_cast<float4 *>(cc + row) =
                             make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]);
                 }
@@ -197,13 +218,194 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t row = m0 + wm * 128 + 32 * t + 8 * gq + 4 * h;
-                    if (row < g.M)
+                    if (!EDGE || row < g.M)
                         *reinterpret_cast<float4 *>(cc + row) =
                             make_float4(acc[t][u][4 * gq + 0], acc[t][u][4 * gq + 1], acc[t][u][4 * gq + 2], acc[t][u][4 * gq + 3]);
                 }
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Interior tiles: no staging registers at all. Each k-tile (A 16 KiB + B 8 KiB) is brought in by LDS-DMA
+// (global_load_lds_dwordx4: 16 B per lane, 1 KiB per wave-instruction) into a ring of 3 LDS slots, TWO tiles ahead of
+// its use, and awaited with a counted `s_waitcnt vmcnt(6)` (this wave's 6 pieces of the newest tile may stay in flight).
+// That is a full k-tile (~8000 cycles with two workgroups per CU) of lead time -- first-touch MALL/HBM latency was
+// measured to exceed the ~2600 cycles a register-staged prefetch of the next tile can give within 256 VGPRs.
+//   A (NN) slot image [16 k][256 m]  == the global layout: one DMA piece per k-row;
+//   B / TN-A slot image [row][16 k] (64-byte rows) with the chunk swizzle c ^ ((row>>2)&3) applied to the SOURCE address.
+// The DMA is issued from inline asm so that hipcc does not serialise it against the LDS reads of the other slots.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SLOT_FLOATS = A_TILE + B_TILE; // 6144 floats = 24 KiB
+constexpr int NRING = 3;
+
+__device__ __forceinline__ void dma16(uint32_t voff, const void *sbase, uint32_t lds_dst) {
+    if (WG_ABLATE & 2) return;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst));
+}
+
+template <bool TRANS_A>
+__device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem, const float *A, const float *B, float *C,
+                                                  uint32_t m0, uint32_t n0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i = lane & 31, h = lane >> 5;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    // ---- DMA addressing: this wave stages 4 pieces of A and 2 of B per k-tile ----
+    uint32_t a_voff[4], b_voff[2];
+    const float *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
+    if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if constexpr (!TRANS_A) { // piece = k-row 4*wave + q: 256 consecutive m, lane -> m = 4*lane
+            a_voff[q] = ((4u * wave + q) * g.lda + 4u * lane) * 4u;
+        } else { // piece P = 4*wave + q: rows 16P..16P+15, lane -> row 16P + (lane>>2), chunk (lane&3) ^ (lane>>4)
+            const uint32_t row = 16u * (4u * wave + q) + (lane >> 2);
+            a_voff[q] = (row * g.lda + 4u * ((lane & 3) ^ (lane >> 4))) * 4u;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t row = 16u * (2u * wave + q) + (lane >> 2);
+        b_voff[q] = (row * g.ldb + 4u * ((lane & 3) ^ (lane >> 4))) * 4u;
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float *)smem;
+    auto dma_piece = [&](uint32_t slot, uint32_t k0, int p) { // p: 0..3 -> A pieces, 4..5 -> B pieces
+        const uint32_t sl = lds_base + slot * (SLOT_FLOATS * 4);
+        if (p < 4) {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(sl + (4 * wave + p) * 1024);
+            if constexpr (TRANS_A) dma16(a_voff[p], a_base + k0, dst);
+            else dma16(a_voff[p], a_base + (uint64_t)k0 * g.lda, dst);
+        } else {
+            const uint32_t dst = __builtin_amdgcn_readfirstlane(sl + A_TILE * 4 + (2 * wave + (p - 4)) * 1024);
+            dma16(b_voff[p - 4], b_base + k0, dst);
+        }
+    };
+
+    float4 af[2][4], bf[2][2]; // fragment sets (by substep parity)
+    auto read_one = [&](uint32_t slot, int ks, int r, int set) { // r: 0..3 -> A, 4..5 -> B
+        const float *As = smem + slot * SLOT_FLOATS;
+        const float *Bs = As + A_TILE;
+        const int chunk = 2 * ks + h;
+        if (WG_ABLATE & 4) { if (r < 4) af[set][r] = make_float4(slot, ks, r, set); else bf[set][r - 4] = make_float4(slot, ks, r, set); return; }
+        if (r < 4) {
+            if constexpr (!TRANS_A) {
+                af[set][r] = *reinterpret_cast<const float4 *>(&As[(4 * chunk + r) * BM + wm * 128 + 4 * i]);
+            } else {
+                const int mm = wm * 128 + 32 * r + i;
+                af[set][r] = *reinterpret_cast<const float4 *>(&As[mm * BK + 4 * (chunk ^ ((mm >> 2) & 3))]);
+            }
+        } else {
+            const int nn = wn * 64 + 32 * (r - 4) + i;
+            bf[set][r - 4] = *reinterpret_cast<const float4 *>(&Bs[nn * BK + 4 * (chunk ^ ((nn >> 2) & 3))]);
+        }
+    };
+    auto mfma_slot = [&](int set, int j) {
+        const int sidx = j >> 3, t = (j >> 1) & 3, u = j & 1;
+        const float a = TRANS_A ? comp(af[set][t], sidx) : comp(af[set][sidx], t);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, comp(bf[set][u], sidx), acc[t][u], 0, 0, 0);
+    };
+
+    const uint32_t nk = g.K / BK; // interior => K % 16 == 0, nk >= 1
+    // one k-tile on ring slot `cur`; `nxt` holds tile t+1; the DMA of tile t+2 goes to `dst`
+    auto tile_body = [&](uint32_t cur, uint32_t nxt, uint32_t dst, uint32_t k_dma, auto do_dma, auto has_next) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { // substep 0
+            mfma_slot(0, j);
+            if (j < 6) read_one(cur, 1, j, 1);
+            if constexpr (decltype(do_dma)::value) {
+                if (j >= 8 && ((j - 8) & 3) == 0 && (j - 8) / 4 < 6) dma_piece(dst, k_dma, (j - 8) / 4); // slots 8,12,...,28
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 32; ++j) { // substep 1
+            mfma_slot(1, j);
+            if constexpr (decltype(has_next)::value) {
+                if (j == 3) { // tile t+1 has landed (it was issued a whole tile ago); tile t+2's 6 pieces may stay in flight
+                    if constexpr (decltype(do_dma)::value) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (j >= 4 && j < 10) read_one(nxt, 0, j - 4, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto next_slot = [](uint32_t x) { return x + 1 == NRING ? 0u : x + 1; };
+
+    for (uint32_t t = 0; t < 2 && t < nk; ++t) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) dma_piece(t, t * BK, p);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 6; ++r) read_one(0, 0, r, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    uint32_t cur = 0, t = 0;
+    for (; t + 2 < nk; ++t) {
+        const uint32_t nxt = next_slot(cur);
+        tile_body(cur, nxt, next_slot(nxt), (t + 2) * BK, std::true_type{}, std::true_type{});
+        cur = nxt;
+    }
+    for (; t + 1 < nk; ++t) {
+        const uint32_t nxt = next_slot(cur);
+        tile_body(cur, nxt, 0, 0, std::false_type{}, std::true_type{});
+        cur = nxt;
+    }
+    tile_body(cur, cur, 0, 0, std::false_type{}, std::false_type{});
+
+    // epilogue (interior: no predication)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        float *cc = C + (uint64_t)(n0 + wn * 64 + 32 * u + i) * g.ldc;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            if constexpr (!TRANS_A) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4 *>(cc + m0 + wm * 128 + 32 * gq + 16 * h + 4 * q) =
+                        make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]);
+            } else {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    *reinterpret_cast<float4 *>(cc + m0 + wm * 128 + 32 * t4 + 8 * gq + 4 * h) =
+                        make_float4(acc[t4][u][4 * gq + 0], acc[t4][u][4 * gq + 1], acc[t4][u][4 * gq + 2], acc[t4][u][4 * gq + 3]);
+            }
+        }
+    }
+}
+
+template <bool TRANS_A>
+__global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float smem[NRING * SLOT_FLOATS]; // 72 KiB: 3 DMA slots, or 2 staged buffers on edge tiles
+    const uint32_t tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    const uint32_t m0 = tm * BM, n0 = tn * BN;
+    const uint32_t z = blockIdx.y;
+    const float *A = g.a + z * g.a_batch;
+    const float *B = g.b + z * g.b_batch;
+    float *C = g.c + z * g.c_batch;
+    // workgroup-uniform: the whole tile is inside the matrices, K is a whole number of k-tiles, and 32-bit DMA offsets suffice
+    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BK == 0) && g.K >= (uint32_t)BK && g.dma_ok;
+    if (interior) gemm_f32_tile_dma<TRANS_A>(g, smem, A, B, C, m0, n0);
+    else gemm_f32_tile<TRANS_A, true>(g, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
 }
 
 } // namespace
@@ -219,6 +421,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.M = M; g.N = N; g.K = K;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
+    g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
     const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
     const dim3 grid((uint32_t)tiles, nmats), block(kThreads);
