@@ -205,9 +205,12 @@ class GemvWorkload(Workload):
     metric = "gemv_gbs"
     unit = "GB/s"
 
-    def __init__(self, name, R, C, trans):
+    def __init__(self, name, R, C, trans, graph_batch=0):
         self.name, self.R, self.C, self.trans = name, R, C, trans
         self.kernel = "gemv_t_kernel" if trans else "gemv_n_kernel"
+        # graph_batch > 0: the dispatch is launch-bound (a few MB): record `graph_batch` dispatches into ONE command buffer
+        # (a hipGraph) and replay it -- a step is then one Queue::submit of that buffer
+        self.graph_batch = graph_batch
 
     def setup(self, wg, gpu, rank, world):
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
@@ -222,18 +225,33 @@ class GemvWorkload(Workload):
         self.enc = gpu.device().create_command_encoder()
         self.pass_ = self.enc.compute_pass("bench", None)
         self.variant = wg.GemvVariant.GemvTr if self.trans else wg.GemvVariant.Gemv
+        self.cmdbuf = None
+        if self.graph_batch:
+            self.step()  # sizes the split-K workspace before recording
+            gpu.sync()
+            enc = gpu.device().create_command_encoder(record=True)
+            with enc.compute_pass("recorded", None) as p:
+                for _ in range(self.graph_batch):
+                    self.gemv.dispatch_generic(gpu.device(), self.shapes, p, self.out, self.m, self.v, self.variant)
+            self.cmdbuf = enc.finish()
 
     def step(self):
-        self.gemv.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.out, self.m, self.v, self.variant)
+        if self.cmdbuf is not None:
+            self.gpu.queue().submit([self.cmdbuf])
+        else:
+            self.gemv.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.out, self.m, self.v, self.variant)
 
     def _bytes(self):
         return 4.0 * (self.R * self.C + self.R + self.C)  # matrix + vector + result
 
     def units_per_step(self):
-        return self._bytes() * self.world  # every rank streams its own matrix (independent units, no collective)
+        return self._bytes() * self.world * max(self.graph_batch, 1)  # every rank streams its own matrix (no collective)
 
     def algorithmic_per_launch(self):
         return self._bytes()
+
+    def launches_per_step(self):
+        return max(self.graph_batch, 1)
 
     def check(self):
         gpu = self.gpu
@@ -327,6 +345,62 @@ class ReduceWorkload(Workload):
                           f"mean of {reps} runs, {dt * 1e3:.1f} ms each"}
 
 
+class OpAssignWorkload(Workload):
+    bound = "hbm"
+    metric = "op_assign_gbs"
+    unit = "GB/s"
+    kernel = "op_assign_f32_vec"
+
+    def __init__(self, name, n):
+        self.name, self.n = name, n
+
+    def setup(self, wg, gpu, rank, world):
+        self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
+        self.a = device_random(wg, gpu, (self.n,), np.float32, 0xF000 + rank)
+        self.b = device_random(wg, gpu, (self.n,), np.float32, 0xF100 + rank)
+        self.op = wg.OpAssign.new(gpu.device(), wg.OpAssignVariant.Add)
+        self.shapes = wg.ViewShapeBuffers()
+        self.enc = gpu.device().create_command_encoder()
+        self.pass_ = self.enc.compute_pass("bench", None)
+        self.a0 = self.a.read(gpu.device())[:4096].copy()
+        self.b0 = self.b.read(gpu.device())[:4096].copy()
+        self.count = 0
+
+    def step(self):
+        self.op.dispatch(self.gpu.device(), self.shapes, self.pass_, self.a, self.b)
+        self.count += 1
+
+    def _bytes(self):
+        return 12.0 * self.n  # read a, read b, write a
+
+    def units_per_step(self):
+        return self._bytes() * self.world
+
+    def algorithmic_per_launch(self):
+        return self._bytes()
+
+    def check(self):
+        exp = self.a0.copy()
+        for _ in range(self.count):
+            exp = exp + self.b0
+        got = self.a.read(self.gpu.device())[:4096]
+        assert got.tobytes() == exp.tobytes(), "bench sanity check failed (op_assign is not bit-exact)"
+
+    def cpu_baseline(self, budget_s):
+        from oracle import wgsl_oracle as wo
+        C = wo.CLib()
+        n = min(self.n, 1 << 26)
+        a, b = rand_block(6, n, np.float32), rand_block(7, n, np.float32)
+        C.op_assign(wo.ADD, a, wo.Shape(n), b, wo.Shape(n))
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min(budget_s, 5.0) or reps < 3:
+            C.op_assign(wo.ADD, a, wo.Shape(n), b, wo.Shape(n))
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": 12.0 * n / dt / 1e9, "unit": "GB/s", "cores": C.num_threads(), "kind": "port",
+                "sample": f"oracle/wgsl_oracle.c op_assign(Add) on {n} elements, mean of {reps} runs, {dt * 1e3:.1f} ms each"}
+
+
 WORKLOADS = {
     "gemm_f32_4096": lambda: GemmWorkload("gemm_f32_4096", 4096, 4096, 4096, "f32"),
     "gemm_f16_8192": lambda: GemmWorkload("gemm_f16_8192", 8192, 8192, 8192, "f16"),
@@ -334,12 +408,15 @@ WORKLOADS = {
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
     "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
+    "gemv_f32_1024_graph": lambda: GemvWorkload("gemv_f32_1024_graph", 1024, 1024, False, graph_batch=64),
     "reduce_f32_4096x65536": lambda: ReduceWorkload("reduce_f32_4096x65536", 4096, 65536),
+    "op_assign_f32_256M": lambda: OpAssignWorkload("op_assign_f32_256M", 1 << 28),
 }
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536"]
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536",
+             "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
 def load_traffic(workload: str):
@@ -351,11 +428,21 @@ def load_traffic(workload: str):
         return None
 
 
-def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget):
+def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0):
+    """Times EXACTLY `steps` steps (after `warmup` untimed ones). With min_seconds > 0 (secondary configs only) `steps` is raised
+    so that the timed region lasts at least that long: millisecond kernels timed for a few tens of ms still see the clocks
+    ramping (measured: f32 GEMM 140 TF over 30 ms vs 148 TF sustained)."""
     w = WORKLOADS[name]()
     w.setup(wg, gpu, rank, world)
-    for _ in range(warmup):
+    t_w = time.perf_counter()
+    for _ in range(max(warmup, 1)):
         w.step()
+    gpu.sync()
+    if min_seconds > 0:
+        per_step = max((time.perf_counter() - t_w) / max(warmup, 1), 1e-6)
+        steps = int(min(max(steps, min_seconds / per_step), 20000))
+        for _ in range(min(steps, 50)):  # a little more warm-up at the final cadence
+            w.step()
     ts = wg.GpuTimestamps.new(gpu.device(), 2)
     barrier()
     gpu.sync()
@@ -372,7 +459,7 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     kernel_ms = (ev[1] - ev[0]) / (steps * launches)  # HIP events on the stream the kernels run on
     if not os.environ.get("WG_BENCH_NO_CHECK"):
         w.check()
-    res = {"workload": w, "elapsed": elapsed, "kernel_ms": kernel_ms}
+    res = {"workload": w, "elapsed": elapsed, "kernel_ms": kernel_ms, "steps": steps}
     res["cpu"] = w.cpu_baseline(cpu_budget) if (with_cpu and rank == 0 and world == 1) else None
     return res
 
@@ -395,6 +482,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")
+    ap.add_argument("--secondary-seconds", type=float, default=0.6, help="minimum timed duration of each secondary config")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
 
@@ -450,11 +538,11 @@ def main():
             if name == args.workload:
                 continue
             try:
-                r = run_workload(wg, gpu, name, max(10, min(args.steps, 50)), min(args.warmup, 5), rank, world, barrier,
-                                 not args.no_cpu_baseline, min(args.cpu_budget, 6.0))
-                v, rf = summarize(r["workload"], r["elapsed"], r["kernel_ms"], max(10, min(args.steps, 50)), world)
+                r = run_workload(wg, gpu, name, 10, 3, rank, world, barrier, not args.no_cpu_baseline, min(args.cpu_budget, 5.0),
+                                 min_seconds=args.secondary_seconds)
+                v, rf = summarize(r["workload"], r["elapsed"], r["kernel_ms"], r["steps"], world)
                 others.append({"workload": name, "metric": r["workload"].metric, "value": round(v, 3), "unit": r["workload"].unit,
-                               "dtype": r["workload"].dtype, "roofline": rf, "cpu_baseline": r["cpu"]})
+                               "dtype": r["workload"].dtype, "steps": r["steps"], "roofline": rf, "cpu_baseline": r["cpu"]})
             except Exception as e:  # a secondary config must never take the headline down with it
                 others.append({"workload": name, "error": f"{type(e).__name__}: {e}"})
 

@@ -327,6 +327,8 @@ F16_SHAPES = [
     # M,   K,   N, mats      (multiples of 256/64 -> MFMA fast path; anything else -> generic path)
     (256, 64, 256, 1), (512, 128, 256, 1), (256, 192, 768, 2), (1024, 1024, 512, 1),
     (36, 20, 28, 1), (260, 72, 132, 1), (256, 60, 256, 1), (64, 1024, 64, 3),
+    # ragged edge tiles on the MFMA path (M, N multiples of 8 but not of 256; K multiple of 32)
+    (8, 32, 8, 1), (264, 96, 520, 1), (1000, 256, 776, 2), (4096 + 8, 64, 256 - 8, 1), (248, 32, 4104, 1),
 ]
 
 

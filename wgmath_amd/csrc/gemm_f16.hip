@@ -20,7 +20,8 @@
 //     16-byte store.
 //   * workgroup ids are remapped into 16 x 16 super-tiles (the 256 workgroups resident at once), each XCD working
 //     on a 4 x 8 patch of it, so that A/B panels are shared in the XCD's L2 and across XCDs in the 256 MiB MALL.
-// Shapes the fast path does not cover (M, N % 256, K % 64, misaligned views) take a small generic kernel.
+// Ragged M, N (any multiple of 8) stay on this path: DMA source rows are clamped, the epilogue is predicated.
+// Shapes it does not cover (M or N % 8, K % 32, misaligned views) take a small generic kernel.
 #include "wg_internal.hpp"
 
 #include <type_traits>
@@ -153,9 +154,17 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
         const uint32_t P = PCS * wave + q;
         const int chunk = (lane & 3) ^ (lane >> 4);
         const uint32_t row = 16u * P + (lane >> 2);
-        b_voff[q] = (row * g.ldb + 8u * chunk) * 2u;
-        if constexpr (TRANS_A) a_voff[q] = (row * g.lda + 8u * chunk) * 2u;
-        else a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + 128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3)) * 2u;
+        // ragged edge tiles: rows / row-pieces past the end of the matrix are CLAMPED to the last valid one (valid memory,
+        // results discarded by the predicated epilogue) -- computed once here, so the K loop is identical for every tile
+        const uint32_t rb = min(row, g.N - 1u - n0);
+        b_voff[q] = (rb * g.ldb + 8u * chunk) * 2u;
+        if constexpr (TRANS_A) {
+            const uint32_t ra = min(row, g.M - 1u - m0);
+            a_voff[q] = (ra * g.lda + 8u * chunk) * 2u;
+        } else {
+            const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3), g.M - 8u - m0); // M % 8 == 0
+            a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u;
+        }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
     // point p (0 .. 2*PCS-1) of a half-step issues ONE DMA piece: A piece p>>1 when p is even, B piece p>>1 when odd
@@ -297,9 +306,13 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
 
     // ---- epilogue: f32 -> f16 (RNE), 16-byte stores. C/D map of the 32x32 MFMA: register e -> row (e&3) + 8 (e>>2) + 4 hk ----
     // rows of tile (T, tb): m = 64 T + 16 gq + 8 hk + 4 (tb ^ (gq>>1)) + (e&3)  => the pair (tb = gq>>1, tb = 1 - (gq>>1)) is 8 consecutive rows
+    const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        _Float16 *cc = C + (uint64_t)(n0 + (uint32_t)WN_COLS * wn + 32u * u + i32) * g.ldc + m0 + 128u * wm + 8u * hk;
+        const uint32_t col = n0 + (uint32_t)WN_COLS * wn + 32u * u + i32;
+        if (!full_tile && col >= g.N) continue;
+        const uint32_t row0 = m0 + 128u * wm + 8u * hk;
+        _Float16 *cc = C + (uint64_t)col * g.ldc + row0;
 #pragma unroll
         for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
                     v[q] = (_Float16)acc[T][lo][u][4 * gq + q];
                     v[4 + q] = (_Float16)acc[T][hi][u][4 * gq + q];
                 }
-                *reinterpret_cast<half8_t *>(cc + 64 * T + 16 * gq) = v;
+                if (full_tile || row0 + 64 * T + 16 * gq < g.M) // 8 consecutive rows, all in or all out (M % 8 == 0)
+                    *reinterpret_cast<half8_t *>(cc + 64 * T + 16 * gq) = v;
             }
     }
 }
@@ -387,11 +401,13 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
-    const bool fast = (M % BM == 0) && (N % BN == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
-                      (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok;
+    // 32-bit DMA offsets within a tile: rows * ld * 2 bytes must stay below 2^31
+    const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);
+    const bool fast = (M % 8 == 0) && (N % 8 == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
+                      (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
     if (fast) {
-        g.tiles_m = M / BM;
-        g.tiles_n = N / BN;
+        g.tiles_m = (M + BM - 1) / BM;
+        g.tiles_n = (N + BN - 1) / BN;
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
         const dim3 grid((uint32_t)tiles, nmats);
