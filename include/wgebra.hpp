@@ -295,4 +295,13 @@ struct OpAssign {
     }
 };
 
+// extension: y = fma(alpha, x, y) (the north-star's "Axpy"; the reference has only OpAssign)
+struct Axpy {
+    static Axpy from_device(const Device &) { return {}; }
+    template <typename T>
+    void dispatch(const Device &, const ViewShapeBuffers &, ComputePass &pass, float alpha, GpuTensorView<T> in_out_y, GpuTensorView<T> in_x) const {
+        check(wg_axpy(pass.ctx(), alpha, dtype_of<T>::value, in_out_y.buffer(), in_out_y.shape(), in_x.buffer(), in_x.shape()));
+    }
+};
+
 } // namespace wgebra

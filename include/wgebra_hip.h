@@ -195,6 +195,13 @@ int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
 int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype,
                  wg_buf *a, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
 
+/*
+ * Extension (the north-star's "Axpy" -- the reference has no such operator, only OpAssign):
+ * y[i] = fma(alpha, x[i], y[i]), i < y.size[0], one rounding per element. alpha = +1 / -1 reproduce WG_OP_ADD / WG_OP_SUB
+ * (as `y += x` / `y -= x`) bit for bit. Same indexing, errors and skips as wg_op_assign. f16: computed in f32, rounded once.
+ */
+int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y_shape, const wg_buf *x, wg_view_shape x_shape);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* record / replay: CommandEncoder -> finish() -> CommandBuffer -> Queue::submit, as a hipGraph      */
 /* ------------------------------------------------------------------------------------------------ */

@@ -522,6 +522,20 @@ int wgo_op_assign(int op, float *a, uint64_t a_len, wgo_shape sa, const float *b
     return oob_any ? WGO_ERR_OOB : WGO_OK;
 }
 
+/* Extension checked by the oracle too (no reference counterpart): y[i] = fmaf(alpha, x[i], y[i]), op_assign's indexing. */
+int wgo_axpy(float alpha, float *y, uint64_t y_len, wgo_shape sy, const float *x, uint64_t x_len, wgo_shape sx) {
+    if (sy.nrows != sx.nrows) return WGO_ERR_DIM;
+    if (y_len == 0 || x_len == 0) return WGO_OK;
+    int oob_any = 0;
+#pragma omp parallel for schedule(static) reduction(| : oob_any)
+    for (int64_t i = 0; i < (int64_t)sy.nrows; ++i) {
+        uint32_t iy = sh_iv(sy, (uint32_t)i), ix = sh_iv(sx, (uint32_t)i);
+        if ((uint64_t)iy >= y_len || (uint64_t)ix >= x_len) { oob_any |= 1; continue; }
+        y[iy] = fmaf(alpha, x[ix], y[iy]);
+    }
+    return oob_any ? WGO_ERR_OOB : WGO_OK;
+}
+
 /* ------------------------------------------------------------------------------------- */
 int wgo_num_threads(void) {
 #ifdef _OPENMP

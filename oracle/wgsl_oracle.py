@@ -309,6 +309,8 @@ class CLib:
         self.lib.wgo_reduce.argtypes = [ci, fp, u64, _CShape, fp, u64]
         self.lib.wgo_reduce_batched.argtypes = [ci, fp, u64, _CShape, fp, u64]
         self.lib.wgo_op_assign.argtypes = [ci, fp, u64, _CShape, fp, u64, _CShape]
+        self.lib.wgo_axpy.argtypes = [ctypes.c_float, fp, u64, _CShape, fp, u64, _CShape]
+        self.lib.wgo_axpy.restype = ci
         for f in ("wgo_gemm", "wgo_gemv", "wgo_reduce", "wgo_reduce_batched", "wgo_op_assign", "wgo_num_threads"):
             getattr(self.lib, f).restype = ci
         self.lib.wgo_set_num_threads.argtypes = [ci]
@@ -351,6 +353,9 @@ class CLib:
 
     def op_assign(self, op, a, sa, b, sb):
         self._chk(self.lib.wgo_op_assign(op, *self._p(a), _cshape(sa), *self._p(b), _cshape(sb)), "OpAssign")
+
+    def axpy(self, alpha, y, sy, x, sx):
+        self._chk(self.lib.wgo_axpy(ctypes.c_float(alpha), *self._p(y), _cshape(sy), *self._p(x), _cshape(sx)), "Axpy")
 
 
 # --------------------------------------------------------------------------------------------

@@ -387,3 +387,31 @@ def test_gemm_f16_identity_asymmetric(gpu, tr):
     run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1p, m2, variant))
     got = out.read(gpu.device()).reshape(M, N, order="F")
     assert np.array_equal(got, B[perm]), f"mismatch at {np.argwhere(got != B[perm])[:5]}"
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_axpy(gpu, oracle_c, dtype):
+    """Extension: y = fma(alpha, x, y); alpha = +-1 must give the bits of OpAssign Add / Sub."""
+    wg, wo = _wg(), _wo()
+    n, off_y, off_x = 100003, 3, 8
+    rng = np.random.default_rng(11)
+    py = (rng.random(n + 16, dtype=np.float32) * 4 - 2).astype(dtype)
+    px = (rng.random(n + 16, dtype=np.float32) * 4 - 2).astype(dtype)
+    shapes, axpy = wg.ViewShapeBuffers(), wg.Axpy.from_device(gpu.device())
+    for alpha in (1.0, -1.0, 0.0, 0.3, -2.5e3):
+        ty, tx = upload(gpu, (n + 16,), py, dtype), upload(gpu, (n + 16,), px, dtype)
+        run_pass(gpu, lambda p: axpy.dispatch(gpu.device(), shapes, p, alpha, ty.rows(off_y, n), tx.rows(off_x, n)))
+        got = ty.read(gpu.device())
+        exp32 = py.astype(np.float32)
+        oracle_c.axpy(alpha, exp32, wo.Shape(n, 1, 1, 1, 1, off_y), px.astype(np.float32), wo.Shape(n, 1, 1, 1, 1, off_x))
+        with np.errstate(over="ignore"):
+            exp = exp32.astype(dtype)
+        U.assert_bits_equal(got, exp, f"axpy alpha={alpha} {np.dtype(dtype).name}")
+        if alpha in (1.0, -1.0):
+            t2 = upload(gpu, (n + 16,), py, dtype)
+            op = wg.OpAssign.new(gpu.device(), wg.OpAssignVariant.Add if alpha > 0 else wg.OpAssignVariant.Sub)
+            run_pass(gpu, lambda p: op.dispatch(gpu.device(), shapes, p, t2.rows(off_y, n), tx.rows(off_x, n)))
+            U.assert_bits_equal(got, t2.read(gpu.device()), f"axpy(alpha={alpha}) vs OpAssign")
+    with pytest.raises(wg.DimensionMismatch, match="Axpy: dimension mismatch."):
+        enc = gpu.device().create_command_encoder()
+        axpy.dispatch(gpu.device(), shapes, enc.compute_pass("e", None), 1.0, ty.rows(0, 8), tx.rows(0, 12))

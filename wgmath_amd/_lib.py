@@ -89,6 +89,7 @@ def _load() -> ctypes.CDLL:
         "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
+        "wg_axpy": (ci, [vp, ctypes.c_float, ci, vp, S, vp, S]),
         "wg_encoder_begin": (ci, [vp]),
         "wg_encoder_finish": (ci, [vp, pvp]),
         "wg_queue_submit": (ci, [vp, vp]),

@@ -183,4 +183,19 @@ int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype, wg_buf *a
     return wgk_op_assign(ctx, (int)op, dtype, (void *)elem_ptr(a, va.offset, dtype), elem_ptr(b, vb.offset, dtype), n);
 }
 
+int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y_shape, const wg_buf *x, wg_view_shape x_shape) {
+    const wg_buf *bufs[2] = { y, x };
+    if (int rc = check_common("Axpy", ctx, dtype, bufs, 2)) return rc;
+    if (y_shape.size[0] != x_shape.size[0])
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "Axpy: dimension mismatch. (y has %u rows, x has %u)", y_shape.size[0], x_shape.size[0]);
+    if (y->bytes == 0 || x->bytes == 0) return WG_OK;
+    const uint32_t n = y_shape.size[0];
+    if (n == 0) return WG_OK;
+    const View vy = { n, 1, 1, 1, 1, y_shape.offset }, vx = { n, 1, 1, 1, 1, x_shape.offset };
+    if (int rc = check_bounds("Axpy", "y", vy, y, dtype)) return rc;
+    if (int rc = check_bounds("Axpy", "x", vx, x, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_op_assign(ctx, 5 /* axpy */, dtype, (void *)elem_ptr(y, vy.offset, dtype), elem_ptr(x, vx.offset, dtype), n, alpha);
+}
+
 } // extern "C"

@@ -10,11 +10,12 @@
 
 namespace {
 
-enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_DIV = 3, OP_COPY = 4 };
+enum { OP_ADD = 0, OP_SUB = 1, OP_MUL = 2, OP_DIV = 3, OP_COPY = 4, OP_AXPY = 5 /* a = fma(alpha, b, a): wg_axpy */ };
 
 template <int OP>
-__device__ __forceinline__ float apply(float a, float b) {
-    if constexpr (OP == OP_ADD) return __fadd_rn(a, b);
+__device__ __forceinline__ float apply(float a, float b, float alpha) {
+    if constexpr (OP == OP_AXPY) return fmaf(alpha, b, a);
+    else if constexpr (OP == OP_ADD) return __fadd_rn(a, b);
     else if constexpr (OP == OP_SUB) return __fsub_rn(a, b);
     else if constexpr (OP == OP_MUL) return __fmul_rn(a, b);
     else if constexpr (OP == OP_DIV) return __fdiv_rn(a, b);
@@ -22,8 +23,8 @@ __device__ __forceinline__ float apply(float a, float b) {
 }
 
 template <int OP>
-__device__ __forceinline__ float4 apply4(float4 a, float4 b) {
-    return make_float4(apply<OP>(a.x, b.x), apply<OP>(a.y, b.y), apply<OP>(a.z, b.z), apply<OP>(a.w, b.w));
+__device__ __forceinline__ float4 apply4(float4 a, float4 b, float alpha) {
+    return make_float4(apply<OP>(a.x, b.x, alpha), apply<OP>(a.y, b.y, alpha), apply<OP>(a.z, b.z, alpha), apply<OP>(a.w, b.w, alpha));
 }
 
 #ifndef OPA_UNROLL
@@ -50,7 +51,7 @@ __device__ __forceinline__ void st4(float4 *p, float4 v) {
 // `a`/`b` point at the first element; [head, head + 4*n4) is the 16-byte aligned body, the <= 3 elements before
 // and after it are done by the first lanes of block 0.
 template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const float *b0, uint32_t head, uint32_t n4, uint32_t n) {
+__global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const float *b0, uint32_t head, uint32_t n4, uint32_t n, float alpha) {
     if (blockIdx.x == 0) {
         const uint32_t body_end = head + 4u * n4;
         const uint32_t edge = head + (n - body_end);
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
             const uint32_t i = threadIdx.x < head ? threadIdx.x : body_end + (threadIdx.x - head);
             float vb = b0[i], va = vb;
             if constexpr (OP != OP_COPY) va = a0[i];
-            a0[i] = apply<OP>(va, vb);
+            a0[i] = apply<OP>(va, vb, alpha);
         }
     }
     float4 *a = reinterpret_cast<float4 *>(a0 + head);
@@ -74,38 +75,44 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
             if constexpr (OP != OP_COPY) va[u] = ld4(&a[i + u * stride]);
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) st4(&a[i + u * stride], apply4<OP>(va[u], vb[u]));
+        for (int u = 0; u < kUnroll; ++u) st4(&a[i + u * stride], apply4<OP>(va[u], vb[u], alpha));
     }
     for (; i < n4; i += stride) {
         float4 vb = b[i], va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
-        a[i] = apply4<OP>(va, vb);
+        a[i] = apply4<OP>(va, vb, alpha);
     }
 }
 
 // any alignment; also the head/tail of the vector path
 template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f32_scalar(float *a, const float *b, uint32_t n) {
+__global__ __launch_bounds__(kThreads) void op_assign_f32_scalar(float *a, const float *b, uint32_t n, float alpha) {
     const uint32_t stride = gridDim.x * kThreads;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
         float vb = b[i], va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
-        a[i] = apply<OP>(va, vb);
+        a[i] = apply<OP>(va, vb, alpha);
     }
 }
 
 // f16 (extension): computed in f32 and rounded once; for + - * / that equals the correctly rounded f16 result
 // (24 >= 2*11 + 2 significand bits, so the double rounding is innocuous).
 template <int OP>
-__device__ __forceinline__ __half apply_h(__half a, __half b) {
+__device__ __forceinline__ __half apply_h(__half a, __half b, float alpha) {
     if constexpr (OP == OP_COPY) return b;
-    else return __float2half_rn(apply<OP>(__half2float(a), __half2float(b)));
+    else {
+        float r = apply<OP>(__half2float(a), __half2float(b), alpha);
+        // axpy: keep the f32 rounding of the fma (the stated contract, and what the float4-wide path does); without this
+        // fence hipcc selects v_fma_mixlo_f16 on the scalar path, which rounds the exact result straight to f16.
+        if constexpr (OP == OP_AXPY) asm volatile("" : "+v"(r));
+        return __float2half_rn(r);
+    }
 }
 
 struct alignas(16) half8 { __half h[8]; };
 
 template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const __half *b0, uint32_t head, uint32_t n8, uint32_t n) {
+__global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const __half *b0, uint32_t head, uint32_t n8, uint32_t n, float alpha) {
     if (blockIdx.x == 0) {
         const uint32_t body_end = head + 8u * n8;
         const uint32_t edge = head + (n - body_end);
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const 
             const uint32_t i = threadIdx.x < head ? threadIdx.x : body_end + (threadIdx.x - head);
             __half vb = b0[i], va = vb;
             if constexpr (OP != OP_COPY) va = a0[i];
-            a0[i] = apply_h<OP>(va, vb);
+            a0[i] = apply_h<OP>(va, vb, alpha);
         }
     }
     half8 *a = reinterpret_cast<half8 *>(a0 + head);
@@ -124,17 +131,17 @@ __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const 
         if constexpr (OP != OP_COPY) va = a[i];
         half8 r;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) r.h[k] = apply_h<OP>(va.h[k], vb.h[k]);
+        for (int k = 0; k < 8; ++k) r.h[k] = apply_h<OP>(va.h[k], vb.h[k], alpha);
         a[i] = r;
     }
 }
 template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f16_scalar(__half *a, const __half *b, uint32_t n) {
+__global__ __launch_bounds__(kThreads) void op_assign_f16_scalar(__half *a, const __half *b, uint32_t n, float alpha) {
     const uint32_t stride = gridDim.x * kThreads;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
         __half vb = b[i], va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
-        a[i] = apply_h<OP>(va, vb);
+        a[i] = apply_h<OP>(va, vb, alpha);
     }
 }
 
@@ -147,7 +154,7 @@ inline uint32_t grid_for(uint64_t work_items, int cus) {
 }
 
 template <int OP>
-int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n) {
+int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n, float alpha) {
     const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
     if ((pa & 15) == (pb & 15)) {
         // scalar head up to the 16-byte boundary, vector body, scalar tail
@@ -155,25 +162,25 @@ int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n) {
         if (head > n) head = n;
         uint32_t n4 = (n - head) / 4;
         hipLaunchKernelGGL(op_assign_f32_vec<OP>, dim3(grid_for(n4, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
-                           head, n4, n);
+                           head, n4, n, alpha);
     } else {
-        hipLaunchKernelGGL(op_assign_f32_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n);
+        hipLaunchKernelGGL(op_assign_f32_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
     }
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
 
 template <int OP>
-int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n) {
+int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n, float alpha) {
     const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
     if ((pa & 15) == (pb & 15) && (pa & 1) == 0) {
         uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 2);
         if (head > n) head = n;
         uint32_t n8 = (n - head) / 8;
         hipLaunchKernelGGL(op_assign_f16_vec<OP>, dim3(grid_for(n8, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
-                           head, n8, n);
+                           head, n8, n, alpha);
     } else {
-        hipLaunchKernelGGL(op_assign_f16_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n);
+        hipLaunchKernelGGL(op_assign_f16_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
     }
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
@@ -181,18 +188,19 @@ int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n) {
 
 } // namespace
 
-int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, uint32_t n) {
+int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, uint32_t n, float alpha) {
     if (n == 0) return WG_OK;
 #define WG_CASE(OPV)                                                                              \
     case OPV:                                                                                     \
-        return dtype == WG_F32 ? launch_f32<OPV>(ctx, (float *)a, (const float *)b, n)            \
-                               : launch_f16<OPV>(ctx, (__half *)a, (const __half *)b, n);
+        return dtype == WG_F32 ? launch_f32<OPV>(ctx, (float *)a, (const float *)b, n, alpha)     \
+                               : launch_f16<OPV>(ctx, (__half *)a, (const __half *)b, n, alpha);
     switch (op) {
         WG_CASE(OP_ADD)
         WG_CASE(OP_SUB)
         WG_CASE(OP_MUL)
         WG_CASE(OP_DIV)
         WG_CASE(OP_COPY)
+        WG_CASE(OP_AXPY)
     }
 #undef WG_CASE
     return wg_set_error(WG_ERR_INVALID_ARG, "OpAssign: unknown variant %d", op);

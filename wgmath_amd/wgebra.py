@@ -153,3 +153,21 @@ class OpAssign:
         dt = _common_dtype(a, b)
         check(lib.wg_op_assign(pass_._ctx.handle, int(self.op), dt, a.buffer()._h, a.shape().to_c(), b.buffer()._h,
                                b.shape().to_c()))
+
+
+class Axpy:
+    """Extension: the BLAS axpy the north-star names; the reference only has OpAssign (no scalar).
+    `dispatch(device, shapes, pass, alpha, in_out_y, in_x)`: y[i] = fma(alpha, x[i], y[i]).  alpha = +1 / -1 give the bits of
+    OpAssignVariant.Add / Sub."""
+
+    def __init__(self, device=None):
+        self.device = device
+
+    @staticmethod
+    def from_device(device) -> "Axpy":
+        return Axpy(device)
+
+    def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, alpha: float, in_out_y, in_x) -> None:
+        y, x = as_view(in_out_y, 1), as_view(in_x, 1)
+        dt = _common_dtype(y, x)
+        check(lib.wg_axpy(pass_._ctx.handle, float(alpha), dt, y.buffer()._h, y.shape().to_c(), x.buffer()._h, x.shape().to_c()))
