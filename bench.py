@@ -94,9 +94,10 @@ class GemmWorkload(Workload):
     metric = "gemm_tflops"
     unit = "TFLOP/s"
 
-    def __init__(self, name, M, N, K, dtype):
+    def __init__(self, name, M, N, K, dtype, trans=False):
         self.name, self.M, self.N, self.K = name, M, N, K
         self.dtype = dtype
+        self.trans = trans  # GemmTr: m1 is stored K x M (op(A) = m1^T)
         self.np_dtype = np.float32 if dtype == "f32" else np.float16
         self.kernel = "gemm_f32_kernel" if dtype == "f32" else "gemm_f16_kernel"
 
@@ -104,16 +105,17 @@ class GemmWorkload(Workload):
         from wgmath_amd.sharded import MShardPlan, ShardedGemm
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
         # N-panels: the all-gather of panel i overlaps the GEMM of panel i+1 (only meaningful with > 1 rank)
-        npanels = 1 if world == 1 else max(1, min(8, self.N // 2048))
+        self.dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
+        npanels = 1 if not self.dist_mode else max(1, min(8, self.N // 2048))
         self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels)
         self.Mg = plan.Mg  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
-        self.A = device_random(wg, gpu, (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
+        self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
         self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
         self.gemm = wg.Gemm.from_device(gpu.device())
         self.shapes = wg.ViewShapeBuffers()
         self.torch_out = None
         S = wg.BufferUsages
-        if world == 1:
+        if not self.dist_mode:
             self.C = wg.TensorBuilder.vector(plan.gathered_elems(), S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
         else:
             import torch
@@ -126,16 +128,18 @@ class GemmWorkload(Workload):
         self.pass_ = self.enc.compute_pass("bench", None)
         a_view = self.A.as_embedded_view(3)
 
+        variant = wg.GemmVariant.GemmTr if self.trans else wg.GemmVariant.Gemm
+
         def local_gemm(out_shape, a_shape, b_shape):
-            self.gemm.dispatch(gpu.device(), self.shapes, self.pass_, wg.GpuTensorView(out_shape, self.C, 2), a_view,
-                               wg.GpuTensorView(b_shape, self.B, 2))
+            self.gemm.dispatch_generic(gpu.device(), self.shapes, self.pass_, wg.GpuTensorView(out_shape, self.C, 2), a_view,
+                                       wg.GpuTensorView(b_shape, self.B, 2), variant)
 
         def all_gather(start, count, rk):
             import torch.distributed as dist
             out = self.torch_out[start:start + world * count]
             return dist.all_gather_into_tensor(out, out[rk * count:(rk + 1) * count], async_op=True)
 
-        self.driver = ShardedGemm(plan, rank, local_gemm, all_gather, wait=lambda w: w.wait())
+        self.driver = ShardedGemm(plan, rank, local_gemm, all_gather, wait=lambda w: w.wait(), always_gather=self.dist_mode)
 
     def step(self):
         self.driver.step()
@@ -157,7 +161,8 @@ class GemmWorkload(Workload):
         cols = np.unique(rng.integers(0, self.N, 24))
         item = np.dtype(self.np_dtype).itemsize
         from wgmath_amd._lib import check, lib
-        A = self.A.read(gpu.device()).reshape(self.Mg, self.K, order="F")[rows].astype(np.float64)
+        A = self.A.read(gpu.device())
+        A = (A.reshape(self.K, self.Mg, order="F").T if self.trans else A.reshape(self.Mg, self.K, order="F"))[rows].astype(np.float64)
 
         def read_range(t, start, n):
             out = np.empty(n, self.np_dtype)
@@ -405,6 +410,8 @@ WORKLOADS = {
     "gemm_f32_4096": lambda: GemmWorkload("gemm_f32_4096", 4096, 4096, 4096, "f32"),
     "gemm_f16_8192": lambda: GemmWorkload("gemm_f16_8192", 8192, 8192, 8192, "f16"),
     "gemm_f16_32768": lambda: GemmWorkload("gemm_f16_32768", 32768, 32768, 32768, "f16"),
+    "gemmtr_f16_8192": lambda: GemmWorkload("gemmtr_f16_8192", 8192, 8192, 8192, "f16", trans=True),
+    "gemmtr_f32_4096": lambda: GemmWorkload("gemmtr_f32_4096", 4096, 4096, 4096, "f32", trans=True),
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
     "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
@@ -495,10 +502,20 @@ def main():
                      f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...`")
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    # WG_BENCH_FORCE_DIST=1: take the torch.distributed/RCCL path even with one rank (single-GPU test of the N > 1 plumbing)
+    dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
+    if dist_mode:
+        # torch bundles its own ROCm runtime (same soname as /opt/rocm's): it must be loaded FIRST so that libwgebra_hip.so
+        # binds to that one copy -- two HIP runtimes in one process cannot both drive the GPU (wgmath_amd checks for this)
+        import torch  # noqa: F401
     import wgmath_amd as wg
 
-    if world > 1:
+    if dist_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -519,7 +536,7 @@ def main():
     main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
                             not args.no_cpu_baseline, args.cpu_budget)
     elapsed = main_res["elapsed"]
-    if world > 1:
+    if dist_mode:
         import torch
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
@@ -557,7 +574,7 @@ def main():
             "roofline": roof, "cpu_baseline": main_cpu, "others": others,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_mode:
         import torch.distributed as dist
         dist.destroy_process_group()
 

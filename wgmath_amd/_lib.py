@@ -109,6 +109,29 @@ def _load() -> ctypes.CDLL:
     return lib
 
 
+def hip_runtime_paths() -> list[str]:
+    """Distinct libamdhip64 images mapped into this process."""
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
+
+
+def assert_single_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64. If this library was loaded BEFORE torch, the
+    process ends up with two HIP runtimes and the second one cannot open the GPU ("no HIP device visible"). Import torch
+    first whenever both are used in one process (bench.py does for --gpus > 1)."""
+    p = hip_runtime_paths()
+    if len(p) > 1:
+        raise ImportError("two HIP runtimes are loaded in this process: " + ", ".join(p) +
+                          ". Import torch BEFORE wgmath_amd so that libwgebra_hip.so binds to torch's bundled runtime.")
+
+
 lib = _load()
 
 _EXC = {WG_ERR_DIM_MISMATCH: DimensionMismatch, WG_ERR_PRECONDITION: PreconditionFailed, WG_ERR_NO_DEVICE: NoDevice}

@@ -97,11 +97,13 @@ class ShardedGemm:
     wait(handle)                             blocks the compute stream on that collective
     """
 
-    def __init__(self, plan: MShardPlan, rank: int, local_gemm: Callable, all_gather: Callable, wait: Callable = lambda h: None):
+    def __init__(self, plan: MShardPlan, rank: int, local_gemm: Callable, all_gather: Callable, wait: Callable = lambda h: None,
+                 always_gather: bool = False):
         if not 0 <= rank < plan.world:
             raise ValueError("rank out of range")
         self.plan, self.rank = plan, rank
         self._gemm, self._gather, self._wait = local_gemm, all_gather, wait
+        self._always_gather = always_gather  # run the collective even with one rank (exercises the plumbing)
 
     def step(self) -> None:
         """All panels: GEMM of panel i, then start its all-gather; the collectives drain while later panels compute."""
@@ -109,7 +111,7 @@ class ShardedGemm:
         handles: List = []
         for p in range(pl.npanels):
             self._gemm(pl.out_shape(p, self.rank), pl.a_shape(), pl.b_panel_shape(p))
-            if pl.world > 1:
+            if pl.world > 1 or self._always_gather:
                 start, _ = pl.panel_range(p)
                 handles.append(self._gather(start, pl.panel_elems, self.rank))
         for h in handles:

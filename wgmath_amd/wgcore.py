@@ -244,6 +244,7 @@ class GpuInstance:
 
     @staticmethod
     def new(device_index: int = 0, stream: Optional[int] = None) -> "GpuInstance":
+        _lib.assert_single_hip_runtime()
         h = ctypes.c_void_p()
         if stream is None:
             check(lib.wg_ctx_create(device_index, ctypes.byref(h)))
