@@ -121,6 +121,8 @@ GEMM_SHAPES = [
     # M,   K,   N, mats
     (4, 4, 4, 1), (8, 4, 12, 1), (36, 20, 28, 1), (256, 256, 128, 1), (260, 264, 132, 1), (512, 48, 260, 2),
     (128, 1024, 64, 1), (1024, 16, 512, 1), (252, 1000, 124, 3),
+    # few output tiles + long K -> split-K path (f32 slabs + ordered reduce), incl. ragged K and batches
+    (256, 4096, 128, 1), (512, 8192, 256, 1), (260, 2064, 132, 2), (64, 16384, 64, 1),
 ]
 
 
@@ -329,6 +331,8 @@ F16_SHAPES = [
     (36, 20, 28, 1), (260, 72, 132, 1), (256, 60, 256, 1), (64, 1024, 64, 3),
     # ragged edge tiles on the MFMA path (M, N multiples of 8 but not of 256; K multiple of 32)
     (8, 32, 8, 1), (264, 96, 520, 1), (1000, 256, 776, 2), (4096 + 8, 64, 256 - 8, 1), (248, 32, 4104, 1),
+    # split-K (few tiles, long K), incl. a K that does not divide evenly and a batch
+    (256, 8192, 256, 1), (512, 4096 + 32, 264, 1), (1024, 16384, 512, 2),
 ]
 
 

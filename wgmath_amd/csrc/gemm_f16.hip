@@ -51,6 +51,9 @@ struct GemmArgs {
     _Float16 *c; uint32_t ldc; uint64_t c_batch;
     uint32_t M, N, K;
     uint32_t tiles_m, tiles_n;
+    // split-K: grid.y = nmats * nsplit, workgroup (z, s) covers K range s and writes an f32 slab of `part` ([z][s][N][M])
+    uint32_t nsplit, k_per_split;
+    float *part;
 };
 
 // LDS-DMA: 16 bytes per lane from `gsrc` (per-lane) to LDS byte address `lds_dst` + 16*lane (`lds_dst` wave-uniform).
@@ -136,9 +139,11 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
     uint32_t tm, tn;
     tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
-    const uint32_t z = blockIdx.y;
-    const _Float16 *A = g.a + z * g.a_batch;
-    const _Float16 *B = g.b + z * g.b_batch;
+    const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
+    const uint32_t k_begin = split * g.k_per_split; // multiple of BKH
+    const uint32_t K_loc = min(g.K - k_begin, g.k_per_split);
+    const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
+    const _Float16 *B = g.b + z * g.b_batch + k_begin;
     _Float16 *C = g.c + z * g.c_batch;
 
     // ---- DMA addressing: this wave stages pieces P = PCS*wave + q (q < PCS) of A and of B; 1 KiB per piece ----
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
     };
     auto next_slot = [](uint32_t s) { return s + 1 == NSLOT ? 0u : s + 1; };
 
-    const uint32_t nh = g.K / BKH; // half-steps
+    const uint32_t nh = K_loc / BKH; // half-steps
     // prologue: up to 4 half-stages in flight, everything landed before the first barrier (once per tile)
     for (uint32_t h = 0; h < 4 && h < nh; ++h) {
 #pragma unroll
@@ -307,6 +312,28 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
     // ---- epilogue: f32 -> f16 (RNE), 16-byte stores. C/D map of the 32x32 MFMA: register e -> row (e&3) + 8 (e>>2) + 4 hk ----
     // rows of tile (T, tb): m = 64 T + 16 gq + 8 hk + 4 (tb ^ (gq>>1)) + (e&3)  => the pair (tb = gq>>1, tb = 1 - (gq>>1)) is 8 consecutive rows
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
+    if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M); wg_splitk_reduce finishes the job
+        float *P = g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const uint32_t col = n0 + (uint32_t)WN_COLS * wn + 32u * u + i32;
+            if (!full_tile && col >= g.N) continue;
+            const uint32_t row0 = m0 + 128u * wm + 8u * hk;
+            float *pc = P + (uint64_t)col * g.M + row0;
+#pragma unroll
+            for (int T = 0; T < 2; ++T)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int lo = gq >> 1, hi = 1 - lo;
+                    if (full_tile || row0 + 64 * T + 16 * gq < g.M) {
+                        float4 *d = reinterpret_cast<float4 *>(pc + 64 * T + 16 * gq);
+                        d[0] = make_float4(acc[T][lo][u][4 * gq], acc[T][lo][u][4 * gq + 1], acc[T][lo][u][4 * gq + 2], acc[T][lo][u][4 * gq + 3]);
+                        d[1] = make_float4(acc[T][hi][u][4 * gq], acc[T][hi][u][4 * gq + 1], acc[T][hi][u][4 * gq + 2], acc[T][hi][u][4 * gq + 3]);
+                    }
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const uint32_t col = n0 + (uint32_t)WN_COLS * wn + 32u * u + i32;
@@ -410,16 +437,33 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         g.tiles_n = (N + BN - 1) / BN;
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-        const dim3 grid((uint32_t)tiles, nmats);
+        // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split
+        const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+        uint32_t nsplit = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
+        g.nsplit = nsplit;
+        g.k_per_split = nsplit > 1 ? ((K / BKH + nsplit - 1) / nsplit) * BKH : K;
+        g.part = nullptr;
+        if (nsplit > 1) {
+            g.nsplit = nsplit = (K + g.k_per_split - 1) / g.k_per_split; // no empty splits
+            void *ws = nullptr;
+            if (int rc = wg_ctx_workspace(ctx, (size_t)nsplit * M * N * nmats * sizeof(float), &ws)) return rc;
+            g.part = (float *)ws;
+        }
+        if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
+        const dim3 grid((uint32_t)tiles, nmats * nsplit);
 #ifndef WG_F16_NWN
 #define WG_F16_NWN 2 // 2 = 4 waves, one per SIMD (measured 1198 TF at 8192^3, less LDS traffic); 4 = 8 waves, two per SIMD (1184 TF)
 #endif
         const dim3 block(128 * WG_F16_NWN);
         if (trans) hipLaunchKernelGGL((gemm_f16_kernel<true, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<false, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
+        WG_HIP_TRY(hipGetLastError());
+        if (nsplit > 1) return wg_splitk_reduce(ctx, g.part, nsplit, M, N, nmats, WG_F16, out, out_ld, out_batch);
+        return WG_OK;
     } else {
         g.tiles_m = (M + 63) / 64;
         g.tiles_n = (N + 63) / 64;
+        g.nsplit = 1; g.k_per_split = K; g.part = nullptr;
         if (g.tiles_n > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: N too large for the generic f16 path");
         const dim3 grid(g.tiles_m, g.tiles_n, nmats), block(256);
         if (trans) hipLaunchKernelGGL(gemm_f16_generic_kernel<true>, grid, block, 0, ctx->stream, g);

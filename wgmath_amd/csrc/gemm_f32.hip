@@ -49,6 +49,7 @@ struct GemmArgs {
     uint32_t M, N, K;
     uint32_t tiles_m, tiles_n;
     uint32_t dma_ok; // leading dimensions small enough for 32-bit byte offsets within a tile
+    uint32_t nsplit, k_per_split; // split-K: grid.y = nmats * nsplit; c then points at the f32 slabs [z][s][N][M]
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
@@ -398,14 +399,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     const uint32_t tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
     const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
     const uint32_t m0 = tm * BM, n0 = tn * BN;
-    const uint32_t z = blockIdx.y;
-    const float *A = g.a + z * g.a_batch;
-    const float *B = g.b + z * g.b_batch;
-    float *C = g.c + z * g.c_batch;
+    const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
+    const uint32_t k_begin = split * g.k_per_split; // split-K: this workgroup's K range (k_per_split is a multiple of BK)
+    GemmArgs gl = g;
+    gl.K = min(g.K - k_begin, g.k_per_split);
+    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
+    const float *B = g.b + z * g.b_batch + k_begin;
+    float *C = g.c + ((uint64_t)z * g.nsplit + split) * g.c_batch;
     // workgroup-uniform: the whole tile is inside the matrices, K is a whole number of k-tiles, and 32-bit DMA offsets suffice
-    const bool interior = (m0 + BM <= g.M) && (n0 + BN <= g.N) && (g.K % BK == 0) && g.K >= (uint32_t)BK && g.dma_ok;
-    if (interior) gemm_f32_tile_dma<TRANS_A>(g, smem, A, B, C, m0, n0);
-    else gemm_f32_tile<TRANS_A, true>(g, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
+    const bool interior = (m0 + BM <= gl.M) && (n0 + BN <= gl.N) && (gl.K % BK == 0) && gl.K >= (uint32_t)BK && gl.dma_ok;
+    if (interior) gemm_f32_tile_dma<TRANS_A>(gl, smem, A, B, C, m0, n0);
+    else gemm_f32_tile<TRANS_A, true>(gl, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
 }
 
 } // namespace
@@ -424,9 +428,24 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
     const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-    const dim3 grid((uint32_t)tiles, nmats), block(kThreads);
+    // split-K when the output has too few tiles for the chip (2 workgroups per CU): >= 8 k-tiles (128 k) per split
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    uint32_t nsplit = wg_splitk_plan(tiles * nmats, 2u * cus, (K + BK - 1) / BK, 8, (uint64_t)M * N * nmats, 512ull << 20);
+    float *part = nullptr;
+    g.nsplit = nsplit;
+    g.k_per_split = nsplit > 1 ? (((K + BK - 1) / BK + nsplit - 1) / nsplit) * BK : K;
+    if (nsplit > 1) {
+        g.nsplit = nsplit = (K + g.k_per_split - 1) / g.k_per_split; // no empty splits
+        void *ws = nullptr;
+        if (int rc = wg_ctx_workspace(ctx, (size_t)nsplit * M * N * nmats * sizeof(float), &ws)) return rc;
+        part = (float *)ws;
+        g.c = part; g.ldc = M; g.c_batch = (uint64_t)M * N; // slab (z, s) at ((z * nsplit + s) * M * N)
+    }
+    if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
+    const dim3 grid((uint32_t)tiles, nmats * nsplit), block(kThreads);
     if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
+    if (nsplit > 1) return wg_splitk_reduce(ctx, part, nsplit, M, N, nmats, WG_F32, out, out_ld, out_batch);
     return WG_OK;
 }

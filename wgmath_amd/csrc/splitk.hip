@@ -1,0 +1,53 @@
+// Split-K support shared by the two GEMM kernels.
+// A GEMM whose output has too few tiles to fill 256 CUs (small M x N, long K) is cut along K: workgroup (tile, s) computes the
+// partial product over K-range s into an f32 slab of the context workspace ([z][s][N][M], dense column-major), and this
+// kernel adds the slabs in ASCENDING s (deterministic; no atomics) and writes the result in the output's dtype and layout.
+#include "wg_internal.hpp"
+
+namespace {
+
+template <typename OUT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, uint32_t nsplit, uint32_t M, uint32_t N,
+                                                            OUT *__restrict__ out, uint32_t ldc, uint64_t c_batch) {
+    const uint32_t m4 = blockIdx.x * 256u + threadIdx.x; // float4 index within a column (M % 4 == 0)
+    if (m4 * 4u >= M) return;
+    const uint32_t col = blockIdx.y, z = blockIdx.z;
+    const uint64_t slab = (uint64_t)M * N;
+    const float4 *p = reinterpret_cast<const float4 *>(part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M) + m4;
+    float4 s = p[0];
+    for (uint32_t i = 1; i < nsplit; ++i) {
+        const float4 q = p[(uint64_t)i * (slab / 4u)];
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    OUT *o = out + z * c_batch + (uint64_t)col * ldc + 4u * m4;
+    if constexpr (sizeof(OUT) == 4) {
+        *reinterpret_cast<float4 *>(o) = s;
+    } else {
+        struct alignas(8) h4 { _Float16 v[4]; };
+        h4 r = { { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w } };
+        *reinterpret_cast<h4 *>(o) = r;
+    }
+}
+
+} // namespace
+
+// How many K-splits to use (1 = none). `tiles` = output tiles x matrices, `slots` = workgroups the chip holds at once,
+// `k_units` = K / (kernel's K granule), `min_units` = fewest granules worth a workgroup's prologue/epilogue.
+uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32_t min_units, uint64_t out_elems, uint64_t max_ws_bytes) {
+    if (tiles == 0 || tiles * 2 > slots) return 1; // at least half the chip is busy already
+    uint32_t s = (uint32_t)(slots / tiles);
+    const uint32_t by_k = k_units / min_units;
+    if (s > by_k) s = by_k;
+    while (s > 1 && (uint64_t)s * out_elems * 4u > max_ws_bytes) --s;
+    return s < 2 ? 1 : s;
+}
+
+int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
+                     uint32_t ldc, uint64_t c_batch) {
+    if (N > 65535 || nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: N or nmats above 65535");
+    const dim3 grid((M / 4u + 255u) / 256u, N, nmats), block(256);
+    if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch);
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}

@@ -90,3 +90,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);
+
+// split-K (splitk.hip)
+uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32_t min_units, uint64_t out_elems, uint64_t max_ws_bytes);
+int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
+                     uint32_t ldc, uint64_t c_batch);
