@@ -2,9 +2,11 @@
 //
 // HBM-bound streaming kernel: 12 bytes per f32 element (8 for Copy, which never reads `a`).
 // Layout: both views are contiguous runs of n elements starting at (buffer + offset).
-// The reference launches ceil(n/64) workgroups of 64 threads doing one 4-byte access each; here each lane moves
-// 16 bytes per access (float4 / 8 x half), UNROLL accesses in flight per lane, over a grid capped at a few
-// workgroups per CU (grid-stride), with a scalar head/tail so that any offset/length is accepted.
+// The reference launches ceil(n/64) workgroups of 64 threads doing one 4-byte access each; here each lane moves 16 bytes
+// (float4 / 8 x half) with non-temporal loads and stores, ONE access per lane over a flat grid of n/4/256 workgroups --
+// measured 6.3 TB/s (Add) / 6.6 TB/s (Copy) on 2^28 elements vs 4.9 TB/s for a capped grid-stride loop with 4-8 accesses
+// in flight per lane: in dispatch order the flat grid sweeps the three streams sequentially, which is what HBM wants.
+// A scalar head/tail (first lanes of block 0) makes any offset/length legal.
 // IEEE-correct + - * / (no fast-math, correctly rounded division): results are bit-identical to the CPU.
 #include "wg_internal.hpp"
 
@@ -28,13 +30,17 @@ __device__ __forceinline__ float4 apply4(float4 a, float4 b, float alpha) {
 }
 
 #ifndef OPA_UNROLL
-#define OPA_UNROLL 4
+#define OPA_UNROLL 1
 #endif
 #ifndef OPA_NT
 #define OPA_NT 2 // 1: non-temporal loads, 2: + non-temporal stores (measured best: 4.9 TB/s on a 2-read/1-write stream)
 #endif
 #ifndef OPA_WG_PER_CU
 #define OPA_WG_PER_CU 8
+#endif
+#ifndef OPA_MODE
+#define OPA_MODE 2 // 2: one workgroup per kUnroll*256 consecutive float4, flat uncapped grid (measured 6.3 TB/s Add, 6.6 TB/s Copy);
+                   // 0: capped grid + grid-stride loop (4.9 TB/s: the streams interleave badly across the chip)
 #endif
 constexpr int kThreads = 256;
 constexpr int kUnroll = OPA_UNROLL;
@@ -64,6 +70,24 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
     }
     float4 *a = reinterpret_cast<float4 *>(a0 + head);
     const float4 *b = reinterpret_cast<const float4 *>(b0 + head);
+    if (OPA_MODE == 2) {
+        const uint64_t base = (uint64_t)blockIdx.x * (kUnroll * kThreads) + threadIdx.x;
+        float4 va[kUnroll], vb[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint64_t i = base + (uint64_t)u * kThreads;
+            if (i < n4) {
+                vb[u] = ld4(&b[i]);
+                if constexpr (OP != OP_COPY) va[u] = ld4(&a[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const uint64_t i = base + (uint64_t)u * kThreads;
+            if (i < n4) st4(&a[i], apply4<OP>(va[u], vb[u], alpha));
+        }
+        return;
+    }
     const uint32_t stride = gridDim.x * kThreads;
     uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     // main: kUnroll independent 16-byte accesses per lane per trip
@@ -125,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const 
     }
     half8 *a = reinterpret_cast<half8 *>(a0 + head);
     const half8 *b = reinterpret_cast<const half8 *>(b0 + head);
-    const uint32_t stride = gridDim.x * kThreads;
+    const uint32_t stride = gridDim.x * kThreads; // flat grid: at most one trip
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n8; i += stride) {
         half8 vb = b[i], va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
@@ -161,8 +185,8 @@ int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n, float alpha) {
         uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 4);
         if (head > n) head = n;
         uint32_t n4 = (n - head) / 4;
-        hipLaunchKernelGGL(op_assign_f32_vec<OP>, dim3(grid_for(n4, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
-                           head, n4, n, alpha);
+        const uint32_t blocks = OPA_MODE == 2 ? (uint32_t)(((uint64_t)n4 + kUnroll * kThreads - 1) / (kUnroll * kThreads)) : grid_for(n4, ctx->compute_units);
+        hipLaunchKernelGGL(op_assign_f32_vec<OP>, dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n4, n, alpha);
     } else {
         hipLaunchKernelGGL(op_assign_f32_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
     }
@@ -177,8 +201,8 @@ int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n, float alpha)
         uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 2);
         if (head > n) head = n;
         uint32_t n8 = (n - head) / 8;
-        hipLaunchKernelGGL(op_assign_f16_vec<OP>, dim3(grid_for(n8, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b,
-                           head, n8, n, alpha);
+        const uint32_t blocks = (n8 + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(op_assign_f16_vec<OP>, dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n8, n, alpha);
     } else {
         hipLaunchKernelGGL(op_assign_f16_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
     }
