@@ -533,6 +533,9 @@ def main():
             gpu.sync()
 
     info = gpu.adapter()
+    _pad = None
+    if os.environ.get("WG_BENCH_PAD"):  # experiment hook: shift every later allocation by this many bytes
+        _pad = wg.TensorBuilder.vector(int(os.environ["WG_BENCH_PAD"]) // 4, wg.BufferUsages.STORAGE).build(gpu.device(), np.float32)
     main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
                             not args.no_cpu_baseline, args.cpu_budget)
     elapsed = main_res["elapsed"]

@@ -27,7 +27,16 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kMaxRhs = 4; // RHS columns handled per pass over the matrix (m is read once for all of them)
 
-__device__ __forceinline__ float4 ld_stream(const float4 *p) { return wg_ld_nt(p); }
+#ifndef GEMV_NT
+#define GEMV_NT 1
+#endif
+#ifndef GEMV_NU
+#define GEMV_NU 4 // N kernel: columns (float4 loads) in flight per lane (4: 6.45 TB/s, 8/16: 6.40 at 4096 x 65536)
+#endif
+#ifndef GEMV_TS
+#define GEMV_TS 1 // T kernel: row-steps (4 float4 each) in flight per lane (1: 6.40 TB/s, 2/4: 6.34)
+#endif
+__device__ __forceinline__ float4 ld_stream(const float4 *p) { return GEMV_NT ? wg_ld_nt(p) : *p; }
 __device__ __forceinline__ float readlane_f(float x, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
 }
@@ -95,12 +104,12 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
         const uint64_t ld4 = a.ldm / 4u;
         if (cb + 64u <= w_end) {
 #pragma unroll
-            for (int u8 = 0; u8 < 64; u8 += 8) {
-                float4 mv[8];
+            for (int u8 = 0; u8 < 64; u8 += GEMV_NU) {
+                float4 mv[GEMV_NU];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) mv[u] = ld_stream(col + (uint64_t)(u8 + u) * ld4);
+                for (int u = 0; u < GEMV_NU; ++u) mv[u] = ld_stream(col + (uint64_t)(u8 + u) * ld4);
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < GEMV_NU; ++u)
 #pragma unroll
                     for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv[u], readlane_f(vv[y], u8 + u));
             }
@@ -180,10 +189,10 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
     };
 
     uint32_t r = r_begin + 4u * lane;
-    // two row-steps per trip: 8 matrix float4 + 2*NRHS vector float4 in flight per lane
-    for (; (uint64_t)r + 256u < r_end; r += 512u) {
-        step(r);
-        step(r + 256u);
+    // GEMV_TS row-steps per trip: 4*GEMV_TS matrix float4 (+ vector float4) in flight per lane
+    for (; (uint64_t)r + 256u * (GEMV_TS - 1) < r_end; r += 256u * GEMV_TS) {
+#pragma unroll
+        for (int t = 0; t < GEMV_TS; ++t) step(r + 256u * t);
     }
     for (; r < r_end; r += 256u) step(r);
 
