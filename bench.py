@@ -489,6 +489,7 @@ def main():
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")
+    ap.add_argument("--skip", default="", help="comma-separated secondary workloads to skip (e.g. under rocprofv3)")
     ap.add_argument("--secondary-seconds", type=float, default=0.6, help="minimum timed duration of each secondary config")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
     args = ap.parse_args()
@@ -555,7 +556,7 @@ def main():
     others = []
     if world == 1 and not args.no_secondary:
         for name in SECONDARY:
-            if name == args.workload:
+            if name == args.workload or name in args.skip.split(","):
                 continue
             try:
                 r = run_workload(wg, gpu, name, 10, 3, rank, world, barrier, not args.no_cpu_baseline, min(args.cpu_budget, 5.0),
