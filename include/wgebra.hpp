@@ -245,6 +245,12 @@ struct Gemm {
     void dispatch(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m1, GpuTensorView<T> m2) const {
         dispatch_generic(d, s, p, out, m1, m2, GemmVariant::Gemm);
     }
+    template <typename T> // extension: out = alpha * op(m1) * m2 + beta * out
+    void dispatch_ex(const Device &, const ViewShapeBuffers &, ComputePass &pass, float alpha, float beta, GpuTensorView<T> out,
+                     GpuTensorView<T> m1, GpuTensorView<T> m2, GemmVariant variant = GemmVariant::Gemm) const {
+        check(wg_gemm_ex(pass.ctx(), (wg_gemm_variant)variant, dtype_of<T>::value, alpha, beta, out.buffer(), out.shape(), m1.buffer(),
+                         m1.shape(), m2.buffer(), m2.shape()));
+    }
     template <typename T>
     void dispatch_tr(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m1, GpuTensorView<T> m2) const {
         dispatch_generic(d, s, p, out, m1, m2, GemmVariant::GemmTr);

@@ -159,6 +159,16 @@ int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype,
             const wg_buf *m2, wg_view_shape m2_shape);
 
 /*
+ * Extension: BLAS-style update  out = alpha * op(m1) * m2 + beta * out.  Same views, checks and variants as
+ * wg_gemm; beta == 0 never reads `out` (NaN/Inf there are overwritten, like wg_gemm), and (alpha, beta) = (1, 0) is
+ * bit-identical to wg_gemm. alpha, beta are f32 for both dtypes; f16: alpha*acc + beta*c is formed in f32 and rounded once.
+ */
+int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha, float beta,
+               wg_buf *out, wg_view_shape out_shape,
+               const wg_buf *m1, wg_view_shape m1_shape,
+               const wg_buf *m2, wg_view_shape m2_shape);
+
+/*
  * Gemv::dispatch_generic (wgebra gemv.rs:64-137): out[:,y,z] = m[:,:,z] * v[:,y,z] (or m^T), for every RHS
  * column y < out.size[1] and matrix z < out.size[2]; `out` is overwritten.
  *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).

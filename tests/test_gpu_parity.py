@@ -419,3 +419,34 @@ def test_axpy(gpu, oracle_c, dtype):
     with pytest.raises(wg.DimensionMismatch, match="Axpy: dimension mismatch."):
         enc = gpu.device().create_command_encoder()
         axpy.dispatch(gpu.device(), shapes, enc.compute_pass("e", None), 1.0, ty.rows(0, 8), tx.rows(0, 12))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("M,K,N,mats", [(256, 64, 256, 1), (264, 96, 136, 2), (512, 4096, 256, 1), (36, 20, 28, 1)])
+def test_gemm_ex_alpha_beta(gpu, dtype, M, K, N, mats):
+    """Extension: out = alpha * A B + beta * out; (1, 0) is bit-identical to Gemm::dispatch; beta = 0 ignores NaNs in out."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + K + N)
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(dtype)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(dtype)
+    c0 = (rng.random(M * N * mats, dtype=np.float32) * 2 - 1).astype(dtype)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    m1, m2 = upload(gpu, (M, K, mats), a, dtype), upload(gpu, (K, N, mats), b, dtype)
+    plain = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, dtype), dtype)
+    run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, plain, m1, m2))
+    ref_plain = plain.read(gpu.device())
+    ex10 = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, dtype), dtype)  # beta = 0: NaNs must not leak
+    run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, 1.0, 0.0, ex10, m1, m2))
+    U.assert_bits_equal(ex10.read(gpu.device()), ref_plain, "gemm_ex(1, 0) vs gemm")
+    for alpha, beta in ((0.5, 0.0), (1.0, 1.0), (-1.5, 0.25)):
+        out = upload(gpu, (M, N, mats), c0, dtype)
+        run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, alpha, beta, out, m1, m2))
+        got = wo.view(out.read(gpu.device()), wo.Shape(M, N, mats)).astype(np.float64)
+        A, B, C0 = wo.view(a, wo.Shape(M, K, mats)), wo.view(b, wo.Shape(K, N, mats)), wo.view(c0, wo.Shape(M, N, mats))
+        for t in range(mats):
+            a64, b64 = A[:, :, t].astype(np.float64), B[:, :, t].astype(np.float64)
+            truth = alpha * (a64 @ b64) + beta * C0[:, :, t].astype(np.float64)
+            sabs = abs(alpha) * (np.abs(a64) @ np.abs(b64)) + abs(beta) * np.abs(C0[:, :, t]).astype(np.float64)
+            tol = U.f32_gate(K + 2, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0)
+            err = np.abs(got[:, :, t] - truth)
+            assert (err <= tol).all(), f"gemm_ex({alpha},{beta}) {np.dtype(dtype).name}: worst err/tol {(err / tol).max():.3g}"

@@ -85,6 +85,7 @@ def _load() -> ctypes.CDLL:
         "wg_buf_copy": (ci, [vp, vp, sz, vp, sz, sz]),
         "wg_buf_fill_zero": (ci, [vp, vp]),
         "wg_gemm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_gemm_ex": (ci, [vp, ci, ci, ctypes.c_float, ctypes.c_float, vp, S, vp, S, vp, S]),
         "wg_gemv": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),

@@ -57,6 +57,11 @@ extern "C" {
 
 int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m1,
             wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape) {
+    return wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, out, out_shape, m1, m1_shape, m2, m2_shape);
+}
+
+int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha, float beta, wg_buf *out, wg_view_shape out_shape,
+               const wg_buf *m1, wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape) {
     const wg_buf *bufs[3] = { out, m1, m2 };
     if (int rc = check_common("Gemm", ctx, dtype, bufs, 3)) return rc;
     if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
@@ -88,8 +93,8 @@ int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out, w
     wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
     wgk_mat B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };
     void *C = (void *)elem_ptr(out, o.offset, dtype);
-    if (dtype == WG_F32) return wgk_gemm_f32(ctx, tr, m_rows, o.cols, m_cols, o.mats, (float *)C, o.stride, o.stride_mat, A, B);
-    return wgk_gemm_f16(ctx, tr, m_rows, o.cols, m_cols, o.mats, (__half *)C, o.stride, o.stride_mat, A, B);
+    if (dtype == WG_F32) return wgk_gemm_f32(ctx, tr, m_rows, o.cols, m_cols, o.mats, (float *)C, o.stride, o.stride_mat, A, B, alpha, beta);
+    return wgk_gemm_f16(ctx, tr, m_rows, o.cols, m_cols, o.mats, (__half *)C, o.stride, o.stride_mat, A, B, alpha, beta);
 }
 
 int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m,

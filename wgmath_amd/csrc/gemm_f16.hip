@@ -54,6 +54,7 @@ struct GemmArgs {
     // split-K: grid.y = nmats * nsplit, workgroup (z, s) covers K range s and writes an f32 slab of `part` ([z][s][N][M])
     uint32_t nsplit, k_per_split;
     float *part;
+    float alpha, beta; // out = alpha * acc + beta * out (wg_gemm_ex)
 };
 
 // LDS-DMA: 16 bytes per lane from `gsrc` (per-lane) to LDS byte address `lds_dst` + 16*lane (`lds_dst` wave-uniform).
@@ -345,14 +346,26 @@ __global__ __launch_bounds__(128 * NWN, NWN / 2) void gemm_f16_kernel(GemmArgs g
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int lo = gq >> 1, hi = 1 - lo;
-                half8_t v;
+                if (!(full_tile || row0 + 64 * T + 16 * gq < g.M)) continue; // 8 consecutive rows, all in or all out (M % 8 == 0)
+                float r[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v[q] = (_Float16)acc[T][lo][u][4 * gq + q];
-                    v[4 + q] = (_Float16)acc[T][hi][u][4 * gq + q];
+                    r[q] = acc[T][lo][u][4 * gq + q];
+                    r[4 + q] = acc[T][hi][u][4 * gq + q];
                 }
-                if (full_tile || row0 + 64 * T + 16 * gq < g.M) // 8 consecutive rows, all in or all out (M % 8 == 0)
-                    *reinterpret_cast<half8_t *>(cc + 64 * T + 16 * gq) = v;
+                if (g.alpha != 1.f) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] *= g.alpha;
+                }
+                if (g.beta != 0.f) { // beta == 0 never reads C
+                    const half8_t c = *reinterpret_cast<const half8_t *>(cc + 64 * T + 16 * gq);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] = fmaf(g.beta, (float)c[q], r[q]);
+                }
+                half8_t v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
+                *reinterpret_cast<half8_t *>(cc + 64 * T + 16 * gq) = v;
             }
     }
 }
@@ -409,7 +422,11 @@ __global__ __launch_bounds__(256) void gemm_f16_generic_kernel(GemmArgs g) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint32_t m = m0 + 4 * tx + p;
-            if (m < g.M) C[(uint64_t)n * g.ldc + m] = (_Float16)acc[p][q];
+            if (m < g.M) {
+                float r = g.alpha == 1.f ? acc[p][q] : g.alpha * acc[p][q];
+                if (g.beta != 0.f) r = fmaf(g.beta, (float)C[(uint64_t)n * g.ldc + m], r);
+                C[(uint64_t)n * g.ldc + m] = (_Float16)r;
+            }
         }
     }
 }
@@ -417,7 +434,7 @@ __global__ __launch_bounds__(256) void gemm_f16_generic_kernel(GemmArgs g) {
 } // namespace
 
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2) {
+                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: more than 65535 matrices in one call");
     GemmArgs g;
@@ -425,6 +442,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.b = (const _Float16 *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.c = (_Float16 *)out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta;
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
@@ -458,7 +476,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (trans) hipLaunchKernelGGL((gemm_f16_kernel<true, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f16_kernel<false, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
         WG_HIP_TRY(hipGetLastError());
-        if (nsplit > 1) return wg_splitk_reduce(ctx, g.part, nsplit, M, N, nmats, WG_F16, out, out_ld, out_batch);
+        if (nsplit > 1) return wg_splitk_reduce(ctx, g.part, nsplit, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
         return WG_OK;
     } else {
         g.tiles_m = (M + 63) / 64;

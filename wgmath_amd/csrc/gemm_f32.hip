@@ -50,10 +50,20 @@ struct GemmArgs {
     uint32_t tiles_m, tiles_n;
     uint32_t dma_ok; // leading dimensions small enough for 32-bit byte offsets within a tile
     uint32_t nsplit, k_per_split; // split-K: grid.y = nmats * nsplit; c then points at the f32 slabs [z][s][N][M]
+    float alpha, beta;            // out = alpha * acc + beta * out (wg_gemm_ex); (1, 0) in split mode (the reduce kernel applies them)
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
     return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// epilogue element: alpha * acc (+ beta * old). (alpha, beta) = (1, 0) returns acc unchanged and never reads old.
+__device__ __forceinline__ void store_c(float *p, float4 v, float alpha, float beta) {
+    if (alpha != 1.f) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
+    if (beta != 0.f) {
+        const float4 c = *reinterpret_cast<const float4 *>(p);
+        v.x = fmaf(beta, c.x, v.x); v.y = fmaf(beta, c.y, v.y); v.z = fmaf(beta, c.z, v.z); v.w = fmaf(beta, c.w, v.w);
+    }
+    *reinterpret_cast<float4 *>(p) = v;
 }
 __device__ __forceinline__ float comp(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
@@ -212,16 +222,16 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, floa
                 for (int q = 0; q < 4; ++q) {
                     const uint32_t row = m0 + wm * 128 + 32 * gq + 16 * h + 4 * q;
                     if (!EDGE || row < g.M)
-                        *reinterpret_cast<float4 *>(cc + row) =
-                            make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]);
+                        store_c(cc + row, make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]),
+                                g.alpha, g.beta);
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const uint32_t row = m0 + wm * 128 + 32 * t + 8 * gq + 4 * h;
                     if (!EDGE || row < g.M)
-                        *reinterpret_cast<float4 *>(cc + row) =
-                            make_float4(acc[t][u][4 * gq + 0], acc[t][u][4 * gq + 1], acc[t][u][4 * gq + 2], acc[t][u][4 * gq + 3]);
+                        store_c(cc + row, make_float4(acc[t][u][4 * gq + 0], acc[t][u][4 * gq + 1], acc[t][u][4 * gq + 2], acc[t][u][4 * gq + 3]),
+                                g.alpha, g.beta);
                 }
             }
         }
@@ -381,13 +391,13 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
             if constexpr (!TRANS_A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4 *>(cc + m0 + wm * 128 + 32 * gq + 16 * h + 4 * q) =
-                        make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]);
+                    store_c(cc + m0 + wm * 128 + 32 * gq + 16 * h + 4 * q,
+                            make_float4(acc[0][u][4 * gq + q], acc[1][u][4 * gq + q], acc[2][u][4 * gq + q], acc[3][u][4 * gq + q]), g.alpha, g.beta);
             } else {
 #pragma unroll
                 for (int t4 = 0; t4 < 4; ++t4)
-                    *reinterpret_cast<float4 *>(cc + m0 + wm * 128 + 32 * t4 + 8 * gq + 4 * h) =
-                        make_float4(acc[t4][u][4 * gq + 0], acc[t4][u][4 * gq + 1], acc[t4][u][4 * gq + 2], acc[t4][u][4 * gq + 3]);
+                    store_c(cc + m0 + wm * 128 + 32 * t4 + 8 * gq + 4 * h,
+                            make_float4(acc[t4][u][4 * gq + 0], acc[t4][u][4 * gq + 1], acc[t4][u][4 * gq + 2], acc[t4][u][4 * gq + 3]), g.alpha, g.beta);
             }
         }
     }
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 } // namespace
 
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2) {
+                 float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: more than 65535 matrices in one call");
     GemmArgs g;
@@ -423,6 +433,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.c = out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
@@ -440,12 +451,13 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = wg_ctx_workspace(ctx, (size_t)nsplit * M * N * nmats * sizeof(float), &ws)) return rc;
         part = (float *)ws;
         g.c = part; g.ldc = M; g.c_batch = (uint64_t)M * N; // slab (z, s) at ((z * nsplit + s) * M * N)
+        g.alpha = 1.f; g.beta = 0.f;                         // raw partial sums; alpha/beta are applied by the reduce
     }
     if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
     const dim3 grid((uint32_t)tiles, nmats * nsplit), block(kThreads);
     if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
-    if (nsplit > 1) return wg_splitk_reduce(ctx, part, nsplit, M, N, nmats, WG_F32, out, out_ld, out_batch);
+    if (nsplit > 1) return wg_splitk_reduce(ctx, part, nsplit, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
     return WG_OK;
 }

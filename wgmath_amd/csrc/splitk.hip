@@ -8,7 +8,7 @@ namespace {
 
 template <typename OUT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, uint32_t nsplit, uint32_t M, uint32_t N,
-                                                            OUT *__restrict__ out, uint32_t ldc, uint64_t c_batch) {
+                                                            OUT *__restrict__ out, uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
     const uint32_t m4 = blockIdx.x * 256u + threadIdx.x; // float4 index within a column (M % 4 == 0)
     if (m4 * 4u >= M) return;
     const uint32_t col = blockIdx.y, z = blockIdx.z;
@@ -20,10 +20,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     OUT *o = out + z * c_batch + (uint64_t)col * ldc + 4u * m4;
+    struct alignas(8) h4 { _Float16 v[4]; };
+    if (alpha != 1.f) { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
+    if (beta != 0.f) { // out = alpha * sum + beta * out (wg_gemm_ex); beta == 0 never reads `out`
+        float4 c;
+        if constexpr (sizeof(OUT) == 4) c = *reinterpret_cast<const float4 *>(o);
+        else { const h4 t = *reinterpret_cast<const h4 *>(o); c = make_float4((float)t.v[0], (float)t.v[1], (float)t.v[2], (float)t.v[3]); }
+        s.x = fmaf(beta, c.x, s.x); s.y = fmaf(beta, c.y, s.y); s.z = fmaf(beta, c.z, s.z); s.w = fmaf(beta, c.w, s.w);
+    }
     if constexpr (sizeof(OUT) == 4) {
         *reinterpret_cast<float4 *>(o) = s;
     } else {
-        struct alignas(8) h4 { _Float16 v[4]; };
         h4 r = { { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w } };
         *reinterpret_cast<h4 *>(o) = r;
     }
@@ -43,11 +50,11 @@ uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32
 }
 
 int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
-                     uint32_t ldc, uint64_t c_batch) {
+                     uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
     if (N > 65535 || nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: N or nmats above 65535");
     const dim3 grid((M / 4u + 255u) / 256u, N, nmats), block(256);
-    if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch);
+    if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch, alpha, beta);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch, alpha, beta);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

@@ -87,11 +87,11 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 
 // out (M x N) = op(m1) (M x K) * m2 (K x N); trans: m1 stored K x M
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);
+                 float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2);
+                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 
 // split-K (splitk.hip)
 uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32_t min_units, uint64_t out_elems, uint64_t max_ws_bytes);
 int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
-                     uint32_t ldc, uint64_t c_batch);
+                     uint32_t ldc, uint64_t c_batch, float alpha = 1.f, float beta = 0.f);

@@ -83,6 +83,16 @@ class Gemm:
                           m2.buffer()._h, m2.shape().to_c()))
 
 
+    def dispatch_ex(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, alpha: float, beta: float, out, m1, m2,
+                    variant: GemmVariant = GemmVariant.Gemm) -> None:
+        """Extension: out = alpha * op(m1) * m2 + beta * out.  (1, 0) is bit-identical to dispatch_generic."""
+        out, m1, m2 = as_view(out, 3), as_view(m1, 3), as_view(m2, 3)
+        dt = _common_dtype(out, m1, m2)
+        check(lib.wg_gemm_ex(pass_._ctx.handle, int(variant), dt, float(alpha), float(beta),
+                             out.buffer()._h, out.shape().to_c(), m1.buffer()._h, m1.shape().to_c(),
+                             m2.buffer()._h, m2.shape().to_c()))
+
+
 class Gemv:
     """gemv.rs:9-21."""
 
