@@ -155,3 +155,41 @@ def test_op_assign_256M(gpu):
     U.assert_bits_equal(ta.read(gpu.device()), a * b, "op_assign Mul 2^28")
     run(gpu, lambda p: wg.OpAssign.new(gpu.device(), wg.OpAssignVariant.Copy).dispatch(gpu.device(), shapes, p, ta, tb))
     U.assert_bits_equal(ta.read(gpu.device()), b, "op_assign Copy 2^28")
+
+
+def test_addressing_beyond_4GiB(gpu):
+    """An 8 GiB f32 matrix (32768 x 65536: 2^31 elements, > the reference's 600 MB buffer cap and > 2^32 bytes): GEMV N/T and a
+    batched Reduce must address it with 64-bit arithmetic. The matrix is a 2^24-element random block tiled on the device, so the
+    expectation is computable on the host: column c equals block column c % 512."""
+    wg = _wg()
+    from wgmath_amd._lib import check, lib
+    R, C, BLK = 32768, 65536, 1 << 24
+    blk = rnd(77, BLK)
+    S = wg.BufferUsages
+    tm = wg.TensorBuilder.matrix(R, C, S.STORAGE | S.COPY_DST).build(gpu.device())
+    tb = up(gpu, (BLK,), blk)
+    for off in range(0, R * C, BLK):
+        check(lib.wg_buf_copy(gpu._ctx.handle, tb._h, 0, tm._h, off * 4, BLK * 4))
+    Mb = blk.reshape(R, BLK // R, order="F").astype(np.float64)  # R x 512: the distinct columns
+    reps = C // (BLK // R)
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    v = rnd(78, C)
+    tv, to = up(gpu, (C,), v), up(gpu, (R,), np.zeros(R, np.float32))
+    run(gpu, lambda p: gemv.dispatch(gpu.device(), shapes, p, to, tm, tv))
+    got = to.read(gpu.device()).astype(np.float64)
+    v64 = v.astype(np.float64).reshape(reps, BLK // R)
+    truth = Mb @ v64.sum(0)
+    sabs = np.abs(Mb) @ np.abs(v64).sum(0)
+    U.assert_close_f64(got, truth, C, sabs, "8 GiB gemv N")
+    w = rnd(79, R)
+    tw, to2 = up(gpu, (R,), w), up(gpu, (C,), np.zeros(C, np.float32))
+    run(gpu, lambda p: gemv.dispatch_tr(gpu.device(), shapes, p, to2, tm, tw))
+    got2 = to2.read(gpu.device()).astype(np.float64)
+    col = Mb.T @ w.astype(np.float64)  # 512 distinct dot products
+    U.assert_close_f64(got2, np.tile(col, reps), R, np.tile(np.abs(Mb).T @ np.abs(w).astype(np.float64), reps), "8 GiB gemv T")
+    red = wg.Reduce.new(gpu.device(), wg.ReduceOp.Sum)
+    res = up(gpu, (C,), np.zeros(C, np.float32))
+    run(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, tm, res))
+    sums = res.read(gpu.device())
+    assert np.array_equal(sums, np.tile(sums[:BLK // R], reps)), "columns past 4 GiB do not repeat the block's sums bit for bit"
+    assert np.allclose(sums[:BLK // R], Mb.sum(0), rtol=0, atol=R * 2.0 ** -24 * np.abs(Mb).sum(0).max())

@@ -450,3 +450,37 @@ def test_gemm_ex_alpha_beta(gpu, dtype, M, K, N, mats):
             tol = U.f32_gate(K + 2, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0)
             err = np.abs(got[:, :, t] - truth)
             assert (err <= tol).all(), f"gemm_ex({alpha},{beta}) {np.dtype(dtype).name}: worst err/tol {(err / tol).max():.3g}"
+
+
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemv_strided_views(gpu, oracle_c, tr):
+    """m = rows/columns sub-view of a bigger matrix in a cube, v / out = offset views with a column stride > length, 3 RHS."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(55 + tr)
+    PR, PC = 200, 160
+    pm = (rng.random(PR * PC * 2, dtype=np.float32) - 0.5).astype(np.float32)
+    tm = upload(gpu, (PR, PC, 2), pm)
+    m_view = tm.as_view().matrix(1).columns(8, 96).rows(12, 128)  # 128 x 96 inside matrix 1
+    R, C = 128, 96
+    vlen, olen = (R, C) if tr else (C, R)
+    pv = (rng.random(4 + 3 * (vlen + 8), dtype=np.float32) - 0.5).astype(np.float32)
+    po = rng.random(8 + 3 * (olen + 4), dtype=np.float32)
+    tv, to = upload(gpu, (pv.size,), pv), upload(gpu, (po.size,), po)
+    v_view = wg.GpuTensorView(wg.ViewShape((vlen, 3, 1), vlen + 8, 1, 4), tv, 2)
+    o_view = wg.GpuTensorView(wg.ViewShape((olen, 3, 1), olen + 4, 1, 8), to, 2)
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, o_view, m_view, v_view, variant))
+    got = to.read(gpu.device())
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    orc = po.copy()
+    oracle_c.gemv(int(variant), orc, sh(o_view), pm, sh(m_view), pv, sh(v_view))
+    A, X = wo.view(pm, sh(m_view))[:, :, 0], wo.view(pv, sh(v_view))[:, :, 0]
+    A = A.T if tr else A
+    truth, sabs = wo.gemm_f64(A, X)
+    U.assert_close_f64(wo.view(got, sh(o_view))[:, :, 0], truth, vlen, sabs, "strided gemv vs f64")
+    U.assert_close_oracle(wo.view(got, sh(o_view))[:, :, 0], wo.view(orc, sh(o_view))[:, :, 0], vlen, sabs, "strided gemv vs oracle")
+    mask = np.ones(po.size, bool)
+    s = sh(o_view).resolved()
+    mask[(s.offset + np.arange(olen)[:, None] + np.arange(3)[None, :] * s.stride).ravel()] = False
+    assert np.array_equal(got[mask], po[mask]), "gemv wrote outside its output view"
