@@ -149,6 +149,105 @@ __global__ __launch_bounds__(kThreads) void reduce_rows1(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Long vectors, few of them (the reference's own use: ONE vector per dispatch): the per-lane chain order pins the arithmetic
+// to one half-wave, and a half-wave alone keeps only ~8 KiB of loads in flight (measured 10 GB/s from HBM). Here all 8 waves
+// of a 512-thread workgroup stream the vector into a ring of 8 LDS slots (16 KiB = 32 rows of 128 floats each) with LDS-DMA,
+// 7 slots ahead, awaited with a counted vmcnt; lanes 0-31 of wave 0 then fold the rows IN ORDER out of LDS -- same expression
+// tree, same bits, but the memory system sees 100+ KiB in flight from the CU: 9.5 -> 37 GB/s on a 256 MiB vector.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLongThreads = 512;
+constexpr int kLongSlots = 8;
+constexpr int kLongSlotRows = 32;                       // rows of 128 floats (512 B) per slot
+constexpr int kLongSlotBytes = kLongSlotRows * 512;     // 16 KiB
+constexpr int kLongPieces = kLongSlotBytes / 1024 / 8;  // DMA pieces per wave per slot (= 2)
+
+__device__ __forceinline__ void red_dma16(const float *gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst));
+}
+
+template <int OP>
+__global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restrict__ base, uint32_t n, uint32_t ncols, uint32_t nvec,
+                                                            uint32_t stride, uint32_t stride_mat, float *__restrict__ results) {
+    __shared__ __attribute__((aligned(16))) char ring[kLongSlots * kLongSlotBytes];
+    const uint32_t q = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float *x = vector_base(base, q, ncols, stride, stride_mat);
+    const uint32_t full_rows = n / 128u;
+    const uint32_t nslots = full_rows / kLongSlotRows; // whole slots; the rest is folded straight from global memory below
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
+
+    auto issue = [&](uint32_t slot) { // this wave's 2 KiB of vector slot `slot` -> ring position slot % 8
+        const float *src = x + (uint64_t)slot * (kLongSlotRows * 128u) + (uint32_t)wave * (kLongPieces * 256u) + 4u * lane;
+        const uint32_t dst = lds_base + (slot % kLongSlots) * kLongSlotBytes + wave * (kLongPieces * 1024);
+#pragma unroll
+        for (int p = 0; p < kLongPieces; ++p) red_dma16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+    };
+
+    float acc[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
+    for (uint32_t s = 0; s < kLongSlots - 1 && s < nslots; ++s) issue(s);
+    for (uint32_t s = 0; s < nslots; ++s) {
+        // slot s has landed once at most the (up to 6) younger slots' pieces of this wave are still in flight
+        const uint32_t younger = min(nslots - 1 - s, (uint32_t)kLongSlots - 2);
+        switch (younger) { // vmcnt takes an immediate
+        case 6: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        __syncthreads(); // everyone's pieces of slot s are in LDS; the consumer has left slot s-1
+        if (s + kLongSlots - 1 < nslots) issue(s + kLongSlots - 1); // refill the position slot s-1 occupied
+        if (wave == 0 && lane < 32) {
+            // (measured: 37 GB/s, bound by what ONE wave can pull out of LDS. Reading two rows per 64-lane ds_read_b128 and
+            // handing the upper half down with v_permlane32_swap, with the reads of slot s issued before slot s-1 is folded,
+            // was slower -- 17.6 GB/s: hipcc hoists the swaps onto the freshly read registers and serialises the lot.)
+            const float4 *rows = reinterpret_cast<const float4 *>(ring + (s % kLongSlots) * kLongSlotBytes) + lane;
+            float4 v[kLongSlotRows];
+#pragma unroll
+            for (int r = 0; r < kLongSlotRows; ++r) v[r] = rows[r * 32];
+#pragma unroll
+            for (int r = 0; r < kLongSlotRows; ++r) { // ascending rows: the per-lane chain of reduce.wgsl:71-74
+                acc[0] = r_ws<OP>(acc[0], v[r].x);
+                acc[1] = r_ws<OP>(acc[1], v[r].y);
+                acc[2] = r_ws<OP>(acc[2], v[r].z);
+                acc[3] = r_ws<OP>(acc[3], v[r].w);
+            }
+        }
+    }
+    if (wave != 0 || lane >= 32) return;
+    const uint32_t p = lane;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (uint32_t r = nslots * kLongSlotRows; r < full_rows; ++r) { // < 32 left-over full rows
+        const float4 v = x4[(uint64_t)r * 32u + p];
+        acc[0] = r_ws<OP>(acc[0], v.x);
+        acc[1] = r_ws<OP>(acc[1], v.y);
+        acc[2] = r_ws<OP>(acc[2], v.z);
+        acc[3] = r_ws<OP>(acc[3], v.w);
+    }
+    {
+        const uint32_t i0 = full_rows * 128u + 4u * p;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (i0 + c < n) acc[c] = r_ws<OP>(acc[c], x[i0 + c]);
+    }
+#pragma unroll
+    for (int sft = 16; sft >= 1; sft >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = r_red<OP>(acc[c], __shfl_down(acc[c], sft, 32));
+    }
+    acc[0] = r_red<OP>(acc[0], acc[2]);
+    acc[1] = r_red<OP>(acc[1], acc[3]);
+    acc[0] = r_red<OP>(acc[0], acc[1]);
+    if (p == 0) results[q] = acc[0];
+}
+
 template <int OP>
 int launch(wg_ctx *ctx, const float *base, uint32_t n, uint32_t ncols, uint32_t nmats, uint32_t stride,
            uint32_t stride_mat, float *results) {
@@ -157,7 +256,9 @@ int launch(wg_ctx *ctx, const float *base, uint32_t n, uint32_t ncols, uint32_t 
     if (nvec64 > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: more than 2^31 vectors in one call");
     const uint32_t nvec = (uint32_t)nvec64;
     const bool aligned = ((uintptr_t)base % 16 == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
-    if (aligned) {
+    if (aligned && n >= 65536u && nvec <= 256u) { // long vectors, fewer than there are CUs: one 8-wave workgroup each
+        hipLaunchKernelGGL(reduce_long<OP>, dim3(nvec), dim3(kLongThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
+    } else if (aligned) {
         const uint32_t per_block = kThreads / 32;
         hipLaunchKernelGGL(reduce_rows4<OP>, dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n,
                            ncols, nvec, stride, stride_mat, results);
