@@ -484,3 +484,25 @@ def test_gemv_strided_views(gpu, oracle_c, tr):
     s = sh(o_view).resolved()
     mask[(s.offset + np.arange(olen)[:, None] + np.arange(3)[None, :] * s.stride).ravel()] = False
     assert np.array_equal(got[mask], po[mask]), "gemv wrote outside its output view"
+
+
+def test_reduce_long_vectors_bit_exact(gpu, oracle_c):
+    """Few long vectors take the 8-wave LDS-ring kernel: ragged lengths, several vectors, a strided matrix view -- all bit-exact."""
+    wg, wo = _wg(), _wo()
+    shapes = wg.ViewShapeBuffers()
+    rng = np.random.default_rng(123)
+    n, nvec, ld = 300_007, 5, 300_012  # ragged tail (n % 128 = 103), rows left over after whole 32-row slots, padded columns
+    x = (rng.random(ld * nvec + 8, dtype=np.float32) * 2 - 1).astype(np.float32)
+    tx = upload(gpu, (x.size,), x)
+    view = wg.GpuTensorView(wg.ViewShape((n, nvec, 1), ld, ld * nvec, 4), tx, 2)
+    for op in wg.ReduceOp:
+        red = wg.Reduce.new(gpu.device(), op)
+        res = upload(gpu, (nvec,), np.full(nvec, np.nan, np.float32))
+        run_pass(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, view, res))
+        exp = oracle_c.reduce_batched(int(op), x, wo.Shape(n, nvec, 1, ld, ld * nvec, 4))
+        U.assert_bits_equal(res.read(gpu.device()), exp, f"long-vector reduce {op!r}")
+        one = upload(gpu, (), np.array([np.nan], np.float32))
+        v1 = wg.GpuTensorView(wg.ViewShape((1 << 20, 1, 1), 1, 1, 8), tx, 1)
+        run_pass(gpu, lambda p: red.dispatch(gpu.device(), shapes, p, v1, one))
+        U.assert_bits_equal(one.read(gpu.device()), np.array([oracle_c.reduce(int(op), x, wo.Shape(1 << 20, 1, 1, 1, 1, 8))], np.float32),
+                            f"single 2^20 vector {op!r}")
