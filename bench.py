@@ -106,7 +106,11 @@ class GemmWorkload(Workload):
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
         # N-panels: the all-gather of panel i overlaps the GEMM of panel i+1 (only meaningful with > 1 rank)
         self.dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
-        npanels = 1 if not self.dist_mode else max(1, min(8, self.N // 2048))
+        # Panel count: enough panels to overlap the all-gather with compute, but >= ~512 output tiles (256 x 256) per launch:
+        # the f16 GEMM workgroup needs a whole CU, so CUs occupied by RCCL's copy kernels are unavailable to it and a panel of
+        # exactly 256 tiles (8 ranks: 4096 x 4096 per panel) would take two rounds instead of one.
+        tiles = (self.M // max(world, 1) // 256) * (self.N // 256)
+        npanels = 1 if not self.dist_mode else max(1, min(8, tiles // 512, self.N // 2048))
         self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels)
         self.Mg = plan.Mg  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
         self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
