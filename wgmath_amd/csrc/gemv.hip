@@ -212,31 +212,53 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
 }
 
 // out[r] = sum_{s < nsplit} partial[s][r] in a FIXED order. partial layout: [z][s][y][rows_out] dense.
-// A workgroup covers 16 float4 rows x 16 "split lanes": lane j adds splits j, j+16, ... ascending, then the 16 lane sums
-// are added ascending through LDS -- enough parallelism that the pass costs a couple of microseconds, not 12.
+// A workgroup covers 4 float4 rows x 64 "split lanes": split lane j adds splits j, j+64, ... ascending (4 independent loads
+// in flight per trip), then the 16 split lanes of a wave are folded by a butterfly and the 4 waves ascending through LDS.
+// The pass is latency-, not bandwidth-bound: with 16 split lanes and one dependent load per trip it cost 25-50 us when a
+// skinny matrix needed ~1000 splits (64 x 2^20: 70 us total against a 42 us stream); this layout keeps it at a few us.
+// (Folding the partials in the producing kernel -- last-arriver protocol with device-scope stores and one atomic per
+// workgroup -- was measured and rejected: same-address atomics serialise, 64 x 2^20 went to 120 us and 4096^2 from 15 to
+// 27 us; it only won 1-2 us on the launch-bound 1024^2 case.)
 __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__restrict__ partial, uint32_t nsplit, uint32_t rows_out,
                                                                  uint32_t nrhs, float *__restrict__ out, uint32_t ld_out,
                                                                  uint64_t out_batch) {
-    __shared__ float4 red[16][16];
-    const uint32_t rl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const uint32_t r4 = blockIdx.x * 16u + rl; // float4 index within a column
+    __shared__ float4 red[kWaves][4];
+    const uint32_t rl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const uint32_t r4 = blockIdx.x * 4u + rl; // float4 index within a column
     const bool ok = r4 * 4u < rows_out;
     const uint32_t y = blockIdx.y, z = blockIdx.z;
     const uint64_t split_stride = (uint64_t)nrhs * rows_out;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ok) {
         const float4 *p = reinterpret_cast<const float4 *>(partial + (uint64_t)z * nsplit * split_stride + (uint64_t)y * rows_out) + r4;
-        for (uint32_t i = sl; i < nsplit; i += 16u) {
-            float4 q = p[(uint64_t)i * (split_stride / 4u)];
+        const uint64_t ss4 = split_stride / 4u;
+        uint32_t i = sl;
+        for (; i + 192u < nsplit; i += 256u) {
+            float4 q0 = p[(uint64_t)i * ss4], q1 = p[(uint64_t)(i + 64u) * ss4], q2 = p[(uint64_t)(i + 128u) * ss4],
+                   q3 = p[(uint64_t)(i + 192u) * ss4];
+            s.x += q0.x; s.y += q0.y; s.z += q0.z; s.w += q0.w;
+            s.x += q1.x; s.y += q1.y; s.z += q1.z; s.w += q1.w;
+            s.x += q2.x; s.y += q2.y; s.z += q2.z; s.w += q2.w;
+            s.x += q3.x; s.y += q3.y; s.z += q3.z; s.w += q3.w;
+        }
+        for (; i < nsplit; i += 64u) {
+            float4 q = p[(uint64_t)i * ss4];
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
     }
-    red[sl][rl] = s;
-    __syncthreads();
-    if (sl == 0 && ok) {
+    // the 16 split lanes of this wave (lane bits 2..5), fixed butterfly order
 #pragma unroll
-        for (int j = 1; j < 16; ++j) {
-            float4 q = red[j][rl];
+    for (int st = 4; st <= 32; st <<= 1) {
+        s.x += __shfl_xor(s.x, st, 64); s.y += __shfl_xor(s.y, st, 64);
+        s.z += __shfl_xor(s.z, st, 64); s.w += __shfl_xor(s.w, st, 64);
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) < 4u) red[wave][rl] = s;
+    __syncthreads();
+    if (threadIdx.x < 4u && ok) {
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+            float4 q = red[w][rl];
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
         *reinterpret_cast<float4 *>(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4) = s;
@@ -303,7 +325,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     }
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, 16u), nrhs, nmats), block, 0, ctx->stream, partial,
+        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, 4u), nrhs, nmats), block, 0, ctx->stream, partial,
                            nsplit, rows_out, nrhs, (float *)out, out_ld, out_batch);
         WG_HIP_TRY(hipGetLastError());
     }
