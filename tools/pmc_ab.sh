@@ -10,7 +10,7 @@ import csv, glob, sys, collections
 agg=collections.defaultdict(list); dur=[]
 for f in glob.glob('gpurun_out/pmc_tmp/*/p_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        if 'gemm_f16_kernel' in r['Kernel_Name'] or 'gemm_f32_kernel' in r['Kernel_Name']:
+        if 'gemm_f16_' in r['Kernel_Name'] or 'gemm_f32_kernel' in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
             dur.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
 m={k:sum(v)/len(v) for k,v in agg.items()}
