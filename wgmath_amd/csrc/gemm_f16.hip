@@ -25,6 +25,7 @@
 #include "wg_internal.hpp"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -406,6 +407,12 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
+// compile-time loop: the body sees its index as a constant expression (no reliance on the unroller's size thresholds)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 constexpr int M16_A_RING = 4, M16_B_RING = 3;
 constexpr int M16_BS_BYTES = BN * 64 * 2;              // one full stage of B: 256 rows x 128 bytes = 32 KiB
 constexpr int M16_B_BASE = M16_A_RING * HA_BYTES;      // 64 KiB
@@ -415,10 +422,20 @@ __device__ __forceinline__ void m16_set_m0(uint32_t lds_dst) {
     if (WG_ABLATE & 2) return;
     asm volatile("s_mov_b32 m0, %0" ::"s"(lds_dst));
 }
-__device__ __forceinline__ void m16_dma(uint32_t voff, const void *sbase) { // needs >= 1 instruction since m16_set_m0
+// LDS destination = M0 + IMM + 16 * lane; the instruction's immediate offset moves the GLOBAL address too, so the per-piece
+// voff registers are biased by -IMM (see M16_BIAS). Needs >= 1 instruction since m16_set_m0.
+template <int IMM>
+__device__ __forceinline__ void m16_dma_imm(uint32_t voff, const void *sbase) {
     if (WG_ABLATE & 2) return;
-    asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase));
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
+__device__ __forceinline__ void m16_dma(int q, uint32_t voff, const void *sbase) { // piece q (0..3) of a group of four
+    if (q == 0) m16_dma_imm<0>(voff, sbase);
+    else if (q == 1) m16_dma_imm<1024>(voff, sbase);
+    else if (q == 2) m16_dma_imm<2048>(voff, sbase);
+    else m16_dma_imm<3072>(voff, sbase);
+}
+constexpr uint32_t M16_BIAS = 3072; // scalar bases are lowered by this many bytes, voff of piece q raised by BIAS - 1024 q
 
 template <bool TRANS_A>
 __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
@@ -465,6 +482,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3), g.M - 8u - m0); // M % 8 == 0
             a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u;
         }
+        a_voff[q] += M16_BIAS - 1024u * q;
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { // rows 8P..8P+7, 128 bytes each: lane -> row 8P + (lane>>3), position lane&7
@@ -473,14 +491,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         const uint32_t f = ((4u - ((row >> 2) & 3u)) & 3u) | (((row >> 1) & 1u) << 2);
         const uint32_t chunk = (lane & 7u) ^ f;
         const uint32_t rb = min(row, g.N - 1u - n0);
-        b_voff[q] = (rb * g.ldb + 8u * chunk) * 2u;
+        b_voff[q] = (rb * g.ldb + 8u * chunk) * 2u + (M16_BIAS - 1024u * (q & 3));
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
     const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);            // + slot * 16 KiB + q * 1 KiB
     const uint32_t lds_b_wave = __builtin_amdgcn_readfirstlane(lds_base + M16_B_BASE + wave * 8192); // + slot * 32 KiB + q * 1 KiB
     auto a_src = [&](uint32_t H) -> const _Float16 * { // global base of half-stage H
-        if constexpr (TRANS_A) return a_base + H * BKH; else return a_base + (uint64_t)(H * BKH) * g.lda;
+        const char *p0;
+        if constexpr (TRANS_A) p0 = (const char *)(a_base + H * BKH); else p0 = (const char *)(a_base + (uint64_t)(H * BKH) * g.lda);
+        return (const _Float16 *)(p0 - M16_BIAS);
     };
+    auto b_src = [&](uint32_t stage) -> const _Float16 * { return (const _Float16 *)((const char *)(b_base + 64u * stage) - M16_BIAS); };
 
     // ---- per-lane LDS read offsets ----
     uint32_t b_off[2]; // [half-step parity within the stage]
@@ -580,30 +601,32 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         if constexpr (ADMA) { ga = a_src(H + 4u); la = lds_a_wave + (H & 3u) * HA_BYTES; }
         if constexpr (BDMA) {
             // even H: second half (q = 4..7) of B(st+2); odd H: first half (q = 0..3) of B(st+3)
-            gb = b_base + 64u * (st + 2u + HS);
+            gb = b_src(st + 2u + HS);
             lb = lds_b_wave + (HS == 0 ? bs2 : bs0) * M16_BS_BYTES + (HS == 0 ? 4096u : 0u);
         }
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const int t = j >> 3, u = j & 7;
+        static_for<64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 3, u = j & 7;
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
             if constexpr (decltype(has_next)::value) {
                 if constexpr (TRANS_A) {
-                    if ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1);
+                    if constexpr ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1);
                 } else {
-                    if ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1);
+                    if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1);
                 }
             }
-            const int pi = j >> 3, q = pi >> 1; // piece of this 8-slot window: even = A piece q, odd = B piece q
-            if ((pi & 1) == 0 ? ADMA : BDMA) {
-                if ((j & 7) == 1) m16_set_m0(((pi & 1) == 0 ? la : lb) + q * 1024);
-                if ((j & 7) == 3) {
-                    if ((pi & 1) == 0) m16_dma(a_voff[q], ga);
-                    else m16_dma(b_voff[(HS == 0 ? 4 : 0) + q], gb);
+            // DMA: windows 0..3 = the four A pieces, windows 4..7 = the four B pieces; M0 is set once per group
+            constexpr int pi = j >> 3, q = pi & 3;
+            if constexpr (pi < 4 ? ADMA : BDMA) {
+                if constexpr (j == 1) m16_set_m0(la);
+                if constexpr (j == 33) m16_set_m0(lb);
+                if constexpr ((j & 7) == 3) {
+                    if constexpr (pi < 4) m16_dma_imm<1024 * q>(a_voff[q], ga);
+                    else m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     // end of a half-step: all fragment reads done (also tells the compiler's wait-count pass that no LDS read is pending
     // across the loop back-edge -- otherwise it opens each iteration with lgkmcnt(0) AFTER new reads were issued), at most
@@ -629,17 +652,15 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         for (int hh = 0; hh < 4; ++hh)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                m16_set_m0(lds_a_wave + hh * HA_BYTES + q * 1024);
-                asm volatile("s_nop 0");
-                m16_dma(a_voff[q], a_src(hh));
+                if (q == 0) { m16_set_m0(lds_a_wave + hh * HA_BYTES); asm volatile("s_nop 0"); }
+                m16_dma(q, a_voff[q], a_src(hh));
             }
 #pragma unroll
         for (int sb = 0; sb < 3; ++sb)
 #pragma unroll
             for (int q = 0; q < (sb == 2 ? 4 : 8); ++q) {
-                m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + q * 1024);
-                asm volatile("s_nop 0");
-                m16_dma(b_voff[q], b_base + 64u * sb);
+                if ((q & 3) == 0) { m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
+                m16_dma(q & 3, b_voff[q], b_src(sb));
             }
     }
     wait_dma_all();
