@@ -30,7 +30,7 @@
 namespace {
 
 #ifndef WG_ABLATE
-#define WG_ABLATE 0 // timing experiments only: 1 = no barrier, 2 = no DMA, 4 = no LDS reads, 8 = B fetched as 128-byte rows, 16 = no lane swaps (bitmask); results are garbage
+#define WG_ABLATE 0 // timing experiments only: 1 = no barrier, 2 = no DMA, 4 = no LDS reads, 8 = (unused), 16 = no lane swaps, 32 = no epilogue stores (bitmask); results are garbage
 #endif
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             half8_t v;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-            *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+            if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
         }
     }
 }
