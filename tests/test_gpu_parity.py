@@ -333,6 +333,8 @@ F16_SHAPES = [
     (8, 32, 8, 1), (264, 96, 520, 1), (1000, 256, 776, 2), (4096 + 8, 64, 256 - 8, 1), (248, 32, 4104, 1),
     # split-K (few tiles, long K), incl. a K that does not divide evenly and a batch
     (256, 8192, 256, 1), (512, 4096 + 32, 264, 1), (1024, 16384, 512, 2),
+    # 16x16x32 kernel (K % 64 == 0, >= 3 stages): minimum, odd and even stage counts, several tiles per CU-less grid
+    (512, 192, 512, 1), (512, 320, 512, 1), (768, 448, 264, 2), (2048, 2048, 1024, 1),
 ]
 
 
