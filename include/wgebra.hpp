@@ -232,14 +232,19 @@ enum class GemvVariant { Gemv = WG_GEMV, GemvFast = WG_GEMV_FAST, GemvTr = WG_GE
 enum class ReduceOp { Min = WG_REDUCE_MIN, Max = WG_REDUCE_MAX, Sum = WG_REDUCE_SUM, Prod = WG_REDUCE_PROD, SqNorm = WG_REDUCE_SQNORM };
 enum class OpAssignVariant { Add = WG_OP_ADD, Sub = WG_OP_SUB, Mul = WG_OP_MUL, Div = WG_OP_DIV, Copy = WG_OP_COPY };
 
+// linalg/shape.rs:11-15: the shader definitions that make `Shape` row-major; pass them to Gemm/Gemv::from_device
+struct ShaderDefs { bool row_major = false; };
+inline ShaderDefs row_major_shader_defs() { return ShaderDefs{ true }; }
+
 // gemm.rs:9-127
 struct Gemm {
-    static Gemm from_device(const Device &) { return {}; } // pipelines are ahead-of-time compiled: nothing to build
+    bool row_major = false;
+    static Gemm from_device(const Device &, ShaderDefs defs = {}) { return Gemm{ defs.row_major }; } // pipelines are ahead-of-time compiled
     template <typename T>
     void dispatch_generic(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> out, GpuTensorView<T> m1,
                           GpuTensorView<T> m2, GemmVariant variant) const {
-        check(wg_gemm(pass.ctx(), (wg_gemm_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(), m1.buffer(), m1.shape(),
-                      m2.buffer(), m2.shape()));
+        check((row_major ? wg_gemm_rm : wg_gemm)(pass.ctx(), (wg_gemm_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(),
+                                                 m1.buffer(), m1.shape(), m2.buffer(), m2.shape()));
     }
     template <typename T>
     void dispatch(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m1, GpuTensorView<T> m2) const {
@@ -259,12 +264,13 @@ struct Gemm {
 
 // gemv.rs:9-137
 struct Gemv {
-    static Gemv from_device(const Device &) { return {}; }
+    bool row_major = false;
+    static Gemv from_device(const Device &, ShaderDefs defs = {}) { return Gemv{ defs.row_major }; }
     template <typename T>
     void dispatch_generic(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> out, GpuTensorView<T> m,
                           GpuTensorView<T> v, GemvVariant variant) const {
-        check(wg_gemv(pass.ctx(), (wg_gemv_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(), m.buffer(), m.shape(),
-                      v.buffer(), v.shape()));
+        check((row_major ? wg_gemv_rm : wg_gemv)(pass.ctx(), (wg_gemv_variant)variant, dtype_of<T>::value, out.buffer(), out.shape(),
+                                                 m.buffer(), m.shape(), v.buffer(), v.shape()));
     }
     template <typename T>
     void dispatch(const Device &d, const ViewShapeBuffers &s, ComputePass &p, GpuTensorView<T> out, GpuTensorView<T> m, GpuTensorView<T> v) const {

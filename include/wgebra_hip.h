@@ -181,6 +181,24 @@ int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
             const wg_buf *v, wg_view_shape v_shape);
 
 /*
+ * ROW_MAJOR operator surface. Replaces composing the reference's shaders with
+ * `row_major_shader_defs()` (wgebra linalg/shape.rs:11-15): every matrix view of the call is ROW-major,
+ * index = t*stride_mat + offset + i*stride + j (shape.wgsl:49-52), `stride` = elements between consecutive ROWS;
+ * the vec4 precondition becomes cols, stride, stride_mat, offset % 4 == 0 (shape.wgsl:54-56). Same dimension checks
+ * and messages as wg_gemm / wg_gemv. A row-major view is the column-major view of the transpose, so WG_GEMM runs the
+ * column-major kernel with the operands swapped (no copy); WG_GEMM_TR needs m1 transposed in memory first (one HBM-bound
+ * pass into a context-owned scratch buffer). wg_gemv_rm supports single right-hand-side vectors (ncols == 1).
+ */
+int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype,
+               wg_buf *out, wg_view_shape out_shape,
+               const wg_buf *m1, wg_view_shape m1_shape,
+               const wg_buf *m2, wg_view_shape m2_shape);
+int wg_gemv_rm(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
+               wg_buf *out, wg_view_shape out_shape,
+               const wg_buf *m, wg_view_shape m_shape,
+               const wg_buf *v, wg_view_shape v_shape);
+
+/*
  * Reduce::dispatch (wgebra reduce.rs:100-113): result[0] = reduce(op, value[offset .. offset+size[0])).
  * `result` is the GpuScalar's buffer (>= 4 bytes). The summation ORDER is the reference's (128 strided lanes,
  * then the 64..1 tree; reduce.wgsl:68-87), so Min/Max/Sum/Prod are bit-identical to it; n == 0 gives the init

@@ -508,3 +508,81 @@ def test_reduce_long_vectors_bit_exact(gpu, oracle_c):
         run_pass(gpu, lambda p: red.dispatch(gpu.device(), shapes, p, v1, one))
         U.assert_bits_equal(one.read(gpu.device()), np.array([oracle_c.reduce(int(op), x, wo.Shape(1 << 20, 1, 1, 1, 1, 8))], np.float32),
                             f"single 2^20 vector {op!r}")
+
+
+# --------------------------------------------------------------------------------------------------------
+# ROW_MAJOR operator surface (shape.wgsl:49-57, linalg/shape.rs:11-15)
+# --------------------------------------------------------------------------------------------------------
+def _rm_view(wg, t, rows, cols, mats=1, stride=None, stride_mat=None, offset=0):
+    """A ROW-major view: index = t*stride_mat + offset + i*stride + j."""
+    stride = cols if stride is None else stride
+    stride_mat = rows * stride if stride_mat is None else stride_mat
+    return wg.GpuTensorView(wg.ViewShape([rows, cols, mats], stride, stride_mat, offset), t, 3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N,mats", [(64, 128, 32, 1), (260, 72, 132, 2), (512, 256, 768, 1)])
+def test_gemm_row_major(gpu, dtype, tr, M, K, N, mats):
+    """out = m1 m2 and out = m1^T m2 on ROW-major operands (numpy's default layout), against f64."""
+    wg = _wg()
+    rng = np.random.default_rng(M + K + N + mats + tr)
+    a = (rng.random((mats, K, M) if tr else (mats, M, K), dtype=np.float32) * 2 - 1).astype(dtype)
+    b = (rng.random((mats, K, N), dtype=np.float32) * 2 - 1).astype(dtype)
+    ta, tb = upload(gpu, (a.size,), a.reshape(-1), dtype), upload(gpu, (b.size,), b.reshape(-1), dtype)
+    tc = upload(gpu, (mats * M * N,), np.full(mats * M * N, np.nan, dtype), dtype)
+    gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    va = _rm_view(wg, ta, K, M, mats) if tr else _rm_view(wg, ta, M, K, mats)
+    vb, vc = _rm_view(wg, tb, K, N, mats), _rm_view(wg, tc, M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, vc, va, vb, variant))
+    got = tc.read(gpu.device()).reshape(mats, M, N).astype(np.float64)
+    for t in range(mats):
+        a64 = (a[t].T if tr else a[t]).astype(np.float64)
+        b64 = b[t].astype(np.float64)
+        truth, sabs = a64 @ b64, np.abs(a64) @ np.abs(b64)
+        tol = U.f32_gate(K, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0)
+        err = np.abs(got[t] - truth)
+        assert (err <= tol).all(), f"row-major gemm tr={tr} mat {t}: worst err/tol {(err / tol).max():.3g}"
+
+
+def test_gemm_row_major_strided_view_and_errors(gpu):
+    """A row-major sub-view (row stride > cols, offset) of a larger buffer, and the reference's dimension panic."""
+    wg = _wg()
+    rng = np.random.default_rng(11)
+    big = (rng.random((96, 80), dtype=np.float32) * 2 - 1)
+    tbig = upload(gpu, (big.size,), big.reshape(-1), np.float32)
+    a = big[8:8 + 64, 12:12 + 32]                      # 64 x 32 block, row stride 80, offset 8*80 + 12
+    b = (rng.random((32, 48), dtype=np.float32) * 2 - 1)
+    tb = upload(gpu, (b.size,), b.reshape(-1), np.float32)
+    tc = upload(gpu, (64 * 48,), np.zeros(64 * 48, np.float32), np.float32)
+    gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    va = _rm_view(wg, tbig, 64, 32, 1, stride=80, offset=8 * 80 + 12)
+    run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, _rm_view(wg, tc, 64, 48), va, _rm_view(wg, tb, 32, 48)))
+    got = tc.read(gpu.device()).reshape(64, 48).astype(np.float64)
+    truth, sabs = a.astype(np.float64) @ b.astype(np.float64), np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    assert (np.abs(got - truth) <= U.f32_gate(32, sabs)).all()
+    with pytest.raises(wg.DimensionMismatch, match="Gemm: dimension mismatch."):
+        run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, _rm_view(wg, tc, 64, 48), va, _rm_view(wg, tb, 48, 32)))
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("R,Cn", [(64, 256), (1024, 1024), (260, 72)])
+def test_gemv_row_major(gpu, tr, R, Cn):
+    wg = _wg()
+    rng = np.random.default_rng(R + Cn + tr)
+    m = rng.random((R, Cn), dtype=np.float32) * 2 - 1
+    vlen, olen = (R, Cn) if tr else (Cn, R)
+    v = rng.random(vlen, dtype=np.float32) * 2 - 1
+    tm, tv = upload(gpu, (m.size,), m.reshape(-1), np.float32), upload(gpu, (vlen,), v, np.float32)
+    to = upload(gpu, (olen,), np.full(olen, np.nan, np.float32), np.float32)
+    gemv = wg.Gemv.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, to, _rm_view(wg, tm, R, Cn), tv, variant))
+    got = to.read(gpu.device()).astype(np.float64)
+    m64 = (m.T if tr else m).astype(np.float64)
+    truth, sabs = m64 @ v.astype(np.float64), np.abs(m64) @ np.abs(v).astype(np.float64)
+    assert (np.abs(got - truth) <= U.f32_gate(vlen, sabs)).all()

@@ -8,6 +8,7 @@ from ._lib import (LIB_PATH, DimensionMismatch, NoDevice, PreconditionFailed, Wg
 from .wgcore import (BufferUsages, CommandBuffer, CommandEncoder, ComputePass, Device, GpuCube, GpuInstance,  # noqa: F401
                      GpuMatrix, GpuScalar, GpuTensor, GpuTensorView, GpuTimestamps, GpuVector, Queue, TensorBuilder,
                      ViewShape, ViewShapeBuffers, as_view)
-from .wgebra import (Axpy, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp)  # noqa: F401
+from .wgebra import (Axpy, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
+                     row_major_shader_defs)
 
 __version__ = "0.1.0"

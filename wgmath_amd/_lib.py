@@ -87,6 +87,8 @@ def _load() -> ctypes.CDLL:
         "wg_gemm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_gemm_ex": (ci, [vp, ci, ci, ctypes.c_float, ctypes.c_float, vp, S, vp, S, vp, S]),
         "wg_gemv": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_gemm_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_gemv_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),

@@ -203,4 +203,75 @@ int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y
     return wgk_op_assign(ctx, 5 /* axpy */, dtype, (void *)elem_ptr(y, vy.offset, dtype), elem_ptr(x, vx.offset, dtype), n, alpha);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ROW_MAJOR operator surface. The reference's `Shape` is row-major when its shaders are composed with
+// `row_major_shader_defs()` (shape.rs:11-15; shape.wgsl:49-57: index = t*stride_mat + offset + i*stride + j). A row-major
+// R x C view is the same memory as the column-major C x R view with the same stride, so:
+//   out = m1 m2      <=>  out^T = m2^T m1^T      : the column-major Gemm on the re-labelled views, operands swapped;
+//   out = m1^T m2    <=>  out^T = m2^T (m1^T)^T  : needs the second operand transposed in memory: one HBM-bound transpose
+//                                                  (transpose.hip) into a scratch buffer, then the column-major Gemm;
+//   out = m v        <=>  column-major GemvTr on the re-labelled matrix;   out = m^T v  <=>  column-major Gemv.
+// Vector views (Reduce, OpAssign) index `offset + i` in both orderings: nothing to do.
+// ---------------------------------------------------------------------------------------------------------------
+static wg_view_shape relabel(wg_view_shape s) {
+    const uint32_t r = s.size[0];
+    s.size[0] = s.size[1];
+    s.size[1] = r;
+    return s;
+}
+
+int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m1,
+               wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape) {
+    const wg_buf *bufs[3] = { out, m1, m2 };
+    if (int rc = check_common("Gemm", ctx, dtype, bufs, 3)) return rc;
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
+    const bool tr = variant == WG_GEMM_TR || variant == WG_GEMM_TR_FAST;
+    const View o = mk(out_shape), a = mk(m1_shape), b = mk(m2_shape);
+    const uint32_t m_rows = tr ? a.cols : a.rows, m_cols = tr ? a.rows : a.cols; // gemm.rs:81-96, on the row-major shapes
+    if (m_cols != b.rows || m_rows != o.rows || o.cols != b.cols || o.mats != a.mats || o.mats != b.mats)
+        return wg_set_error(WG_ERR_DIM_MISMATCH,
+                            "Gemm: dimension mismatch. (out [%u,%u,%u], m1 [%u,%u,%u]%s, m2 [%u,%u,%u])", o.rows, o.cols, o.mats,
+                            a.rows, a.cols, a.mats, tr ? "^T" : "", b.rows, b.cols, b.mats);
+    if (!tr) return wg_gemm_ex(ctx, WG_GEMM, dtype, 1.f, 0.f, out, relabel(out_shape), m2, relabel(m2_shape), m1, relabel(m1_shape));
+
+    // m1 is K x M row-major == column-major M x K (ld = stride); the column-major Gemm needs it as K x M column-major
+    if (out->bytes == 0 || m1->bytes == 0 || m2->bytes == 0 || o.rows == 0 || o.cols == 0 || o.mats == 0) return WG_OK;
+    const View a_cm = mk(relabel(m1_shape)); // M x K column-major
+    if (int rc = check_vec4("Gemm", "m1", a_cm)) return rc;
+    if (int rc = check_bounds("Gemm", "m1", a_cm, m1, dtype)) return rc;
+    const size_t es = dtype == WG_F32 ? 4 : 2;
+    const uint32_t K = a.rows, M = a.cols;
+    void *ws = nullptr;
+    if (int rc = wg_ctx_tr_workspace(ctx, (size_t)K * M * a.mats * es, &ws)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = wgk_transpose(ctx, dtype, M, K, a.mats, elem_ptr(m1, a_cm.offset, dtype), a_cm.stride, a_cm.stride_mat, ws, K, (uint64_t)K * M))
+        return rc;
+    wg_buf tmp;
+    tmp.ctx = ctx; tmp.ptr = ws; tmp.bytes = (size_t)K * M * a.mats * es; tmp.usage = 0; tmp.owned = false; tmp.host_pinned = false;
+    wg_view_shape ts;
+    ts.size[0] = K; ts.size[1] = M; ts.size[2] = a.mats; ts.stride = K; ts.stride_mat = K * M; ts.offset = 0;
+    return wg_gemm_ex(ctx, WG_GEMM, dtype, 1.f, 0.f, out, relabel(out_shape), m2, relabel(m2_shape), &tmp, ts);
+}
+
+int wg_gemv_rm(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m,
+               wg_view_shape m_shape, const wg_buf *v, wg_view_shape v_shape) {
+    const wg_buf *bufs[3] = { out, m, v };
+    if (int rc = check_common("Gemv", ctx, dtype, bufs, 3)) return rc;
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemv: unknown variant %d", (int)variant);
+    const bool tr = variant == WG_GEMV_TR || variant == WG_GEMV_TR_FAST;
+    const View o = mk(out_shape), mm = mk(m_shape), vv = mk(v_shape);
+    const uint32_t m_rows = tr ? mm.cols : mm.rows, m_cols = tr ? mm.rows : mm.cols; // gemv.rs:79-91, on the row-major shapes
+    if (m_cols != vv.rows || m_rows != o.rows)
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "Gemv: dimension mismatch. (out [%u,%u,%u], m [%u,%u,%u]%s, v [%u,%u,%u])", o.rows,
+                            o.cols, o.mats, mm.rows, mm.cols, mm.mats, tr ? "^T" : "", vv.rows, vv.cols, vv.mats);
+    if ((variant == WG_GEMV_FAST || variant == WG_GEMV_TR_FAST) && o.rows % 4u != 0)
+        return wg_set_error(WG_ERR_PRECONDITION, "Gemv: assertion `left == right` failed (out_nrows %% 4 == 0, gemv.rs:122): out has %u rows",
+                            o.rows);
+    // a row-major matrix of right-hand sides has its columns strided by 1 element: only single vectors map onto the kernels
+    if (o.cols > 1 || vv.cols > 1)
+        return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv (row-major): %u right-hand-side columns; only vectors (ncols == 1) are supported",
+                            o.cols > vv.cols ? o.cols : vv.cols);
+    return wg_gemv(ctx, tr ? WG_GEMV : WG_GEMV_TR, dtype, out, out_shape, m, relabel(m_shape), v, v_shape);
+}
+
 } // extern "C"

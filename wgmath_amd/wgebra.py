@@ -58,16 +58,27 @@ def _common_dtype(*views: GpuTensorView):
     return wg_dtype(dt)
 
 
+def row_major_shader_defs() -> dict:
+    """linalg/shape.rs:11-15: the shader definitions that switch `Shape` to row-major.  Pass them to `Gemm.from_device` /
+    `Gemv.from_device` (the reference passes them to the shader composer) to get operators whose matrix views are row-major."""
+    return {"ROW_MAJOR": True}
+
+
+def _is_row_major(shader_defs) -> bool:
+    return bool(shader_defs) and bool(shader_defs.get("ROW_MAJOR", False))
+
+
 class Gemm:
     """gemm.rs:9-21.  The four pipelines of the reference are one ahead-of-time compiled MFMA kernel family here, so
     construction is free (no shader compilation)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, shader_defs=None):
         self.device = device
+        self.row_major = _is_row_major(shader_defs)
 
     @staticmethod
-    def from_device(device) -> "Gemm":
-        return Gemm(device)
+    def from_device(device, shader_defs=None) -> "Gemm":
+        return Gemm(device, shader_defs)
 
     def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m1, m2) -> None:
         self.dispatch_generic(device, shapes, pass_, out, m1, m2, GemmVariant.Gemm)
@@ -78,9 +89,10 @@ class Gemm:
     def dispatch_generic(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m1, m2, variant: GemmVariant) -> None:
         out, m1, m2 = as_view(out, 3), as_view(m1, 3), as_view(m2, 3)
         dt = _common_dtype(out, m1, m2)
-        check(lib.wg_gemm(pass_._ctx.handle, int(variant), dt,
-                          out.buffer()._h, out.shape().to_c(), m1.buffer()._h, m1.shape().to_c(),
-                          m2.buffer()._h, m2.shape().to_c()))
+        fn = lib.wg_gemm_rm if self.row_major else lib.wg_gemm
+        check(fn(pass_._ctx.handle, int(variant), dt,
+                 out.buffer()._h, out.shape().to_c(), m1.buffer()._h, m1.shape().to_c(),
+                 m2.buffer()._h, m2.shape().to_c()))
 
 
     def dispatch_ex(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, alpha: float, beta: float, out, m1, m2,
@@ -96,12 +108,13 @@ class Gemm:
 class Gemv:
     """gemv.rs:9-21."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, shader_defs=None):
         self.device = device
+        self.row_major = _is_row_major(shader_defs)
 
     @staticmethod
-    def from_device(device) -> "Gemv":
-        return Gemv(device)
+    def from_device(device, shader_defs=None) -> "Gemv":
+        return Gemv(device, shader_defs)
 
     def dispatch(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m, v) -> None:
         self.dispatch_generic(device, shapes, pass_, out, m, v, GemvVariant.Gemv)
@@ -112,9 +125,10 @@ class Gemv:
     def dispatch_generic(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, out, m, v, variant: GemvVariant) -> None:
         out, m, v = as_view(out, 3), as_view(m, 3), as_view(v, 3)
         dt = _common_dtype(out, m, v)
-        check(lib.wg_gemv(pass_._ctx.handle, int(variant), dt,
-                          out.buffer()._h, out.shape().to_c(), m.buffer()._h, m.shape().to_c(),
-                          v.buffer()._h, v.shape().to_c()))
+        fn = lib.wg_gemv_rm if self.row_major else lib.wg_gemv
+        check(fn(pass_._ctx.handle, int(variant), dt,
+                 out.buffer()._h, out.shape().to_c(), m.buffer()._h, m.shape().to_c(),
+                 v.buffer()._h, v.shape().to_c()))
 
 
 class Reduce:
