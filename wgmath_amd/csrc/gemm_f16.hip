@@ -25,6 +25,8 @@
 #include "wg_internal.hpp"
 
 #include <type_traits>
+#include <vector>
+#include <cstdio>
 #include <utility>
 
 namespace {
@@ -448,6 +450,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     const int aq = i16 >> 2, bb = i16 & 3;
     const int gq = (4 - aq) & 3; // G(aq)
 
+#ifdef WG_F16_TRACE
+    // timing experiment: wave 0 records s_memrealtime (100 MHz) at 5 points + its hardware id into g.part[blockIdx.x * 8 ..]
+    uint64_t tr_t[5];
+    tr_t[0] = __builtin_amdgcn_s_memrealtime();
+#define WG_TRACE_POINT(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tr_t[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WG_TRACE_POINT(i) do { } while (0)
+#endif
     uint32_t tm, tn;
     tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
@@ -669,6 +679,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     for (int op = 0; op < kOps; ++op) frag_op(smem, smem + b_off[0], op, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing pending on entry to the loop either
     __builtin_amdgcn_sched_barrier(0);
+    WG_TRACE_POINT(1);
 
     // No parity branches (two accumulator-modifying arms merging in a loop make the register allocator shuffle all 256
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
@@ -686,6 +697,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     next_stage();
     half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
     half_step(c1{}, no{}, no{}, no{});
+    WG_TRACE_POINT(2);
 
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
@@ -736,6 +748,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
         }
     }
+#ifdef WG_F16_TRACE
+    WG_TRACE_POINT(3);                       // all stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_TRACE_POINT(4);                       // all stores acknowledged
+    if (threadIdx.x == 0 && g.nsplit == 1 && g.part) {
+        uint64_t *o = (uint64_t *)g.part + (uint64_t)blockIdx.x * 8u;
+        for (int i = 0; i < 5; ++i) o[i] = tr_t[i];
+        o[5] = __builtin_amdgcn_s_getreg((3 << 0) | (0 << 6) | (31 << 11)); // HW_ID
+        o[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID (gfx940+)
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -847,8 +870,25 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // shorter) must be a multiple of 64 k and >= 192 k
         const uint32_t last_k = K - (nsplit - 1) * g.k_per_split;
         if (WG_F16_M16 && g.k_per_split % 64u == 0 && last_k % 64u == 0 && last_k >= 192u && (nsplit == 1 || g.k_per_split >= 192u)) {
+#ifdef WG_F16_TRACE
+            uint64_t *trace = nullptr;
+            if (nsplit == 1) {
+                WG_HIP_TRY(hipMalloc((void **)&trace, tiles * nmats * 64));
+                g.part = (float *)trace;
+            }
+#endif
             if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), grid, dim3(256), 0, ctx->stream, g);
             else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), grid, dim3(256), 0, ctx->stream, g);
+#ifdef WG_F16_TRACE
+            if (trace) {
+                WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+                std::vector<uint64_t> h(tiles * nmats * 8);
+                WG_HIP_TRY(hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE *f = fopen("/tmp/wg_f16_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+                (void)hipFree(trace);
+                g.part = nullptr;
+            }
+#endif
         } else {
             const dim3 block(128 * WG_F16_NWN);
             if (trans) hipLaunchKernelGGL((gemm_f16_kernel<true, WG_F16_NWN>), grid, block, 0, ctx->stream, g);
