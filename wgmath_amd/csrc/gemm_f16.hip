@@ -656,28 +656,34 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     using k4 = std::integral_constant<int, 4>;
     using k0 = std::integral_constant<int, 0>;
 
-    // prologue: A(0..3), B(0), B(1) and the first half of B(2); everything landed before the first barrier (once per tile)
+    // prologue (once per tile): A(0..3), B(0), B(1) and the first half of B(2). Only what the first two half-steps read --
+    // A(0), B(0), A(1), issued first -- must have landed before the first barrier; the rest is issued in the order the steady
+    // state's counted waits expect it to retire: A(2), B(1) (needed after half-step 0), A(3), B(2) first half (after half-step 1).
+    auto pro_a = [&](int hh) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q == 0) { m16_set_m0(lds_a_wave + hh * HA_BYTES); asm volatile("s_nop 0"); }
+            m16_dma(q, a_voff[q], a_src(hh));
+        }
+    };
+    auto pro_b = [&](int sb, int nq) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q >= nq) break;
+            if ((q & 3) == 0) { m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
+            m16_dma(q & 3, b_voff[q], b_src(sb));
+        }
+    };
     if (!(WG_ABLATE & 2)) {
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (q == 0) { m16_set_m0(lds_a_wave + hh * HA_BYTES); asm volatile("s_nop 0"); }
-                m16_dma(q, a_voff[q], a_src(hh));
-            }
-#pragma unroll
-        for (int sb = 0; sb < 3; ++sb)
-#pragma unroll
-            for (int q = 0; q < (sb == 2 ? 4 : 8); ++q) {
-                if ((q & 3) == 0) { m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
-                m16_dma(q & 3, b_voff[q], b_src(sb));
-            }
+        pro_a(0); pro_b(0, 8); pro_a(1);
+        pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4);
     }
-    wait_dma_all();
+    wait_dma_keep<20>();
     __syncthreads();
 #pragma unroll
     for (int op = 0; op < kOps; ++op) frag_op(smem, smem + b_off[0], op, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing pending on entry to the loop either
+    if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier(); // every wave has read A(0): half-step 0 may overwrite its slot with A(4)
     __builtin_amdgcn_sched_barrier(0);
     WG_TRACE_POINT(1);
 
