@@ -216,8 +216,9 @@ class GemvWorkload(Workload):
     metric = "gemv_gbs"
     unit = "GB/s"
 
-    def __init__(self, name, R, C, trans, graph_batch=0):
+    def __init__(self, name, R, C, trans, graph_batch=0, nrhs=1):
         self.name, self.R, self.C, self.trans = name, R, C, trans
+        self.nrhs = nrhs  # right-hand-side columns (`out_ncols` of the reference: grid.y of gemv.wgsl); the matrix is read ONCE for up to 8
         self.kernel = "gemv_t_kernel" if trans else "gemv_n_kernel"
         # graph_batch > 0: the dispatch is launch-bound (a few MB): record `graph_batch` dispatches into ONE command buffer
         # (a hipGraph) and replay it -- a step is then one Queue::submit of that buffer
@@ -228,9 +229,13 @@ class GemvWorkload(Workload):
         R, C = self.R, self.C
         self.m = device_random(wg, gpu, (R, C), np.float32, 0xC000 + rank)
         vlen, olen = (R, C) if self.trans else (C, R)
-        self.v = device_random(wg, gpu, (vlen,), np.float32, 0xD000)
         S = wg.BufferUsages
-        self.out = wg.TensorBuilder.vector(olen, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+        if self.nrhs == 1:
+            self.v = device_random(wg, gpu, (vlen,), np.float32, 0xD000)
+            self.out = wg.TensorBuilder.vector(olen, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+        else:
+            self.v = device_random(wg, gpu, (vlen, self.nrhs), np.float32, 0xD000)
+            self.out = wg.TensorBuilder.matrix(olen, self.nrhs, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
         self.gemv = wg.Gemv.from_device(gpu.device())
         self.shapes = wg.ViewShapeBuffers()
         self.enc = gpu.device().create_command_encoder()
@@ -253,7 +258,7 @@ class GemvWorkload(Workload):
             self.gemv.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.out, self.m, self.v, self.variant)
 
     def _bytes(self):
-        return 4.0 * (self.R * self.C + self.R + self.C)  # matrix + vector + result
+        return 4.0 * (self.R * self.C + self.nrhs * (self.R + self.C))  # matrix + vector(s) + result(s)
 
     def units_per_step(self):
         return self._bytes() * self.world * max(self.graph_batch, 1)  # every rank streams its own matrix (no collective)
@@ -267,12 +272,13 @@ class GemvWorkload(Workload):
     def check(self):
         gpu = self.gpu
         m = self.m.read(gpu.device()).reshape(self.R, self.C, order="F")
-        v = self.v.read(gpu.device()).astype(np.float64)
-        got = self.out.read(gpu.device()).astype(np.float64)
-        idx = np.unique(np.random.default_rng(2).integers(0, got.size, 64))
+        vlen, olen = (self.R, self.C) if self.trans else (self.C, self.R)
+        v = self.v.read(gpu.device()).astype(np.float64).reshape(vlen, self.nrhs, order="F")
+        got = self.out.read(gpu.device()).astype(np.float64).reshape(olen, self.nrhs, order="F")
+        idx = np.unique(np.random.default_rng(2).integers(0, olen, 64))
         a = (m[:, idx].T if self.trans else m[idx, :]).astype(np.float64)
         truth, sabs = a @ v, np.abs(a) @ np.abs(v)
-        tol = 2 * np.sqrt(v.size) * 2.0 ** -24 * sabs
+        tol = 2 * np.sqrt(vlen) * 2.0 ** -24 * sabs
         assert (np.abs(got[idx] - truth) <= tol).all(), "bench sanity check failed (gemv)"
 
     def cpu_baseline(self, budget_s):
@@ -420,6 +426,7 @@ WORKLOADS = {
     "gemmtr_f32_4096": lambda: GemmWorkload("gemmtr_f32_4096", 4096, 4096, 4096, "f32", trans=True),
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
+    "gemv_f32_4096x65536_rhs8": lambda: GemvWorkload("gemv_f32_4096x65536_rhs8", 4096, 65536, False, nrhs=8),
     "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
     "gemv_f32_1024_graph": lambda: GemvWorkload("gemv_f32_1024_graph", 1024, 1024, False, graph_batch=64),
     "reduce_f32_4096x65536": lambda: ReduceWorkload("reduce_f32_4096x65536", 4096, 65536),
@@ -428,7 +435,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 

@@ -204,6 +204,8 @@ GEMV_SHAPES = [
     # R,    C, nrhs, mats
     (4, 4, 1, 1), (8, 260, 1, 1), (260, 8, 1, 1), (1024, 1024, 1, 1), (512, 4096, 2, 1), (4096, 512, 3, 2),
     (252, 1000, 5, 1), (128, 65536, 1, 1), (65536, 128, 1, 1), (2048, 2048, 4, 1),
+    # RHS register tiles 8 (5..8 columns) and more than one RHS group (> 8 columns), with a batch
+    (1024, 2048, 8, 1), (516, 772, 7, 2), (256, 1024, 9, 1), (1024, 512, 12, 2), (64, 128, 17, 1),
 ]
 
 

@@ -25,7 +25,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kMaxRhs = 4; // RHS columns handled per pass over the matrix (m is read once for all of them)
+constexpr int kMaxRhs = 8; // RHS columns handled per pass over the matrix (m is read once for all of them)
 
 #ifndef GEMV_NT
 #define GEMV_NT 1
@@ -276,7 +276,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
     const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
-    if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/4) = %llu exceeds 65535", (unsigned long long)gz64);
+    if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/8) = %llu exceeds 65535", (unsigned long long)gz64);
     const uint32_t gz = (uint32_t)gz64;
 
     // blocks along the output, and how finely the contraction must be split to give every CU ~4 workgroups
@@ -312,16 +312,20 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     }
 
     const dim3 grid(gx, nsplit, gz), block(kThreads);
-    const int tile = nrhs >= 4 ? 4 : (nrhs >= 2 ? 2 : 1);
-    // kMaxRhs RHS columns per group; the kernel template is the per-pass register tile (a group of 3 uses tile 4)
+    // kMaxRhs RHS columns per group (grid.z); the kernel template is the per-pass register tile: the smallest of 1, 2, 4, 8 that
+    // holds min(nrhs, 8) columns (a group of 3 uses tile 4, of 5..7 tile 8)
+    const uint32_t per_group = nrhs < (uint32_t)kMaxRhs ? nrhs : (uint32_t)kMaxRhs;
+    const int tile = per_group > 4 ? 8 : (per_group > 2 ? 4 : (int)per_group);
     if (trans) {
         if (tile == 1) hipLaunchKernelGGL(gemv_t_kernel<1>, grid, block, 0, ctx->stream, a);
-        else if (tile == 2 && nrhs == 2) hipLaunchKernelGGL(gemv_t_kernel<2>, grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL(gemv_t_kernel<4>, grid, block, 0, ctx->stream, a);
+        else if (tile == 2) hipLaunchKernelGGL(gemv_t_kernel<2>, grid, block, 0, ctx->stream, a);
+        else if (tile == 4) hipLaunchKernelGGL(gemv_t_kernel<4>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(gemv_t_kernel<8>, grid, block, 0, ctx->stream, a);
     } else {
         if (tile == 1) hipLaunchKernelGGL(gemv_n_kernel<1>, grid, block, 0, ctx->stream, a);
-        else if (tile == 2 && nrhs == 2) hipLaunchKernelGGL(gemv_n_kernel<2>, grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL(gemv_n_kernel<4>, grid, block, 0, ctx->stream, a);
+        else if (tile == 2) hipLaunchKernelGGL(gemv_n_kernel<2>, grid, block, 0, ctx->stream, a);
+        else if (tile == 4) hipLaunchKernelGGL(gemv_n_kernel<4>, grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL(gemv_n_kernel<8>, grid, block, 0, ctx->stream, a);
     }
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
