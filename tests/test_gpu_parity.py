@@ -588,3 +588,105 @@ def test_gemv_row_major(gpu, tr, R, Cn):
     m64 = (m.T if tr else m).astype(np.float64)
     truth, sabs = m64 @ v.astype(np.float64), np.abs(m64) @ np.abs(v).astype(np.float64)
     assert (np.abs(got - truth) <= U.f32_gate(vlen, sabs)).all()
+
+
+# --------------------------------------------------------------------------------------------------------
+# seeded fuzz over the f16 MFMA paths: random ragged sizes, strides, offsets, batches, both variants, alpha/beta
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_gemm_f16_fuzz(gpu, seed):
+    wg = _wg()
+    rng = np.random.default_rng(1000 + seed)
+    M, N = int(rng.integers(1, 80)) * 8, int(rng.integers(1, 80)) * 8
+    K = int(rng.choice([192, 256, 320, 448, 576, 1024, 96, 160, 2048 + 64]))  # mostly the 16x16x32 kernel, some 32x32x16
+    mats = int(rng.choice([1, 1, 2, 3]))
+    tr = bool(rng.integers(0, 2))
+    ex = bool(rng.integers(0, 2))
+    alpha, beta = (float(rng.choice([1.0, -1.0, 0.5, 2.0])), float(rng.choice([0.0, 1.0, -0.5]))) if ex else (1.0, 0.0)
+    # operand views inside larger buffers: leading dimension padded by a multiple of 8, offset a multiple of 8 (16-byte aligned)
+    def view_of(rows, cols):
+        ld = rows + 8 * int(rng.integers(0, 3))
+        sm = ld * cols + 8 * int(rng.integers(0, 3))
+        off = 8 * int(rng.integers(0, 4))
+        data = (rng.random(off + sm * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+        return data, ld, sm, off
+    ar, ac = (K, M) if tr else (M, K)
+    a, lda, sma, offa = view_of(ar, ac)
+    b, ldb, smb, offb = view_of(K, N)
+    c, ldc, smc, offc = view_of(M, N)
+    ta, tb, tc = upload(gpu, (a.size,), a, np.float16), upload(gpu, (b.size,), b, np.float16), upload(gpu, (c.size,), c, np.float16)
+    mk = lambda t, r, cc, ld, sm, off: wg.GpuTensorView(wg.ViewShape([r, cc, mats], ld, sm, off), t, 3)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    va, vb, vc = mk(ta, ar, ac, lda, sma, offa), mk(tb, K, N, ldb, smb, offb), mk(tc, M, N, ldc, smc, offc)
+    if ex:
+        run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, alpha, beta, vc, va, vb, variant))
+    else:
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, vc, va, vb, variant))
+    got = tc.read(gpu.device())
+
+    def mat(buf, rows, cols, ld, sm, off, t):
+        idx = off + t * sm + np.arange(rows)[:, None] + np.arange(cols)[None, :] * ld
+        return buf[idx]
+    touched = np.zeros(c.size, bool)
+    for t in range(mats):
+        A = mat(a, ar, ac, lda, sma, offa, t).astype(np.float64)
+        A = A.T if tr else A
+        B = mat(b, K, N, ldb, smb, offb, t).astype(np.float64)
+        C0 = mat(c, M, N, ldc, smc, offc, t).astype(np.float64)
+        truth = alpha * (A @ B) + beta * C0
+        sabs = abs(alpha) * (np.abs(A) @ np.abs(B)) + abs(beta) * np.abs(C0)
+        tol = U.f32_gate(K + 2, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        idx = offc + t * smc + np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+        err = np.abs(got[idx].astype(np.float64) - truth)
+        assert (err <= tol).all(), f"fuzz {seed}: M={M} N={N} K={K} mats={mats} tr={tr} ab=({alpha},{beta}) worst {(err / tol).max():.3g}"
+        touched[idx.reshape(-1)] = True
+    # nothing outside the output view was written (padding between columns / matrices, the offset prefix)
+    assert np.array_equal(got[~touched], c[~touched]), f"fuzz {seed}: bytes outside the output view changed"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_gemm_f32_fuzz(gpu, seed):
+    """Same idea for the f32 kernel (vec4 granularity: everything a multiple of 4), incl. split-K-sized K and (alpha, beta)."""
+    wg = _wg()
+    rng = np.random.default_rng(2000 + seed)
+    M, N = int(rng.integers(1, 130)) * 4, int(rng.integers(1, 100)) * 4
+    K = int(rng.choice([4, 16, 64, 132, 512, 1024, 4096 + 16]))
+    mats = int(rng.choice([1, 1, 2]))
+    tr = bool(rng.integers(0, 2))
+    ex = bool(rng.integers(0, 2))
+    alpha, beta = (float(rng.choice([1.0, -1.0, 0.5])), float(rng.choice([0.0, 1.0, -0.5]))) if ex else (1.0, 0.0)
+    def view_of(rows, cols):
+        ld = rows + 4 * int(rng.integers(0, 3))
+        sm = ld * cols + 4 * int(rng.integers(0, 3))
+        off = 4 * int(rng.integers(0, 4))
+        return (rng.random(off + sm * mats, dtype=np.float32) * 2 - 1), ld, sm, off
+    ar, ac = (K, M) if tr else (M, K)
+    a, lda, sma, offa = view_of(ar, ac)
+    b, ldb, smb, offb = view_of(K, N)
+    c, ldc, smc, offc = view_of(M, N)
+    ta, tb, tc = upload(gpu, (a.size,), a), upload(gpu, (b.size,), b), upload(gpu, (c.size,), c)
+    mk = lambda t, r, cc, ld, sm, off: wg.GpuTensorView(wg.ViewShape([r, cc, mats], ld, sm, off), t, 3)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    va, vb, vc = mk(ta, ar, ac, lda, sma, offa), mk(tb, K, N, ldb, smb, offb), mk(tc, M, N, ldc, smc, offc)
+    if ex:
+        run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, alpha, beta, vc, va, vb, variant))
+    else:
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, vc, va, vb, variant))
+    got = tc.read(gpu.device())
+    touched = np.zeros(c.size, bool)
+    for t in range(mats):
+        ia = offa + t * sma + np.arange(ar)[:, None] + np.arange(ac)[None, :] * lda
+        A = a[ia].astype(np.float64)
+        A = A.T if tr else A
+        B = b[offb + t * smb + np.arange(K)[:, None] + np.arange(N)[None, :] * ldb].astype(np.float64)
+        idx = offc + t * smc + np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+        C0 = c[idx].astype(np.float64)
+        truth = alpha * (A @ B) + beta * C0
+        sabs = abs(alpha) * (np.abs(A) @ np.abs(B)) + abs(beta) * np.abs(C0)
+        err = np.abs(got[idx].astype(np.float64) - truth)
+        tol = U.f32_gate(K + 2, sabs)
+        assert (err <= tol).all(), f"f32 fuzz {seed}: M={M} N={N} K={K} mats={mats} tr={tr} ab=({alpha},{beta}) worst {(err / tol).max():.3g}"
+        touched[idx.reshape(-1)] = True
+    assert np.array_equal(got[~touched], c[~touched]), f"f32 fuzz {seed}: bytes outside the output view changed"
