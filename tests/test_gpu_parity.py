@@ -690,3 +690,50 @@ def test_gemm_f32_fuzz(gpu, seed):
         assert (err <= tol).all(), f"f32 fuzz {seed}: M={M} N={N} K={K} mats={mats} tr={tr} ab=({alpha},{beta}) worst {(err / tol).max():.3g}"
         touched[idx.reshape(-1)] = True
     assert np.array_equal(got[~touched], c[~touched]), f"f32 fuzz {seed}: bytes outside the output view changed"
+
+
+def test_record_replay_gemm_chain(gpu):
+    """A recorded command buffer (hipGraph) holding a dependent chain of GEMMs, incl. a split-K f16 GEMM (workspace), a row-major
+    GemmTr (transpose scratch) and a GEMV: replaying it with new inputs gives the same result as eager dispatch."""
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    rng = np.random.default_rng(77)
+    M, K, N = 256, 4096, 256  # few tiles, long K: split-K path
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16) / 16
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16) / 16
+    ta, tb = upload(gpu, (M, K), a, np.float16), upload(gpu, (K, N), b, np.float16)
+    t1 = upload(gpu, (M, N), np.zeros(M * N, np.float16), np.float16)      # t1 = a b
+    t2 = upload(gpu, (M, N), np.zeros(M * N, np.float16), np.float16)      # t2 = t1^T t1 (row-major GemmTr)
+    tv = upload(gpu, (N,), (rng.random(N, dtype=np.float32)).astype(np.float32))
+    t1f = upload(gpu, (M, N), np.zeros(M * N, np.float32))                 # f32 copy target for the GEMV
+    to = upload(gpu, (M,), np.zeros(M, np.float32))
+    gemm = wg.Gemm.from_device(dev)
+    gemm_rm = wg.Gemm.from_device(dev, wg.row_major_shader_defs())
+    gemv = wg.Gemv.from_device(dev)
+    rm = lambda t, r, c: wg.GpuTensorView(wg.ViewShape([r, c, 1], c, r * c, 0), t, 3)
+
+    def chain(p):
+        gemm.dispatch(dev, shapes, p, t1, ta, tb)
+        gemm_rm.dispatch_tr(dev, shapes, p, rm(t2, M, N), rm(t1, M, N), rm(t1, M, N))  # the same memory read as row-major M x N
+        gemv.dispatch(dev, shapes, p, to, t1f, tv)
+
+    run_pass(gpu, chain)  # eager once: sizes the workspaces, gives the expected values
+    exp1, exp2, exp_o = t1.read(dev).copy(), t2.read(dev).copy(), to.read(dev).copy()
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p:
+        chain(p)
+    cb = enc.finish()
+    zero = wg.OpAssign.new(dev, wg.OpAssignVariant.Sub)  # clear the outputs on the device (x -= x) so that the replay has to recompute them
+    run_pass(gpu, lambda p: (zero.dispatch(dev, shapes, p, to, to), None)[1])
+    assert not to.read(dev).any()
+    for _ in range(3):
+        gpu.queue().submit([cb])
+    assert np.array_equal(t1.read(dev), exp1) and np.array_equal(t2.read(dev), exp2) and np.array_equal(to.read(dev), exp_o)
+    # sanity of the chain itself against f64
+    A, B = a.reshape(M, K, order="F").astype(np.float64), b.reshape(K, N, order="F").astype(np.float64)
+    T1 = exp1.reshape(M, N, order="F").astype(np.float64)
+    assert np.abs(T1 - A @ B).max() <= 2.0 ** -9 * np.abs(A @ B).max() + 1e-3
+    T1rm = exp1.reshape(M, N).astype(np.float64)  # the same bytes as a row-major M x N matrix
+    T2 = exp2.reshape(M, N).astype(np.float64)
+    ref = T1rm.T @ T1rm
+    assert np.abs(T2 - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3
