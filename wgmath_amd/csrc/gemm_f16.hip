@@ -477,22 +477,26 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
 
     // ---- DMA addressing; ragged tiles: rows past the end are clamped to the last valid one (results discarded by the epilogue) ----
     // A half-stage = 16 pieces of 1 KiB, wave stages P = 4 wave + q; B full stage = 32 pieces, wave stages P = 8 wave + q.
-    uint32_t a_voff[4], b_voff[8];
+    uint32_t a_voff[TRANS_A ? 8 : 4], b_voff[8];
     const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
+    if constexpr (TRANS_A) { // op(A) rows are k-contiguous: full stages like B -- rows 8P..8P+7, 128 bytes each, P = 8 wave + q
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t P = 4u * wave + q;
-        if constexpr (TRANS_A) { // rows 16P..16P+15, 64 bytes each: lane -> row 16P + (lane>>2), position lane&3
-            const uint32_t row = 16u * P + (lane >> 2);
-            const uint32_t chunk = (lane & 3u) ^ ((4u - ((row >> 3) & 3u)) & 3u);
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t P = 8u * wave + q;
+            const uint32_t row = 8u * P + (lane >> 3);
+            const uint32_t f = ((4u - ((row >> 3) & 3u)) & 3u) | (((row >> 1) & 1u) << 2); // A's rows are permuted: G index (row>>3)&3
+            const uint32_t chunk = (lane & 7u) ^ f;
             const uint32_t ra = min(row, g.M - 1u - m0);
-            a_voff[q] = (ra * g.lda + 8u * chunk) * 2u;
-        } else { // blocks 4P..4P+3: kq = P>>1, mblk = 4 (P&1) + (lane>>4), k row (lane>>2)&3, 16-byte unit lane&3
-            const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3), g.M - 8u - m0); // M % 8 == 0
-            a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u;
+            a_voff[q] = (ra * g.lda + 8u * chunk) * 2u + (M16_BIAS - 1024u * (q & 3));
         }
-        a_voff[q] += M16_BIAS - 1024u * q;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { // blocks 4P..4P+3: kq = P>>1, mblk = 4 (P&1) + (lane>>4), k row (lane>>2)&3, 16-byte unit lane&3
+            const uint32_t P = 4u * wave + q;
+            const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3), g.M - 8u - m0); // M % 8 == 0
+            a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u + (M16_BIAS - 1024u * q);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { // rows 8P..8P+7, 128 bytes each: lane -> row 8P + (lane>>3), position lane&7
@@ -504,11 +508,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         b_voff[q] = (rb * g.ldb + 8u * chunk) * 2u + (M16_BIAS - 1024u * (q & 3));
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
-    const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);            // + slot * 16 KiB + q * 1 KiB
+    // NN: + slot * 16 KiB + q * 1 KiB (4 half-stage slots); TN: + slot * 32 KiB + q * 1 KiB (2 full-stage slots)
+    const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * (TRANS_A ? 8192 : 4096));
     const uint32_t lds_b_wave = __builtin_amdgcn_readfirstlane(lds_base + M16_B_BASE + wave * 8192); // + slot * 32 KiB + q * 1 KiB
-    auto a_src = [&](uint32_t H) -> const _Float16 * { // global base of half-stage H
+    auto a_src = [&](uint32_t H) -> const _Float16 * { // NN: global base of half-stage H;  TN: of full stage H
         const char *p0;
-        if constexpr (TRANS_A) p0 = (const char *)(a_base + H * BKH); else p0 = (const char *)(a_base + (uint64_t)(H * BKH) * g.lda);
+        if constexpr (TRANS_A) p0 = (const char *)(a_base + H * 64u); else p0 = (const char *)(a_base + (uint64_t)(H * BKH) * g.lda);
         return (const _Float16 *)(p0 - M16_BIAS);
     };
     auto b_src = [&](uint32_t stage) -> const _Float16 * { return (const _Float16 *)((const char *)(b_base + 64u * stage) - M16_BIAS); };
@@ -518,15 +523,19 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs)
         b_off[hs] = M16_B_BASE + ((uint32_t)128 * wn + i16) * 128u + (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
-    uint32_t a_off[2];
+    uint32_t a_off[2], a_off1[2]; // TN: [tb] for half-step parity 0 / 1 of the stage; NN: a_off[0] only
     if constexpr (TRANS_A) {
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) a_off[tb] = (128u * wm + 8u * aq + 4u * tb + bb) * 64u + (uint32_t)((kg ^ gq) * 16);
+        for (int tb = 0; tb < 2; ++tb) {
+            const uint32_t rowb = (128u * wm + 8u * aq + 4u * tb + bb) * 128u;
+            a_off[tb] = rowb + (uint32_t)(((kg ^ gq) | ((0 ^ (bb >> 1)) << 2)) * 16);
+            a_off1[tb] = rowb + (uint32_t)(((kg ^ gq) | ((1 ^ (bb >> 1)) << 2)) * 16);
+        }
     } else {
         // lane row kg reads k-group (kg&2) + ins, 8-byte half (kg&1) of unit i16 of block (kq = 2*kgroup + h, mblk = 4 wm + p)
         if (WG_F16_NN_SWAP) a_off[0] = (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
         else a_off[0] = (uint32_t)(kg * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u; // lane row kg reads its own k-group
-        a_off[1] = 0;
+        a_off[1] = 0; a_off1[0] = a_off1[1] = 0;
     }
 
     floatx4 acc[8][8]; // [t][u]
@@ -543,12 +552,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // the fragment-producing operations of one half-stage, in the order the next half-step needs them.
     // sa = A slot, sb = smem + B slot offset + b_off[parity]
     constexpr int kOps = TRANS_A ? 16 : (WG_F16_NN_SWAP ? 40 : 24);
-    auto frag_op = [&](const char *sa, const char *sb, int op, int set) {
+    auto frag_op = [&](const char *sa, const char *sb, int op, int set, int hsn) { // hsn: parity of the half-step being prepared (TN)
         auto rb = [&](int u) { b_f[set][u] = lds_h8(sb + u * 2048); };
         if constexpr (TRANS_A) {
-            if (op == 0) a_r[set][0] = __builtin_bit_cast(uintx4, lds_h8(sa + a_off[0]));
+            auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8(sa + (hsn ? a_off1[t & 1] : a_off[t & 1]) + (t >> 1) * 4096)); };
+            if (op == 0) ra(0);
             else if (op <= 8) rb(op - 1);
-            else { const int t = op - 8; a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8(sa + a_off[t & 1] + (t >> 1) * 2048)); }
+            else ra(op - 8);
         } else {
             // tr(p, i): transpose read i = 2 h + ins of pair p lands in tile 2p+ins, dwords 2h, 2h+1;
             // sw(p, i): lane-row swap of dword i of the pair's two tiles
@@ -597,20 +607,26 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     uint32_t st = 0;                // current stage
     uint32_t bs0 = 0, bs1 = 1, bs2 = 2; // B ring slots of stages st, st+1, st+2 (== st+3 for bs0)
 
-    // One half-step H = 2 st + HS on register set HS: 64 MFMAs, one per slot; the fragment ops of half-step H+1 fill set HS^1;
-    // the DMA pieces (4 of A(H+4), 4 of B) are issued at slots 8 i + 3, their M0 two slots earlier.
+    // One half-step H = 2 st + HS on register set HS: 64 MFMAs, one per slot; the fragment ops of half-step H+1 fill set HS^1.
+    // DMA, NN: the 4 pieces of A(H+4) at slots 8 i + 3 (i < 4), 4 pieces of B at i >= 4 (even H: second half of B(st+2), odd H:
+    // first half of B(st+3)). TN: even H only B; odd H the 8 pieces of the full stage A(st+2) first (its slot held A(st), read
+    // out by now; it must land by the end of the NEXT half-step, so it goes ahead of B in the in-order vmcnt queue), then B:
+    // 12 pieces at slots 4 i + 2. M0 is set once per group of four pieces, two slots ahead.
     auto half_step = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next) {
         constexpr int HS = decltype(hs_c)::value;
         constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
         const uint32_t H = 2u * st + HS;
-        const char *sa = smem + ((H + 1u) & 3u) * HA_BYTES;
+        const char *sa;
+        if constexpr (TRANS_A) sa = smem + ((st + HS) & 1u) * M16_BS_BYTES; else sa = smem + ((H + 1u) & 3u) * HA_BYTES;
         const char *sb = smem + (HS == 0 ? bs0 : bs1) * M16_BS_BYTES + b_off[HS ^ 1];
         // DMA targets of this half-step
         const _Float16 *ga = nullptr, *gb = nullptr;
         uint32_t la = 0, lb = 0;
-        if constexpr (ADMA) { ga = a_src(H + 4u); la = lds_a_wave + (H & 3u) * HA_BYTES; }
+        if constexpr (ADMA) {
+            if constexpr (TRANS_A) { ga = a_src(st + 2u); la = lds_a_wave + (st & 1u) * M16_BS_BYTES; }
+            else { ga = a_src(H + 4u); la = lds_a_wave + (H & 3u) * HA_BYTES; }
+        }
         if constexpr (BDMA) {
-            // even H: second half (q = 4..7) of B(st+2); odd H: first half (q = 0..3) of B(st+3)
             gb = b_src(st + 2u + HS);
             lb = lds_b_wave + (HS == 0 ? bs2 : bs0) * M16_BS_BYTES + (HS == 0 ? 4096u : 0u);
         }
@@ -620,19 +636,33 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
             if constexpr (decltype(has_next)::value) {
                 if constexpr (TRANS_A) {
-                    if constexpr ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1);
+                    if constexpr ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1, HS ^ 1);
                 } else {
-                    if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1);
+                    if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1, HS ^ 1);
                 }
             }
-            // DMA: windows 0..3 = the four A pieces, windows 4..7 = the four B pieces; M0 is set once per group
-            constexpr int pi = j >> 3, q = pi & 3;
-            if constexpr (pi < 4 ? ADMA : BDMA) {
-                if constexpr (j == 1) m16_set_m0(la);
-                if constexpr (j == 33) m16_set_m0(lb);
-                if constexpr ((j & 7) == 3) {
-                    if constexpr (pi < 4) m16_dma_imm<1024 * q>(a_voff[q], ga);
-                    else m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb);
+            if constexpr (!TRANS_A) {
+                constexpr int pi = j >> 3, q = pi & 3;
+                if constexpr (pi < 4 ? ADMA : BDMA) {
+                    if constexpr (j == 1) m16_set_m0(la);
+                    if constexpr (j == 33) m16_set_m0(lb);
+                    if constexpr ((j & 7) == 3) {
+                        if constexpr (pi < 4) m16_dma_imm<1024 * q>(a_voff[q], ga);
+                        else m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb);
+                    }
+                }
+            } else {
+                // piece list of this half-step: [A0..A7 if ADMA] + [B0..B3 if BDMA]; piece n is issued at slot 4 n + 2
+                constexpr int nA = ADMA ? 8 : 0, nB = BDMA ? 4 : 0;
+                if constexpr ((j & 3) == 0 && (j >> 2) < nA + nB && ((j >> 2) & 3) == 0 ) {
+                    // group start (pieces j>>2 .. j>>2 + 3): M0 two slots before the group's first DMA
+                    constexpr int n = j >> 2;
+                    if constexpr (n < nA) m16_set_m0(la + (n >> 2) * 4096); else m16_set_m0(lb);
+                }
+                if constexpr ((j & 3) == 2 && (j >> 2) < nA + nB) {
+                    constexpr int n = j >> 2;
+                    if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], ga);
+                    else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -666,22 +696,33 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             m16_dma(q, a_voff[q], a_src(hh));
         }
     };
-    auto pro_b = [&](int sb, int nq) {
+    auto pro_b = [&](int sb, int nq) { // sb >= 0: stage sb of B;  sb = -1 / -2 (TN only): stage 0 / 1 of A
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             if (q >= nq) break;
-            if ((q & 3) == 0) { m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
-            m16_dma(q & 3, b_voff[q], b_src(sb));
+            if (sb >= 0) {
+                if ((q & 3) == 0) { m16_set_m0(lds_b_wave + sb * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
+                m16_dma(q & 3, b_voff[q], b_src(sb));
+            } else if constexpr (TRANS_A) {
+                const int sa_ = -1 - sb;
+                if ((q & 3) == 0) { m16_set_m0(lds_a_wave + sa_ * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
+                m16_dma(q & 3, a_voff[q], a_src(sa_));
+            }
         }
     };
     if (!(WG_ABLATE & 2)) {
-        pro_a(0); pro_b(0, 8); pro_a(1);
-        pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4);
+        if constexpr (TRANS_A) { // full stages of A as well: A(0), B(0) | A(1), B(1), first half of B(2)
+            pro_b(-1, 8); pro_b(0, 8);
+            pro_b(-2, 8); pro_b(1, 8); pro_b(2, 4);
+        } else {
+            pro_a(0); pro_b(0, 8); pro_a(1);
+            pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4);
+        }
     }
     wait_dma_keep<20>();
     __syncthreads();
 #pragma unroll
-    for (int op = 0; op < kOps; ++op) frag_op(smem, smem + b_off[0], op, 0);
+    for (int op = 0; op < kOps; ++op) frag_op(smem, smem + b_off[0], op, 0, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing pending on entry to the loop either
     if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier(); // every wave has read A(0): half-step 0 may overwrite its slot with A(4)
     __builtin_amdgcn_sched_barrier(0);
@@ -690,19 +731,38 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // No parity branches (two accumulator-modifying arms merging in a loop make the register allocator shuffle all 256
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
     // because they issue fewer (then no) DMA pieces.
-    for (; st + 3 < S;) {
-        half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{});
-        half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
+    using k8 = std::integral_constant<int, 8>;
+    if constexpr (!TRANS_A) {
+        for (; st + 3 < S;) {
+            half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{});
+            half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
+            next_stage();
+        }
+        half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{}); // stage S-3: A(2S-2), second half of B(S-1)
+        half_step(c1{}, yes{}, no{}, yes{});  advance(k12{}); //            A(2S-1)
         next_stage();
+        half_step(c0{}, no{}, no{}, yes{}); advance(k4{});    // stage S-2
+        half_step(c1{}, no{}, no{}, yes{}); advance(k0{});
+        next_stage();
+        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
+        half_step(c1{}, no{}, no{}, no{});
+    } else {
+        // TN: after an even half-step only the 4 + 4 newest pieces (first and second half of a B stage) may be in flight -- the
+        // full stage of A issued in the odd half-step before must have landed; after an odd one the 12 just issued + 4.
+        for (; st + 3 < S;) {
+            half_step(c0{}, no{}, yes{}, yes{});  advance(k8{});
+            half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
+            next_stage();
+        }
+        half_step(c0{}, no{}, yes{}, yes{}); advance(k8{});   // stage S-3: second half of B(S-1)
+        half_step(c1{}, yes{}, no{}, yes{}); advance(k12{});  //            A(S-1)
+        next_stage();
+        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-2: A(S-1) must have landed
+        half_step(c1{}, no{}, no{}, yes{}); advance(k0{});
+        next_stage();
+        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
+        half_step(c1{}, no{}, no{}, no{});
     }
-    half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{}); // stage S-3: A(2S-2), second half of B(S-1)
-    half_step(c1{}, yes{}, no{}, yes{});  advance(k12{}); //            A(2S-1)
-    next_stage();
-    half_step(c0{}, no{}, no{}, yes{}); advance(k4{});    // stage S-2
-    half_step(c1{}, no{}, no{}, yes{}); advance(k0{});
-    next_stage();
-    half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
-    half_step(c1{}, no{}, no{}, no{});
     WG_TRACE_POINT(2);
 
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
