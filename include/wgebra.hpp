@@ -290,6 +290,10 @@ struct Reduce {
     void dispatch(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> value, const GpuScalar<T> &result) const {
         check(wg_reduce(pass.ctx(), (wg_reduce_op)op, dtype_of<T>::value, value.buffer(), value.shape(), result.buffer()));
     }
+    template <typename T> // extension: two-pass multi-workgroup reduce of one long vector (Min/Max same bits; Sum/Prod/SqNorm re-associated)
+    void dispatch_fast(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> value, const GpuScalar<T> &result) const {
+        check(wg_reduce_fast(pass.ctx(), (wg_reduce_op)op, dtype_of<T>::value, value.buffer(), value.shape(), result.buffer()));
+    }
     template <typename T> // extension: every column of a matrix/cube view in one launch
     void dispatch_batched(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> values, const GpuVector<T> &results) const {
         check(wg_reduce_batched(pass.ctx(), (wg_reduce_op)op, dtype_of<T>::value, values.buffer(), values.shape(), results.buffer()));

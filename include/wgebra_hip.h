@@ -208,6 +208,15 @@ int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
               const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
 
 /*
+ * Extension: two-pass, multi-workgroup reduce of ONE long vector at HBM speed. Same arguments and
+ * checks as wg_reduce, but NOT the reference's summation order (which serialises a vector onto one workgroup): Min/Max
+ * are bit-identical to wg_reduce, Sum/Prod/SqNorm are re-associated -- deterministic (fixed chunking and tree, no
+ * atomics) and within n * 2^-24 * sum|x| (sum x^2 for SqNorm) of the reference order.
+ */
+int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
+                   const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
+
+/*
  * Extension (BASELINE config 4): one launch for many vectors. Column c of matrix t of the
  * column-major view is reduced exactly as wg_reduce would reduce the vector view at
  * offset + c*stride + t*stride_mat; results[c + t*size[1]] (f32 each).

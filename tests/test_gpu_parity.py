@@ -737,3 +737,40 @@ def test_record_replay_gemm_chain(gpu):
     T2 = exp2.reshape(M, N).astype(np.float64)
     ref = T1rm.T @ T1rm
     assert np.abs(T2 - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3
+
+
+# --------------------------------------------------------------------------------------------------------
+# two-pass multi-workgroup reduce (extension): Min/Max bit-identical, Sum/Prod/SqNorm within the re-association bound
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (5, 3), (4097, 1), (65536, 0), (300007, 2), ((1 << 22) + 3, 5)])
+def test_reduce_fast(gpu, oracle_c, n, off):
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(n + off)
+    x = np.concatenate([np.zeros(off, np.float32), (rng.random(n, dtype=np.float32) * 2 - 1)]).astype(np.float32)
+    if n:
+        x[off + rng.integers(0, n)] = -0.0
+    tx = upload(gpu, (x.size,), x) if x.size else None
+    if tx is None:
+        return
+    view = wg.GpuTensorView(wg.ViewShape([n, 1, 1], n, n, off), tx, 1)
+    x64 = x[off:].astype(np.float64)
+    for op, wop in ((wg.ReduceOp.Min, wo.MIN), (wg.ReduceOp.Max, wo.MAX), (wg.ReduceOp.Sum, wo.SUM), (wg.ReduceOp.SqNorm, wo.SQNORM),
+                    (wg.ReduceOp.Prod, wo.PROD)):
+        res = upload(gpu, (), np.full(1, np.nan, np.float32))
+        red = wg.Reduce.new(gpu.device(), op)
+        run_pass(gpu, lambda p: red.dispatch_fast(gpu.device(), wg.ViewShapeBuffers(), p, view, res))
+        got = res.read(gpu.device())[0]
+        ref = np.float32(oracle_c.reduce(wop, x, wo.Shape(n, 1, 1, n, n, off)))
+        if op in (wg.ReduceOp.Min, wg.ReduceOp.Max):
+            assert got.tobytes() == ref.tobytes(), f"fast {op.name} n={n}: {got} vs {ref}"
+        elif op == wg.ReduceOp.Sum:
+            assert abs(float(got) - x64.sum()) <= max(n, 1) * 2.0 ** -24 * np.abs(x64).sum() + 1e-30
+            assert abs(float(got) - float(ref)) <= 2 * max(n, 1) * 2.0 ** -24 * np.abs(x64).sum() + 1e-30
+        elif op == wg.ReduceOp.SqNorm:
+            assert abs(float(got) - (x64 * x64).sum()) <= max(n, 1) * 2.0 ** -23 * (x64 * x64).sum() + 1e-30
+        else:  # Prod of |x| < 1 underflows to 0 quickly; for short vectors compare relatively
+            truth = np.prod(x64)
+            assert abs(float(got) - truth) <= max(n, 1) * 2.0 ** -23 * abs(truth) + 1e-37
+        # determinism: a second run gives the same bits
+        run_pass(gpu, lambda p: red.dispatch_fast(gpu.device(), wg.ViewShapeBuffers(), p, view, res))
+        assert res.read(gpu.device())[0].tobytes() == got.tobytes()

@@ -90,6 +90,7 @@ def _load() -> ctypes.CDLL:
         "wg_gemm_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_gemv_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
+        "wg_reduce_fast": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
         "wg_axpy": (ci, [vp, ctypes.c_float, ci, vp, S, vp, S]),

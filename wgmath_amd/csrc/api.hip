@@ -151,6 +151,18 @@ int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *value,
     return wgk_reduce(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, 1, 1, 0, 0, (float *)result->ptr);
 }
 
+int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *value, wg_view_shape value_shape, wg_buf *result) {
+    const wg_buf *bufs[2] = { value, result };
+    if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;
+    if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
+    if (value->bytes == 0 || result->bytes == 0) return WG_OK; // kernel.rs:111-123
+    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    const View vec = { value_shape.size[0], 1, 1, 1, 1, value_shape.offset };
+    if (int rc = check_bounds("Reduce", "value", vec, value, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_reduce_fast(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, (float *)result->ptr);
+}
+
 int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *values, wg_view_shape values_shape, wg_buf *results) {
     const wg_buf *bufs[2] = { values, results };
     if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;

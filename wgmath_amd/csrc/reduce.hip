@@ -270,7 +270,102 @@ int launch(wg_ctx *ctx, const float *base, uint32_t n, uint32_t ncols, uint32_t 
     return WG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Two-pass, multi-workgroup reduce of ONE long vector. NOT the reference's summation order: the 128
+// strided chains of reduce.wgsl serialise a vector onto one workgroup (37 GB/s above); this variant lets the whole chip
+// stream it. Min/Max are the same bits as the reference order (min/max of non-NaN floats is associative and commutative);
+// Sum/Prod/SqNorm are re-associated -- deterministic (fixed chunking and tree, no atomics), within n * 2^-24 * sum|x| of the
+// reference order. Pass 1: workgroup b folds the contiguous chunk b (float4 non-temporal loads, 8 in flight per
+// lane, per-lane accumulators, wave butterfly, LDS across the 4 waves) -> partial[b]; pass 2: one workgroup folds the partials.
+// ------------------------------------------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ float fast_block_fold(float acc) { // fold the 256 per-thread values of a workgroup; valid in thread 0
+    __shared__ float red[kThreads / 64];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) acc = r_red<OP>(acc, __shfl_xor(acc, s, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < kThreads / 64; ++w) r = r_red<OP>(r, red[w]);
+    return r;
+}
+
+template <int OP>
+__global__ __launch_bounds__(kThreads) void reduce_fast_pass1(const float *__restrict__ x, uint32_t n, uint32_t chunk, float *__restrict__ partial) {
+    const uint64_t begin = (uint64_t)blockIdx.x * chunk; // chunk is a multiple of 4; x + begin keeps x's alignment class
+    const uint32_t len = (uint32_t)min((uint64_t)chunk, (uint64_t)n - begin);
+    const float *p = x + begin;
+    float acc = r_init<OP>();
+    // scalar head up to 16-byte alignment, float4 body, scalar tail
+    const uint32_t mis = (uint32_t)(((uintptr_t)p >> 2) & 3u);
+    const uint32_t head = mis ? min(4u - mis, len) : 0u;
+    if (threadIdx.x < head) acc = r_ws<OP>(acc, p[threadIdx.x]);
+    const float4 *p4 = reinterpret_cast<const float4 *>(p + head);
+    const uint32_t n4 = (len - head) / 4u;
+    uint32_t i = threadIdx.x;
+    for (; (uint64_t)i + 7u * kThreads < n4; i += 8u * kThreads) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = wg_ld_nt(p4 + i + u * kThreads);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc = r_ws<OP>(acc, v[u].x); acc = r_ws<OP>(acc, v[u].y); acc = r_ws<OP>(acc, v[u].z); acc = r_ws<OP>(acc, v[u].w);
+        }
+    }
+    for (; i < n4; i += kThreads) {
+        const float4 v = wg_ld_nt(p4 + i);
+        acc = r_ws<OP>(acc, v.x); acc = r_ws<OP>(acc, v.y); acc = r_ws<OP>(acc, v.z); acc = r_ws<OP>(acc, v.w);
+    }
+    const uint32_t tail0 = head + n4 * 4u;
+    if (tail0 + threadIdx.x < len) acc = r_ws<OP>(acc, p[tail0 + threadIdx.x]);
+    const float r = fast_block_fold<OP>(acc);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+template <int OP>
+__global__ __launch_bounds__(kThreads) void reduce_fast_pass2(const float *__restrict__ partial, uint32_t nparts, float *__restrict__ result) {
+    // partials are already reduce_fn-domain values (sums of squares for SqNorm): fold with reduce_fn; the neutral start is the op's init
+    float acc = r_init<OP>();
+    for (uint32_t i = threadIdx.x; i < nparts; i += kThreads) acc = r_red<OP>(acc, partial[i]);
+    const float r = fast_block_fold<OP>(acc);
+    if (threadIdx.x == 0) result[0] = r;
+}
+
+template <int OP>
+int launch_fast(wg_ctx *ctx, const float *x, uint32_t n, float *result) {
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    // >= 16 Ki elements per workgroup, at most 4 workgroups per CU
+    const uint64_t want = ((uint64_t)n + 16383u) / 16384u, cap = (uint64_t)cus * 4u;
+    uint32_t nparts = (uint32_t)(want < cap ? want : cap);
+    if (nparts == 0) nparts = 1;
+    uint32_t chunk = (uint32_t)((((uint64_t)n + nparts - 1) / nparts + 3u) & ~3ull);
+    if (chunk == 0) chunk = 4;
+    nparts = (uint32_t)(((uint64_t)n + chunk - 1) / chunk);
+    if (nparts == 0) nparts = 1; // n == 0: one workgroup writes the init value, like the reference (reduce.wgsl with an empty loop)
+    void *ws = nullptr;
+    if (int rc = wg_ctx_workspace(ctx, (size_t)nparts * sizeof(float), &ws)) return rc;
+    hipLaunchKernelGGL(reduce_fast_pass1<OP>, dim3(nparts), dim3(kThreads), 0, ctx->stream, x, n, chunk, (float *)ws);
+    WG_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(reduce_fast_pass2<OP>, dim3(1), dim3(kThreads), 0, ctx->stream, (const float *)ws, nparts, result);
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
 } // namespace
+
+int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, float *result) {
+    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: only f32 is implemented (the reference kernel is f32: reduce.wgsl:5-8)");
+    const float *b = (const float *)base;
+    switch (op) {
+    case R_MIN: return launch_fast<R_MIN>(ctx, b, n, result);
+    case R_MAX: return launch_fast<R_MAX>(ctx, b, n, result);
+    case R_SUM: return launch_fast<R_SUM>(ctx, b, n, result);
+    case R_PROD: return launch_fast<R_PROD>(ctx, b, n, result);
+    case R_SQNORM: return launch_fast<R_SQNORM>(ctx, b, n, result);
+    }
+    return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", op);
+}
 
 int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
                uint32_t stride, uint32_t stride_mat, float *results) {

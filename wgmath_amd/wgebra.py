@@ -147,6 +147,13 @@ class Reduce:
         check(lib.wg_reduce(pass_._ctx.handle, int(self.op), wg_dtype(value.dtype), value.buffer()._h, value.shape().to_c(),
                             result._h))
 
+    def dispatch_fast(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, value, result: GpuTensor) -> None:
+        """Extension: two-pass multi-workgroup reduce of one long vector at HBM speed. Min/Max: same bits as
+        `dispatch`; Sum/Prod/SqNorm: re-associated (deterministic), within n * 2^-24 * sum|x| of the reference order."""
+        value = as_view(value, 1)
+        check(lib.wg_reduce_fast(pass_._ctx.handle, int(self.op), wg_dtype(value.dtype), value.buffer()._h, value.shape().to_c(),
+                                 result._h))
+
     def dispatch_batched(self, device, shapes: ViewShapeBuffers, pass_: ComputePass, values, results: GpuTensor) -> None:
         """Extension (one launch for every column of a matrix/cube view): results[c + t*ncols], each equal to what
         `dispatch` gives for that column."""
