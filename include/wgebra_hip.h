@@ -208,6 +208,14 @@ int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
               const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
 
 /*
+ * Extension: result[0] = reduce(op, op(m) * v) in one call -- Gemv into a context-owned scratch vector, then
+ * Reduce in the reference order on the same stream (e.g. SqNorm for |m v|^2, Max for the largest entry). Bit-identical to
+ * wg_gemv followed by wg_reduce; `m` is one matrix, `v` one vector.
+ */
+int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dtype dtype, wg_buf *result,
+                   const wg_buf *m, wg_view_shape m_shape, const wg_buf *v, wg_view_shape v_shape);
+
+/*
  * Extension: two-pass, multi-workgroup reduce of ONE long vector at HBM speed. Same arguments and
  * checks as wg_reduce, but NOT the reference's summation order (which serialises a vector onto one workgroup): Min/Max
  * are bit-identical to wg_reduce, Sum/Prod/SqNorm are re-associated -- deterministic (fixed chunking and tree, no

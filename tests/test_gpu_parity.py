@@ -774,3 +774,27 @@ def test_reduce_fast(gpu, oracle_c, n, off):
         # determinism: a second run gives the same bits
         run_pass(gpu, lambda p: red.dispatch_fast(gpu.device(), wg.ViewShapeBuffers(), p, view, res))
         assert res.read(gpu.device())[0].tobytes() == got.tobytes()
+
+
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemv_reduce(gpu, tr):
+    """reduce(op, op(m) v) in one call == Gemv then Reduce, bit for bit."""
+    wg = _wg()
+    rng = np.random.default_rng(5 + tr)
+    R, Cn = 1024, 2048
+    m = rng.random(R * Cn, dtype=np.float32) * 2 - 1
+    vlen, olen = (R, Cn) if tr else (Cn, R)
+    v = rng.random(vlen, dtype=np.float32) * 2 - 1
+    tm, tv = upload(gpu, (R, Cn), m), upload(gpu, (vlen,), v)
+    to = upload(gpu, (olen,), np.zeros(olen, np.float32))
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    for op in (wg.ReduceOp.SqNorm, wg.ReduceOp.Max, wg.ReduceOp.Sum):
+        r1, r2 = upload(gpu, (), np.zeros(1, np.float32)), upload(gpu, (), np.zeros(1, np.float32))
+        red = wg.Reduce.new(gpu.device(), op)
+        def two(p):
+            gemv.dispatch_generic(gpu.device(), shapes, p, to, tm, tv, variant)
+            red.dispatch(gpu.device(), shapes, p, to, r1)
+        run_pass(gpu, two)
+        run_pass(gpu, lambda p: wg.gemv_reduce(p, op, r2, tm, tv, variant))
+        assert r1.read(gpu.device()).tobytes() == r2.read(gpu.device()).tobytes()

@@ -9,6 +9,6 @@ from .wgcore import (BufferUsages, CommandBuffer, CommandEncoder, ComputePass, D
                      GpuMatrix, GpuScalar, GpuTensor, GpuTensorView, GpuTimestamps, GpuVector, Queue, TensorBuilder,
                      ViewShape, ViewShapeBuffers, as_view)
 from .wgebra import (Axpy, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
-                     row_major_shader_defs)
+                     gemv_reduce, row_major_shader_defs)
 
 __version__ = "0.1.0"

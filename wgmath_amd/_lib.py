@@ -89,6 +89,7 @@ def _load() -> ctypes.CDLL:
         "wg_gemv": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_gemm_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
         "wg_gemv_rm": (ci, [vp, ci, ci, vp, S, vp, S, vp, S]),
+        "wg_gemv_reduce": (ci, [vp, ci, ci, ci, vp, vp, S, vp, S]),
         "wg_reduce": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_fast": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),

@@ -163,6 +163,30 @@ int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *v
     return wgk_reduce_fast(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, (float *)result->ptr);
 }
 
+int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dtype dtype, wg_buf *result, const wg_buf *m,
+                   wg_view_shape m_shape, const wg_buf *v, wg_view_shape v_shape) {
+    // result[0] = reduce(op, op(m) v): Gemv into a context-owned scratch vector, then Reduce in the reference order on the same
+    // stream -- one call, no intermediate tensor for the caller; bit-identical to wg_gemv followed by wg_reduce.
+    const wg_buf *bufs[3] = { result, m, v };
+    if (int rc = check_common("Gemv", ctx, dtype, bufs, 3)) return rc;
+    if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemv: unknown variant %d", (int)variant);
+    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    const bool tr = variant == WG_GEMV_TR || variant == WG_GEMV_TR_FAST;
+    const View mm = mk(m_shape), vv = mk(v_shape);
+    if (vv.cols != 1 || vv.mats != 1 || mm.mats != 1)
+        return wg_set_error(WG_ERR_UNSUPPORTED, "gemv_reduce: one matrix and one vector only");
+    const uint32_t out_rows = tr ? mm.cols : mm.rows;
+    void *ws = nullptr;
+    if (int rc = wg_ctx_tr_workspace(ctx, (size_t)(out_rows ? out_rows : 4) * sizeof(float), &ws)) return rc;
+    wg_buf tmp;
+    tmp.ctx = ctx; tmp.ptr = ws; tmp.bytes = (size_t)(out_rows ? out_rows : 4) * sizeof(float); tmp.usage = 0; tmp.owned = false; tmp.host_pinned = false;
+    wg_view_shape os;
+    os.size[0] = out_rows; os.size[1] = 1; os.size[2] = 1; os.stride = out_rows; os.stride_mat = out_rows; os.offset = 0;
+    if (int rc = wg_gemv(ctx, variant, dtype, &tmp, os, m, m_shape, v, v_shape)) return rc;
+    return wg_reduce(ctx, op, dtype, &tmp, os, result);
+}
+
 int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *values, wg_view_shape values_shape, wg_buf *results) {
     const wg_buf *bufs[2] = { values, results };
     if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;

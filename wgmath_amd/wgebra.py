@@ -131,6 +131,15 @@ class Gemv:
                  v.buffer()._h, v.shape().to_c()))
 
 
+def gemv_reduce(pass_: ComputePass, op: "ReduceOp", result: GpuTensor, m, v, variant: "GemvVariant" = None) -> None:
+    """Extension: result = reduce(op, op(m) v) in one call (scratch vector owned by the context); bit-identical
+    to Gemv.dispatch followed by Reduce.dispatch."""
+    m, v = as_view(m, 3), as_view(v, 3)
+    variant = GemvVariant.Gemv if variant is None else variant
+    check(lib.wg_gemv_reduce(pass_._ctx.handle, int(variant), int(op), _common_dtype(m, v), result._h,
+                             m.buffer()._h, m.shape().to_c(), v.buffer()._h, v.shape().to_c()))
+
+
 class Reduce:
     """reduce.rs:62-113: `Reduce::new(device, op)` then `dispatch(device, shapes, pass, value, result)`."""
 
