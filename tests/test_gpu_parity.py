@@ -337,6 +337,8 @@ F16_SHAPES = [
     (256, 8192, 256, 1), (512, 4096 + 32, 264, 1), (1024, 16384, 512, 2),
     # 16x16x32 kernel (K % 64 == 0, >= 3 stages): minimum, odd and even stage counts, several tiles per CU-less grid
     (512, 192, 512, 1), (512, 320, 512, 1), (768, 448, 264, 2), (2048, 2048, 1024, 1),
+    # tail split: 17 x 17 = 289 tiles on 256 CUs -> 256 tiles as they are + 33 tiles cut along K (full and ragged tiles)
+    (4352, 1024, 4352, 1), (4104, 512, 4104, 1),
 ]
 
 

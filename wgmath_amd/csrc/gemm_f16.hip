@@ -58,6 +58,9 @@ struct GemmArgs {
     uint32_t nsplit, k_per_split;
     float *part;
     float alpha, beta; // out = alpha * acc + beta * out (wg_gemm_ex)
+    // "tail split" launches of the 16x16x32 kernel: tile id = tile_base + blockIdx.x; with tail_tiles > 0 the workgroup (tile, split)
+    // writes its f32 partial tile to part[(split * tail_tiles + blockIdx.x) * 65536 + col_local * 256 + row_local]
+    uint32_t tile_base, tail_tiles;
 };
 
 // LDS-DMA: 16 bytes per lane from `gsrc` (per-lane) to LDS byte address `lds_dst` + 16*lane (`lds_dst` wave-uniform).
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
 #define WG_TRACE_POINT(i) do { } while (0)
 #endif
     uint32_t tm, tn;
-    tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split;
@@ -768,6 +771,21 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
     const uint32_t row0 = m0 + 128u * wm + 8u * kg;
+    if (g.tail_tiles > 0) { // tail split: raw f32 partial TILE (256 x 256, dense) of this split; gemm_f16_tail_reduce finishes the job
+        float *P = part + ((uint64_t)split * g.tail_tiles + blockIdx.x) * 65536u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t cl = 128u * wn + 16u * u + i16; // column within the tile
+            float *pc = P + (uint64_t)cl * 256u + 128u * wm + 8u * kg;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 *d = reinterpret_cast<float4 *>(pc + 32 * p);
+                d[0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
+                d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
+            }
+        }
+        return;
+    }
     if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M)
         float *P = part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
 #pragma unroll
@@ -825,6 +843,33 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         o[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID (gfx940+)
     }
 #endif
+}
+
+// Tail split (tile quantisation): when the tile count is a little more than a multiple of the CU count, the last round would
+// run on a nearly empty chip for a full tile time. The launcher then runs the full rounds normally and cuts the few tail tiles
+// along K over the idle CUs (f32 partial tiles in the workspace); this kernel adds a tile's partials in ASCENDING split order
+// (deterministic) and writes it with the usual alpha / beta / ragged-edge rules. grid = (tail tiles, 64): 4 columns per block.
+__global__ __launch_bounds__(256) void gemm_f16_tail_reduce(GemmArgs g) {
+    uint32_t tm, tn;
+    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    const uint32_t row = tm * BM + 4u * (threadIdx.x & 63u), col = tn * BN + blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (row >= g.M || col >= g.N) return; // M % 8 == 0: the 4 rows are all in or all out
+    const float *p = g.part + (uint64_t)blockIdx.x * 65536u + (uint64_t)(col - tn * BN) * 256u + (row - tm * BM);
+    float4 s = *reinterpret_cast<const float4 *>(p);
+    for (uint32_t i = 1; i < g.nsplit; ++i) {
+        const float4 q = *reinterpret_cast<const float4 *>(p + (uint64_t)i * g.tail_tiles * 65536u);
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    _Float16 *o = g.c + (uint64_t)col * g.ldc + row;
+    struct alignas(8) h4 { _Float16 v[4]; };
+    if (g.alpha != 1.f) { s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha; }
+    if (g.beta != 0.f) {
+        const h4 t = *reinterpret_cast<const h4 *>(o);
+        s.x = fmaf(g.beta, (float)t.v[0], s.x); s.y = fmaf(g.beta, (float)t.v[1], s.y);
+        s.z = fmaf(g.beta, (float)t.v[2], s.z); s.w = fmaf(g.beta, (float)t.v[3], s.w);
+    }
+    const h4 r = { { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w } };
+    *reinterpret_cast<h4 *>(o) = r;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -900,6 +945,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.c = (_Float16 *)out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
+    g.tile_base = 0; g.tail_tiles = 0;
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
@@ -943,6 +989,40 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 g.part = (float *)trace;
             }
 #endif
+            // tail split: full rounds as they are, the few tiles of a nearly empty last round cut along K over the idle CUs
+            uint32_t tail = 0, tail_split = 1, tail_kps = K;
+#ifndef WG_F16_TAIL_SPLIT
+#define WG_F16_TAIL_SPLIT 1
+#endif
+            if (WG_F16_TAIL_SPLIT && nsplit == 1 && nmats == 1 && tiles > (uint64_t)cus) {
+                const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
+                if (r > 0 && r * 2u <= (uint32_t)cus) {
+                    uint32_t sp = (uint32_t)cus / r;
+                    const uint32_t stages = K / 64u;
+                    if (sp > stages / 3u) sp = stages / 3u; // >= 3 stages per split
+                    while (sp >= 2) {
+                        const uint32_t kps = ((stages + sp - 1) / sp) * 64u;
+                        const uint32_t n = (K + kps - 1) / kps, last = K - (n - 1) * kps;
+                        if (n >= 2 && last >= 192u && (size_t)n * r * 65536u * sizeof(float) <= (512ull << 20)) { tail = r; tail_split = n; tail_kps = kps; break; }
+                        --sp;
+                    }
+                }
+            }
+            if (tail) {
+                void *ws = nullptr;
+                if (int rc = wg_ctx_workspace(ctx, (size_t)tail_split * tail * 65536u * sizeof(float), &ws)) return rc;
+                const uint32_t full = (uint32_t)tiles - tail;
+                GemmArgs gm = g; // the full rounds
+                if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(full, 1), dim3(256), 0, ctx->stream, gm);
+                else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(full, 1), dim3(256), 0, ctx->stream, gm);
+                GemmArgs gt = g; // the tail tiles, cut along K
+                gt.tile_base = full; gt.tail_tiles = tail; gt.nsplit = tail_split; gt.k_per_split = tail_kps; gt.part = (float *)ws;
+                if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(tail, tail_split), dim3(256), 0, ctx->stream, gt);
+                else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(tail, tail_split), dim3(256), 0, ctx->stream, gt);
+                hipLaunchKernelGGL(gemm_f16_tail_reduce, dim3(tail, 64), dim3(256), 0, ctx->stream, gt);
+                WG_HIP_TRY(hipGetLastError());
+                return WG_OK;
+            }
             if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), grid, dim3(256), 0, ctx->stream, g);
             else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), grid, dim3(256), 0, ctx->stream, g);
 #ifdef WG_F16_TRACE
