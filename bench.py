@@ -489,8 +489,11 @@ def summarize(w, elapsed, kernel_ms, steps, world):
     value = w.units_per_step() * steps / elapsed / scale
     achieved = w.algorithmic_per_launch() / (kernel_ms * 1e-3) / scale
     peak = PEAK_MFMA_TFLOPS[w.dtype] if w.bound == "mfma" else PEAK_HBM_GBS
+    # the PMC traffic figure was measured on the single-GPU, one-launch-per-step form of the workload: null for any other launch shape
+    launches = getattr(w, "launches_per_step", lambda: 1)()
+    traffic = load_traffic(w.name) if (world == 1 and launches in (1, getattr(w, "graph_batch", 0))) else None
     roof = {"bound": w.bound, "kernel": w.kernel, "achieved": round(achieved, 3), "peak": peak, "unit": w.unit,
-            "frac": round(achieved / peak, 4), "kernel_ms": round(kernel_ms, 5), "traffic": load_traffic(w.name)}
+            "frac": round(achieved / peak, 4), "kernel_ms": round(kernel_ms, 5), "traffic": traffic}
     return value, roof
 
 
