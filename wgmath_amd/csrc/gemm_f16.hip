@@ -68,14 +68,8 @@ struct GemmArgs {
 // stage t (one LDS array, no alias scopes) and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of every
 // K-step, serialising HBM latency with the MFMAs. Hidden from its scoreboard, the DMA stays in flight during the whole
 // K-step; the kernel waits for it itself (wait_dma) right before the barrier that publishes the stage.
-__device__ __forceinline__ void glds16(const _Float16 *gsrc, uint32_t lds_dst) {
-    if (WG_ABLATE & 2) return;
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst));
-}
-// Same DMA with the cheaper address form: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + immediate.
+// Address form: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + immediate (cheaper to issue than a 64-bit
+// per-lane address: ~36 vs ~60 cycles among MFMAs).
 template <int IMM>
 __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_dst) {
     if (WG_ABLATE & 2) return;
@@ -736,7 +730,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // because they issue fewer (then no) DMA pieces.
     using k8 = std::integral_constant<int, 8>;
     if constexpr (!TRANS_A) {
-        for (; st + 3 < S;) {
+        while (st + 3 < S) { // st advances in next_stage()
             half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{});
             half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
             next_stage();
@@ -752,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     } else {
         // TN: after an even half-step only the 4 + 4 newest pieces (first and second half of a B stage) may be in flight -- the
         // full stage of A issued in the odd half-step before must have landed; after an odd one the 12 just issued + 4.
-        for (; st + 3 < S;) {
+        while (st + 3 < S) {
             half_step(c0{}, no{}, yes{}, yes{});  advance(k8{});
             half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
             next_stage();

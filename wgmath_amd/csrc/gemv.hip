@@ -115,8 +115,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
             }
         } else {
             const int rem = (int)(w_end - cb); // wave-uniform
-#pragma unroll 4
-            for (int u = 0; u < rem; ++u) {
+            for (int u = 0; u < rem; ++u) { // < 64 columns left in this wave's range
                 float4 mv = ld_stream(col + (uint64_t)u * ld4);
 #pragma unroll
                 for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv, __shfl(vv[y], u, 64));
