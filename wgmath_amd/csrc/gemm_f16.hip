@@ -633,6 +633,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
             if constexpr (decltype(has_next)::value) {
                 if constexpr (TRANS_A) {
+                    // one fragment read every 4 slots (every 2 or 3, leaving slack before the end-of-half-step wait: no faster)
                     if constexpr ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1, HS ^ 1);
                 } else {
                     if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1, HS ^ 1);
