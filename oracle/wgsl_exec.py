@@ -1,0 +1,600 @@
+"""A small executor for the WGSL subset the reference's dense linear-algebra shaders are written in.
+
+TEST INFRASTRUCTURE ONLY (like everything under oracle/): nothing under wgmath_amd/ or include/ may import it.
+
+Purpose: pin the CPU restatement (oracle/wgsl_oracle.{c,py}) against the reference's OWN shader text. The reference is
+Rust + WGSL executed by wgpu/naga; neither exists in this environment, so the shaders cannot be run "for real". What can be
+done is to take the .wgsl files as they are (crates/wgebra/src/linalg/{shape,gemm,gemv,reduce,op_assign}.wgsl), translate them
+mechanically into Python generators (one generator per invocation, `workgroupBarrier()` = yield, the invocations of a workgroup
+advanced in lock-step) and run them on f32 NumPy values. tests/golden/make_wgsl_golden.py does that HERE (where /root/reference
+is mounted) and commits inputs + outputs as fixtures; tests/test_oracle.py checks both restatements against them bit for bit.
+A transcription slip in the restatement (a wrong stride, an off-by-one in a tree, a swapped index) shows up as a mismatch.
+
+What this executor fixes that WGSL leaves to the implementation (and the restatement fixes the same way):
+  * `mat4x4 * mat4x4`, `mat4x4 * vec4`: column-major, the four products of an output element are added left to right,
+    every product and every sum rounded to f32 (no FMA contraction);
+  * u32 arithmetic wraps modulo 2^32; f32 arithmetic is IEEE round-to-nearest-even (NumPy float32).
+
+Supported (all that the five files use): `#import .. as ..`, `#define_import_path`, `#ifdef/#else/#endif`, struct declarations,
+module-scope `const`, `var<uniform>`, `var<storage,...>`, `var<workgroup>`, functions, `@compute` entry points with
+`@builtin(global_invocation_id | local_invocation_id | workgroup_id)`, `let`/`var`, assignment and compound assignment, `x++`,
+`if`/`else`, `for`, `return`, calls, `vec4`, `mat4x4`, `mat4x4f`, `transpose`, `min`, `max`, member access, indexing, and the
+function redirection the Rust side performs through naga_oil's `Redirector` (reduce.rs:74-91, op_assign.rs:59-63).
+"""
+from __future__ import annotations
+
+import re
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+f32 = np.float32
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# runtime
+# ------------------------------------------------------------------------------------------------------------------
+def _is_int(x):
+    return isinstance(x, int) and not isinstance(x, bool)
+
+
+def _num(x):
+    """Abstract numeric literals meet f32 values: promote Python numbers to float32."""
+    return x if isinstance(x, (np.ndarray, np.floating)) else f32(x)
+
+
+def _matmul(a, b):
+    """a: mat4x4 as a (4, 4) array of COLUMNS (a[k] = column k); b: mat4x4 (columns) or vec4."""
+    if b.ndim == 1:
+        r = a[0] * b[0]
+        for k in (1, 2, 3):
+            r = r + a[k] * b[k]
+        return r
+    return np.stack([_matmul(a, b[j]) for j in range(4)])
+
+
+def op_add(a, b):
+    if _is_int(a) and _is_int(b):
+        return (a + b) & M32
+    return _num(a) + _num(b)
+
+
+def op_sub(a, b):
+    if _is_int(a) and _is_int(b):
+        return (a - b) & M32
+    return _num(a) - _num(b)
+
+
+def op_mul(a, b):
+    if _is_int(a) and _is_int(b):
+        return (a * b) & M32
+    a, b = _num(a), _num(b)
+    if isinstance(a, np.ndarray) and a.ndim == 2 and isinstance(b, np.ndarray):
+        return _matmul(a, b)
+    return a * b
+
+
+def op_div(a, b):
+    if _is_int(a) and _is_int(b):
+        return a // b
+    return _num(a) / _num(b)
+
+
+def fn_transpose(m):
+    return np.ascontiguousarray(m.T)
+
+
+def fn_min(a, b):
+    if _is_int(a) and _is_int(b):
+        return min(a, b)
+    return np.minimum(_num(a), _num(b))
+
+
+def fn_max(a, b):
+    if _is_int(a) and _is_int(b):
+        return max(a, b)
+    return np.maximum(_num(a), _num(b))
+
+
+def fn_vec4(*args):
+    if len(args) == 1:
+        return np.full(4, _num(args[0]), f32)
+    return np.array([_num(a) for a in args], f32)
+
+
+def fn_mat4x4(*cols):
+    if not cols:
+        return np.zeros((4, 4), f32)
+    return np.stack([np.asarray(c, f32) for c in cols])
+
+
+def load(arr, i):
+    v = arr[i]
+    return v.copy() if isinstance(v, np.ndarray) else v
+
+
+class Vec3:
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x, y, z):
+        self.x, self.y, self.z = int(x), int(y), int(z)
+
+
+class Struct:
+    def __init__(self, fields, values):
+        assert len(fields) == len(values), (fields, values)
+        for f, v in zip(fields, values):
+            setattr(self, f, v)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# lexer / parser  ->  Python source
+# ------------------------------------------------------------------------------------------------------------------
+TOKEN = re.compile(r"\s*(?:(//[^\n]*)|(\d+\.\d*(?:[eE][+-]?\d+)?f?|\d+[eE][+-]?\d+f?|\d+u?)|([A-Za-z_][A-Za-z_0-9]*)|(::|\+\+|--|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||->|[-+*/%<>=!(){}\[\];:,.@&|]))")
+
+
+def preprocess(src: str, defs: set) -> str:
+    out, stack = [], []
+    for line in src.splitlines():
+        s = line.strip()
+        if s.startswith("#ifdef"):
+            stack.append(s.split()[1] in defs)
+        elif s.startswith("#ifndef"):
+            stack.append(s.split()[1] not in defs)
+        elif s.startswith("#else"):
+            stack[-1] = not stack[-1]
+        elif s.startswith("#endif"):
+            stack.pop()
+        elif all(stack):
+            out.append(line)
+    return "\n".join(out)
+
+
+def tokenize(src: str):
+    toks, pos = [], 0
+    while pos < len(src):
+        m = TOKEN.match(src, pos)
+        if not m:
+            if src[pos:].strip() == "":
+                break
+            raise SyntaxError(f"cannot tokenize at {src[pos:pos + 40]!r}")
+        pos = m.end()
+        if m.group(1):
+            continue
+        toks.append(m.group(2) or m.group(3) or m.group(4))
+    return toks
+
+
+class Module:
+    """One WGSL file translated to Python. `imports` maps an alias (e.g. 'Shape') to another Module."""
+
+    def __init__(self, src: str, imports: dict | None = None, defs: set | None = None, redirect: dict | None = None):
+        self.imports = imports or {}
+        self.redirect = redirect or {}
+        self.structs, self.consts, self.globals_, self.functions, self.entries = {}, {}, {}, {}, {}
+        lines = []
+        for line in preprocess(src, defs or set()).splitlines():
+            s = line.strip()
+            if s.startswith("#import") or s.startswith("#define_import_path"):
+                continue
+            lines.append(line)
+        self.toks = tokenize("\n".join(lines))
+        self.i = 0
+        self.py = []
+        self._parse_module()
+        self.ns = {"op_add": op_add, "op_sub": op_sub, "op_mul": op_mul, "op_div": op_div, "load": load, "Struct": Struct,
+                   "fn_transpose": fn_transpose, "fn_min": fn_min, "fn_max": fn_max, "fn_vec4": fn_vec4, "fn_mat4x4": fn_mat4x4,
+                   "f32": f32, "M32": M32, "MOD": self}
+        for alias, mod in self.imports.items():
+            self.ns["IMP_" + alias] = mod
+        exec("\n".join(self.py), self.ns)
+
+    # -- token helpers
+    def peek(self, k=0):
+        return self.toks[self.i + k] if self.i + k < len(self.toks) else None
+
+    def next(self):
+        t = self.toks[self.i]
+        self.i += 1
+        return t
+
+    def expect(self, t):
+        got = self.next()
+        if got != t:
+            raise SyntaxError(f"expected {t!r}, got {got!r} near {' '.join(self.toks[max(0, self.i - 8):self.i + 4])}")
+
+    def accept(self, t):
+        if self.peek() == t:
+            self.i += 1
+            return True
+        return False
+
+    def skip_attrs(self):
+        attrs = []
+        while self.peek() == "@":
+            self.next()
+            name = self.next()
+            args = []
+            if self.accept("("):
+                while not self.accept(")"):
+                    args.append(self.next())
+            attrs.append((name, [a for a in args if a != ","]))
+        return attrs
+
+    def parse_type(self):
+        """Returns the type as a flat string such as 'array<vec4<f32>,64>' or 'Shape::Shape'."""
+        t = self.next()
+        while self.peek() == "::":
+            t += self.next() + self.next()
+        if self.accept("<"):
+            t += "<"
+            depth = 1
+            while depth:
+                x = self.next()
+                depth += (x == "<") - (x == ">")
+                t += x
+        return t
+
+    # -- module level
+    def _parse_module(self):
+        while self.peek() is not None:
+            attrs = self.skip_attrs()
+            t = self.peek()
+            if t == ";":
+                self.next()
+            elif t == "struct":
+                self.next()
+                name = self.next()
+                self.expect("{")
+                fields = []
+                while not self.accept("}"):
+                    self.skip_attrs()
+                    fields.append(self.next())
+                    self.expect(":")
+                    self.parse_type()
+                    self.accept(",")
+                self.structs[name] = fields
+            elif t == "const":
+                self.next()
+                name = self.next()
+                if self.accept(":"):
+                    self.parse_type()
+                self.expect("=")
+                self.consts[name] = self.parse_expr(Scope(self, None))
+                self.expect(";")
+            elif t == "var":
+                self.next()
+                space = ""
+                if self.accept("<"):
+                    while not self.accept(">"):
+                        space += self.next()
+                name = self.next()
+                self.expect(":")
+                ty = self.parse_type()
+                self.expect(";")
+                self.globals_[name] = (space, ty)
+            elif t == "fn":
+                self._parse_fn(attrs)
+            else:
+                raise SyntaxError(f"unexpected {t!r} at module scope")
+
+    def _parse_fn(self, attrs):
+        self.expect("fn")
+        name = self.next()
+        self.expect("(")
+        params = []
+        while not self.accept(")"):
+            pattrs = self.skip_attrs()
+            pname = self.next()
+            self.expect(":")
+            self.parse_type()
+            self.accept(",")
+            params.append((pname, pattrs))
+        if self.accept("->"):
+            self.skip_attrs()
+            self.parse_type()
+        scope = Scope(self, None)
+        for p, _ in params:
+            scope.declare(p)
+        body = self.parse_block(scope, 1)
+        args = ", ".join(scope.local(p) for p, _ in params)
+        self.py.append(f"def F_{name}(G{', ' if args else ''}{args}):")
+        self.py.append("    if False: yield")
+        self.py.extend(body if body else ["    pass"])
+        self.py.append("")
+        self.functions[name] = [p for p, _ in params]
+        if any(a[0] == "compute" for a in attrs):
+            wg = next(a[1] for a in attrs if a[0] == "workgroup_size")
+            self.entries[name] = {"workgroup_size": wg, "builtins": [(p, pa[0][1][0]) for p, pa in params]}
+
+    # -- statements (emit Python lines at indentation `ind`)
+    def parse_block(self, scope, ind):
+        self.expect("{")
+        inner = Scope(self, scope)
+        out = []
+        while not self.accept("}"):
+            out.extend(self.parse_stmt(inner, ind))
+        return out
+
+    def parse_simple(self, scope):
+        """let / var / assignment / call / ++ without the trailing ';' -> list of python statements (no indentation)."""
+        t = self.peek()
+        if t in ("let", "var"):
+            self.next()
+            name = self.next()
+            if self.accept(":"):
+                self.parse_type()
+            self.expect("=")
+            rhs = self.parse_expr(scope)
+            scope.declare(name)  # after the right-hand side: `let shape = f(shape)` reads the outer `shape`
+            return [f"{scope.local(name)} = {rhs}"]
+        lhs = self.parse_postfix(scope, lvalue=True)
+        t = self.peek()
+        if t in ("=", "+=", "-=", "*=", "/="):
+            self.next()
+            rhs = self.parse_expr(scope)
+            if t != "=":
+                cur = lhs.read()
+                rhs = {"+=": "op_add", "-=": "op_sub", "*=": "op_mul", "/=": "op_div"}[t] + f"({cur}, {rhs})"
+            return [lhs.write(rhs)]
+        if t in ("++", "--"):
+            self.next()
+            return [lhs.write(("op_add" if t == "++" else "op_sub") + f"({lhs.read()}, 1)")]
+        return [lhs.read()]  # expression statement (a call)
+
+    def parse_stmt(self, scope, ind):
+        pad = "    " * ind
+        t = self.peek()
+        if t == "{":
+            return self.parse_block(scope, ind)
+        if t == "if":
+            self.next()
+            cond = self.parse_expr(scope)
+            out = [f"{pad}if {cond}:"] + (self.parse_block(scope, ind + 1) or [f"{pad}    pass"])
+            if self.accept("else"):
+                if self.peek() == "if":
+                    out += [f"{pad}else:"] + self.parse_stmt(scope, ind + 1)
+                else:
+                    out += [f"{pad}else:"] + (self.parse_block(scope, ind + 1) or [f"{pad}    pass"])
+            return out
+        if t == "for":
+            self.next()
+            self.expect("(")
+            inner = Scope(self, scope)
+            init = self.parse_simple(inner) if self.peek() != ";" else []
+            self.expect(";")
+            cond = self.parse_expr(inner) if self.peek() != ";" else "True"
+            self.expect(";")
+            upd = self.parse_simple(inner) if self.peek() != ")" else []
+            self.expect(")")
+            body = self.parse_block(inner, ind + 1)
+            return [pad + s for s in init] + [f"{pad}while {cond}:"] + body + [f"{pad}    {s}" for s in upd]
+        if t == "return":
+            self.next()
+            if self.accept(";"):
+                return [f"{pad}return"]
+            e = self.parse_expr(scope)
+            self.expect(";")
+            return [f"{pad}return {e}"]
+        if t == "workgroupBarrier":
+            self.next(); self.expect("("); self.expect(")"); self.expect(";")
+            return [f"{pad}yield"]
+        out = [pad + s for s in self.parse_simple(scope)]
+        self.expect(";")
+        return out
+
+    # -- expressions -> python expression strings
+    def parse_expr(self, scope):
+        return self.parse_bin(scope, 0)
+
+    LEVELS = [["||"], ["&&"], ["==", "!=", "<", ">", "<=", ">="], ["+", "-"], ["*", "/", "%"]]
+
+    def parse_bin(self, scope, lvl):
+        if lvl == len(self.LEVELS):
+            return self.parse_unary(scope)
+        lhs = self.parse_bin(scope, lvl + 1)
+        while self.peek() in self.LEVELS[lvl]:
+            op = self.next()
+            rhs = self.parse_bin(scope, lvl + 1)
+            if op in ("+", "-", "*", "/"):
+                lhs = {"+": "op_add", "-": "op_sub", "*": "op_mul", "/": "op_div"}[op] + f"({lhs}, {rhs})"
+            elif op == "||":
+                lhs = f"({lhs} or {rhs})"
+            elif op == "&&":
+                lhs = f"({lhs} and {rhs})"
+            elif op == "%":
+                lhs = f"({lhs} % {rhs})"
+            else:
+                lhs = f"({lhs} {op} {rhs})"
+        return lhs
+
+    def parse_unary(self, scope):
+        if self.accept("-"):
+            return f"op_sub(0, {self.parse_unary(scope)})"
+        if self.accept("!"):
+            return f"(not {self.parse_unary(scope)})"
+        return self.parse_postfix(scope).read()
+
+    def parse_postfix(self, scope, lvalue=False):
+        t = self.next()
+        if t == "(":
+            e = self.parse_expr(scope)
+            self.expect(")")
+            node = LV(f"({e})")
+        elif re.fullmatch(r"\d+u", t):
+            node = LV(t[:-1])
+        elif re.fullmatch(r"\d+", t):
+            node = LV(t)
+        elif re.fullmatch(r"[\d.]+(?:[eE][+-]?\d+)?f?", t):
+            node = LV(f"f32({t.rstrip('f')})")
+        else:
+            # identifier, possibly namespaced (Alias::name)
+            alias = None
+            if self.peek() == "::":
+                self.next()
+                alias, t = t, self.next()
+            if self.peek() == "<" and t in ("vec4", "mat4x4", "array"):  # explicit template arguments: vec4<f32>(...)
+                self.parse_type_args()
+            if self.peek() == "(":
+                self.next()
+                args = []
+                while not self.accept(")"):
+                    args.append(self.parse_expr(scope))
+                    self.accept(",")
+                node = LV(self.call(scope, alias, t, args))
+            else:
+                node = scope.resolve(alias, t)
+        while True:
+            if self.accept("."):
+                node = LV(f"{node.read()}.{self.next()}", attr=True)
+            elif self.accept("["):
+                idx = self.parse_expr(scope)
+                self.expect("]")
+                node = LV(None, base=node.read(), index=idx)
+            else:
+                return node
+
+    def parse_type_args(self):
+        self.expect("<")
+        depth = 1
+        while depth:
+            x = self.next()
+            depth += (x == "<") - (x == ">")
+
+    def call(self, scope, alias, name, args):
+        a = ", ".join(args)
+        if alias is None:
+            if name in ("vec4", "vec4f"):
+                return f"fn_vec4({a})"
+            if name in ("mat4x4", "mat4x4f"):
+                return f"fn_mat4x4({a})"
+            if name in ("transpose", "min", "max"):
+                return f"fn_{name}({a})"
+            if name in self.structs:
+                return f"Struct({self.structs[name]!r}, [{a}])"
+            name = self.redirect.get(name, name)
+            return f"(yield from F_{name}(G{', ' if a else ''}{a}))"
+        mod = self.imports[alias]
+        if name in mod.structs:
+            return f"Struct({mod.structs[name]!r}, [{a}])"
+        return f"(yield from IMP_{alias}.ns['F_{name}'](None{', ' if a else ''}{a}))"
+
+    # -- execution
+    def run(self, entry: str, grid, bindings: dict):
+        """Executes entry point `entry` over grid = (gx, gy, gz) workgroups. `bindings`: uniform structs (dicts or Struct) and
+        storage arrays (NumPy float32; arrays of vec4 are passed flat and viewed as (n, 4))."""
+        info = self.entries[entry]
+        wgs = [self._const(x) for x in info["workgroup_size"]] + [1, 1]
+        wx, wy, wz = wgs[0], wgs[1], wgs[2]
+
+        class G:
+            pass
+        g = G()
+        for k, v in self.consts.items():
+            setattr(g, k, eval(v, self.ns, {"G": g}))
+        storage_views = {}
+        for name, (space, ty) in self.globals_.items():
+            if "workgroup" in space:
+                continue
+            v = bindings[name]
+            if "uniform" in space:
+                sname = ty.split("::")[-1]
+                fields = (self.structs.get(sname) or next(m.structs[sname] for m in self.imports.values() if sname in m.structs))
+                v = v if isinstance(v, Struct) else Struct(fields, [int(v[f]) for f in fields])
+            elif ty.startswith("array<vec4"):
+                assert v.dtype == np.float32 and v.size % 4 == 0
+                v = v.reshape(-1, 4)
+            elif ty.startswith("array<"):
+                assert v.dtype == np.float32
+            else:  # a single storage scalar: kept as a 1-element array, see LV.write
+                assert v.dtype == np.float32 and v.size >= 1
+            setattr(g, name, v)
+            storage_views[name] = v
+        fn = self.ns["F_" + entry]
+        for gz in range(grid[2]):
+            for gy in range(grid[1]):
+                for gx in range(grid[0]):
+                    for name, (space, ty) in self.globals_.items():
+                        if "workgroup" in space:
+                            setattr(g, name, self._alloc_workgroup(ty, g))
+                    gens = []
+                    for lz in range(wz):
+                        for ly in range(wy):
+                            for lx in range(wx):
+                                vals = {"global_invocation_id": Vec3(gx * wx + lx, gy * wy + ly, gz * wz + lz),
+                                        "local_invocation_id": Vec3(lx, ly, lz), "workgroup_id": Vec3(gx, gy, gz)}
+                                gens.append(fn(g, *[vals[b] for _, b in info["builtins"]]))
+                    live = gens
+                    while live:  # advance every invocation to its next barrier (or to its end)
+                        nxt = []
+                        for it in live:
+                            try:
+                                next(it)
+                                nxt.append(it)
+                            except StopIteration:
+                                pass
+                        live = nxt
+        return storage_views
+
+    def _const(self, tok):
+        return int(tok) if tok.isdigit() else int(eval(self.consts[tok], self.ns, {}))
+
+    def _alloc_workgroup(self, ty, g):
+        m = re.fullmatch(r"array<(.*),(\w+)>", ty)
+        elem, n = m.group(1), m.group(2)
+        n = int(n) if n.isdigit() else int(getattr(g, n))
+        shape = {"f32": (n,), "vec4<f32>": (n, 4), "mat4x4<f32>": (n, 4, 4)}[elem]
+        return np.zeros(shape, np.float32)
+
+
+class LV:
+    """An expression that may also be assigned to."""
+
+    def __init__(self, expr, base=None, index=None, attr=False, scalar_global=False):
+        self.expr, self.base, self.index, self.attr, self.scalar_global = expr, base, index, attr, scalar_global
+
+    def read(self):
+        if self.base is not None:
+            return f"load({self.base}, {self.index})"
+        return self.expr + ("[0]" if self.scalar_global else "")
+
+    def write(self, rhs):
+        if self.base is not None:
+            return f"{self.base}[{self.index}] = {rhs}"
+        if self.scalar_global:
+            return f"{self.expr}[0] = {rhs}"
+        return f"{self.expr} = {rhs}"
+
+
+class Scope:
+    def __init__(self, mod, parent):
+        self.mod, self.parent, self.names = mod, parent, set()
+
+    def declare(self, name):
+        self.names.add(name)
+
+    def local(self, name):
+        return "L_" + name
+
+    def has(self, name):
+        return name in self.names or (self.parent is not None and self.parent.has(name))
+
+    def resolve(self, alias, name):
+        if alias is not None:
+            raise SyntaxError(f"namespaced value {alias}::{name} is not supported")
+        if self.has(name):
+            return LV(self.local(name))
+        if name in self.mod.consts or name in self.mod.globals_:
+            space, ty = self.mod.globals_.get(name, ("", ""))
+            scalar = name in self.mod.globals_ and "storage" in space and not ty.startswith("array")
+            return LV(f"G.{name}", scalar_global=scalar)
+        if name in ("true", "false"):
+            return LV(name.capitalize())
+        raise NameError(f"unknown identifier {name!r}")
+
+
+def load_linalg(ref_dir: str, file: str, defs: set | None = None, redirect: dict | None = None) -> Module:
+    """`ref_dir` = .../crates/wgebra/src/linalg of the reference checkout. Every kernel file imports shape.wgsl as `Shape`."""
+    import os
+    shape = Module(open(os.path.join(ref_dir, "shape.wgsl")).read(), defs=defs)
+    return Module(open(os.path.join(ref_dir, file)).read(), imports={"Shape": shape}, defs=defs, redirect=redirect)

@@ -21,14 +21,19 @@
  * the same shared-memory tree.  One OpenMP work item per workgroup (fast variants) or
  * per invocation (naive variants), which is also how the cpu_baseline leg times it.
  *
- * PARITY STATUS: "parity unpinned" against a real WGSL execution for Gemm/Gemv/Reduce:
+ * PARITY STATUS: "parity unpinned" against a real wgpu/naga EXECUTION for Gemm/Gemv/Reduce:
  * the reference (Rust + wgpu + naga) cannot be built or run in this environment and its
  * own tests hold no golden vectors (unseeded random inputs vs nalgebra, abs eps 1e-3).
- * It is pinned to (a) the reference's own test procedure and bars, reproduced literally in
- * tests/test_oracle.py (gemm.rs:149-200, gemv.rs:158-195, reduce.rs:143-177), (b) the one
- * deterministic known-answer test the reference holds, gpu_op_assign (op_assign.rs:110-155),
- * and (c) an independently written NumPy restatement (oracle/wgsl_oracle.py) that must
- * agree bit-for-bit.
+ * It is pinned to (a) the reference's OWN SHADER TEXT: tests/golden/wgsl_exec_*.npz hold the
+ * outputs of crates/wgebra/src/linalg/*.wgsl executed as they are by oracle/wgsl_exec.py (a
+ * small WGSL-subset executor; generator tests/golden/make_wgsl_golden.py) for all ten entry
+ * points, and this file reproduces them BIT FOR BIT (tests/test_oracle.py::
+ * test_restatement_matches_executed_wgsl_*); (b) the reference's own test procedure and bars,
+ * reproduced literally in tests/test_oracle.py (gemm.rs:149-200, gemv.rs:158-195,
+ * reduce.rs:143-177); (c) the one deterministic known-answer test the reference holds,
+ * gpu_op_assign (op_assign.rs:110-155); (d) an independently written NumPy restatement
+ * (oracle/wgsl_oracle.py) that must agree bit-for-bit. What stays unpinned is only what WGSL
+ * leaves to the implementation (next paragraph).
  *
  * Unspecified-by-WGSL choices made here (and in the NumPy twin), stated once:
  *   - mat4x4*vec4 and mat4x4*mat4x4 are evaluated as  ((c0*v.x + c1*v.y) + c2*v.z) + c3*v.w

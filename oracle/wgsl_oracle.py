@@ -11,8 +11,10 @@ Two independent restatements live under oracle/:
 They must agree BIT-FOR-BIT on vec4-aligned inputs (tests/test_oracle.py); that cross-check is what
 guards against a transcription slip in either one.
 
-PARITY STATUS: "parity unpinned" against a real WGSL execution for Gemm/Gemv/Reduce (see the header of
-wgsl_oracle.c and DESIGN.md): the reference cannot run here and holds no golden vectors.
+PARITY STATUS: "parity unpinned" against a real wgpu/naga EXECUTION for Gemm/Gemv/Reduce (the reference cannot run here
+and holds no golden vectors), but pinned bit-for-bit against the reference's own shader TEXT executed by oracle/wgsl_exec.py
+(tests/golden/wgsl_exec_*.npz, tests/test_oracle.py::test_restatement_matches_executed_wgsl_*) -- see the header of
+wgsl_oracle.c and DESIGN.md section 4.
 
 Reference files restated (relative to /root/reference/crates/wgebra/src/linalg/):
   shape.wgsl:36-47,60-66 ; gemm.wgsl:28-200 ; gemv.wgsl:28-155 ; reduce.wgsl:12-96 ; op_assign.wgsl:14-47

@@ -1,5 +1,7 @@
 """CPU tests of the oracle itself (no GPU): the two restatements agree bit-for-bit, reproduce the committed golden
 vectors, and clear the reference's own test bars on the reference's own test shapes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -171,3 +173,68 @@ def test_oracle_sampled_grid_matches_full(C):
     C.gemm(wo.GEMM, part, wo.Shape(M, N), a, wo.Shape(M, K), b, wo.Shape(K, N), 1, 2)  # invocations 64..127 -> rows 256..511
     f, p = full.reshape(M, N, order="F"), part.reshape(M, N, order="F")
     assert np.array_equal(p[256:512], f[256:512]) and (p[:256] == -1.0).all()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Pinning against the reference's OWN shader text: tests/golden/wgsl_exec_*.npz hold the outputs of the reference's .wgsl files
+# executed by oracle/wgsl_exec.py (generator: tests/golden/make_wgsl_golden.py, run where /root/reference is mounted).
+# Both restatements must reproduce them bit for bit.
+# ------------------------------------------------------------------------------------------------------------
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _shape_of(row):
+    return wo.Shape(*[int(x) for x in row])
+
+
+def test_restatement_matches_executed_wgsl_gemm(oracle_c):
+    g = np.load(os.path.join(GOLD, "wgsl_exec_gemm.npz"))
+    keys = sorted({k[: -len("_out")] for k in g.files if k.endswith("_out")})
+    assert len(keys) >= 13
+    variants = {"gemm": wo.GEMM, "gemm_fast": wo.GEMM_FAST, "gemm_tr": wo.GEMM_TR, "gemm_tr_fast": wo.GEMM_TR_FAST}
+    for k in keys:
+        entry = k.split("_", 1)[1]
+        variant = variants[entry]
+        so, s1, s2 = (_shape_of(r) for r in g[k + "_shapes"])
+        m1, m2, exp = g[k + "_m1"], g[k + "_m2"], g[k + "_out"]
+        for name, impl in (("numpy", wo.gemm), ("C", oracle_c.gemm)):
+            out = np.full(exp.size, np.nan, np.float32)
+            impl(variant, out, so, m1, s1, m2, s2)
+            assert out.tobytes() == exp.tobytes(), f"{name} restatement of {entry} ({k}) differs from the executed WGSL"
+
+
+def test_restatement_matches_executed_wgsl_gemv(oracle_c):
+    g = np.load(os.path.join(GOLD, "wgsl_exec_gemv.npz"))
+    keys = sorted({k[: -len("_out")] for k in g.files if k.endswith("_out")})
+    assert len(keys) >= 10
+    variants = {"gemv": wo.GEMV, "gemv_fast": wo.GEMV_FAST, "gemv_tr": wo.GEMV_TR, "gemv_tr_fast": wo.GEMV_TR_FAST}
+    for k in keys:
+        entry = k.split("_", 1)[1]
+        so, sm, sv = (_shape_of(r) for r in g[k + "_shapes"])
+        m, v, exp = g[k + "_m"], g[k + "_v"], g[k + "_out"]
+        for name, impl in (("numpy", wo.gemv), ("C", oracle_c.gemv)):
+            out = np.full(exp.size, np.nan, np.float32)
+            impl(variants[entry], out, so, m, sm, v, sv)
+            assert out.tobytes() == exp.tobytes(), f"{name} restatement of {entry} ({k}) differs from the executed WGSL"
+
+
+def test_restatement_matches_executed_wgsl_reduce_and_op_assign(oracle_c):
+    g = np.load(os.path.join(GOLD, "wgsl_exec_reduce.npz"))
+    keys = sorted({k[: -len("_res")] for k in g.files if k.endswith("_res")})
+    assert len(keys) == 35
+    for k in keys:
+        op, n, off = int(k.split("_")[0][2:]), int(k.split("_")[1][1:]), int(k.split("_")[2][1:])
+        x, exp = g[k + "_x"], g[k + "_res"]
+        sh = wo.Shape(n, 1, 1, n, n, off)
+        assert np.float32(wo.reduce(op, x, sh)).tobytes() == exp[0].tobytes(), f"numpy reduce op {op} n {n}"
+        assert np.float32(oracle_c.reduce(op, x, sh)).tobytes() == exp[0].tobytes(), f"C reduce op {op} n {n}"
+    g = np.load(os.path.join(GOLD, "wgsl_exec_op_assign.npz"))
+    keys = sorted({k[: -len("_a0")] for k in g.files if k.endswith("_a0")})
+    assert len(keys) == 15
+    for k in keys:
+        op, n, oa, ob = int(k.split("_")[0][2:]), int(k.split("_")[1][1:]), int(k.split("_")[2]), int(k.split("_")[3])
+        a0, b, exp = g[k + "_a0"], g[k + "_b"], g[k + "_a"]
+        for name, impl in (("numpy", wo.op_assign), ("C", oracle_c.op_assign)):
+            a = a0.copy()
+            impl(op, a, wo.Shape(n, 1, 1, n, n, oa), b, wo.Shape(n, 1, 1, n, n, ob))
+            assert a.tobytes() == exp.tobytes(), f"{name} op_assign op {op} ({k}) differs from the executed WGSL"
