@@ -1,0 +1,101 @@
+// Shared by the f16 GEMM translation units (gemm_f16.hip: the shipped 16x16x32 kernel + launcher; gemm_f16_legacy.hip: the
+// 32x32x16 kernel it replaced, still used for K % 64 != 0 and short K splits, and the generic fallback).
+#pragma once
+#include "wg_internal.hpp"
+
+#include <cstdio>
+#include <type_traits>
+#include <utility>
+#include <vector>
+
+namespace wgf16 {
+
+
+#ifndef WG_ABLATE
+#define WG_ABLATE 0 // timing experiments only: 1 = no barrier, 2 = no DMA, 4 = no LDS reads, 8 = (unused), 16 = no lane swaps, 32 = no epilogue stores (bitmask); results are garbage
+#endif
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+#define WG_AS1 __attribute__((address_space(1)))
+#define WG_AS3 __attribute__((address_space(3)))
+
+constexpr int BM = 256, BN = 256, BKH = 32; // K advances in half-steps of 32
+constexpr int HA_BYTES = BM * BKH * 2;      // 16 KiB
+constexpr int HB_BYTES = BN * BKH * 2;
+constexpr int HSTAGE_BYTES = HA_BYTES + HB_BYTES; // 32 KiB
+constexpr int NSLOT = 5;                    // 5 x 32 KiB = all 160 KiB of LDS
+
+struct GemmArgs {
+    const _Float16 *a; uint32_t lda; uint64_t a_batch;
+    const _Float16 *b; uint32_t ldb; uint64_t b_batch;
+    _Float16 *c; uint32_t ldc; uint64_t c_batch;
+    uint32_t M, N, K;
+    uint32_t tiles_m, tiles_n;
+    // split-K: grid.y = nmats * nsplit, workgroup (z, s) covers K range s and writes an f32 slab of `part` ([z][s][N][M])
+    uint32_t nsplit, k_per_split;
+    float *part;
+    float alpha, beta; // out = alpha * acc + beta * out (wg_gemm_ex)
+    // "tail split" launches of the 16x16x32 kernel: tile id = tile_base + blockIdx.x; with tail_tiles > 0 the workgroup (tile, split)
+    // writes its f32 partial tile to part[(split * tail_tiles + blockIdx.x) * 65536 + col_local * 256 + row_local]
+    uint32_t tile_base, tail_tiles;
+};
+
+// LDS-DMA: 16 bytes per lane from `gsrc` (per-lane) to LDS byte address `lds_dst` + 16*lane (`lds_dst` wave-uniform).
+// Issued through inline asm ON PURPOSE: hipcc cannot tell that the DMA into stage t+1 does not alias the ds_reads of
+// stage t (one LDS array, no alias scopes) and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of every
+// K-step, serialising HBM latency with the MFMAs. Hidden from its scoreboard, the DMA stays in flight during the whole
+// K-step; the kernel waits for it itself (wait_dma) right before the barrier that publishes the stage.
+// Address form: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + immediate (cheaper to issue than a 64-bit
+// per-lane address: ~36 vs ~60 cycles among MFMAs).
+template <int IMM>
+static __device__ __forceinline__ void glds16s(uint32_t voff, const void *sbase, uint32_t lds_dst) {
+    if (WG_ABLATE & 2) return;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%c4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst), "i"(IMM));
+}
+static __device__ __forceinline__ void wait_dma_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's DMA pieces are still in flight (they retire in issue order)
+template <int N>
+static __device__ __forceinline__ void wait_dma_keep() { asm volatile("s_waitcnt vmcnt(%c0)" ::"i"(N) : "memory"); }
+static __device__ __forceinline__ short4_t lds_tr(const char *p) {
+    if (WG_ABLATE & 4) { short4_t v; asm volatile("" : "=v"(v)); return v; }
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WG_AS3 short4_t *)p);
+}
+static __device__ __forceinline__ half8_t lds_h8(const char *p) {
+    if (WG_ABLATE & 4) { half8_t v; asm volatile("" : "=v"(v)); return v; }
+    return *reinterpret_cast<const half8_t *>(p);
+}
+static __device__ __forceinline__ half8_t cat(short4_t lo, short4_t hi) {
+    short8_t v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
+    return __builtin_bit_cast(half8_t, v);
+}
+
+// workgroup id -> (tile_m, tile_n)
+static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t &tm, uint32_t &tn) {
+    if ((tiles_m % 16u) == 0 && (tiles_n % 16u) == 0) {
+        // 256 consecutive ids = one 16x16 super-tile; hardware deals ids round-robin to the 8 XCDs: XCD x gets a 4x8 patch
+        const uint32_t super = bid >> 8, within = bid & 255u;
+        const uint32_t xcd = within & 7u, local = within >> 3;
+        const uint32_t sm = super % (tiles_m / 16u), sn = super / (tiles_m / 16u);
+        tm = sm * 16u + (xcd & 3u) * 4u + (local & 3u);
+        tn = sn * 16u + (xcd >> 2) * 8u + (local >> 2);
+    } else {
+        const uint32_t nwg = tiles_m * tiles_n;
+        const uint32_t q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, local = bid / 8u;
+        const uint32_t id = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
+        tm = id % tiles_m;
+        tn = id / tiles_m;
+    }
+}
+
+
+// launch wrappers of gemm_f16_legacy.hip (grid / arguments prepared by wgk_gemm_f16)
+int legacy_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
+int generic_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
+
+} // namespace wgf16
