@@ -123,6 +123,8 @@ GEMM_SHAPES = [
     (128, 1024, 64, 1), (1024, 16, 512, 1), (252, 1000, 124, 3),
     # few output tiles + long K -> split-K path (f32 slabs + ordered reduce), incl. ragged K and batches
     (256, 4096, 128, 1), (512, 8192, 256, 1), (260, 2064, 132, 2), (64, 16384, 64, 1),
+    # tail split: 17 x 31 = 527 and 17 x 33 = 561 tiles on 512 resident workgroups (full and ragged tiles)
+    (4352, 512, 3968, 1), (4104, 256, 4104, 1),
 ]
 
 

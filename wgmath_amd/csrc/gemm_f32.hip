@@ -51,6 +51,10 @@ struct GemmArgs {
     uint32_t dma_ok; // leading dimensions small enough for 32-bit byte offsets within a tile
     uint32_t nsplit, k_per_split; // split-K: grid.y = nmats * nsplit; c then points at the f32 slabs [z][s][N][M]
     float alpha, beta;            // out = alpha * acc + beta * out (wg_gemm_ex); (1, 0) in split mode (the reduce kernel applies them)
+    // "tail split" launches (tile quantisation, see wgk_gemm_f32): tile id = tile_base + blockIdx.x; with tail_tiles > 0 workgroup
+    // (tile, split) writes its partial tile densely to c[(split * tail_tiles + blockIdx.x) * BM * BN + col_local * BM + row_local]
+    uint32_t tile_base, tail_tiles;
+    float *out_c; uint32_t out_ldc; float out_alpha, out_beta; // the real output, for gemm_f32_tail_reduce
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
@@ -406,7 +410,7 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
 template <bool TRANS_A>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[NRING * SLOT_FLOATS]; // 72 KiB: 3 DMA slots, or 2 staged buffers on edge tiles
-    const uint32_t tile = xcd_remap(blockIdx.x, g.tiles_m * g.tiles_n);
+    const uint32_t tile = xcd_remap(blockIdx.x + g.tile_base, g.tiles_m * g.tiles_n);
     const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
@@ -416,10 +420,37 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const float *B = g.b + z * g.b_batch + k_begin;
     float *C = g.c + ((uint64_t)z * g.nsplit + split) * g.c_batch;
+    if (g.tail_tiles > 0) { // dense partial tile: C[n * BM + m] with (m, n) relative to the tile
+        C = g.c + ((uint64_t)split * g.tail_tiles + blockIdx.x) * (uint64_t)(BM * BN) - ((uint64_t)n0 * BM + m0);
+        gl.ldc = BM;
+    }
     // workgroup-uniform: the whole tile is inside the matrices, K is a whole number of k-tiles, and 32-bit DMA offsets suffice
     const bool interior = (m0 + BM <= gl.M) && (n0 + BN <= gl.N) && (gl.K % BK == 0) && gl.K >= (uint32_t)BK && gl.dma_ok;
     if (interior) gemm_f32_tile_dma<TRANS_A>(gl, smem, A, B, C, m0, n0);
     else gemm_f32_tile<TRANS_A, true>(gl, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
+}
+
+// Tail split (tile quantisation): see wgk_gemm_f32. Adds a tail tile's partials in ASCENDING split order (deterministic) and writes
+// it with the usual alpha / beta / edge rules. grid = (tail tiles, BN / 4): 4 columns per block, float4 (4 rows) per thread.
+__global__ __launch_bounds__(256) void gemm_f32_tail_reduce(GemmArgs g) {
+    const uint32_t tile = xcd_remap(blockIdx.x + g.tile_base, g.tiles_m * g.tiles_n);
+    const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    const uint32_t rl = 4u * (threadIdx.x & 63u), cl = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const uint32_t row = tm * BM + rl, col = tn * BN + cl;
+    if (row >= g.M || col >= g.N) return; // M % 4 == 0: the 4 rows are all in or all out
+    const float *p = g.c + (uint64_t)blockIdx.x * (uint64_t)(BM * BN) + (uint64_t)cl * BM + rl;
+    float4 s = *reinterpret_cast<const float4 *>(p);
+    for (uint32_t i = 1; i < g.nsplit; ++i) {
+        const float4 q = *reinterpret_cast<const float4 *>(p + (uint64_t)i * g.tail_tiles * (uint64_t)(BM * BN));
+        s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    float *o = g.out_c + (uint64_t)col * g.out_ldc + row;
+    if (g.out_alpha != 1.f) { s.x *= g.out_alpha; s.y *= g.out_alpha; s.z *= g.out_alpha; s.w *= g.out_alpha; }
+    if (g.out_beta != 0.f) {
+        const float4 c = *reinterpret_cast<const float4 *>(o);
+        s.x = fmaf(g.out_beta, c.x, s.x); s.y = fmaf(g.out_beta, c.y, s.y); s.z = fmaf(g.out_beta, c.z, s.z); s.w = fmaf(g.out_beta, c.w, s.w);
+    }
+    *reinterpret_cast<float4 *>(o) = s;
 }
 
 } // namespace
@@ -434,6 +465,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.c = out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
+    g.tile_base = 0; g.tail_tiles = 0; g.out_c = out; g.out_ldc = out_ld; g.out_alpha = alpha; g.out_beta = beta;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
@@ -455,6 +487,34 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     }
     if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
     const dim3 grid((uint32_t)tiles, nmats * nsplit), block(kThreads);
+    // Tail split: with a tile count a little above a multiple of the 2 x CUs resident workgroups, the last round would run on a
+    // nearly empty chip for a whole tile time. The full rounds run as they are; the few tail tiles are cut along K over the idle
+    // slots (dense f32 partial tiles in the workspace + an ordered reduce). Interior-sized K only (whole k-tiles per split).
+#ifndef WG_F32_TAIL_SPLIT
+#define WG_F32_TAIL_SPLIT 1
+#endif
+    const uint32_t slots = 2u * (uint32_t)cus;
+    if (WG_F32_TAIL_SPLIT && nsplit == 1 && nmats == 1 && tiles > slots && K % BK == 0) {
+        const uint32_t r = (uint32_t)(tiles % slots), ktiles = K / BK;
+        uint32_t sp = r ? slots / r : 0;
+        if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
+        if (r > 0 && r * 2u <= slots && sp >= 2 && (size_t)sp * r * BM * BN * sizeof(float) <= (512ull << 20)) {
+            const uint32_t kps = ((ktiles + sp - 1) / sp) * BK, n = (K + kps - 1) / kps;
+            void *ws = nullptr;
+            if (int rc = wg_ctx_workspace(ctx, (size_t)n * r * BM * BN * sizeof(float), &ws)) return rc;
+            const uint32_t full = (uint32_t)tiles - r;
+            if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(full, 1), block, 0, ctx->stream, g);
+            else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(full, 1), block, 0, ctx->stream, g);
+            GemmArgs gt = g;
+            gt.tile_base = full; gt.tail_tiles = r; gt.nsplit = n; gt.k_per_split = kps;
+            gt.c = (float *)ws; gt.c_batch = 0; gt.alpha = 1.f; gt.beta = 0.f;
+            if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(r, n), block, 0, ctx->stream, gt);
+            else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(r, n), block, 0, ctx->stream, gt);
+            hipLaunchKernelGGL(gemm_f32_tail_reduce, dim3(r, BN / 4), dim3(256), 0, ctx->stream, gt);
+            WG_HIP_TRY(hipGetLastError());
+            return WG_OK;
+        }
+    }
     if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
