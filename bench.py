@@ -113,7 +113,27 @@ class GemmWorkload(Workload):
         # exactly 256 tiles (8 ranks: 4096 x 4096 per panel) would take two rounds instead of one.
         tiles = (self.M // max(world, 1) // 256) * (self.N // 256)
         npanels = 1 if not self.dist_mode else max(1, min(8, tiles // 512, self.N // 2048))
-        self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels)
+        panel_cols = None
+        cus = int(gpu.adapter().get("stream_compute_units") or gpu.adapter()["compute_units"])
+        if self.dist_mode and self.np_dtype == np.float16 and self.M % (256 * world) == 0 and self.N % 256 == 0:
+            # The compute stream may use `cus` CUs (bench main(): the rest is left to RCCL's copy kernels). Size the panels to a whole
+            # number of rounds of `cus` workgroups (a 256 x 256 tile each): c tile-columns per panel with the least idle CUs in the
+            # last round, between ~1 and ~4 rounds per panel (enough panels to overlap, few enough launches), + one remainder panel.
+            tiles_m, tcols = self.M // world // 256, self.N // 256
+            best = None
+            for c in range(1, tcols + 1):
+                t = tiles_m * c
+                rounds = -(-t // cus)
+                if rounds > 8 or tcols // c < 2:
+                    continue
+                score = (round(rounds * cus / t, 6), abs(rounds - 2))  # least idle CUs first, then closest to 2 rounds per panel
+                if best is None or score < best[0]:
+                    best = (score, c)
+            if best is not None:
+                c = best[1]
+                cols = [256 * c] * (tcols // c) + ([256 * (tcols % c)] if tcols % c else [])
+                panel_cols, npanels = tuple(cols), len(cols)
+        self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels, panel_cols)
         self.Mg = plan.Mg  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
         self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
         self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
@@ -141,7 +161,11 @@ class GemmWorkload(Workload):
                                        wg.GpuTensorView(b_shape, self.B, 2), variant)
 
         def all_gather(start, count, rk):
+            import torch
             import torch.distributed as dist
+            ext = getattr(gpu, "_torch_ext_stream", None)
+            if ext is not None:  # the GEMMs run on the library's own (CU-masked) stream: the collective must wait for it
+                torch.cuda.current_stream().wait_stream(ext)
             out = self.torch_out[start:start + world * count]
             return dist.all_gather_into_tensor(out, out[rk * count:(rk + 1) * count], async_op=True)
 
@@ -149,12 +173,18 @@ class GemmWorkload(Workload):
 
     def step(self):
         self.driver.step()
+        ext = getattr(self.gpu, "_torch_ext_stream", None)
+        if ext is not None:
+            # a step is self-contained: the next step's GEMMs (library stream) start after this step's all-gathers (torch's stream,
+            # which step() just made wait for them) -- no overlap across steps
+            import torch
+            ext.wait_stream(torch.cuda.current_stream())
 
     def units_per_step(self):
         return 2.0 * self.M * self.N * self.K
 
     def algorithmic_per_launch(self):
-        return 2.0 * self.Mg * self.plan.np_ * self.K  # one launch = one N-panel of this rank's row block
+        return 2.0 * self.Mg * self.N * self.K / self.plan.npanels  # mean over the launches of a step (one launch = one N-panel of this rank's row block)
 
     def launches_per_step(self):
         return self.plan.npanels
@@ -178,8 +208,7 @@ class GemmWorkload(Workload):
         Bc = np.stack([read_range(self.B, c * self.K, self.K) for c in cols], axis=1).astype(np.float64)  # K x ncols
         got = np.empty((rows.size, cols.size))
         for jc, c in enumerate(cols):
-            p, j = divmod(int(c), pl.np_)
-            colbuf = read_range(self.C, (p * pl.world + self.rank) * pl.panel_elems + j * self.Mg, self.Mg)
+            colbuf = read_range(self.C, pl.element_index(self.rank * self.Mg, int(c)), self.Mg)
             got[:, jc] = colbuf[rows]
         truth, sabs = A @ Bc, np.abs(A) @ np.abs(Bc)
         tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
@@ -535,12 +564,31 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
+        # CU partitioning between compute and communication. Every f16 GEMM workgroup needs a whole CU (160 KiB LDS, 512 registers per
+        # lane), so a copy kernel of the collective library, launched from a second queue while a GEMM grid is resident, only gets CUs
+        # when GEMM workgroups retire -- measured with tools/overlap_probe.py: its workgroups start ~0.75-1.4 ms late, i.e. the
+        # all-gather of panel i would barely overlap the GEMM of panel i+1. So the GEMM stream is CU-masked to leave `comm_cus` CUs
+        # free: the copy kernels (small workgroups, several fit on one CU) then start within ~20 us of their launch. 32 = one CU per
+        # shader engine of every XCD (a mask that is not a multiple of 32 unbalances the shader engines: 240 CUs ran 20 % slower than
+        # 224). Per tile the GEMM is ~4 % slower on 224 CUs than on 256 shared with a copy kernel (tools/overlap_probe2.py).
+        comm_cus = int(os.environ.get("WG_BENCH_COMM_CUS", "32"))
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        # share torch's current stream so that the GEMM and the all-gather are ordered without extra events
-        gpu = wg.GpuInstance.new(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        total_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+        gpu = None
+        if comm_cus > 0 and total_cus > 2 * comm_cus:
+            try:
+                gpu = wg.GpuInstance.new(local_rank, cu_count=total_cus - comm_cus)
+                gpu._torch_ext_stream = torch.cuda.ExternalStream(gpu.stream(), device=torch.device(f"cuda:{local_rank}"))
+            except Exception as e:  # no CU-masked stream on this runtime: share torch's stream (the transport is unchanged)
+                log(f"[bench] CU-masked compute stream unavailable ({e}); sharing torch's stream")
+                gpu = None
+        if gpu is None:
+            # share torch's current stream so that the GEMM and the all-gather are ordered without extra events
+            gpu = wg.GpuInstance.new(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
         def barrier():
+            gpu.sync()
             dist.barrier()
             torch.cuda.synchronize()
     else:

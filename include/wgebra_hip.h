@@ -110,6 +110,10 @@ int wg_device_count(void);
 int wg_ctx_create(int device, wg_ctx **out);
 /* Same, but enqueue on an existing hipStream_t (e.g. the stream another runtime owns). Not destroyed with the ctx. */
 int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out);
+/* A context whose stream may use only `cu_count` of the device's compute units (CU-masked stream; every XCD loses the same
+ * share). For multi-GPU runs: the compute stream leaves a few CUs to the collective library's copy kernels. The tile / split
+ * heuristics then plan for `cu_count` CUs. */
+int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out);
 int wg_ctx_destroy(wg_ctx *ctx);
 /* queue.submit(..) + device.poll(PollType::wait()) (tensor.rs:304-312): block until all enqueued work is done. */
 int wg_ctx_sync(wg_ctx *ctx);
@@ -117,6 +121,13 @@ int wg_ctx_device(const wg_ctx *ctx);
 void *wg_ctx_stream(const wg_ctx *ctx); /* the hipStream_t, for interop */
 /* Device facts the bench prints next to every roofline: name (<=255 chars), CU count, clock MHz, HBM bytes. */
 int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int *clock_mhz, uint64_t *hbm_bytes);
+/*
+ * Diagnostics only (tools/overlap_probe.py): enqueue `blocks` workgroups of 256 threads that spin for `usec` microseconds and
+ * record their start tick (s_memrealtime, 100 MHz) into start_ticks[0 .. blocks) (u64 each; start_ticks[blocks] = tick of a
+ * 1-thread kernel enqueued just before). Stand-in for a collective library's copy kernel when studying queue interleaving.
+ */
+int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_ticks);
+
 /* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. */
 int wg_ctx_reserve_workspace(wg_ctx *ctx, size_t bytes);
 

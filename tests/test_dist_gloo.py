@@ -57,7 +57,9 @@ def _worker(rank, world, port, M, N, K, npanels, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        pl = MShardPlan(M, N, K, world, npanels)
+        # npanels may be an int (uniform panels) or a tuple of panel widths (ragged: what bench.py plans for a CU-masked compute stream)
+        pl = MShardPlan(M, N, K, world, npanels) if isinstance(npanels, int) else MShardPlan(M, N, K, world, panel_cols=npanels)
+        npanels = pl.npanels
         rng = np.random.default_rng(1234)  # same full A, B on every rank; each keeps its row block
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = rng.standard_normal((K, N)).astype(np.float32)
@@ -92,8 +94,9 @@ def _worker(rank, world, port, M, N, K, npanels, q):
         for p in range(npanels):  # read back through the cube views, matrix by matrix
             cube = pl.cube_shape(p)
             for g in range(world):
-                blk = g_np[cube.offset + g * cube.stride_mat + np.arange(pl.Mg)[:, None] + np.arange(pl.np_)[None, :] * cube.stride]
-                got[g * pl.Mg:(g + 1) * pl.Mg, p * pl.np_:(p + 1) * pl.np_] = blk
+                nc, c0 = pl.cols_of(p), pl.col0_of(p)
+                blk = g_np[cube.offset + g * cube.stride_mat + np.arange(pl.Mg)[:, None] + np.arange(nc)[None, :] * cube.stride]
+                got[g * pl.Mg:(g + 1) * pl.Mg, c0:c0 + nc] = blk
         ok = bool(np.allclose(got, C, rtol=1e-5, atol=1e-5)) and not np.isnan(g_np).any()
         q.put((rank, ok, ""))
     except Exception as e:  # pragma: no cover
@@ -102,7 +105,7 @@ def _worker(rank, world, port, M, N, K, npanels, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("npanels", [1, 4])
+@pytest.mark.parametrize("npanels", [1, 4, (8, 12, 8, 4)])
 def test_sharded_gemm_world2_gloo(npanels):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -116,3 +119,31 @@ def test_sharded_gemm_world2_gloo(npanels):
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in results), results
+
+
+def test_ragged_panel_plan():
+    """Panels of unequal width (bench.py sizes them to whole rounds of the CUs the compute stream may use + a remainder):
+    every element of C has exactly one home in the gathered buffer and the views tile it without gaps."""
+    from wgmath_amd.sharded import MShardPlan
+    pl = MShardPlan(64, 40, 8, 2, panel_cols=(16, 16, 8))
+    assert pl.npanels == 3 and pl.Mg == 32
+    assert [pl.cols_of(p) for p in range(3)] == [16, 16, 8] and [pl.col0_of(p) for p in range(3)] == [0, 16, 32]
+    seen = np.zeros(pl.gathered_elems(), np.int32)
+    for p in range(pl.npanels):
+        start, n = pl.panel_range(p)
+        assert n == pl.world * pl.slot_elems_of(p)
+        for g in range(pl.world):
+            o = pl.out_shape(p, g)
+            assert o.offset == start + g * pl.slot_elems_of(p) and tuple(o.size[:2]) == (pl.Mg, pl.cols_of(p))
+            idx = o.offset + np.arange(pl.Mg)[:, None] + np.arange(pl.cols_of(p))[None, :] * o.stride
+            seen[idx.reshape(-1)] += 1
+        b = pl.b_panel_shape(p)
+        assert b.offset == pl.col0_of(p) * pl.K and tuple(b.size[:2]) == (pl.K, pl.cols_of(p))
+    assert (seen == 1).all()
+    for row, col in [(0, 0), (31, 15), (32, 16), (63, 39), (5, 33)]:
+        p, j = pl.panel_of_col(col)
+        g, i = divmod(row, pl.Mg)
+        o = pl.out_shape(p, g)
+        assert pl.element_index(row, col) == o.offset + i + j * o.stride
+    with pytest.raises(ValueError):
+        MShardPlan(64, 40, 8, 2, panel_cols=(16, 16, 4, 2))

@@ -68,12 +68,14 @@ def _load() -> ctypes.CDLL:
         "wg_device_count": (ci, []),
         "wg_ctx_create": (ci, [ci, pvp]),
         "wg_ctx_create_on_stream": (ci, [ci, vp, pvp]),
+        "wg_ctx_create_with_cu_count": (ci, [ci, ctypes.c_uint32, ctypes.POINTER(vp)]),
         "wg_ctx_destroy": (ci, [vp]),
         "wg_ctx_sync": (ci, [vp]),
         "wg_ctx_device": (ci, [vp]),
         "wg_ctx_stream": (vp, [vp]),
         "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
         "wg_ctx_reserve_workspace": (ci, [vp, sz]),
+        "wg_debug_spin": (ci, [vp, ctypes.c_uint32, ctypes.c_uint32, vp]),
         "wg_buf_create": (ci, [vp, sz, u32, pvp]),
         "wg_buf_create_init": (ci, [vp, vp, sz, u32, pvp]),
         "wg_buf_wrap": (ci, [vp, vp, sz, pvp]),

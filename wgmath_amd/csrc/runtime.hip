@@ -3,6 +3,8 @@
 // create/copy/read), kernel.rs:15-27 (compute pass), timestamps.rs (GpuTimestamps).
 #include "wg_internal.hpp"
 
+#include <vector>
+
 #include <cstring>
 #include <new>
 #include <string>
@@ -104,6 +106,34 @@ int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out) {
     return ctx_create_common(device, (hipStream_t)hip_stream, false, out);
 }
 
+// A context whose stream may only use `cu_count` of the device's compute units (hipExtStreamCreateWithCUMask: the first
+// `cu_count` bits of the CU mask; the driver spreads mask bits round-robin over the XCDs, so every XCD loses the same number of
+// CUs). For multi-GPU runs: the GEMM stream leaves a few CUs free, so that the collective library's copy kernels (a second
+// queue) start at once instead of waiting for a GEMM workgroup -- which needs a whole CU -- to retire. The kernels' tile/split
+// heuristics see `cu_count` CUs.
+int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out) {
+    if (!out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create_with_cu_count: out is NULL");
+    *out = nullptr;
+    int n = wg_device_count();
+    if (n <= 0) return wg_set_error(WG_ERR_NO_DEVICE, "Failed to initialize gpu adapter.: no HIP device visible");
+    if (device < 0 || device >= n) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create_with_cu_count: device %d not in [0,%d)", device, n);
+    WG_HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    WG_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const uint32_t total = (uint32_t)prop.multiProcessorCount;
+    if (cu_count == 0 || cu_count > total) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create_with_cu_count: %u not in [1,%u]", cu_count, total);
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (uint32_t i = 0; i < cu_count; ++i) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t stream = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) return wg_set_error(WG_ERR_HIP, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
+    int rc = ctx_create_common(device, stream, false, out);
+    if (rc) { (void)hipStreamDestroy(stream); return rc; }
+    (*out)->owns_stream = true;
+    (*out)->compute_units = (int)cu_count;
+    return WG_OK;
+}
+
 int wg_ctx_destroy(wg_ctx *ctx) {
     if (!ctx) return WG_OK;
     (void)hipSetDevice(ctx->device);
@@ -132,6 +162,27 @@ int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
     if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return WG_OK;
+}
+
+// Diagnostics (tools/overlap_probe.py): `blocks` workgroups of 256 threads spin for `usec` microseconds each and record the
+// s_memrealtime tick (100 MHz) at which they started -- a stand-in for a communication library's copy kernel, to observe how the
+// hardware interleaves a second queue's workgroups with a resident GEMM grid whose workgroups each need a whole CU.
+__global__ void wg_debug_spin_kernel(uint64_t *start_ticks, uint32_t usec) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && start_ticks) start_ticks[blockIdx.x] = t0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (uint64_t)usec * 100u) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void wg_debug_now_kernel(uint64_t *tick) { *tick = __builtin_amdgcn_s_memrealtime(); }
+
+int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_ticks) {
+    if (!ctx || blocks == 0) return wg_set_error(WG_ERR_INVALID_ARG, "wg_debug_spin: bad arguments");
+    if (start_ticks && start_ticks->bytes < (size_t)(blocks + 1) * 8) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "wg_debug_spin: start_ticks too small");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    uint64_t *p = start_ticks ? (uint64_t *)start_ticks->ptr : nullptr;
+    if (p) hipLaunchKernelGGL(wg_debug_now_kernel, dim3(1), dim3(1), 0, ctx->stream, p + blocks); // tick at enqueue position
+    hipLaunchKernelGGL(wg_debug_spin_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p, usec);
+    WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
 

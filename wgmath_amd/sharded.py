@@ -20,7 +20,7 @@ injected so that the same driver runs under gloo in the CPU tests and on the HIP
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List
+from typing import Callable, List, Optional, Tuple
 
 from .wgcore import ViewShape
 
@@ -32,13 +32,21 @@ class MShardPlan:
     K: int
     world: int
     npanels: int = 1
+    # optional ragged panels: column count of every panel (multiples of 4, summing to N; overrides the uniform N / npanels).
+    # bench.py sizes panels to a whole number of rounds of the CUs the compute stream may use, plus one remainder panel.
+    panel_cols: Optional[Tuple[int, ...]] = None
 
     def __post_init__(self):
+        if self.panel_cols is not None:
+            object.__setattr__(self, "panel_cols", tuple(int(c) for c in self.panel_cols))
+            object.__setattr__(self, "npanels", len(self.panel_cols))
+            if not self.panel_cols or sum(self.panel_cols) != self.N or any(c <= 0 or c % 4 for c in self.panel_cols):
+                raise ValueError(f"panel_cols={self.panel_cols} must be positive multiples of 4 summing to N={self.N}")
         if self.world < 1 or self.npanels < 1:
             raise ValueError("world and npanels must be >= 1")
         if self.M % (4 * self.world):
             raise ValueError(f"M={self.M} must split into {self.world} row blocks that are multiples of 4 (vec4 views)")
-        if self.N % (4 * self.npanels):
+        if self.panel_cols is None and self.N % (4 * self.npanels):
             raise ValueError(f"N={self.N} must split into {self.npanels} column panels that are multiples of 4")
         if self.K % 4:
             raise ValueError("K must be a multiple of 4")
@@ -51,12 +59,23 @@ class MShardPlan:
         return self.M // self.world
 
     @property
-    def np_(self) -> int:  # columns per panel
+    def np_(self) -> int:  # columns per panel (uniform plans only)
+        if self.panel_cols is not None:
+            raise ValueError("ragged plan: use cols_of(panel)")
         return self.N // self.npanels
 
     @property
-    def panel_elems(self) -> int:  # one rank's slot of one panel
+    def panel_elems(self) -> int:  # one rank's slot of one panel (uniform plans only)
         return self.Mg * self.np_
+
+    def cols_of(self, panel: int) -> int:
+        return self.panel_cols[panel] if self.panel_cols is not None else self.N // self.npanels
+
+    def col0_of(self, panel: int) -> int:  # first column of a panel
+        return sum(self.panel_cols[:panel]) if self.panel_cols is not None else panel * (self.N // self.npanels)
+
+    def slot_elems_of(self, panel: int) -> int:  # one rank's slot of this panel
+        return self.Mg * self.cols_of(panel)
 
     def gathered_elems(self) -> int:
         return self.M * self.N
@@ -69,23 +88,37 @@ class MShardPlan:
         return ViewShape((self.Mg, self.K, 1), self.Mg, self.Mg * self.K, 0)
 
     def b_panel_shape(self, panel: int) -> ViewShape:  # B[:, panel columns] == GpuMatrix::columns (tensor.rs:596-610)
-        return ViewShape((self.K, self.np_, 1), self.K, self.K * self.N, panel * self.np_ * self.K)
+        return ViewShape((self.K, self.cols_of(panel), 1), self.K, self.K * self.N, self.col0_of(panel) * self.K)
+
+    def _panel_start(self, panel: int) -> int:  # the gathered buffer is [panel][rank][cols * Mg]: M elements per column
+        return self.col0_of(panel) * self.M
 
     def out_shape(self, panel: int, rank: int) -> ViewShape:  # where rank's GEMM of `panel` writes inside the gathered buffer
-        return ViewShape((self.Mg, self.np_, 1), self.Mg, self.panel_elems, (panel * self.world + rank) * self.panel_elems)
+        se = self.slot_elems_of(panel)
+        return ViewShape((self.Mg, self.cols_of(panel), 1), self.Mg, se, self._panel_start(panel) + rank * se)
 
     def panel_range(self, panel: int):  # contiguous element range of a panel in the gathered buffer (the all-gather's output)
-        start = panel * self.world * self.panel_elems
-        return start, self.world * self.panel_elems
+        return self._panel_start(panel), self.world * self.slot_elems_of(panel)
 
     def cube_shape(self, panel: int) -> ViewShape:  # the gathered panel as a GpuCube [Mg, np, P]
-        return ViewShape((self.Mg, self.np_, self.world), self.Mg, self.panel_elems, panel * self.world * self.panel_elems)
+        se = self.slot_elems_of(panel)
+        return ViewShape((self.Mg, self.cols_of(panel), self.world), self.Mg, se, self._panel_start(panel))
+
+    def panel_of_col(self, col: int):
+        """(panel, column within the panel) of global column `col`."""
+        if self.panel_cols is None:
+            return divmod(col, self.N // self.npanels)
+        p = 0
+        while col >= self.panel_cols[p]:
+            col -= self.panel_cols[p]
+            p += 1
+        return p, col
 
     def element_index(self, row: int, col: int) -> int:
         """Flat index of C[row, col] in the gathered buffer."""
         g, i = divmod(row, self.Mg)
-        p, j = divmod(col, self.np_)
-        return (p * self.world + g) * self.panel_elems + j * self.Mg + i
+        p, j = self.panel_of_col(col)
+        return self._panel_start(p) + g * self.slot_elems_of(p) + j * self.Mg + i
 
 
 class ShardedGemm:
@@ -113,6 +146,6 @@ class ShardedGemm:
             self._gemm(pl.out_shape(p, self.rank), pl.a_shape(), pl.b_panel_shape(p))
             if pl.world > 1 or self._always_gather:
                 start, _ = pl.panel_range(p)
-                handles.append(self._gather(start, pl.panel_elems, self.rank))
+                handles.append(self._gather(start, pl.slot_elems_of(p), self.rank))
         for h in handles:
             self._wait(h)

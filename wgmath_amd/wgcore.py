@@ -243,10 +243,17 @@ class GpuInstance:
         self._queue = Queue(ctx)
 
     @staticmethod
-    def new(device_index: int = 0, stream: Optional[int] = None) -> "GpuInstance":
+    def new(device_index: int = 0, stream: Optional[int] = None, cu_count: Optional[int] = None) -> "GpuInstance":
+        """`cu_count`: create the context on a CU-masked stream that may use only that many compute units (multi-GPU runs leave a
+        few CUs to the collective library's copy kernels)."""
         _lib.assert_single_hip_runtime()
         h = ctypes.c_void_p()
-        if stream is None:
+        if cu_count is not None:
+            check(lib.wg_ctx_create_with_cu_count(device_index, int(cu_count), ctypes.byref(h)))
+            inst = GpuInstance(_Ctx(h.value, device_index))
+            inst._stream_compute_units = int(cu_count)
+            return inst
+        elif stream is None:
             check(lib.wg_ctx_create(device_index, ctypes.byref(h)))
         else:
             check(lib.wg_ctx_create_on_stream(device_index, ctypes.c_void_p(stream), ctypes.byref(h)))
@@ -263,7 +270,10 @@ class GpuInstance:
         name = ctypes.create_string_buffer(256)
         cus, mhz, hbm = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
         check(lib.wg_ctx_device_info(self._ctx.handle, name, ctypes.byref(cus), ctypes.byref(mhz), ctypes.byref(hbm)))
-        return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value, "hbm_bytes": hbm.value}
+        info = {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value, "hbm_bytes": hbm.value}
+        if getattr(self, "_stream_compute_units", None):  # CU-masked stream (GpuInstance.new(cu_count=...))
+            info["stream_compute_units"] = int(self._stream_compute_units)
+        return info
 
     def device(self) -> Device:
         return self._device
