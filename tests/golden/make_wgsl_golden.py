@@ -152,7 +152,35 @@ def op_assign_cases():
     save("wgsl_exec_op_assign", **out)
 
 
+def shape_cases():
+    """shape.wgsl's index functions, column-major and with the ROW_MAJOR definition (shape.wgsl:36-66), on random shapes / indices."""
+    out = {}
+    for tag, defs in (("cm", set()), ("rm", {"ROW_MAJOR"})):
+        mod = wx.Module(open(os.path.join(LINALG, "shape.wgsl")).read(), defs=defs)
+        rng = np.random.default_rng(500)
+        rows = []
+        for _ in range(64):
+            nrows, ncols, nmats = (int(x) for x in rng.integers(1, 200, 3))
+            stride, stride_mat, offset = int(rng.integers(1, 400)), int(rng.integers(1, 100000)), int(rng.integers(0, 1000))
+            i, j, t = int(rng.integers(0, nrows)), int(rng.integers(0, ncols)), int(rng.integers(0, nmats))
+            sh = wx.Struct(FIELDS, [nrows, ncols, nmats, stride, stride_mat, offset])
+
+            def call(name, *args):
+                g = mod.ns["F_" + name](None, *args)
+                try:
+                    while True:
+                        next(g)
+                except StopIteration as e:
+                    return e.value
+            v4 = call("with_vec4_elts", sh)
+            rows.append([nrows, ncols, nmats, stride, stride_mat, offset, i, j, t, call("it", sh, i, j, t), call("iv", sh, i),
+                         v4.nrows, v4.ncols, v4.nmats, v4.stride, v4.stride_mat, v4.offset])
+        out[tag] = np.array(rows, np.int64)
+    save("wgsl_exec_shape", **out)
+
+
 if __name__ == "__main__":
+    shape_cases()
     op_assign_cases()
     reduce_cases()
     gemv_cases()

@@ -238,3 +238,21 @@ def test_restatement_matches_executed_wgsl_reduce_and_op_assign(oracle_c):
             a = a0.copy()
             impl(op, a, wo.Shape(n, 1, 1, n, n, oa), b, wo.Shape(n, 1, 1, n, n, ob))
             assert a.tobytes() == exp.tobytes(), f"{name} op_assign op {op} ({k}) differs from the executed WGSL"
+
+
+def test_index_math_matches_executed_wgsl():
+    """shape.wgsl's `it` / `iv` / `with_vec4_elts`, column-major and ROW_MAJOR, executed from the reference's text, against the
+    formulas this repo uses (column-major: the oracle's Shape; row-major: index = t*stride_mat + offset + i*stride + j, the
+    semantics of wg_gemm_rm / wg_gemv_rm)."""
+    g = np.load(os.path.join(GOLD, "wgsl_exec_shape.npz"))
+    for tag in ("cm", "rm"):
+        for r in g[tag]:
+            nrows, ncols, nmats, stride, stride_mat, offset, i, j, t, it, iv, v_nr, v_nc, v_nm, v_st, v_sm, v_off = (int(x) for x in r)
+            assert iv == offset + i
+            if tag == "cm":
+                assert it == t * stride_mat + offset + i + j * stride
+                assert (v_nr, v_nc) == ((nrows + 3) // 4, ncols)
+            else:
+                assert it == t * stride_mat + offset + i * stride + j
+                assert (v_nr, v_nc) == (nrows, (ncols + 3) // 4)
+            assert (v_nm, v_st, v_sm, v_off) == (nmats, (stride + 3) // 4, (stride_mat + 3) // 4, offset // 4)
