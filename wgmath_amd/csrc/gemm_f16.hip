@@ -384,20 +384,24 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
         half_step(c1{}, no{}, no{}, no{});
     } else {
-        // TN: after an even half-step only the 4 + 4 newest pieces (first and second half of a B stage) may be in flight -- the
-        // full stage of A issued in the odd half-step before must have landed; after an odd one the 12 just issued + 4.
+        // TN: both operands live in full-stage slots, so ONE wait + barrier per stage suffices, at the end of the EVEN half-step:
+        // it publishes stage st+1 (read by the odd half-step that follows and by the even one after it) and releases the slots of
+        // stage st (refilled from the odd half-step on). There, only the 4 + 4 newest pieces (the two halves of a B stage) may
+        // still be in flight -- the full stage of A issued in the odd half-step before must have landed. Odd half-steps end
+        // without any synchronisation (lgkmcnt(0) only: see advance()).
+        auto soft = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); };
         while (st + 3 < S) {
             half_step(c0{}, no{}, yes{}, yes{});  advance(k8{});
-            half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
+            half_step(c1{}, yes{}, yes{}, yes{}); soft();
             next_stage();
         }
         half_step(c0{}, no{}, yes{}, yes{}); advance(k8{});   // stage S-3: second half of B(S-1)
-        half_step(c1{}, yes{}, no{}, yes{}); advance(k12{});  //            A(S-1)
+        half_step(c1{}, yes{}, no{}, yes{}); soft();          //            A(S-1)
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-2: A(S-1) must have landed
-        half_step(c1{}, no{}, no{}, yes{}); advance(k0{});
+        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-2: A(S-1), B(S-1) must have landed
+        half_step(c1{}, no{}, no{}, yes{}); soft();
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
+        half_step(c0{}, no{}, no{}, yes{}); soft();           // stage S-1
         half_step(c1{}, no{}, no{}, no{});
     }
     WG_TRACE_POINT(2);
