@@ -122,6 +122,18 @@ void *wg_ctx_stream(const wg_ctx *ctx); /* the hipStream_t, for interop */
 /* Device facts the bench prints next to every roofline: name (<=255 chars), CU count, clock MHz, HBM bytes. */
 int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int *clock_mhz, uint64_t *hbm_bytes);
 /*
+ * Geometry: the reference's `wgebra::geometry` WGSL modules (the .wgsl files under crates/wgebra/src/geometry) are device
+ * functions used inside other shaders; their HIP counterpart is the header include/wgebra_geometry.hpp (`__host__ __device__`).
+ * This entry point applies one of them to `count` independent items, one per thread -- the same harness the reference's tests
+ * use (a one-invocation-per-matrix test kernel). Item layouts: wgmath_amd/csrc/geometry.hip.
+ */
+typedef enum wg_geom_op {
+    WG_GEOM_INV = 0, WG_GEOM_CHOLESKY = 1, WG_GEOM_LU = 2, WG_GEOM_QR = 3, WG_GEOM_SYM_EIGEN = 4, WG_GEOM_SVD = 5,
+    WG_GEOM_ROT2 = 6, WG_GEOM_QUAT = 7, WG_GEOM_SIM2 = 8, WG_GEOM_SIM3 = 9
+} wg_geom_op;
+int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in, wg_buf *out, uint32_t count);
+
+/*
  * Diagnostics only (tools/overlap_probe.py): enqueue `blocks` workgroups of 256 threads that spin for `usec` microseconds and
  * record their start tick (s_memrealtime, 100 MHz) into start_ticks[0 .. blocks) (u64 each; start_ticks[blocks] = tick of a
  * 1-thread kernel enqueued just before). Stand-in for a collective library's copy kernel when studying queue interleaving.

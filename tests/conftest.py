@@ -22,6 +22,7 @@ def oracle_c():
 @pytest.fixture(scope="session")
 def gpu():
     """GpuInstance::new().  GPU tests must run on the HIP kernels or fail: no skip, no fallback."""
+    # created before any test imports torch: the library binds to the one HIP runtime loaded at that point (INTEGRATION.md section 5)
     import wgmath_amd as wg
     inst = wg.GpuInstance.new()
     yield inst

@@ -10,5 +10,7 @@ from .wgcore import (BufferUsages, CommandBuffer, CommandEncoder, ComputePass, D
                      ViewShape, ViewShapeBuffers, as_view)
 from .wgebra import (Axpy, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
                      gemv_reduce, row_major_shader_defs)
+from . import geometry  # noqa: F401,E402
+from .geometry import GeomOp  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -76,6 +76,7 @@ def _load() -> ctypes.CDLL:
         "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
         "wg_ctx_reserve_workspace": (ci, [vp, sz]),
         "wg_debug_spin": (ci, [vp, ctypes.c_uint32, ctypes.c_uint32, vp]),
+        "wg_geometry_apply": (ci, [vp, ci, ctypes.c_uint32, vp, vp, ctypes.c_uint32]),
         "wg_buf_create": (ci, [vp, sz, u32, pvp]),
         "wg_buf_create_init": (ci, [vp, vp, sz, u32, pvp]),
         "wg_buf_wrap": (ci, [vp, vp, sz, pvp]),

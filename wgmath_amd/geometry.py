@@ -1,0 +1,43 @@
+"""Batched entry to the geometry header (include/wgebra_geometry.hpp), the HIP counterpart of the per-function WGSL modules under
+crates/wgebra/src/geometry/ (inv.rs, cholesky.rs, lu.rs, qr2/3/4.rs, eig2/3/4.rs, svd2/3.rs, rot2.rs, quat.rs, sim2.rs, sim3.rs).
+The reference exposes those as shader libraries other shaders import; its tests drive each through a one-item-per-invocation kernel
+over a storage array, which is what `apply` launches. Item layouts: include/wgebra_hip.h (wg_geom_op)."""
+import enum
+
+from ._lib import check, lib
+from .wgcore import GpuInstance, GpuTensor
+
+
+class GeomOp(enum.IntEnum):
+    INV = 0
+    CHOLESKY = 1
+    LU = 2
+    QR = 3
+    SYM_EIGEN = 4
+    SVD = 5
+    ROT2 = 6
+    QUAT = 7
+    SIM2 = 8
+    SIM3 = 9
+
+
+_FIXED_IN = {GeomOp.ROT2: 4, GeomOp.QUAT: 9, GeomOp.SIM2: 10, GeomOp.SIM3: 17}
+_FIXED_OUT = {GeomOp.ROT2: 11, GeomOp.QUAT: 19, GeomOp.SIM2: 14, GeomOp.SIM3: 25}
+
+
+def in_floats(op: GeomOp, dim: int = 0) -> int:
+    return _FIXED_IN.get(GeomOp(op), dim * dim)
+
+
+def out_floats(op: GeomOp, dim: int = 0) -> int:
+    op = GeomOp(op)
+    if op in _FIXED_OUT:
+        return _FIXED_OUT[op]
+    n = dim
+    return {GeomOp.INV: n * n, GeomOp.CHOLESKY: n * n, GeomOp.LU: n * n + 2 * n + 1, GeomOp.QR: 2 * n * n,
+            GeomOp.SYM_EIGEN: n * n + n, GeomOp.SVD: 2 * n * n + n}[op]
+
+
+def apply(gpu: GpuInstance, op: GeomOp, dim: int, items: GpuTensor, out: GpuTensor, count: int) -> None:
+    """One invocation per item on the instance's stream (asynchronous, like a dispatch); raises WgError on bad arguments."""
+    check(lib.wg_geometry_apply(gpu._ctx.handle, int(op), int(dim), items._h, out._h, int(count)))
