@@ -248,7 +248,8 @@ class GemvWorkload(Workload):
     def __init__(self, name, R, C, trans, graph_batch=0, nrhs=1):
         self.name, self.R, self.C, self.trans = name, R, C, trans
         self.nrhs = nrhs  # right-hand-side columns (`out_ncols` of the reference: grid.y of gemv.wgsl); the matrix is read ONCE for up to 8
-        self.kernel = "gemv_t_kernel" if trans else "gemv_n_kernel"
+        # launch-bound sizes take the one-kernel path (gemv.hip: rows * cols <= 4 Mi, wgk_gemv)
+        self.kernel = "gemv_t_kernel" if trans else ("gemv_n_small_kernel" if R * C <= (4 << 20) and R >= 128 else "gemv_n_kernel")
         # graph_batch > 0: the dispatch is launch-bound (a few MB): record `graph_batch` dispatches into ONE command buffer
         # (a hipGraph) and replay it -- a step is then one Queue::submit of that buffer
         self.graph_batch = graph_batch
@@ -451,6 +452,9 @@ WORKLOADS = {
     "gemm_f32_4096": lambda: GemmWorkload("gemm_f32_4096", 4096, 4096, 4096, "f32"),
     "gemm_f16_8192": lambda: GemmWorkload("gemm_f16_8192", 8192, 8192, 8192, "f16"),
     "gemm_f16_32768": lambda: GemmWorkload("gemm_f16_32768", 32768, 32768, 32768, "f16"),
+    # tall-skinny (M >> N), the other shape family the north star names
+    "gemm_f16_ts_131072x1024x8192": lambda: GemmWorkload("gemm_f16_ts_131072x1024x8192", 131072, 1024, 8192, "f16"),
+    "gemm_f32_ts_65536x512x4096": lambda: GemmWorkload("gemm_f32_ts_65536x512x4096", 65536, 512, 4096, "f32"),
     "gemmtr_f16_8192": lambda: GemmWorkload("gemmtr_f16_8192", 8192, 8192, 8192, "f16", trans=True),
     "gemmtr_f32_4096": lambda: GemmWorkload("gemmtr_f32_4096", 4096, 4096, 4096, "f32", trans=True),
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
@@ -464,8 +468,13 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
+
+
+# With N > 1 ranks the HBM-bound operators shard by independent units with no data-path collective: every rank
+# streams its own row block of an N-times taller matrix ("weak"); (name, fixed step count -- the same on every rank).
+DIST_SECONDARY = [("gemv_f32_4096x65536", 2000), ("gemvtr_f32_65536x4096", 2000), ("reduce_f32_4096x65536", 2000)]
 
 
 def load_traffic(workload: str):
@@ -630,6 +639,36 @@ def main():
                                "dtype": r["workload"].dtype, "steps": r["steps"], "roofline": rf, "cpu_baseline": r["cpu"]})
             except Exception as e:  # a secondary config must never take the headline down with it
                 others.append({"workload": name, "error": f"{type(e).__name__}: {e}"})
+
+    if dist_mode and not args.no_secondary:
+        import torch
+        import torch.distributed as dist
+        gpu_all = wg.GpuInstance.new(local_rank)  # its own stream, all CUs: no collective runs next to these
+
+        def barrier_all():
+            gpu_all.sync()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        for name, nsteps in DIST_SECONDARY:
+            if name in args.skip.split(","):
+                continue
+            err = None
+            try:
+                r = run_workload(wg, gpu_all, name, nsteps, 20, rank, world, barrier_all, False, 0.0)
+                el = r["elapsed"]
+            except Exception as e:
+                err, el = f"{type(e).__name__}: {e}", float("inf")
+            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every rank takes part, also one whose run failed
+            if not np.isfinite(float(t.item())):
+                others.append({"workload": name, "error": err or "failed on another rank"})
+                continue
+            v, rf = summarize(r["workload"], float(t.item()), r["kernel_ms"], r["steps"], world)
+            others.append({"workload": name, "metric": r["workload"].metric, "value": round(v, 3), "unit": r["workload"].unit,
+                           "dtype": r["workload"].dtype, "steps": r["steps"], "n_gpus": world, "scaling": "weak",
+                           "parallelism": f"row-sharded x{world}, no collective", "roofline": rf})
+            r = None
 
     if rank == 0:
         line = {
