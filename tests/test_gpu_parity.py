@@ -344,6 +344,20 @@ F16_SHAPES = [
 ]
 
 
+@pytest.fixture(params=["auto", "128", "256"])
+def f16_tile(request):
+    """The f16 launcher picks between the 256 x 256 kernels and the 128 x 128 kernel (mid-size outputs) by shape; WG_F16_TILE forces
+    one family (read per call), so that every shape below exercises both."""
+    import os
+    old = os.environ.pop("WG_F16_TILE", None)
+    if request.param != "auto":
+        os.environ["WG_F16_TILE"] = request.param
+    yield request.param
+    os.environ.pop("WG_F16_TILE", None)
+    if old is not None:
+        os.environ["WG_F16_TILE"] = old
+
+
 def f16_check(got, a64, b64, K, what):
     truth = a64 @ b64
     sabs = np.abs(a64) @ np.abs(b64)
@@ -354,7 +368,7 @@ def f16_check(got, a64, b64, K, what):
 
 @pytest.mark.parametrize("M,K,N,mats", F16_SHAPES)
 @pytest.mark.parametrize("tr", [False, True])
-def test_gemm_f16_shapes(gpu, M, K, N, mats, tr):
+def test_gemm_f16_shapes(gpu, f16_tile, M, K, N, mats, tr):
     wg, wo = _wg(), _wo()
     rng = np.random.default_rng(M * 31 + K * 17 + N + mats + int(tr))
     a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
@@ -376,7 +390,7 @@ def test_gemm_f16_shapes(gpu, M, K, N, mats, tr):
 
 
 @pytest.mark.parametrize("tr", [False, True])
-def test_gemm_f16_identity_asymmetric(gpu, tr):
+def test_gemm_f16_identity_asymmetric(gpu, f16_tile, tr):
     """A = I, asymmetric small-integer B (exact in f16): any row/column permutation or transposition in the tr-read,
     the interleaved tile map or the epilogue shows up as a bit mismatch."""
     wg = _wg()
@@ -598,7 +612,7 @@ def test_gemv_row_major(gpu, tr, R, Cn):
 # seeded fuzz over the f16 MFMA paths: random ragged sizes, strides, offsets, batches, both variants, alpha/beta
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("seed", range(24))
-def test_gemm_f16_fuzz(gpu, seed):
+def test_gemm_f16_fuzz(gpu, f16_tile, seed):
     wg = _wg()
     rng = np.random.default_rng(1000 + seed)
     M, N = int(rng.integers(1, 80)) * 8, int(rng.integers(1, 80)) * 8

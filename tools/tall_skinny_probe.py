@@ -15,6 +15,8 @@ import wgmath_amd as wg  # noqa: E402
 gpu = wg.GpuInstance.new(0)
 SHAPES = [("f16", 131072, 1024, 8192), ("f16", 262144, 256, 4096), ("f16", 65536, 2048, 8192), ("f16", 524288, 256, 1024),
           ("f16", 1048576, 256, 256), ("f32", 65536, 512, 4096), ("f32", 262144, 128, 2048), ("f32", 131072, 256, 4096)]
+if len(sys.argv) > 1:  # e.g. f16:2048x2048x2048 f32:1024x1024x1024
+    SHAPES = [(a.split(":")[0],) + tuple(int(x) for x in a.split(":")[1].split("x")) for a in sys.argv[1:]]
 for dt, M, N, K in SHAPES:
     npdt = np.float16 if dt == "f16" else np.float32
     A = B.device_random(wg, gpu, (M, K), npdt, 1)
@@ -31,7 +33,7 @@ for dt, M, N, K in SHAPES:
         for _ in range(5):
             go()
         gpu.sync()
-        reps = 30
+        reps = 200 if M * N * K < (1 << 36) else 30
         t0 = time.perf_counter()
         for _ in range(reps):
             go()

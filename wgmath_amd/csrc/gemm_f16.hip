@@ -538,8 +538,35 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         g.tiles_n = (N + BN - 1) / BN;
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-        // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split
         const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+        // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip, two workgroups per CU) fills the chip
+        // with four times as many tiles instead of split-K partial slabs. WG_F16_TILE=128|256 forces the choice (experiments).
+        {
+            const char *force = getenv("WG_F16_TILE");
+            const bool want128 = force ? atoi(force) == 128 : tiles * nmats < (uint64_t)cus;
+            if (want128 && K % 64u == 0) {
+                GemmArgs t = g;
+                t.tiles_m = (M + 127u) / 128u;
+                t.tiles_n = (N + 127u) / 128u;
+                const uint64_t tiles128 = (uint64_t)t.tiles_m * t.tiles_n;
+                uint32_t ns = wg_splitk_plan(tiles128 * nmats, 2u * (uint32_t)cus, K / 64u, 4, (uint64_t)M * N * nmats, 512ull << 20);
+                t.nsplit = ns;
+                t.k_per_split = ns > 1 ? ((K / 64u + ns - 1) / ns) * 64u : K;
+                t.part = nullptr;
+                if (ns > 1) {
+                    t.nsplit = ns = (K + t.k_per_split - 1) / t.k_per_split;
+                    void *ws = nullptr;
+                    if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
+                    t.part = (float *)ws;
+                }
+                if (tiles128 <= 0x7fffffffull && (uint64_t)nmats * ns <= 65535) {
+                    if (int rc = t128_launch(ctx, trans, dim3((uint32_t)tiles128, nmats * ns), t)) return rc;
+                    if (ns > 1) return wg_splitk_reduce(ctx, t.part, ns, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
+                    return WG_OK;
+                }
+            }
+        }
+        // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split
         uint32_t nsplit = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
         g.nsplit = nsplit;
         g.k_per_split = nsplit > 1 ? ((K / BKH + nsplit - 1) / nsplit) * BKH : K;

@@ -4,6 +4,7 @@
 #include "wg_internal.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -97,5 +98,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
 // launch wrappers of gemm_f16_legacy.hip (grid / arguments prepared by wgk_gemm_f16)
 int legacy_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
 int generic_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
+// gemm_f16_t128.hip: 128 x 128 tiles (g.tiles_m / g.tiles_n count those), grid = (tiles, nmats * nsplit); K per split % 64 == 0
+int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
 
 } // namespace wgf16
