@@ -157,11 +157,12 @@ def test_reduce_eval_cpu_matches_reference_helper():
     assert wg.Reduce(None, wg.ReduceOp.Min).eval_cpu(x) == x.min()
 
 
-def test_f16_gemm_kernel_owns_m0():
-    """The 16x16x32 f16 kernel issues its LDS-DMA as `s_mov_b32 m0, sN` + `global_load_lds_dwordx4` from inline asm WITHOUT
+@pytest.mark.parametrize("source,kernel,min_dma", [("gemm_f16.hip", "gemm_f16_m16_kernel", 16), ("gemm_f16_t128.hip", "gemm_f16_t128_kernel", 8)])
+def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma):
+    """The 16x16x32 f16 kernels issue their LDS-DMA as `s_mov_b32 m0, sN` + `global_load_lds_dwordx4` from inline asm WITHOUT
     saving/restoring M0 (M0 is a reserved register: the compiler does not track it across asm statements). That is only sound
-    while the compiler itself never uses M0 in that kernel -- check the generated ISA: every M0 reference in gemm_f16_m16_kernel
-    must be one of ours."""
+    while the compiler itself never uses M0 in those kernels -- check the generated ISA: every M0 reference in them must be one
+    of ours."""
     import re
     import shutil
     import subprocess
@@ -169,19 +170,19 @@ def test_f16_gemm_kernel_owns_m0():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "wgmath_amd", "csrc", "gemm_f16.hip")
+    src = os.path.join(ROOT, "wgmath_amd", "csrc", source)
     with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "gemm_f16.s")
+        out = os.path.join(td, "k.s")
         subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=on", "-I", os.path.join(ROOT, "include"),
                         "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         text = open(out).read()
-    kernels = re.findall(r"^(_ZN\S*gemm_f16_m16_kernel\w*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    kernels = re.findall(r"^(_ZN\S*" + kernel + r"\w*):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
     assert len(kernels) == 2, [k for k, _ in kernels]
     for name, body in kernels:
         lines = [l.strip() for l in body.splitlines() if re.search(r"\bm0\b", l) and not l.strip().startswith(";")]
         assert lines, f"{name}: expected our own M0 writes"
         bad = [l for l in lines if not re.fullmatch(r"s_mov_b32 m0, s\d+", l)]
         assert not bad, f"{name}: M0 used outside the LDS-DMA asm: {bad[:5]}"
-        assert body.count("global_load_lds_dwordx4") >= 16
-        assert "scratch_" not in body[body.index("Inner Loop Header"):body.index("s_cbranch_scc1", body.index("Inner Loop Header"))], \
-            f"{name}: register spills inside the main loop"
+        assert body.count("global_load_lds_dwordx4") >= min_dma
+        loop = body[body.index("Inner Loop Header"):]
+        assert "scratch_" not in loop[:loop.index("s_cbranch_scc1")], f"{name}: register spills inside the main loop"

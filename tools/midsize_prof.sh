@@ -1,11 +1,23 @@
 #!/bin/bash
-# kernel-level breakdown of mid-size GEMMs (which kernels, how long): rocprofv3 --kernel-trace --stats around tall_skinny_probe.py
+# GPU-side kernel durations of mid-size GEMMs (the Python probe is launch-bound below ~25 us): rocprofv3 --kernel-trace around
+# tools/tall_skinny_probe.py; usage: tools/midsize_prof.sh <tag> <shape>...   (env WG_F16_TILE / WGEBRA_HIP_LIB / TR pass through)
+tag=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/midsize
+OUT=$ROOT/gpurun_out/midsize/$tag
 rm -rf $OUT; mkdir -p $OUT
-for shp in f16:2048x2048x2048 f16:1024x1024x1024 f16:3072x3072x3072 f32:2048x2048x2048 f32:3072x3072x3072 f32:1024x1024x1024; do
-  tag=${shp//:/_}
-  rocprofv3 --kernel-trace --stats -d $OUT/$tag -o p -- python3 $GRAFT_REPO_ROOT/tools/tall_skinny_probe.py $shp > $OUT/$tag.log 2>&1
-  f=$(find $OUT/$tag -name '*kernel_stats.csv' | head -1)
-  echo "== $shp"; tail -1 $OUT/$tag.log; head -8 "$f" | cut -d, -f1-8
+for shp in "$@"; do
+  t=${shp//:/_}
+  rocprofv3 --kernel-trace -d $OUT/$t -o p -- python3 $ROOT/tools/tall_skinny_probe.py $shp > $OUT/$t.log 2>&1
+  python3 - $OUT/$t/p_results.db $shp <<'PY'
+import sqlite3, sys
+con = sqlite3.connect(sys.argv[1])
+tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
+kd = [t for t in tabs if 'kernel_dispatch' in t][0]
+sym = [t for t in tabs if 'kernel_symbol' in t][0]
+q = f"select s.kernel_name, count(*), avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3 from {kd} d join {sym} s on d.kernel_id=s.id group by 1 having count(*) > 50 order by 3 desc"
+print("==", sys.argv[2])
+for r in con.execute(q):
+    print("   %-58s n=%d avg=%.1f us min=%.1f" % (r[0][:58], r[1], r[2], r[3]))
+PY
 done

@@ -19,7 +19,8 @@ if len(sys.argv) > 1:  # e.g. f16:2048x2048x2048 f32:1024x1024x1024
     SHAPES = [(a.split(":")[0],) + tuple(int(x) for x in a.split(":")[1].split("x")) for a in sys.argv[1:]]
 for dt, M, N, K in SHAPES:
     npdt = np.float16 if dt == "f16" else np.float32
-    A = B.device_random(wg, gpu, (M, K), npdt, 1)
+    TR = os.environ.get("TR") == "1"  # GemmTr: m1 stored K x M
+    A = B.device_random(wg, gpu, (K, M) if TR else (M, K), npdt, 1)
     Bm = B.device_random(wg, gpu, (K, N), npdt, 2)
     S = wg.BufferUsages
     C = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC).build(gpu.device(), npdt)
@@ -29,7 +30,8 @@ for dt, M, N, K in SHAPES:
     p = enc.compute_pass("ts", None)
     for tr in (False,):
         def go():
-            gemm.dispatch(gpu.device(), shapes, p, C.as_embedded_view(3), A.as_embedded_view(3), Bm.as_embedded_view(3))
+            gemm.dispatch_generic(gpu.device(), shapes, p, C.as_embedded_view(3), A.as_embedded_view(3), Bm.as_embedded_view(3),
+                                  wg.GemmVariant.GemmTr if TR else wg.GemmVariant.Gemm)
         for _ in range(5):
             go()
         gpu.sync()

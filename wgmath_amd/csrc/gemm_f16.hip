@@ -539,17 +539,37 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
         const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
-        // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip, two workgroups per CU) fills the chip
-        // with four times as many tiles instead of split-K partial slabs. WG_F16_TILE=128|256 forces the choice (experiments).
-        {
-            const char *force = getenv("WG_F16_TILE");
-            const bool want128 = force ? atoi(force) == 128 : tiles * nmats < (uint64_t)cus;
-            if (want128 && K % 64u == 0) {
-                GemmArgs t = g;
-                t.tiles_m = (M + 127u) / 128u;
-                t.tiles_n = (N + 127u) / 128u;
-                const uint64_t tiles128 = (uint64_t)t.tiles_m * t.tiles_n;
-                uint32_t ns = wg_splitk_plan(tiles128 * nmats, 2u * (uint32_t)cus, K / 64u, 4, (uint64_t)M * N * nmats, 512ull << 20);
+        // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip) fills the chip with four times as many
+        // tiles instead of split-K partial slabs, at ~2/3 of the big kernel's rate per busy CU. Estimates from measured rates
+        // (profiles/r01_evidence.md section 12; us per k of one tile: 256 x 256 0.0234 with 8 us per workgroup of prologue + epilogue;
+        // 128 x 128 0.00875 alone on a CU, 0.0108 each when several share it, + 6 us; f32 partial slabs written at ~3.5 TB/s + 3 us,
+        // reduced at ~7 TB/s + 4 us). WG_F16_TILE=128|256 forces the choice (tests, experiments).
+        if (K % 64u == 0) {
+            const double out_bytes = (double)M * N * nmats * 4.0;
+            auto slabs = [&](uint32_t ns) { return ns > 1 ? ns * out_bytes / 3.5e6 + 3.0 + 4.0 + ns * out_bytes / 7.0e6 : 0.0; };
+            GemmArgs t = g;
+            t.tiles_m = (M + 127u) / 128u;
+            t.tiles_n = (N + 127u) / 128u;
+            const uint64_t tiles128 = (uint64_t)t.tiles_m * t.tiles_n;
+            // split-K only when even these tiles leave more than half of the CUs empty, and then >= 1024 k per split
+            uint32_t ns = 1;
+            if (tiles128 * nmats * 2u <= (uint64_t)cus) {
+                ns = (uint32_t)((uint64_t)cus / (tiles128 * nmats));
+                if (ns > K / 1024u) ns = K / 1024u;
+                while (ns > 1 && (double)ns * out_bytes > (double)(512ull << 20)) --ns;
+                if (ns < 2) ns = 1;
+            }
+            bool want128 = false;
+            if (const char *force = getenv("WG_F16_TILE")) want128 = atoi(force) == 128;
+            else if (tiles * nmats < (uint64_t)cus) {
+                const double w128 = (double)(tiles128 * nmats * ns) / cus, k128 = (double)(((K / 64u + ns - 1) / ns) * 64u);
+                const double est128 = (w128 <= 1.0 ? k128 * 0.00875 : w128 * k128 * 0.0108) + 6.0 + slabs(ns);
+                const uint32_t ns256 = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
+                const double k256 = (double)(((K / BKH + ns256 - 1) / ns256) * BKH);
+                const double est256 = (double)((tiles * nmats * ns256 + cus - 1) / cus) * (k256 * 0.0234 + 8.0) + slabs(ns256);
+                want128 = est128 < est256;
+            }
+            if (want128 && tiles128 <= 0x7fffffffull) {
                 t.nsplit = ns;
                 t.k_per_split = ns > 1 ? ((K / 64u + ns - 1) / ns) * 64u : K;
                 t.part = nullptr;
@@ -559,7 +579,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                     if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
                     t.part = (float *)ws;
                 }
-                if (tiles128 <= 0x7fffffffull && (uint64_t)nmats * ns <= 65535) {
+                if ((uint64_t)nmats * ns <= 65535) {
                     if (int rc = t128_launch(ctx, trans, dim3((uint32_t)tiles128, nmats * ns), t)) return rc;
                     if (ns > 1) return wg_splitk_reduce(ctx, t.part, ns, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
                     return WG_OK;

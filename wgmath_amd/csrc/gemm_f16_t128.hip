@@ -29,14 +29,23 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
-constexpr int TM = 128, TN = 128, TK = 64;
-constexpr int T_A_BYTES = TM * TK * 2;          // 16 KiB
-constexpr int T_STAGE = T_A_BYTES + TN * TK * 2; // 32 KiB: [A | B]
-constexpr uint32_t T_BIAS = 3072;               // see M16_BIAS in gemm_f16.hip
+template <class F, int... I>
+__device__ __forceinline__ void t_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void t_static_for(F &&f) { t_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-__device__ __forceinline__ void t_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst)); }
+#ifndef WG_T128_ABLATE
+#define WG_T128_ABLATE 0 // timing experiments only (results are garbage): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = no barriers
+#endif
+constexpr int TM = 128, TN = 128;
+constexpr int T_RING = 5;
+constexpr int T_SLOT = 16 * 1024;   // one half-stage: per wave w a 4 KiB region [A piece 2w | A piece 2w+1 | B piece 2w | B piece 2w+1]
+constexpr uint32_t T_BIAS = 3072;   // see M16_BIAS in gemm_f16.hip
+
+__device__ __forceinline__ void t_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0" ::"s"(lds_dst)); }
 template <int IMM>
 __device__ __forceinline__ void t_dma(uint32_t voff, const void *sbase) {
+    if (WG_T128_ABLATE & 2) return;
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
 
@@ -55,7 +64,7 @@ __device__ __forceinline__ void tile_of128(uint32_t bid, uint32_t tiles_m, uint3
 
 template <bool TRANS_A>
 __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * T_STAGE];
+    __shared__ __attribute__((aligned(16))) char smem[T_RING * T_SLOT];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -73,61 +82,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
 
-    // ---- DMA addressing (per wave: pieces 4 wave + q of A and of B; a piece = 1 KiB of LDS = 64 lanes x 16 bytes) ----
-    // Rows / columns past the end of a ragged tile are clamped to the last valid one (their results are never stored).
-    uint32_t a_voff[4], b_voff[4];
+    // ---- DMA addressing: per half-stage this wave stages pieces P = 2 wave + q (q = 0, 1) of A and of B; a piece = 1 KiB of LDS
+    // (64 lanes x 16 bytes). k-contiguous operands (B; op(A) for TN): piece P = rows 16P..16P+15 of 64 bytes (32 k), lane -> row
+    // 16P + (lane>>2), position lane&3 holds the logical chunk (lane&3) ^ G(key(row)), key = (row>>2)&3 for B (rows read in natural
+    // order) and (row>>3)&3 for op(A) (rows read permuted). Column-major A: piece P = k-quad kq = P, blocks [mblk = lane>>4] of
+    // [4 k][32 m]: k row (lane>>2)&3, 16-byte unit lane&3. Rows past the end of a ragged tile are clamped (results never stored).
+    uint32_t a_voff[2], b_voff[2];
     const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t P = 4u * wave + q;
-        if constexpr (TRANS_A) { // rows 8P..8P+7 of op(A), 128 bytes (64 k) each; chunk swizzle keyed on (row>>3)&3 (rows are read permuted)
-            const uint32_t row = 8u * P + (lane >> 3);
-            const uint32_t f = ((4u - ((row >> 3) & 3u)) & 3u) | (((row >> 1) & 1u) << 2);
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t P = 2u * wave + q;
+        const uint32_t row = 16u * P + (lane >> 2);
+        if constexpr (TRANS_A) {
             const uint32_t ra = min(row, g.M - 1u - m0);
-            a_voff[q] = (ra * g.lda + 8u * ((lane & 7u) ^ f)) * 2u + (T_BIAS - 1024u * q);
-        } else { // half-stage hs = P>>3, k-quad kq = P&7: blocks [kq][mblk = lane>>4] of [4 k][32 m]; k row (lane>>2)&3, 16-byte unit lane&3
-            const uint32_t k = 32u * (P >> 3) + 4u * (P & 7u) + ((lane >> 2) & 3u);
+            a_voff[q] = (ra * g.lda + 8u * ((lane & 3u) ^ ((4u - ((row >> 3) & 3u)) & 3u))) * 2u + (T_BIAS - 1024u * q);
+        } else {
+            const uint32_t k = 4u * P + ((lane >> 2) & 3u);
             const uint32_t m = min(32u * (lane >> 4) + 8u * (lane & 3u), g.M - 8u - m0); // M % 8 == 0
             a_voff[q] = (k * g.lda + m) * 2u + (T_BIAS - 1024u * q);
         }
-        const uint32_t row = 8u * P + (lane >> 3);
-        const uint32_t f = ((4u - ((row >> 2) & 3u)) & 3u) | (((row >> 1) & 1u) << 2);
         const uint32_t rb = min(row, g.N - 1u - n0);
-        b_voff[q] = (rb * g.ldb + 8u * ((lane & 7u) ^ f)) * 2u + (T_BIAS - 1024u * q);
+        b_voff[q] = (rb * g.ldb + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u))) * 2u + (T_BIAS - 1024u * (2 + q));
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
-    const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);
-    const uint32_t lds_b_wave = __builtin_amdgcn_readfirstlane(lds_base + T_A_BYTES + wave * 4096);
-    auto issue_stage = [&](uint32_t s) { // DMA of stage s into slot s & 1
-        const char *ga, *gb = (const char *)(b_base + 64u * s) - T_BIAS;
-        if constexpr (TRANS_A) ga = (const char *)(a_base + 64u * s) - T_BIAS;
-        else ga = (const char *)(a_base + (uint64_t)(64u * s) * g.lda) - T_BIAS;
-        const uint32_t slot = (s & 1u) * T_STAGE;
-        t_set_m0(lds_a_wave + slot);
-        t_dma<0>(a_voff[0], ga); t_dma<1024>(a_voff[1], ga); t_dma<2048>(a_voff[2], ga); t_dma<3072>(a_voff[3], ga);
-        t_set_m0(lds_b_wave + slot);
-        t_dma<0>(b_voff[0], gb); t_dma<1024>(b_voff[1], gb); t_dma<2048>(b_voff[2], gb); t_dma<3072>(b_voff[3], gb);
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);
+    const char *ga0 = (const char *)a_base - T_BIAS, *gb0 = (const char *)b_base - T_BIAS;
+    const uint64_t a_step = TRANS_A ? 64u : (uint64_t)64u * g.lda; // bytes per half-stage (32 k)
+    auto issue = [&](uint32_t H, uint32_t slot_off) { // the 4 pieces of half-stage H into the slot at byte offset slot_off
+        const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * 64u;
+        t_set_m0(lds_wave + slot_off);
+        asm volatile("s_nop 0");
+        t_dma<0>(a_voff[0], ga); t_dma<1024>(a_voff[1], ga); t_dma<2048>(b_voff[0], gb); t_dma<3072>(b_voff[1], gb);
     };
 
-    // ---- per-lane LDS read offsets (within a stage slot) ----
-    // B tile u, half-step hs: row 64 wn + 16 u + i16, logical chunk 4 hs + kg
-    uint32_t b_off[2];
-#pragma unroll
-    for (int hs = 0; hs < 2; ++hs)
-        b_off[hs] = T_A_BYTES + ((uint32_t)64 * wn + i16) * 128u + (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
-    // A, TN: MFMA tile t = 2 p + tb, MFMA row i16 <-> tile row 64 wm + 32 p + 8 aq + 4 tb + bb
-    uint32_t a_off[2][2]; // TN: [tb][hs];  NN: [0][0] only
+    // ---- per-lane LDS read offsets within a slot ----
+    // B tile u: row 64 wn + 16 u + i16 = piece 4 wn + u, row i16 of it -> (2 wn + (u>>1)) * 4096 + 2048 + (u&1) * 1024 + i16 * 64 + pos * 16
+    const uint32_t pos = (uint32_t)(kg ^ gq);
+    const uint32_t b_off = 2u * wn * 4096u + 2048u + (uint32_t)i16 * 64u + pos * 16u;
+    // A, TN: MFMA tile t = 2 p + tb, MFMA row i16 <-> tile row 64 wm + 32 p + 8 aq + 4 tb + bb = piece 4 wm + 2 p + (aq>>1), row 8 (aq&1) + 4 tb + bb
+    // A, NN: transpose read i = 2 h + ins of pair p: k-quad kq = 4 (kg>>1) + 2 ins + h (piece kq), block mblk = 2 wm + p, unit i16, half kg&1
+    uint32_t a_off[2];
     if constexpr (TRANS_A) {
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-            for (int hs = 0; hs < 2; ++hs)
-                a_off[tb][hs] = (64u * wm + 8u * aq + 4u * tb + bb) * 128u + (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
+            a_off[tb] = 2u * wm * 4096u + (uint32_t)(aq >> 1) * 1024u + (uint32_t)(8 * (aq & 1) + 4 * tb + bb) * 64u + pos * 16u;
     } else {
-        // transpose reads: lane row kg reads k-quad 4 (kg>>1) + 2 ins + h, 8-byte half (kg&1) of unit i16 of block (kq, mblk = 2 wm + p)
-        a_off[0][0] = (uint32_t)((kg & 2) * 2) * 1024u + (2u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
-        a_off[0][1] = a_off[1][0] = a_off[1][1] = 0;
+        a_off[0] = (uint32_t)(2 * (kg >> 1)) * 4096u + (2u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        a_off[1] = 0;
     }
 
     floatx4 acc[4][4]; // [t][u]
@@ -137,47 +139,107 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][u][e] = 0.f;
+    uintx4 a_r[2][4]; // [register set][M tile]
+    half8_t b_f[2][4];
 
-    const uint32_t S = K_loc / 64u; // the launcher guarantees K_loc % 64 == 0, S >= 1
-    issue_stage(0);
-    for (uint32_t s = 0; s < S; ++s) {
-        wait_dma_all();   // stage s has landed (this wave's pieces) ...
-        __syncthreads();  // ... everyone's; and every wave is done reading the other slot
-        if (s + 1 < S) issue_stage(s + 1);
-        const char *sl = smem + (s & 1u) * T_STAGE;
+    // fragment-producing operations of one half-stage (slot pointer sl), into register set `set`
+    constexpr int kOps = TRANS_A ? 8 : 20;
+    auto frag_op = [&](const char *sl, int op, int set) {
+        auto rb = [&](int u) { b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * 4096 + (u & 1) * 1024); };
+        if constexpr (TRANS_A) {
+            if (op < 4) a_r[set][op] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[op & 1] + (op >> 1) * 4096));
+            else rb(op - 4);
+        } else {
+            auto tr = [&](int p, int i) { // lands in tile 2 p + ins, dwords 2 h, 2 h + 1
+                const int h = i >> 1, ins = i & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sl + a_off[0] + ins * 4096 + h * 1024 + p * 256));
+                a_r[set][2 * p + ins][2 * h] = v[0];
+                a_r[set][2 * p + ins][2 * h + 1] = v[1];
+            };
+            auto sw = [&](int p, int i) { // put the k-groups back on the lane rows the MFMA expects
+                const uintx2 r = __builtin_amdgcn_permlane16_swap(a_r[set][2 * p][i], a_r[set][2 * p + 1][i], false, false);
+                a_r[set][2 * p][i] = r[0];
+                a_r[set][2 * p + 1][i] = r[1];
+            };
+            if (op < 4) tr(0, op);
+            else if (op < 8) tr(1, op - 4);
+            else if (op < 12) rb(op - 8);
+            else if (op < 16) sw(0, op - 12);
+            else sw(1, op - 16);
+        }
+    };
+
+    const uint32_t NH = K_loc / 32u; // half-steps; the launcher guarantees K_loc % 64 == 0 (NH even, >= 2)
+    // prologue: half-stages 0 .. min(5, NH) - 1; the first two must have landed before the first fragment reads / half-step 0
 #pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-            uintx4 a_r[4];
-            half8_t b_f[4];
+    for (int h = 0; h < T_RING; ++h)
+        if ((uint32_t)h < NH) issue(h, h * T_SLOT);
+    if (NH >= 5) wait_dma_keep<12>(); else if (NH == 4) wait_dma_keep<8>(); else wait_dma_all();
+    __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 4; ++u) b_f[u] = lds_h8(sl + b_off[hs] + u * 2048);
-            if constexpr (TRANS_A) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) a_r[t] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[t & 1][hs] + (t >> 1) * 4096));
-            } else {
-                const char *sa = sl + hs * 8192 + a_off[0][0];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { // read i = 2 h + ins lands in tile 2 p + ins, dwords 2 h, 2 h + 1
-                        const int h = i >> 1, ins = i & 1;
-                        const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sa + (2 * ins + h) * 1024 + p * 256));
-                        a_r[2 * p + ins][2 * h] = v[0];
-                        a_r[2 * p + ins][2 * h + 1] = v[1];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { // put the k-groups back on the lane rows the MFMA expects
-                        const uintx2 r = __builtin_amdgcn_permlane16_swap(a_r[2 * p][i], a_r[2 * p + 1][i], false, false);
-                        a_r[2 * p][i] = r[0];
-                        a_r[2 * p + 1][i] = r[1];
-                    }
+    for (int op = 0; op < kOps; ++op) frag_op(smem, op, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();       // every wave has read slot 0: half-step 0 may refill it
+    __builtin_amdgcn_sched_barrier(0);
+
+    uint32_t cur = 0; // byte offset of the slot of half-stage H
+    // half-step H on register set SET: 16 MFMAs; fragments of H+1 into the other set (NEXT); DMA of H+5 into the slot of H (DMA:
+    // its fragments were read during H-1 and the barrier that ended H-1 has passed); then wait until at most KEEP of this
+    // wave's pieces are in flight (half-stage H+2 has landed; KEEP < 0: nothing to wait for) and publish. The flags are
+    // compile-time in the steady state and the peeled tail: as run-time conditions they put a branch around every fragment
+    // read (measured: MFMA + reads alone 37 % busy); run-time flags only for K < 192 (fewer than 6 half-steps).
+    auto half_step = [&](auto set_c, uint32_t H, auto dma_f, auto next_f, auto keep_f) {
+        constexpr int SET = decltype(set_c)::value;
+        const uint32_t nxt = cur + T_SLOT == T_RING * T_SLOT ? 0u : cur + T_SLOT;
+        const char *sl = smem + nxt;
+        if (dma_f()) issue(H + 5u, cur);
+        t_static_for<16>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 2, u = j & 3;
+            if (!(WG_T128_ABLATE & 1))
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[SET][t]), b_f[SET][u], acc[t][u], 0, 0, 0);
+            if (next_f() && !(WG_T128_ABLATE & 1)) {
+                if constexpr (TRANS_A) {
+                    if constexpr (j < kOps) frag_op(sl, j, SET ^ 1);
+                } else {
+                    if constexpr (j < 12) frag_op(sl, j, SET ^ 1);               // 8 transpose reads, 4 B reads
+                    if constexpr (j >= 8 && j < 16) frag_op(sl, j + 4, SET ^ 1);  // 8 lane swaps, behind their reads
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[t]), b_f[u], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): fragments of H+1 are in registers
+        const int keep = keep_f();
+        if (keep == 12) wait_dma_keep<12>(); else if (keep == 8) wait_dma_keep<8>(); else if (keep == 4) wait_dma_keep<4>(); else if (keep == 0) wait_dma_all();
+        if (next_f() && !(WG_T128_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+        cur = nxt;
+    };
+    using s0 = std::integral_constant<int, 0>;
+    using s1 = std::integral_constant<int, 1>;
+    auto yes = [] { return true; };
+    auto no = [] { return false; };
+    auto k12 = [] { return 12; };
+    auto k8 = [] { return 8; };
+    auto k4 = [] { return 4; };
+    auto k0 = [] { return 0; };
+    auto kn = [] { return -1; };
+    if (NH >= 6) {
+        uint32_t H = 0;
+        for (; H + 6u < NH; H += 2) {
+            half_step(s0{}, H, yes, yes, k12);
+            half_step(s1{}, H + 1u, yes, yes, k12);
+        }
+        // six half-steps left (NH is even): H+5 = NH-1 is the last half-stage to issue
+        half_step(s0{}, H, yes, yes, k12);      // in flight after the wait: H+3, H+4, H+5
+        half_step(s1{}, H + 1u, no, yes, k8);   // H+4, H+5
+        half_step(s0{}, H + 2u, no, yes, k4);   // H+5
+        half_step(s1{}, H + 3u, no, yes, k0);
+        half_step(s0{}, H + 4u, no, yes, kn);
+        half_step(s1{}, H + 5u, no, no, kn);
+    } else {
+        for (uint32_t H = 0; H < NH; H += 2) { // NH = 2 or 4: everything was issued by the prologue
+            half_step(s0{}, H, no, yes, k0);
+            half_step(s1{}, H + 1u, no, [&] { return H + 2u < NH; }, kn);
         }
     }
 

@@ -28,6 +28,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) works on a contiguous band of tiles.
 #include "wg_internal.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -471,9 +472,40 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
     const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-    // split-K when the output has too few tiles for the chip (2 workgroups per CU): >= 8 k-tiles (128 k) per split
+    // Launch plan (tile quantisation). Measured on MI355X (profiles/r01_evidence.md section 12): a CU works through the workgroups it
+    // is dealt at ~0.115 us per k of a 256 x 128 tile whether one or two of them are resident, so a launch takes
+    //     W * (K / ns) * 0.115 us,  W = ceil(workgroups / CUs),
+    // and cutting K into ns splits adds the f32 partial slabs (written at ~3.5 TB/s, + 3 us) and the ordered reduce (4 us + slabs read
+    // at ~7 TB/s). Candidates: plain split-K with ns = 1 .. 16 (>= 128 k per split), and the "tail split" -- full rounds of one tile
+    // per CU as they are, the r < CUs/2 tiles left over cut along K over the idle CUs (partials of those r tiles only).
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
-    uint32_t nsplit = wg_splitk_plan(tiles * nmats, 2u * cus, (K + BK - 1) / BK, 8, (uint64_t)M * N * nmats, 512ull << 20);
+    const uint32_t ktiles = (K + BK - 1) / BK;
+    const double us_per_k = 0.115, out_bytes = (double)M * N * nmats * 4.0;
+    auto rounds = [&](uint64_t wgs) { return (double)((wgs + (uint64_t)cus - 1) / (uint64_t)cus); };
+    uint32_t nsplit = 1;
+    double best = rounds(tiles * nmats) * K * us_per_k;
+    for (uint32_t ns = 2; ns <= 16 && ktiles / ns >= 8; ++ns) {
+        if ((double)ns * out_bytes > (double)(512ull << 20)) break;
+        const uint32_t kps = ((ktiles + ns - 1) / ns) * BK;
+        const double t = rounds(tiles * nmats * ns) * kps * us_per_k + (ns * out_bytes / 3.5e6 + 3.0) + (4.0 + ns * out_bytes / 7.0e6);
+        if (t < best * 0.97) { best = t; nsplit = ns; } // a split must pay for itself by a margin
+    }
+    uint32_t tail_r = 0, tail_sp = 1;
+#ifndef WG_F32_TAIL_SPLIT
+#define WG_F32_TAIL_SPLIT 1
+#endif
+    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus && K % BK == 0) {
+        const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
+        uint32_t sp = r ? (uint32_t)cus / r : 0;
+        if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
+        if (r > 0 && r * 2u <= (uint32_t)cus && sp >= 2 && (size_t)sp * r * BM * BN * sizeof(float) <= (512ull << 20)) {
+            const uint32_t kps = ((ktiles + sp - 1) / sp) * BK;
+            const double part_bytes = (double)sp * r * BM * BN * 4.0;
+            const double t = (double)((tiles - r) / (uint64_t)cus) * K * us_per_k + rounds((uint64_t)r * sp) * kps * us_per_k +
+                             (part_bytes / 3.5e6 + 3.0) + (4.0 + part_bytes / 7.0e6);
+            if (t < best) { best = t; nsplit = 1; tail_r = r; tail_sp = sp; }
+        }
+    }
     float *part = nullptr;
     g.nsplit = nsplit;
     g.k_per_split = nsplit > 1 ? (((K + BK - 1) / BK + nsplit - 1) / nsplit) * BK : K;
@@ -487,33 +519,22 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     }
     if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
     const dim3 grid((uint32_t)tiles, nmats * nsplit), block(kThreads);
-    // Tail split: with a tile count a little above a multiple of the 2 x CUs resident workgroups, the last round would run on a
-    // nearly empty chip for a whole tile time. The full rounds run as they are; the few tail tiles are cut along K over the idle
-    // slots (dense f32 partial tiles in the workspace + an ordered reduce). Interior-sized K only (whole k-tiles per split).
-#ifndef WG_F32_TAIL_SPLIT
-#define WG_F32_TAIL_SPLIT 1
-#endif
-    const uint32_t slots = 2u * (uint32_t)cus;
-    if (WG_F32_TAIL_SPLIT && nsplit == 1 && nmats == 1 && tiles > slots && K % BK == 0) {
-        const uint32_t r = (uint32_t)(tiles % slots), ktiles = K / BK;
-        uint32_t sp = r ? slots / r : 0;
-        if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
-        if (r > 0 && r * 2u <= slots && sp >= 2 && (size_t)sp * r * BM * BN * sizeof(float) <= (512ull << 20)) {
-            const uint32_t kps = ((ktiles + sp - 1) / sp) * BK, n = (K + kps - 1) / kps;
-            void *ws = nullptr;
-            if (int rc = wg_ctx_workspace(ctx, (size_t)n * r * BM * BN * sizeof(float), &ws)) return rc;
-            const uint32_t full = (uint32_t)tiles - r;
-            if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(full, 1), block, 0, ctx->stream, g);
-            else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(full, 1), block, 0, ctx->stream, g);
-            GemmArgs gt = g;
-            gt.tile_base = full; gt.tail_tiles = r; gt.nsplit = n; gt.k_per_split = kps;
-            gt.c = (float *)ws; gt.c_batch = 0; gt.alpha = 1.f; gt.beta = 0.f;
-            if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(r, n), block, 0, ctx->stream, gt);
-            else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(r, n), block, 0, ctx->stream, gt);
-            hipLaunchKernelGGL(gemm_f32_tail_reduce, dim3(r, BN / 4), dim3(256), 0, ctx->stream, gt);
-            WG_HIP_TRY(hipGetLastError());
-            return WG_OK;
-        }
+    if (tail_r > 0 && nsplit == 1) { // tail split (see the plan above): dense f32 partial tiles in the workspace + an ordered reduce
+        const uint32_t r = tail_r, sp = tail_sp;
+        const uint32_t kps = ((ktiles + sp - 1) / sp) * BK, n = (K + kps - 1) / kps;
+        void *ws = nullptr;
+        if (int rc = wg_ctx_workspace(ctx, (size_t)n * r * BM * BN * sizeof(float), &ws)) return rc;
+        const uint32_t full = (uint32_t)tiles - r;
+        if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(full, 1), block, 0, ctx->stream, g);
+        else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(full, 1), block, 0, ctx->stream, g);
+        GemmArgs gt = g;
+        gt.tile_base = full; gt.tail_tiles = r; gt.nsplit = n; gt.k_per_split = kps;
+        gt.c = (float *)ws; gt.c_batch = 0; gt.alpha = 1.f; gt.beta = 0.f;
+        if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(r, n), block, 0, ctx->stream, gt);
+        else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(r, n), block, 0, ctx->stream, gt);
+        hipLaunchKernelGGL(gemm_f32_tail_reduce, dim3(r, BN / 4), dim3(256), 0, ctx->stream, gt);
+        WG_HIP_TRY(hipGetLastError());
+        return WG_OK;
     }
     if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, ctx->stream, g);
