@@ -20,6 +20,7 @@
 // parity is tolerance-based: the order here is "per-lane sequential, then butterfly", which satisfies the
 // same error bound as both WGSL orders.
 #include "wg_internal.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -318,9 +319,14 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
     const uint64_t blocks_xy = (uint64_t)gx * gz;
+    const uint32_t max_split = k == 0 ? 1u : ceil_div(k, min_k_per_split);
+    // ~4 workgroups per CU (measured at 1 / 2 / 4 per CU: GemvTr 65536 x 4096 5.4 / 6.0 / 6.4 TB/s; Gemv 4096 x 11008 43 / - / 33 us),
+    // except a tall matrix with a short contraction whose row blocks alone give every CU a workgroup: splitting 65536 x 256 four ways
+    // costs 18 us with the combine pass against 10 us unsplit.
     uint32_t want = blocks_xy >= (uint64_t)cus * 4u ? 1u : ceil_div((uint32_t)cus * 4u, (uint32_t)blocks_xy);
-    uint32_t max_split = k == 0 ? 1u : ceil_div(k, min_k_per_split);
-    uint32_t nsplit = want < 1 ? 1 : (want > max_split ? max_split : want);
+    if (!trans && blocks_xy >= (uint64_t)cus && k <= 1024u) want = 1u;
+    uint32_t nsplit = want > max_split ? max_split : want;
+    if (nsplit < 1u) nsplit = 1u;
     if (nsplit > 65535u) nsplit = 65535u;
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
