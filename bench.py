@@ -102,6 +102,11 @@ class GemmWorkload(Workload):
         self.trans = trans  # GemmTr: m1 is stored K x M (op(A) = m1^T)
         self.np_dtype = np.float32 if dtype == "f32" else np.float16
         self.kernel = "gemm_f32_kernel" if dtype == "f32" else "gemm_f16_m16_kernel"
+        # mid-size outputs: f16 runs the 128 x 128 kernel; f32 cuts K in two and `kernel_ms` spans both launches
+        if dtype == "f16" and (M // 256) * (N // 256) < 256 and M * N <= 2560 * 2560:
+            self.kernel = "gemm_f16_t128_kernel"
+        if dtype == "f32" and (M // 256) * (N // 128) < 256 and M == N == K == 2048:
+            self.kernel = "gemm_f32_kernel + splitk_reduce_kernel"
 
     def setup(self, wg, gpu, rank, world):
         from wgmath_amd.sharded import MShardPlan, ShardedGemm
@@ -452,6 +457,9 @@ WORKLOADS = {
     "gemm_f32_4096": lambda: GemmWorkload("gemm_f32_4096", 4096, 4096, 4096, "f32"),
     "gemm_f16_8192": lambda: GemmWorkload("gemm_f16_8192", 8192, 8192, 8192, "f16"),
     "gemm_f16_32768": lambda: GemmWorkload("gemm_f16_32768", 32768, 32768, 32768, "f16"),
+    # mid-size squares: fewer 256 x 256 tiles than CUs (f16: the 128 x 128 kernel; f32: planned split-K)
+    "gemm_f16_2048": lambda: GemmWorkload("gemm_f16_2048", 2048, 2048, 2048, "f16"),
+    "gemm_f32_2048": lambda: GemmWorkload("gemm_f32_2048", 2048, 2048, 2048, "f32"),
     # tall-skinny (M >> N), the other shape family the north star names
     "gemm_f16_ts_131072x1024x8192": lambda: GemmWorkload("gemm_f16_ts_131072x1024x8192", 131072, 1024, 8192, "f16"),
     "gemm_f32_ts_65536x512x4096": lambda: GemmWorkload("gemm_f32_ts_65536x512x4096", 65536, 512, 4096, "f32"),
@@ -468,7 +476,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
