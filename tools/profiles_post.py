@@ -30,20 +30,30 @@ for f in find("pmc/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         grid = int(r["Grid_Size"]) if "Grid_Size" in r and r["Grid_Size"] else 0
         agg[(r["Kernel_Name"], grid)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-def pick(substr, nth_largest_grid=0, exclude=None):
+def pick(substr, nth_largest_grid=0, exclude=None, grid=None):
+    """Counters of the kernel whose name contains `substr`, at an exact grid size in threads (`grid`: one kernel serves several
+    workloads of bench.py) or at its n-th largest grid."""
     ks = sorted({k for k in agg if substr in k[0] and not (exclude and exclude in k[0])}, key=lambda k: -k[1])
     grids = sorted({k[1] for k in ks}, reverse=True)
-    if len(grids) <= nth_largest_grid: return None
-    g = grids[nth_largest_grid]
+    if grid is not None:
+        if grid not in grids: return None
+        g = grid
+    else:
+        if len(grids) <= nth_largest_grid: return None
+        g = grids[nth_largest_grid]
     m = collections.defaultdict(list)
     for k in ks:
         if k[1] == g:
             for c, v in agg[k].items(): m[c] += v
     return {c: sum(v) / len(v) for c, v in m.items()}
 work = {
-    "gemm_f16_32768": pick("gemm_f16_m16_kernel<false>", 0) or pick("gemm_f16_kernel<false", 0),
-    "gemm_f16_8192": pick("gemm_f16_m16_kernel<false>", 1) or pick("gemm_f16_kernel<false", 1),
-    "gemm_f32_4096": pick("gemm_f32_tile_dma<false>", 0) or pick("gemm_f32", 0),
+    # grid sizes in threads: tiles x 256 (f16: 256 x 256 tiles; f32: 256 x 128 tiles)
+    "gemm_f16_32768": pick("gemm_f16_m16_kernel<false>", grid=16384 * 256) or pick("gemm_f16_m16_kernel<false>", 0),
+    "gemm_f16_8192": pick("gemm_f16_m16_kernel<false>", grid=1024 * 256) or pick("gemm_f16_m16_kernel<false>", 2),
+    "gemm_f16_ts_131072x1024x8192": pick("gemm_f16_m16_kernel<false>", grid=2048 * 256),
+    "gemm_f16_2048": pick("gemm_f16_t128_kernel<false>", grid=256 * 256),
+    "gemm_f32_4096": pick("gemm_f32_kernel<false>", grid=512 * 256) or pick("gemm_f32", grid=512 * 256),
+    "gemm_f32_ts_65536x512x4096": pick("gemm_f32_kernel<false>", grid=1024 * 256) or pick("gemm_f32", grid=1024 * 256),
     "gemv_f32_4096x65536": pick("gemv_n_kernel", 0),
     "gemvtr_f32_65536x4096": pick("gemv_t_kernel", 0),
     "reduce_f32_4096x65536": pick("reduce_rows4", 0),

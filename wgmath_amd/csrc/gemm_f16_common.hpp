@@ -76,7 +76,23 @@ static __device__ __forceinline__ half8_t cat(short4_t lo, short4_t hi) {
     return __builtin_bit_cast(half8_t, v);
 }
 
-// workgroup id -> (tile_m, tile_n)
+// workgroup id -> tile, general form. Hardware deals ids round-robin to the 8 XCDs; XCD x = id % 8 takes a contiguous range of the
+// order index o, and o walks strips of 4 tile rows column by column: the ~32 workgroups an XCD runs at a time then cover a compact
+// 4 x 8 patch of the output (4 A panels + 8 B panels through its L2) whatever the tile counts -- in particular the tiles that share
+// an A panel of a tall-skinny product (tiles_n = 4: four of them) run together instead of tiles_m ids apart (131072 x 1024 x 8192:
+// 9.2 GB fetched with the column-major order, A read four times).
+static __device__ __forceinline__ void tile_strips(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t &tm, uint32_t &tn) {
+    const uint32_t nwg = tiles_m * tiles_n;
+    const uint32_t q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, local = bid / 8u;
+    const uint32_t o = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
+    const uint32_t strip = o / (4u * tiles_n);
+    const uint32_t within = o - strip * 4u * tiles_n;
+    const uint32_t h = min(4u, tiles_m - 4u * strip);
+    tn = within / h;
+    tm = 4u * strip + (within - tn * h);
+}
+
+// workgroup id -> (tile_m, tile_n) of the 256 x 256 kernels
 static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t &tm, uint32_t &tn) {
     if ((tiles_m % 16u) == 0 && (tiles_n % 16u) == 0) {
         // 256 consecutive ids = one 16x16 super-tile; hardware deals ids round-robin to the 8 XCDs: XCD x gets a 4x8 patch
@@ -86,11 +102,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
         tm = sm * 16u + (xcd & 3u) * 4u + (local & 3u);
         tn = sn * 16u + (xcd >> 2) * 8u + (local >> 2);
     } else {
-        const uint32_t nwg = tiles_m * tiles_n;
-        const uint32_t q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, local = bid / 8u;
-        const uint32_t id = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
-        tm = id % tiles_m;
-        tn = id / tiles_m;
+        tile_strips(bid, tiles_m, tiles_n, tm, tn);
     }
 }
 

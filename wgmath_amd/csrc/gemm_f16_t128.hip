@@ -15,8 +15,8 @@
 //     (64-byte rows for k-contiguous operands, chunk c at c ^ G(.), conflict-free ds_read_b128; 256-byte [4 k][32 m] blocks +
 //     ds_read_b64_tr_b16 + v_permlane16_swap for column-major A), and the same row permutation inside a wave tile so that a
 //     lane's accumulators of a tile pair are 8 consecutive rows of C (16-byte stores);
-//   * tile order: 4-tile-row strips, contiguous ranges per XCD (ids are dealt round-robin to the 8 XCDs), so an XCD's L2 sees
-//     a compact patch of the output.
+//   * tile order: 4-tile-row strips, contiguous ranges per XCD (tile_strips, gemm_f16_common.hpp), so an XCD's L2 sees a compact
+//     patch of the output.
 // M0 is written by the inline asm without save/restore, as in gemm_f16.hip (tests/test_abi_and_host.py checks the ISA).
 // Bound: LDS bandwidth (per CU and half-step pair: 64 KiB of fragment reads + 32 KiB of DMA writes against 512 MFMA cycles per
 // SIMD) and L2 -> CU bandwidth; see DESIGN.md section 3.
@@ -49,19 +49,6 @@ __device__ __forceinline__ void t_dma(uint32_t voff, const void *sbase) {
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
 
-// workgroup id -> tile. Order index o walks strips of 4 tile rows (column by column inside a strip); XCD x = id % 8 takes a
-// contiguous range of o.
-__device__ __forceinline__ void tile_of128(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t &tm, uint32_t &tn) {
-    const uint32_t nwg = tiles_m * tiles_n;
-    const uint32_t q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, local = bid / 8u;
-    const uint32_t o = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
-    const uint32_t strip = o / (4u * tiles_n);
-    const uint32_t within = o - strip * 4u * tiles_n;
-    const uint32_t h = min(4u, tiles_m - 4u * strip);
-    tn = within / h;
-    tm = 4u * strip + (within - tn * h);
-}
-
 template <bool TRANS_A>
 __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[T_RING * T_SLOT];
@@ -74,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const int gq = (4 - aq) & 3; // G(aq), G = {0,3,2,1}
 
     uint32_t tm, tn;
-    tile_of128(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
+    tile_strips(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * TM, n0 = tn * TN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split;

@@ -72,11 +72,22 @@ __device__ __forceinline__ void store_c(float *p, float4 v, float alpha, float b
 }
 __device__ __forceinline__ float comp(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
-// bijective "XCD-contiguous" remap of the linear workgroup id (guide T1): hardware deals ids round-robin to the 8 XCDs
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
+// workgroup id -> tile (bijective). Hardware deals ids round-robin to the 8 XCDs (guide T1); XCD x = id % 8 takes a contiguous range
+// of the order index o, and o walks strips of 4 tile rows column by column: the workgroups an XCD runs at a time cover a compact patch
+// of the output (4 A panels x a run of B panels through its L2), and the tiles sharing an A panel of a tall-skinny product run together.
+#ifndef WG_F32_TILE_ORDER
+#define WG_F32_TILE_ORDER 1 // 1 = strips of 4 tile rows; 0 = column-major (experiments)
+#endif
+__device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, uint32_t tiles_n, uint32_t &tm, uint32_t &tn) {
+    const uint32_t nwg = tiles_m * tiles_n;
     const uint32_t q = nwg / 8u, r = nwg % 8u, xcd = bid % 8u, local = bid / 8u;
-    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + local;
+    const uint32_t o = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + local;
+    if (!WG_F32_TILE_ORDER) { tm = o % tiles_m; tn = o / tiles_m; return; }
+    const uint32_t strip = o / (4u * tiles_n);
+    const uint32_t within = o - strip * 4u * tiles_n;
+    const uint32_t h = min(4u, tiles_m - 4u * strip);
+    tn = within / h;
+    tm = 4u * strip + (within - tn * h);
 }
 
 // One k-tile (16 k) = 2 substeps of 8 k = 2 x 32 MFMAs per wave. The loop body is hand-placed in "slots" (one MFMA +
@@ -411,8 +422,8 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
 template <bool TRANS_A>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[NRING * SLOT_FLOATS]; // 72 KiB: 3 DMA slots, or 2 staged buffers on edge tiles
-    const uint32_t tile = xcd_remap(blockIdx.x + g.tile_base, g.tiles_m * g.tiles_n);
-    const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    uint32_t tm, tn;
+    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split; // split-K: this workgroup's K range (k_per_split is a multiple of BK)
@@ -434,8 +445,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 // Tail split (tile quantisation): see wgk_gemm_f32. Adds a tail tile's partials in ASCENDING split order (deterministic) and writes
 // it with the usual alpha / beta / edge rules. grid = (tail tiles, BN / 4): 4 columns per block, float4 (4 rows) per thread.
 __global__ __launch_bounds__(256) void gemm_f32_tail_reduce(GemmArgs g) {
-    const uint32_t tile = xcd_remap(blockIdx.x + g.tile_base, g.tiles_m * g.tiles_n);
-    const uint32_t tm = tile % g.tiles_m, tn = tile / g.tiles_m;
+    uint32_t tm, tn;
+    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t rl = 4u * (threadIdx.x & 63u), cl = blockIdx.y * 4u + (threadIdx.x >> 6);
     const uint32_t row = tm * BM + rl, col = tn * BN + cl;
     if (row >= g.M || col >= g.N) return; // M % 4 == 0: the 4 rows are all in or all out
