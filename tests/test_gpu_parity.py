@@ -339,6 +339,11 @@ F16_SHAPES = [
     (256, 8192, 256, 1), (512, 4096 + 32, 264, 1), (1024, 16384, 512, 2),
     # 16x16x32 kernel (K % 64 == 0, >= 3 stages): minimum, odd and even stage counts, several tiles per CU-less grid
     (512, 192, 512, 1), (512, 320, 512, 1), (768, 448, 264, 2), (2048, 2048, 1024, 1),
+    # shapes / alignments the MFMA kernels do not take as they are (K % 32, M or N % 8 -- multiples of 4 as the operator demands), large
+    # enough for the zero-padded staging path
+    (1000, 1000, 1000, 1), (2052, 520, 264, 2), (260, 1024, 1004, 1), (512, 4104, 512, 1), (1004, 260, 516, 3),
+    # N a multiple of 4 only (columns are independent: no staging), on every MFMA kernel family
+    (512, 256, 260, 1), (256, 192, 1004, 2), (1024, 64, 4100, 1),
     # tail split: 17 x 17 = 289 tiles on 256 CUs -> 256 tiles as they are + 33 tiles cut along K (full and ragged tiles)
     (4352, 1024, 4352, 1), (4104, 512, 4104, 1),
 ]
@@ -661,6 +666,55 @@ def test_gemm_f16_fuzz(gpu, f16_tile, seed):
         touched[idx.reshape(-1)] = True
     # nothing outside the output view was written (padding between columns / matrices, the offset prefix)
     assert np.array_equal(got[~touched], c[~touched]), f"fuzz {seed}: bytes outside the output view changed"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gemm_f16_fuzz_odd_shapes(gpu, seed):
+    """Sizes, leading dimensions and offsets that are multiples of 4 (the operator's vec4 precondition, shape.wgsl:64-66) but not of 8: the zero-padded staging path in front of the MFMA kernels, with (alpha, beta) and batches; checks the values and
+    that nothing outside the output view is written."""
+    wg = _wg()
+    rng = np.random.default_rng(3000 + seed)
+    M, N, K = 4 * int(rng.integers(33, 175)), 4 * int(rng.integers(33, 175)), 4 * int(rng.integers(65, 375))
+    mats = int(rng.choice([1, 1, 2]))
+    tr = bool(rng.integers(0, 2))
+    ex = bool(rng.integers(0, 2))
+    alpha, beta = (float(rng.choice([1.0, -1.0, 0.5])), float(rng.choice([0.0, 1.0, -0.5]))) if ex else (1.0, 0.0)
+
+    def view_of(rows, cols):
+        ld = rows + 4 * int(rng.integers(0, 3))
+        sm = ld * cols + 4 * int(rng.integers(0, 3))
+        off = 4 * int(rng.integers(0, 4))
+        data = (rng.random(off + sm * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+        return data, ld, sm, off
+    ar, ac = (K, M) if tr else (M, K)
+    a, lda, sma, offa = view_of(ar, ac)
+    b, ldb, smb, offb = view_of(K, N)
+    c, ldc, smc, offc = view_of(M, N)
+    ta, tb, tc = upload(gpu, (a.size,), a, np.float16), upload(gpu, (b.size,), b, np.float16), upload(gpu, (c.size,), c, np.float16)
+    mk = lambda t, r, cc, ld, sm, off: wg.GpuTensorView(wg.ViewShape([r, cc, mats], ld, sm, off), t, 3)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    va, vb, vc = mk(ta, ar, ac, lda, sma, offa), mk(tb, K, N, ldb, smb, offb), mk(tc, M, N, ldc, smc, offc)
+    if ex:
+        run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, alpha, beta, vc, va, vb, variant))
+    else:
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, vc, va, vb, variant))
+    got = tc.read(gpu.device())
+    touched = np.zeros(c.size, bool)
+    for t in range(mats):
+        mat = lambda buf, rows, cols, ld, sm, off: buf[off + t * sm + np.arange(rows)[:, None] + np.arange(cols)[None, :] * ld]
+        A = mat(a, ar, ac, lda, sma, offa).astype(np.float64)
+        A = A.T if tr else A
+        B = mat(b, K, N, ldb, smb, offb).astype(np.float64)
+        C0 = mat(c, M, N, ldc, smc, offc).astype(np.float64)
+        truth = alpha * (A @ B) + beta * C0
+        sabs = abs(alpha) * (np.abs(A) @ np.abs(B)) + abs(beta) * np.abs(C0)
+        tol = U.f32_gate(K + 2, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        idx = offc + t * smc + np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+        err = np.abs(got[idx].astype(np.float64) - truth)
+        assert (err <= tol).all(), f"odd fuzz {seed}: M={M} N={N} K={K} mats={mats} tr={tr} ab=({alpha},{beta}) worst {(err / tol).max():.3g}"
+        touched[idx.reshape(-1)] = True
+    assert np.array_equal(got[~touched], c[~touched]), f"odd fuzz {seed}: bytes outside the output view changed"
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -510,10 +510,36 @@ __global__ __launch_bounds__(256) void gemm_f16_tail_reduce(GemmArgs g) {
     *reinterpret_cast<h4 *>(o) = r;
 }
 
+// Copy of a column-major block with zero fill: dst (rd x cd, ld_dst) = src (rs x cs, ld_src) where it exists, 0 elsewhere. Used to stage
+// operands whose shape or alignment the MFMA kernels do not take (K % 32, M or N % 8, odd leading dimensions, unaligned views) into
+// dense zero-padded scratch copies -- zeros add nothing to a dot product, so the padded product is the product -- and to copy a padded
+// result back. Two-byte accesses, coalesced along the rows: HBM-bound passes over operands the GEMM reads many times.
+__global__ __launch_bounds__(256) void pad_copy_f16(_Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd,
+                                                    const _Float16 *src, uint32_t ld_src, uint64_t src_batch, uint32_t rs, uint32_t cs) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, z = blockIdx.z;
+    if (i >= rd) return;
+    for (uint32_t j = blockIdx.y; j < cd; j += gridDim.y) {
+        const _Float16 v = (i < rs && j < cs) ? src[z * src_batch + (uint64_t)j * ld_src + i] : (_Float16)0.f;
+        dst[z * dst_batch + (uint64_t)j * ld_dst + i] = v;
+    }
+}
+
 } // namespace
 } // namespace wgf16
 
 using namespace wgf16;
+
+namespace {
+thread_local bool g_padding = false; // set while wgk_gemm_f16 runs on padded copies (see the staging branch)
+int pad_copy(wg_ctx *ctx, _Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd, const _Float16 *src, uint32_t ld_src,
+             uint64_t src_batch, uint32_t rs, uint32_t cs, uint32_t nmats) {
+    if (rd == 0 || cd == 0) return WG_OK;
+    const dim3 grid((rd + 255u) / 256u, cd < 65535u ? cd : 65535u, nmats);
+    hipLaunchKernelGGL(wgf16::pad_copy_f16, grid, dim3(256), 0, ctx->stream, dst, ld_dst, dst_batch, rd, cd, src, ld_src, src_batch, rs, cs);
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+} // namespace
 
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
@@ -531,7 +557,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
     // 32-bit DMA offsets within a tile: rows * ld * 2 bytes must stay below 2^31
     const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);
-    const bool fast = (M % 8 == 0) && (N % 8 == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
+    // (N is free: B rows are clamped per column and the epilogues skip columns >= N)
+    const bool fast = (M % 8 == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
     if (fast) {
         g.tiles_m = (M + BM - 1) / BM;
@@ -665,6 +692,40 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         WG_HIP_TRY(hipGetLastError());
         if (nsplit > 1) return wg_splitk_reduce(ctx, g.part, nsplit, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
         return WG_OK;
+    } else if (!g_padding && (uint64_t)M * N * K >= (1ull << 24) && K > 0 && nmats <= 65535u) {
+        struct Guard { Guard() { g_padding = true; } ~Guard() { g_padding = false; } } guard; // the padded call must not pad again
+        // Shapes / alignments the MFMA kernels do not take as they are (K % 32, M or N % 8, leading dimensions % 8, unaligned views): at
+        // ~40 TFLOP/s the generic kernel below is 20x slower (4096 x 4096 x 4104: 3.2 ms against 0.14 ms). Stage zero-padded dense copies
+        // of the operands (and, if the output does not qualify either, a padded output that is copied back) in the context's padding
+        // scratch and run the same call on those: HBM-bound passes over a few MB against a GEMM that re-reads them hundreds of times.
+        // Only what does not qualify is copied: op(A) when K, M, its leading dimension or its alignment is off, B when K or its leading
+        // dimension / alignment is, the output when M or its leading dimension / alignment is (N is free: columns are independent).
+        const bool k_ok = K % BKH == 0;
+        const uint32_t Mp = (M + 7u) & ~7u, Kp = k_ok ? K : ((K + 63u) & ~63u);
+        const bool a_ok = k_ok && M == Mp && m1.ld % 8 == 0 && al16(m1.ptr) && (nmats == 1 || m1.batch % 8 == 0);
+        const bool b_ok = k_ok && m2.ld % 8 == 0 && al16(m2.ptr) && (nmats == 1 || m2.batch % 8 == 0);
+        const bool c_ok = M == Mp && out_ld % 8 == 0 && al16(out) && (nmats == 1 || out_batch % 8 == 0);
+        const uint64_t a_elems = a_ok ? 0 : (uint64_t)Mp * Kp, b_elems = b_ok ? 0 : (uint64_t)Kp * N, c_elems = c_ok ? 0 : (uint64_t)Mp * N;
+        // every region starts 16-byte aligned: element counts rounded up to 8
+        const uint64_t a_sz = ((a_elems + 7u) & ~7ull), b_sz = ((b_elems + 7u) & ~7ull), c_sz = ((c_elems + 7u) & ~7ull);
+        void *ws = nullptr;
+        if (int rc = wg_ctx_pad_workspace(ctx, (size_t)((a_sz + b_sz + c_sz) * nmats * sizeof(_Float16)) + 16, &ws)) return rc;
+        _Float16 *ap = (_Float16 *)ws, *bp = ap + a_sz * nmats, *cp = bp + b_sz * nmats;
+        wgk_mat a2 = m1, b2 = m2;
+        if (!a_ok) { // op(A) is M x K: stored M x K or, transposed, K x M
+            if (trans) { if (int rc = pad_copy(ctx, ap, Kp, a_sz, Kp, Mp, (const _Float16 *)m1.ptr, m1.ld, m1.batch, K, M, nmats)) return rc; }
+            else { if (int rc = pad_copy(ctx, ap, Mp, a_sz, Mp, Kp, (const _Float16 *)m1.ptr, m1.ld, m1.batch, M, K, nmats)) return rc; }
+            a2 = wgk_mat{ ap, trans ? Kp : Mp, a_sz };
+        }
+        if (!b_ok) {
+            if (int rc = pad_copy(ctx, bp, Kp, b_sz, Kp, N, (const _Float16 *)m2.ptr, m2.ld, m2.batch, K, N, nmats)) return rc;
+            b2 = wgk_mat{ bp, Kp, b_sz };
+        }
+        if (c_ok) return wgk_gemm_f16(ctx, trans, M, N, Kp, nmats, out, out_ld, out_batch, a2, b2, alpha, beta);
+        if (beta != 0.f) // the padded output starts as a copy of the old one
+            if (int rc = pad_copy(ctx, cp, Mp, c_sz, Mp, N, (const _Float16 *)out, out_ld, out_batch, M, N, nmats)) return rc;
+        if (int rc = wgk_gemm_f16(ctx, trans, Mp, N, Kp, nmats, (__half *)cp, Mp, c_sz, a2, b2, alpha, beta)) return rc;
+        return pad_copy(ctx, (_Float16 *)out, out_ld, out_batch, M, N, cp, Mp, c_sz, M, N, nmats);
     } else {
         g.tiles_m = (M + 63) / 64;
         g.tiles_n = (N + 63) / 64;

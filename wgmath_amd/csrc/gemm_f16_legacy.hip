@@ -21,7 +21,8 @@
 //   * workgroup ids are remapped into 16 x 16 super-tiles (the 256 workgroups resident at once), each XCD working
 //     on a 4 x 8 patch of it, so that A/B panels are shared in the XCD's L2 and across XCDs in the 256 MiB MALL.
 // Ragged M, N (any multiple of 8) stay on this path: DMA source rows are clamped, the epilogue is predicated.
-// Shapes it does not cover (M or N % 8, K % 32, misaligned views) take a small generic kernel.
+// Shapes it does not cover (M % 8, K % 32, misaligned views) are staged into padded copies by the launcher (gemm_f16.hip) or, when
+// tiny, take the small generic kernel below.
 #include "gemm_f16_common.hpp"
 
 namespace wgf16 {

@@ -57,6 +57,22 @@ int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out) {
     *out = ctx->tr_workspace;
     return WG_OK;
 }
+int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->pad_workspace_bytes) {
+        if (ctx->recording)
+            return wg_set_error(WG_ERR_INVALID_ARG, "padding workspace of %zu bytes needed while recording: run the call once outside the recording first", bytes);
+        WG_HIP_TRY(hipSetDevice(ctx->device));
+        WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->pad_workspace) WG_HIP_TRY(hipFree(ctx->pad_workspace));
+        ctx->pad_workspace = nullptr;
+        ctx->pad_workspace_bytes = 0;
+        size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        WG_HIP_TRY(hipMalloc(&ctx->pad_workspace, want));
+        ctx->pad_workspace_bytes = want;
+    }
+    *out = ctx->pad_workspace;
+    return WG_OK;
+}
 extern "C" {
 
 int wg_abi_version(void) { return WGEBRA_HIP_ABI_VERSION; }
@@ -140,6 +156,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->tr_workspace) (void)hipFree(ctx->tr_workspace);
+    if (ctx->pad_workspace) (void)hipFree(ctx->pad_workspace);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;

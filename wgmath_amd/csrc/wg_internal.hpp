@@ -21,6 +21,8 @@ struct wg_ctx {
     size_t workspace_bytes = 0;
     void *tr_workspace = nullptr; // second scratch: transposed operand of the row-major GemmTr (lives across the GEMM that may use `workspace`)
     size_t tr_workspace_bytes = 0;
+    void *pad_workspace = nullptr; // third scratch: zero-padded operand copies of f16 GEMMs whose shapes the MFMA kernels do not take as they are
+    size_t pad_workspace_bytes = 0;
     int compute_units = 0;
 };
 
@@ -60,6 +62,7 @@ void wg_clear_error();
 // Grow-only scratch. Fails while recording if it would have to allocate.
 int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out);
+int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wgk_transpose(wg_ctx *ctx, wg_dtype dtype, uint32_t rows, uint32_t cols, uint32_t nmats, const void *src, uint32_t ld_src,
                   uint64_t src_batch, void *dst, uint32_t ld_dst, uint64_t dst_batch);
 
