@@ -347,7 +347,7 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, comp(bf[set][u], sidx), acc[t][u], 0, 0, 0);
     };
 
-    const uint32_t nk = g.K / BK; // interior => K % 16 == 0, nk >= 1
+    const uint32_t nk = g.K / BK; // whole k-tiles (>= 1); a K % 16 remainder is handled after the pipelined loop
     // one k-tile on ring slot `cur`; `nxt` holds tile t+1; the DMA of tile t+2 goes to `dst`
     auto tile_body = [&](uint32_t cur, uint32_t nxt, uint32_t dst, uint32_t k_dma, auto do_dma, auto has_next) {
 #pragma unroll
@@ -398,6 +398,46 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
     }
     tile_body(cur, cur, 0, 0, std::false_type{}, std::false_type{});
 
+    // K % 16 != 0 (a multiple of 4 by the operator's precondition): one more k-tile, staged through registers into slot 0 with the
+    // missing k zero-filled (same slot image as the DMA writes), multiplied like any other. Once per tile: not worth pipelining; it
+    // keeps a ragged K on this path instead of the predicated one (4096 x 4096 x 4100: 119 TFLOP/s there).
+    if (nk * BK < g.K) {
+        __syncthreads(); // every wave is done with the ring
+        const uint32_t k0 = nk * BK;
+        float *As = smem, *Bs = smem + A_TILE;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = tid + kThreads * r;
+            if constexpr (!TRANS_A) {
+                const uint32_t k = k0 + (f >> 6);
+                const float4 v = ldg4(A + (uint64_t)k * g.lda + m0 + 4u * (f & 63), k < g.K);
+                *reinterpret_cast<float4 *>(&As[(f >> 6) * BM + 4 * (f & 63)]) = v;
+            } else {
+                const int mm = f >> 2, ch = f & 3;
+                const uint32_t k = k0 + 4u * ch;
+                const float4 v = ldg4(A + (uint64_t)(m0 + mm) * g.lda + k, k < g.K);
+                *reinterpret_cast<float4 *>(&As[mm * BK + 4 * (ch ^ ((mm >> 2) & 3))]) = v;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int f = tid + kThreads * r;
+            const int nn = f >> 2, ch = f & 3;
+            const uint32_t k = k0 + 4u * ch;
+            const float4 v = ldg4(B + (uint64_t)(n0 + nn) * g.ldb + k, k < g.K);
+            *reinterpret_cast<float4 *>(&Bs[nn * BK + 4 * (ch ^ ((nn >> 2) & 3))]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 6; ++r) read_one(0, 0, r, 0);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) read_one(0, 1, r, 1);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) mfma_slot(0, j);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) mfma_slot(1, j);
+    }
+
     // epilogue (interior: no predication)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -436,8 +476,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
         C = g.c + ((uint64_t)split * g.tail_tiles + blockIdx.x) * (uint64_t)(BM * BN) - ((uint64_t)n0 * BM + m0);
         gl.ldc = BM;
     }
-    // workgroup-uniform: the whole tile is inside the matrices, K is a whole number of k-tiles, and 32-bit DMA offsets suffice
-    const bool interior = (m0 + BM <= gl.M) && (n0 + BN <= gl.N) && (gl.K % BK == 0) && gl.K >= (uint32_t)BK && gl.dma_ok;
+    // workgroup-uniform: the whole tile is inside the matrices, at least one whole k-tile, and 32-bit DMA offsets suffice
+    const bool interior = (m0 + BM <= gl.M) && (n0 + BN <= gl.N) && gl.K >= (uint32_t)BK && gl.dma_ok;
     if (interior) gemm_f32_tile_dma<TRANS_A>(gl, smem, A, B, C, m0, n0);
     else gemm_f32_tile<TRANS_A, true>(gl, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
 }
@@ -505,7 +545,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifndef WG_F32_TAIL_SPLIT
 #define WG_F32_TAIL_SPLIT 1
 #endif
-    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus && K % BK == 0) {
+    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus) {
         const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
         uint32_t sp = r ? (uint32_t)cus / r : 0;
         if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
