@@ -325,6 +325,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     // costs 18 us with the combine pass against 10 us unsplit.
     uint32_t want = blocks_xy >= (uint64_t)cus * 4u ? 1u : ceil_div((uint32_t)cus * 4u, (uint32_t)blocks_xy);
     if (!trans && blocks_xy >= (uint64_t)cus && k <= 1024u) want = 1u;
+    if (trans && blocks_xy >= 2ull * (uint64_t)cus) want = 1u; // T with >= 2 workgroups per CU already: 8192 x 8192 47 us unsplit, 57 split in two + combine
     uint32_t nsplit = want > max_split ? max_split : want;
     if (nsplit < 1u) nsplit = 1u;
     if (nsplit > 65535u) nsplit = 65535u;
