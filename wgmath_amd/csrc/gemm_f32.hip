@@ -511,6 +511,12 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: more than 65535 matrices in one call");
+    // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. WG_F32_SKINNY=0 disables
+    // it (experiments / tests of the tiled kernel on these shapes).
+    if (!trans && N <= 64 && M >= 512 && K >= 128) {
+        const char *e = getenv("WG_F32_SKINNY");
+        if (!(e && atoi(e) == 0)) return wgk_gemm_f32_skinny(ctx, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
+    }
     GemmArgs g;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;

@@ -1,0 +1,202 @@
+// f32 Gemm (NN) with few output columns (N <= 64): the small-batch shape of a matrix applied to a handful of vectors.
+//
+// The 256 x 128 tile of gemm_f32.hip spends 50-87 % of its MFMAs on columns that do not exist here (4096 x 16 x 4096: 41 us against
+// 18 us for the vendor's 32 x 16 tile), and the operation is not MFMA-bound anyway: every element of A is used N times, so it is
+// bound by streaming A from HBM like a GEMV. This kernel is built like the GEMV -- no LDS staging, every wave streams its own
+// rows straight from global memory into MFMA operands -- with v_mfma_f32_32x32x2_f32 doing the N dot products per row:
+//   * a workgroup owns 128 rows and one K chunk; its 4 waves take a quarter of the chunk each and are summed through LDS at the end
+//     (fixed order); chunks are further split over grid.y into f32 partial slabs that wg_splitk_reduce adds in ascending order
+//     (deterministic; alpha / beta / output view applied there);
+//   * operands in the layout of gemm_f32.hip: per 8 k, half-wave h takes k = k0 + 4 h + s (s = 0..3); a lane loads, for each s, the
+//     float4 of rows 4 i .. 4 i + 3 of A at that k (512 contiguous bytes per half-wave) -- its components feed four M-tiles, M-tile t
+//     holding rows {4 i + t} -- and one float4 of B (4 consecutive k of column i, k-contiguous) per 32 columns;
+//   * 16 * NT MFMAs per 8 k and wave (NT = 1 or 2 column tiles of 32; columns >= N are zero operands), against 4 + NT 16-byte loads
+//     per lane: the loads run 4 groups of 8 k ahead of the MFMAs (register ring).
+// Bound: HBM (A is read exactly once: 4 * M * K bytes).
+#include "wg_internal.hpp"
+#include <cstdlib>
+
+#ifndef WG_SKINNY_ABLATE
+#define WG_SKINNY_ABLATE 0 // experiments: 1 = no B loads, 2 = no MFMAs (results are garbage)
+#endif
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct SkinnyArgs {
+    const float *a; uint32_t lda; uint64_t a_batch;
+    const float *b; uint32_t ldb; uint64_t b_batch;
+    float *part;               // slabs [z][split][N][M]
+    uint32_t M, N, K;
+    uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
+};
+
+__device__ __forceinline__ float comp4(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
+    __shared__ floatx16 red[2][4 * NT][64]; // two waves' accumulators
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const uint32_t r0 = blockIdx.x * 128u;
+    const uint32_t z = blockIdx.z, split = blockIdx.y;
+    // this wave's k range: a quarter (multiple of 8) of the workgroup's chunk, clipped to K
+    const uint32_t kq = g.k_per_split / 4u;
+    const uint32_t kb = split * g.k_per_split + wave * kq;
+    const uint32_t ke = min(kb + kq, g.K);
+    // No predicated loads in the loop (hipcc turns `ok ? *p : 0` into a branch around every load): addresses are clamped instead. Rows
+    // past M and columns past N only feed outputs that are never stored; k past the wave's range is loaded (from valid memory) but never
+    // multiplied, except in the one half-filled group at the end of a range, whose missing half is zeroed by selects.
+    const float *A = g.a + z * g.a_batch + min(r0 + 4u * i, g.M - 4u); // M % 4 == 0
+    const float *B = g.b + z * g.b_batch;
+    const uint32_t bcol[2] = { min((uint32_t)i, g.N - 1u), min(32u + (uint32_t)i, g.N - 1u) };
+
+    floatx16 acc[4][NT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+    auto load = [&](uint32_t k0, float4 (&af)[4], float4 (&bf)[NT]) { // fragments of the 8 k starting at k0 (this half-wave: k0 + 4 h ..)
+        const uint32_t kh = k0 + 4u * h;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) af[s] = wg_ld_nt(reinterpret_cast<const float4 *>(A + (uint64_t)min(kh + s, g.K - 1u) * g.lda));
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+#if WG_SKINNY_ABLATE & 1
+            bf[u] = make_float4(1.f, 2.f, 3.f, (float)kh);
+#else
+            bf[u] = *reinterpret_cast<const float4 *>(B + (uint64_t)bcol[u] * g.ldb + min(kh, g.K - 4u)); // K % 4 == 0
+#endif
+        }
+    };
+    auto mul = [&](const float4 (&af)[4], const float4 (&bf)[NT]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+#if WG_SKINNY_ABLATE & 2
+                    if (s == 0 && t == 0) acc[t][u][0] += comp4(af[s], t) + af[1].y + af[2].z + af[3].w + comp4(bf[u], s);
+#else
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp4(af[s], t), comp4(bf[u], s), acc[t][u], 0, 0, 0);
+#endif
+                }
+    };
+
+    // DEPTH groups of 8 k in flight per wave: with one wave per SIMD a group's MFMAs take ~0.5 us against ~2 us of HBM latency
+    constexpr int DEPTH = 4;
+    if (kb < ke) {
+        const uint32_t full = (ke - kb) / 8u, half = (ke - kb) & 4u; // whole groups; 4 more k (first half-wave only) or none
+        float4 af[DEPTH][4], bf[DEPTH][NT];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) load(kb + 8u * d, af[d], bf[d]);
+        uint32_t gidx = 0;
+        for (; gidx < full; gidx += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (gidx + d < full) { // wave-uniform
+                    mul(af[d], bf[d]);
+                    load(kb + 8u * (gidx + d + DEPTH), af[d], bf[d]);
+                }
+            }
+        }
+        if (half) { // group `full` sits in ring slot full % DEPTH; its second half-wave's k are outside the range
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if ((full % DEPTH) == (uint32_t)d) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) af[d][s] = h ? make_float4(0.f, 0.f, 0.f, 0.f) : af[d][s];
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) bf[d][u] = h ? make_float4(0.f, 0.f, 0.f, 0.f) : bf[d][u];
+                    mul(af[d], bf[d]);
+                }
+            }
+        }
+    }
+
+    // sum the 4 waves in a fixed order: (w0 + w2) + (w1 + w3)
+    if (wave >= 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) red[wave - 2][t * NT + u][lane] = acc[t][u];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[t][u] += red[wave][t * NT + u][lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) red[0][t * NT + u][lane] = acc[t][u];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // C/D map of the 32x32 MFMA: lane (i, h), register e -> MFMA row (e&3) + 8 (e>>2) + 4 h, column i. M-tile t holds rows {4 row + t}:
+    // for one (e, u) the four tiles are 4 consecutive rows of column 32 u + i -> one float4 of the slab [col][M]
+    float *P = g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const uint32_t col = 32u * u + i;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const uint32_t row = r0 + 4u * ((e & 3) + 8 * (e >> 2) + 4 * h);
+            if (row >= g.M) continue;
+            const floatx16 *q = &red[0][0][lane];
+            float4 v;
+            v.x = acc[0][u][e] + q[(0 * NT + u) * 64][e];
+            v.y = acc[1][u][e] + q[(1 * NT + u) * 64][e];
+            v.z = acc[2][u][e] + q[(2 * NT + u) * 64][e];
+            v.w = acc[3][u][e] + q[(3 * NT + u) * 64][e];
+            *reinterpret_cast<float4 *>(P + (uint64_t)col * g.M + row) = v;
+        }
+    }
+}
+
+} // namespace
+
+// out = alpha * m1 * m2 + beta * out for N <= 64 (NN only). Returns WG_ERR_UNSUPPORTED-free: the caller checks applicability.
+int wgk_gemm_f32_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
+                        wgk_mat m1, wgk_mat m2, float alpha, float beta) {
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    const uint32_t row_blocks = (M + 127u) / 128u;
+    // K splits: the count whose workgroups fill whole rounds of the CUs with the least k per round (11008 rows = 86 row blocks: 3 splits
+    // = 258 workgroups would run a second round for two of them; 5 splits = 430 run two rounds of 820 k). Measured: one long workgroup
+    // per CU beats several short ones (4096 x 16 x 4096: 24 us with 256 workgroups, 32 us with 1024), so ties go to fewer splits and
+    // every extra split is charged the k-equivalent of its slab + epilogue.
+    const uint32_t max_split = (K + 127u) / 128u; // >= 128 k per workgroup
+    const uint64_t blocks = (uint64_t)row_blocks * nmats;
+    uint32_t ns = 1;
+    uint64_t best = ~0ull;
+    for (uint32_t c = 1; c <= max_split && (uint64_t)c * blocks <= 4ull * cus + blocks; ++c) {
+        if ((uint64_t)c * M * N * nmats * 4u > (512ull << 20)) break;
+        const uint64_t rounds = (blocks * c + cus - 1) / cus;
+        const uint64_t cost = rounds * ((K + c - 1) / c + 48u);
+        if (cost < best) { best = cost; ns = c; }
+    }
+    uint32_t kps = (((K + ns - 1) / ns) + 31u) & ~31u;
+    ns = (K + kps - 1) / kps;
+    if (ns > 65535u || nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many splits or matrices for the skinny path");
+    void *ws = nullptr;
+    if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
+    SkinnyArgs g;
+    g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
+    g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
+    g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
+    const dim3 grid(row_blocks, ns, nmats);
+    if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
+    WG_HIP_TRY(hipGetLastError());
+    return wg_splitk_reduce(ctx, g.part, ns, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
+}
