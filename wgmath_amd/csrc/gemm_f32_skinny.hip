@@ -89,22 +89,29 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     };
 
     // DEPTH groups of 8 k in flight per wave: with one wave per SIMD a group's MFMAs take ~0.5 us against ~2 us of HBM latency
-    constexpr int DEPTH = 4;
+#ifndef WG_SKINNY_DEPTH
+#define WG_SKINNY_DEPTH 4
+#endif
+    constexpr int DEPTH = WG_SKINNY_DEPTH;
     if (kb < ke) {
         const uint32_t full = (ke - kb) / 8u, half = (ke - kb) & 4u; // whole groups; 4 more k (first half-wave only) or none
         float4 af[DEPTH][4], bf[DEPTH][NT];
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) load(kb + 8u * d, af[d], bf[d]);
+        // steady state: straight-line code, no condition between a group's MFMAs and the loads that refill its slot -- with branches in
+        // the body hipcc's wait-count pass falls back to vmcnt(0) at every join, and the loads stop overlapping the MFMAs (measured: the
+        // kernel took exactly loads-only + MFMA-only time)
         uint32_t gidx = 0;
-        for (; gidx < full; gidx += DEPTH) {
+        for (; gidx + DEPTH <= full; gidx += DEPTH) {
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
-                if (gidx + d < full) { // wave-uniform
-                    mul(af[d], bf[d]);
-                    load(kb + 8u * (gidx + d + DEPTH), af[d], bf[d]);
-                }
+                mul(af[d], bf[d]);
+                load(kb + 8u * (gidx + d + DEPTH), af[d], bf[d]); // past the range: clamped addresses, values never used
             }
         }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (gidx + d < full) mul(af[d], bf[d]); // the last < DEPTH whole groups are already in the ring (wave-uniform conditions)
         if (half) { // group `full` sits in ring slot full % DEPTH; its second half-wave's k are outside the range
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
