@@ -724,12 +724,26 @@ def test_gemm_f16_fuzz_odd_shapes(gpu, seed):
 @pytest.mark.parametrize("seed", range(12))
 def test_gemm_f32_fuzz(gpu, seed):
     """Same idea for the f32 kernel (vec4 granularity: everything a multiple of 4), incl. split-K-sized K and (alpha, beta)."""
-    wg = _wg()
     rng = np.random.default_rng(2000 + seed)
     M, N = int(rng.integers(1, 130)) * 4, int(rng.integers(1, 100)) * 4
     K = int(rng.choice([4, 16, 64, 132, 512, 1024, 4096 + 16]))
-    mats = int(rng.choice([1, 1, 2]))
-    tr = bool(rng.integers(0, 2))
+    _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 2)))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_gemm_f32_fuzz_few_columns(gpu, seed):
+    """N <= 64 with many rows: the streaming kernel of gemm_f32_skinny.hip -- with and without a K split (direct output with alpha / beta
+    when the row blocks alone fill the chip), ragged row blocks, K % 8 == 4, padded views, batches; GemmTr of the same shapes stays on
+    the tiled kernel."""
+    rng = np.random.default_rng(4000 + seed)
+    M = 4 * int(rng.integers(128, 600)) if seed % 2 else 4 * int(rng.integers(8200, 9000))  # 33-36 k rows: no K split
+    N = 4 * int(rng.integers(1, 17))
+    K = int(rng.choice([128, 132, 260, 1000, 2052]))
+    _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 4) == 0))
+
+
+def _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, mats, tr):
+    wg = _wg()
     ex = bool(rng.integers(0, 2))
     alpha, beta = (float(rng.choice([1.0, -1.0, 0.5])), float(rng.choice([0.0, 1.0, -0.5]))) if ex else (1.0, 0.0)
     def view_of(rows, cols):

@@ -27,7 +27,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct SkinnyArgs {
     const float *a; uint32_t lda; uint64_t a_batch;
     const float *b; uint32_t ldb; uint64_t b_batch;
-    float *part;               // slabs [z][split][N][M]
+    float *part;               // slabs [z][split][N][M] (nsplit > 1)
+    float *c; uint32_t ldc; uint64_t c_batch; float alpha, beta; // the output view: written directly when nsplit == 1
     uint32_t M, N, K;
     uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
 };
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     if (wave != 0) return;
     // C/D map of the 32x32 MFMA: lane (i, h), register e -> MFMA row (e&3) + 8 (e>>2) + 4 h, column i. M-tile t holds rows {4 row + t}:
     // for one (e, u) the four tiles are 4 consecutive rows of column 32 u + i -> one float4 of the slab [col][M]
-    float *P = g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+    const bool direct = g.nsplit == 1; // one chunk covers K: no slab, alpha / beta and the output view applied here
+    float *P = direct ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+    const uint32_t ldp = direct ? g.ldc : g.M;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const uint32_t col = 32u * u + i;
@@ -166,7 +169,15 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             v.y = acc[1][u][e] + q[(1 * NT + u) * 64][e];
             v.z = acc[2][u][e] + q[(2 * NT + u) * 64][e];
             v.w = acc[3][u][e] + q[(3 * NT + u) * 64][e];
-            *reinterpret_cast<float4 *>(P + (uint64_t)col * g.M + row) = v;
+            float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
+            if (direct) {
+                if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+                if (g.beta != 0.f) { // beta == 0 never reads the output
+                    const float4 o = *dst;
+                    v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
+                }
+            }
+            *dst = v;
         }
     }
 }
@@ -196,8 +207,10 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_
     ns = (K + kps - 1) / kps;
     if (ns > 65535u || nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many splits or matrices for the skinny path");
     void *ws = nullptr;
-    if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
+    if (ns > 1)
+        if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
     SkinnyArgs g;
+    g.c = out; g.ldc = out_ld; g.c_batch = out_batch; g.alpha = alpha; g.beta = beta;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
@@ -205,5 +218,6 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_
     if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
+    if (ns == 1) return WG_OK;
     return wg_splitk_reduce(ctx, g.part, ns, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
 }
