@@ -245,6 +245,33 @@ class GemmWorkload(Workload):
                           f"columns x K={K} of the {self.M}x{self.N}x{K} problem, {n} of {active_wgs} active workgroups, {dt:.1f} s"}
 
 
+class FewColumnsGemmWorkload(GemmWorkload):
+    """f32 Gemm with N <= 64 (a matrix applied to a handful of vectors): HBM-bound on streaming A once, like a GEMV with N right-hand
+    sides, so it is reported in GB/s of algorithmic bytes 4 (M K + K N + M N) against the HBM peak (gemm_f32_skinny.hip)."""
+    bound = "hbm"
+    metric = "gemm_few_columns_gbs"
+    unit = "GB/s"
+
+    def __init__(self, name, M, N, K):
+        super().__init__(name, M, N, K, "f32")
+        self.kernel = "gemm_f32_skinny_kernel (+ splitk_reduce_kernel)"
+
+    def _bytes(self):
+        return 4.0 * (self.M * self.K + self.K * self.N + self.M * self.N)
+
+    def units_per_step(self):
+        return self._bytes()
+
+    def algorithmic_per_launch(self):
+        return self._bytes()
+
+    def cpu_baseline(self, budget_s):
+        r = super().cpu_baseline(budget_s)  # the same naive WGSL gemm port, converted to the bytes this workload counts
+        r["value"] = r["value"] * 1e12 / (2.0 * self.M * self.N * self.K) * self._bytes() / 1e9
+        r["unit"] = "GB/s"
+        return r
+
+
 class GemvWorkload(Workload):
     bound = "hbm"
     metric = "gemv_gbs"
@@ -460,6 +487,8 @@ WORKLOADS = {
     # mid-size squares: fewer 256 x 256 tiles than CUs (f16: the 128 x 128 kernel; f32: planned split-K)
     "gemm_f16_2048": lambda: GemmWorkload("gemm_f16_2048", 2048, 2048, 2048, "f16"),
     "gemm_f32_2048": lambda: GemmWorkload("gemm_f32_2048", 2048, 2048, 2048, "f32"),
+    # few columns (small batch): the streaming MFMA kernel, HBM-bound
+    "gemm_f32_fewcols_32000x16x4096": lambda: FewColumnsGemmWorkload("gemm_f32_fewcols_32000x16x4096", 32000, 16, 4096),
     # tall-skinny (M >> N), the other shape family the north star names
     "gemm_f16_ts_131072x1024x8192": lambda: GemmWorkload("gemm_f16_ts_131072x1024x8192", 131072, 1024, 8192, "f16"),
     "gemm_f32_ts_65536x512x4096": lambda: GemmWorkload("gemm_f32_ts_65536x512x4096", 65536, 512, 4096, "f32"),
@@ -476,7 +505,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
