@@ -511,6 +511,11 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: more than 65535 matrices in one call");
+    // GemmTr with a handful of output columns is a GemvTr with several right-hand sides: gemv_t_kernel streams the matrix once per 8
+    // columns at ~6 TB/s, which beats the 256 x 128 tiles (the streaming MFMA kernel below does not take the k-contiguous layout):
+    // 4096 x 16 x 4096 36 vs 46 us, 32000 x 16 x 4096 213 vs 289 us. Plain products only (the GEMV has no alpha / beta). For Gemm the
+    // same route only ties with the streaming kernel (4096 x 8 x 4096: 24.6 vs 24.1 us) and is not taken.
+    if (trans && alpha == 1.f && beta == 0.f && M >= 512 && K >= 128 && N <= 16) return wgk_gemv(ctx, true, WG_F32, M, K, N, nmats, out, out_ld, out_batch, m1, m2);
     // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. WG_F32_SKINNY=0 disables
     // it (experiments / tests of the tiled kernel on these shapes).
     if (!trans && N <= 64 && M >= 512 && K >= 128) {
