@@ -127,6 +127,8 @@ GEMM_SHAPES = [
     (4352, 512, 3968, 1), (4104, 256, 4104, 1),
     # few columns (N <= 64, M >= 512, K >= 128): the streaming MFMA kernel of gemm_f32_skinny.hip (NN; GemmTr stays on the tiled kernel)
     (4096, 4096, 16, 1), (1024, 516, 64, 2), (520, 132, 4, 1), (2048, 1000, 36, 1), (516, 128, 32, 3), (8192, 260, 8, 1),
+    # few rows (M <= 64, N >= 512, K >= 128): computed transposed (GemmTr with few columns + transposes of the small operands)
+    (16, 4096, 4096, 1), (64, 260, 1000, 2), (8, 128, 516, 1), (36, 1024, 2048, 1), (4, 512, 8192, 3),
     # K % 16 != 0 on interior tiles (extra zero-filled k-tile after the pipelined loop), alone, under split-K and under the tail split
     (512, 36, 256, 1), (768, 1044, 384, 2), (256, 4100, 128, 1), (4104, 268, 4104, 1), (3328, 520, 3328, 1),
 ]
