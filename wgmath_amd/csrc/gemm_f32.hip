@@ -514,7 +514,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // Few output ROWS (M <= 64, many columns): every tiling here is built around tall row blocks, so the product is computed transposed,
     // C^T (N x M) = op(B)^T op(A)^T, which is a GemmTr with few columns on m1' = m2 (K x N, already k-contiguous) and m2' = op(A)^T as
     // a K x M column-major matrix -- m1 itself for GemmTr, a transposed copy of the tiny m1 for Gemm -- followed by a transpose of the
-    // small result. 16 x 4096 x 4096: 79 us on the 256 x 128 tiles. beta needs the old output inside the product: not taken then.
+    // small result. 16 x 4096 x 4096: 79 us on the 256 x 128 tiles, 34 us this way. beta needs the old output inside the product: not taken then.
     if (M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
         const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
         void *ws = nullptr;
@@ -528,16 +528,12 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = wgk_gemm_f32(ctx, true, N, M, K, nmats, ct, N, ct_elems, m2, a2, alpha, 0.f)) return rc;
         return wgk_transpose(ctx, WG_F32, N, M, nmats, ct, N, ct_elems, out, out_ld, out_batch);
     }
-    // GemmTr with a handful of output columns is a GemvTr with several right-hand sides: gemv_t_kernel streams the matrix once per 8
-    // columns at ~6 TB/s, which beats the 256 x 128 tiles (the streaming MFMA kernel below does not take the k-contiguous layout):
-    // 4096 x 16 x 4096 36 vs 46 us, 32000 x 16 x 4096 213 vs 289 us. Plain products only (the GEMV has no alpha / beta). For Gemm the
-    // same route only ties with the streaming kernel (4096 x 8 x 4096: 24.6 vs 24.1 us) and is not taken.
-    if (trans && alpha == 1.f && beta == 0.f && M >= 512 && K >= 128 && N <= 16) return wgk_gemv(ctx, true, WG_F32, M, K, N, nmats, out, out_ld, out_batch, m1, m2);
     // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. WG_F32_SKINNY=0 disables
     // it (experiments / tests of the tiled kernel on these shapes).
-    if (!trans && N <= 64 && M >= 512 && K >= 128) {
+    // (GemmTr: 32-bit DMA offsets within a 32-row block and within B)
+    if (N <= 64 && M >= 512 && K >= 128 && (!trans || ((uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)))) {
         const char *e = getenv("WG_F32_SKINNY");
-        if (!(e && atoi(e) == 0)) return wgk_gemm_f32_skinny(ctx, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
+        if (!(e && atoi(e) == 0)) return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }
     GemmArgs g;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;

@@ -182,10 +182,153 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GemmTr with few columns (m1 stored K x M: every output row is a k-contiguous column, like the columns of m2). Lanes reading float4s
+// along k of 32 different columns straight from global memory touch 32 cache lines per instruction (measured: no better than the
+// tiles), so here the rows go through LDS, fetched as WHOLE 128-byte lines by LDS-DMA -- and, since every wave owns its own 32 rows for
+// the whole K range, entirely wave-private: no barrier, no cross-wave sum.
+//   * wave w of a workgroup owns rows 32 w .. 32 w + 31 of a 128-row block = ONE M-tile of v_mfma_f32_32x32x2_f32 (16 NT accumulators);
+//   * a stage is 32 k = one line per row: 4 DMA pieces of A (8 rows x 128 B) + 4 NT of B (the wave's own copy: B is small and comes
+//     from L2) into the wave's slot of a 4- (NT = 2: 3-) stage ring (4 (1 + NT) KiB per wave and stage), counted vmcnt;
+//   * LDS image [row][8 chunks of 16 B], chunk c at position c ^ ((row >> 1) & 7): conflict-free ds_read_b128 for the instruction's
+//     real lane groups; per 8 k, half-wave h takes chunk 2 ks + h, MFMA s its component s (the k order of gemm_f32.hip);
+//   * a K % 32 remainder: the last stage's missing chunks are fetched from clamped addresses and zeroed after the LDS read.
+// M0 is written without save / restore (tests/test_abi_and_host.py checks the ISA). Bound: HBM (A read once).
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t TR_BIAS = 3072; // see M16_BIAS in gemm_f16.hip
+template <int IMM>
+__device__ __forceinline__ void tr_dma(uint32_t voff, const void *sbase) {
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
+}
+__device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst)); }
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g) {
+    constexpr int RING = NT == 1 ? 4 : 3;           // 128 / 144 KiB of LDS: one workgroup per CU
+    constexpr int STAGE_BYTES = 4096 * (1 + NT);      // per wave: A 32 rows x 128 B, then B 32 NT columns x 128 B
+    constexpr int PIECES = 4 * (1 + NT);              // DMA pieces per wave and stage
+    __shared__ __attribute__((aligned(16))) char smem[4 * RING * STAGE_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const uint32_t r0 = blockIdx.x * 128u + 32u * wave;
+    const uint32_t z = blockIdx.z, split = blockIdx.y;
+    const uint32_t kb = split * g.k_per_split;             // multiple of 32
+    const uint32_t ke = min(kb + g.k_per_split, g.K);
+    if (kb >= ke) return;                                   // (the launcher leaves no empty split)
+    const uint32_t nst = (ke - kb + 31u) / 32u;
+    const uint32_t last_chunks = (ke - kb - 32u * (nst - 1u)) / 4u; // valid 16-byte chunks of the last stage: 1 .. 8
+
+    // ---- DMA addressing: piece q = rows 8 q .. 8 q + 7 of the wave's 32 (lane -> row 8 q + (lane >> 3), position lane & 7) ----
+    const float *A = g.a + z * g.a_batch + kb, *B = g.b + z * g.b_batch + kb;
+    uint32_t a_voff[4], b_voff[4 * NT], a_tail[4], b_tail[4 * NT]; // byte offsets; *_tail: the last stage, chunk clamped into the matrix
+    const uint32_t kmax = g.K - 4u - kb - 32u * (nst - 1u);        // largest valid k offset (in floats) of a chunk in the last stage
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t rl = 8u * q + (lane >> 3);
+        const uint32_t chunk = (lane & 7u) ^ ((rl >> 1) & 7u);
+        const uint64_t row = min(r0 + rl, g.M - 1u);
+        // 32-bit offsets relative to the wave's first row keep the per-lane address in one VGPR (rows * lda * 4 < 2^32 is checked by the launcher)
+        const uint32_t rel = (uint32_t)((row - min(r0, g.M - 1u)) * g.lda) * 4u;
+        a_voff[q] = rel + 16u * chunk + (TR_BIAS - 1024u * q);
+        a_tail[q] = rel + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * q);
+    }
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) {
+        const uint32_t cl = 8u * q + (lane >> 3);
+        const uint32_t chunk = (lane & 7u) ^ ((cl >> 1) & 7u);
+        const uint32_t col = min(cl, g.N - 1u);
+        b_voff[q] = col * g.ldb * 4u + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
+        b_tail[q] = col * g.ldb * 4u + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
+    }
+    const char *ga0 = (const char *)(A + (uint64_t)min(r0, g.M - 1u) * g.lda) - TR_BIAS;
+    const char *gb0 = (const char *)B - TR_BIAS;
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (RING * STAGE_BYTES));
+    auto issue = [&](uint32_t st) { // stage st -> ring slot st % RING
+        const uint32_t dst = lds_wave + (st % RING) * STAGE_BYTES;
+        const char *ga = ga0 + (uint64_t)st * 128u, *gb = gb0 + (uint64_t)st * 128u;
+        const bool tail = st + 1u == nst; // wave-uniform
+        tr_set_m0(dst);
+        tr_dma<0>(tail ? a_tail[0] : a_voff[0], ga); tr_dma<1024>(tail ? a_tail[1] : a_voff[1], ga);
+        tr_dma<2048>(tail ? a_tail[2] : a_voff[2], ga); tr_dma<3072>(tail ? a_tail[3] : a_voff[3], ga);
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            tr_set_m0(dst + 4096u * (1 + u));
+            tr_dma<0>(tail ? b_tail[4 * u + 0] : b_voff[4 * u + 0], gb); tr_dma<1024>(tail ? b_tail[4 * u + 1] : b_voff[4 * u + 1], gb);
+            tr_dma<2048>(tail ? b_tail[4 * u + 2] : b_voff[4 * u + 2], gb); tr_dma<3072>(tail ? b_tail[4 * u + 3] : b_voff[4 * u + 3], gb);
+        }
+    };
+
+    floatx16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+
+    const uint32_t rd = (uint32_t)i * 128u, sw = (uint32_t)((i >> 1) & 7);
+    const char *wbase = smem + wave * (RING * STAGE_BYTES);
+    for (uint32_t st = 0; st < (uint32_t)(RING - 1) && st < nst; ++st) issue(st);
+    for (uint32_t st = 0; st < nst; ++st) {
+        // slot (st - 1) % RING was read in the previous trip (lgkmcnt(0) below): refill it with stage st + RING - 1
+        if (st + (uint32_t)(RING - 1) < nst) {
+            issue(st + RING - 1);
+            asm volatile("s_waitcnt vmcnt(%c0)" ::"i"((RING - 1) * PIECES) : "memory"); // stage st has landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last RING - 1 stages: nothing more is issued
+        }
+        const char *sl = wbase + (st % RING) * STAGE_BYTES;
+        const uint32_t valid = st + 1u == nst ? last_chunks : 8u;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint32_t c = 2u * ks + h;
+            const bool live = c < valid;
+            float4 af = *reinterpret_cast<const float4 *>(sl + rd + ((c ^ sw) * 16u));
+            af = live ? af : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 bf[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                bf[u] = *reinterpret_cast<const float4 *>(sl + 4096u * (1 + u) + rd + ((c ^ sw) * 16u));
+                bf[u] = live ? bf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                for (int u = 0; u < NT; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp4(af, sidx), comp4(bf[u], sidx), acc[u], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this slot's reads are done before the next trip's DMA refills it
+    }
+
+    // C/D map: lane (i, h), register e -> row (e&3) + 8 (e>>2) + 4 h of the wave's 32, column i: registers 4 gq .. 4 gq + 3 = 4 consecutive rows
+    const bool direct = g.nsplit == 1;
+    float *P = direct ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+    const uint32_t ldp = direct ? g.ldc : g.M;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const uint32_t col = 32u * u + i;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const uint32_t row = r0 + 8u * gq + 4u * h;
+            if (row >= g.M) continue; // M % 4 == 0
+            float4 v = make_float4(acc[u][4 * gq + 0], acc[u][4 * gq + 1], acc[u][4 * gq + 2], acc[u][4 * gq + 3]);
+            float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
+            if (direct) {
+                if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+                if (g.beta != 0.f) {
+                    const float4 o = *dst;
+                    v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
+                }
+            }
+            *dst = v;
+        }
+    }
+}
+
 } // namespace
 
 // out = alpha * m1 * m2 + beta * out for N <= 64 (NN only). Returns WG_ERR_UNSUPPORTED-free: the caller checks applicability.
-int wgk_gemm_f32_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
+int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t row_blocks = (M + 127u) / 128u;
@@ -215,7 +358,10 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
     const dim3 grid(row_blocks, ns, nmats);
-    if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
+    if (trans) {
+        if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_tr_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL(gemm_f32_skinny_tr_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
+    } else if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (ns == 1) return WG_OK;
