@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// The LDS-staged few-column kernel (TRANS_A = true: GemmTr; false: Gemm, see the launcher for when it replaces the streaming kernel above).
 // GemmTr with few columns (m1 stored K x M: every output row is a k-contiguous column, like the columns of m2). Lanes reading float4s
 // along k of 32 different columns straight from global memory touch 32 cache lines per instruction (measured: no better than the
 // tiles), so here the rows go through LDS, fetched as WHOLE 128-byte lines by LDS-DMA -- and, since every wave owns its own 32 rows for
@@ -193,6 +194,8 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
 //   * LDS image [row][8 chunks of 16 B], chunk c at position c ^ ((row >> 1) & 7): conflict-free ds_read_b128 for the instruction's
 //     real lane groups; per 8 k, half-wave h takes chunk 2 ks + h, MFMA s its component s (the k order of gemm_f32.hip);
 //   * a K % 32 remainder: the last stage's missing chunks are fetched from clamped addresses and zeroed after the LDS read.
+//   * Gemm (column-major A): the wave's 32 rows at one k are one 128-byte line, a piece is 8 k, the LDS image [32 k][32 m] and the A operand
+//     of an MFMA one ds_read_b32 (consecutive lanes, consecutive floats); everything else is the same.
 // M0 is written without save / restore (tests/test_abi_and_host.py checks the ISA). Bound: HBM (A read once).
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t TR_BIAS = 3072; // see M16_BIAS in gemm_f16.hip
@@ -202,7 +205,7 @@ __device__ __forceinline__ void tr_dma(uint32_t voff, const void *sbase) {
 }
 __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst)); }
 
-template <int NT>
+template <bool TRANS_A, int NT>
 __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g) {
     constexpr int RING = NT == 1 ? 4 : 3;           // 128 / 144 KiB of LDS: one workgroup per CU
     constexpr int STAGE_BYTES = 4096 * (1 + NT);      // per wave: A 32 rows x 128 B, then B 32 NT columns x 128 B
@@ -220,18 +223,24 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
     const uint32_t last_chunks = (ke - kb - 32u * (nst - 1u)) / 4u; // valid 16-byte chunks of the last stage: 1 .. 8
 
     // ---- DMA addressing: piece q = rows 8 q .. 8 q + 7 of the wave's 32 (lane -> row 8 q + (lane >> 3), position lane & 7) ----
-    const float *A = g.a + z * g.a_batch + kb, *B = g.b + z * g.b_batch + kb;
-    uint32_t a_voff[4], b_voff[4 * NT], a_tail[4], b_tail[4 * NT]; // byte offsets; *_tail: the last stage, chunk clamped into the matrix
+    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda), *B = g.b + z * g.b_batch + kb;
+    uint32_t a_voff[4], b_voff[4 * NT], a_tail[4], b_tail[4 * NT]; // byte offsets; *_tail: the last stage, k clamped into the matrix
     const uint32_t kmax = g.K - 4u - kb - 32u * (nst - 1u);        // largest valid k offset (in floats) of a chunk in the last stage
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t rl = 8u * q + (lane >> 3);
-        const uint32_t chunk = (lane & 7u) ^ ((rl >> 1) & 7u);
-        const uint64_t row = min(r0 + rl, g.M - 1u);
-        // 32-bit offsets relative to the wave's first row keep the per-lane address in one VGPR (rows * lda * 4 < 2^32 is checked by the launcher)
-        const uint32_t rel = (uint32_t)((row - min(r0, g.M - 1u)) * g.lda) * 4u;
-        a_voff[q] = rel + 16u * chunk + (TR_BIAS - 1024u * q);
-        a_tail[q] = rel + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * q);
+        if constexpr (TRANS_A) { // piece q = rows 8 q .. 8 q + 7, one 128-byte line (32 k) each
+            const uint32_t chunk = (lane & 7u) ^ ((rl >> 1) & 7u);
+            const uint64_t row = min(r0 + rl, g.M - 1u);
+            // 32-bit offsets relative to the wave's first row keep the per-lane address in one VGPR (the launcher checks the range)
+            const uint32_t rel = (uint32_t)((row - min(r0, g.M - 1u)) * g.lda) * 4u;
+            a_voff[q] = rel + 16u * chunk + (TR_BIAS - 1024u * q);
+            a_tail[q] = rel + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * q);
+        } else { // column-major A: piece q = k rows 8 q .. 8 q + 7 of the stage, the wave's 32 rows = one 128-byte line each: image [32 k][32 m]
+            const uint32_t m = min(r0 + 4u * (lane & 7u), g.M - 4u) - min(r0, g.M - 4u); // M % 4 == 0
+            a_voff[q] = (rl * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
+            a_tail[q] = (min(rl, kmax + 3u) * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4 * NT; ++q) {
@@ -241,12 +250,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
         b_voff[q] = col * g.ldb * 4u + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
         b_tail[q] = col * g.ldb * 4u + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
     }
-    const char *ga0 = (const char *)(A + (uint64_t)min(r0, g.M - 1u) * g.lda) - TR_BIAS;
+    const char *ga0 = (const char *)(TRANS_A ? A + (uint64_t)min(r0, g.M - 1u) * g.lda : A + min(r0, g.M - 4u)) - TR_BIAS;
+    const uint64_t a_step = TRANS_A ? 128u : (uint64_t)128u * g.lda; // bytes per stage (32 k)
     const char *gb0 = (const char *)B - TR_BIAS;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (RING * STAGE_BYTES));
     auto issue = [&](uint32_t st) { // stage st -> ring slot st % RING
         const uint32_t dst = lds_wave + (st % RING) * STAGE_BYTES;
-        const char *ga = ga0 + (uint64_t)st * 128u, *gb = gb0 + (uint64_t)st * 128u;
+        const char *ga = ga0 + (uint64_t)st * a_step, *gb = gb0 + (uint64_t)st * 128u;
         const bool tail = st + 1u == nst; // wave-uniform
         tr_set_m0(dst);
         tr_dma<0>(tail ? a_tail[0] : a_voff[0], ga); tr_dma<1024>(tail ? a_tail[1] : a_voff[1], ga);
@@ -282,7 +292,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
         for (int ks = 0; ks < 4; ++ks) {
             const uint32_t c = 2u * ks + h;
             const bool live = c < valid;
-            float4 af = *reinterpret_cast<const float4 *>(sl + rd + ((c ^ sw) * 16u));
+            float4 af;
+            if constexpr (TRANS_A) af = *reinterpret_cast<const float4 *>(sl + rd + ((c ^ sw) * 16u));
+            else { // [k][32 m]: k = 4 c + s, one float per MFMA (lanes i consecutive: conflict-free)
+                const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + i;
+                af = make_float4(ak[0], ak[32], ak[64], ak[96]);
+            }
             af = live ? af : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 bf[NT];
 #pragma unroll
@@ -358,9 +373,15 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
     const dim3 grid(row_blocks, ns, nmats);
+    // Gemm: the LDS-staged kernel as well (4096 x 64 x 4096 29 vs 38 us, 4096 x 16 x 4096 18.7 vs 20.1), except for one long chunk per row
+    // block with <= 32 columns, where the register-streaming kernel is ahead (32000 x 16 x 4096: 110 vs 128 us)
+    const bool staged = !(ns == 1 && N <= 32);
     if (trans) {
-        if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_tr_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
-        else hipLaunchKernelGGL(gemm_f32_skinny_tr_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
+        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 2>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (staged) {
+        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<false, 1>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<false, 2>), grid, dim3(256), 0, ctx->stream, g);
     } else if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
