@@ -214,6 +214,8 @@ GEMV_SHAPES = [
     (252, 1000, 5, 1), (128, 65536, 1, 1), (65536, 128, 1, 1), (2048, 2048, 4, 1),
     # RHS register tiles 8 (5..8 columns) and more than one RHS group (> 8 columns), with a batch
     (1024, 2048, 8, 1), (516, 772, 7, 2), (256, 1024, 9, 1), (1024, 512, 12, 2), (64, 128, 17, 1),
+    # 9 .. 64 right-hand sides with >= 512 outputs and k >= 128: one pass on the few-column Gemm kernels
+    (1024, 512, 12, 1), (1024, 516, 17, 2), (516, 1028, 40, 1), (1024, 640, 64, 1),
 ]
 
 

@@ -309,6 +309,11 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: only f32 is implemented (the reference kernel is f32: gemv.wgsl:9-14)");
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
+    // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
+    // one GEMV pass per 8 columns. (GemvTr: m is the K x M operand of a GemmTr; the 32-bit DMA offsets of that kernel must suffice.)
+    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
+        (!trans || ((uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))))
+        return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
     const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
