@@ -516,6 +516,12 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // a K x M column-major matrix -- m1 itself for GemmTr, a transposed copy of the tiny m1 for Gemm -- followed by a transpose of the
     // small result. 16 x 4096 x 4096: 79 us on the 256 x 128 tiles, 34 us this way. beta needs the old output inside the product: not taken then.
     if (M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
+        // the few-column GemmTr kernel takes m2' = op(A)^T either k-contiguous (GemmTr: m1 as it is) or with its columns contiguous (Gemm:
+        // m1 as it is, "k-major"), and writes -- or its split-K reduce does -- straight into the transposed position: "row" n of C^T is
+        // column n of C (out_ld apart), "column" m is row m (adjacent). No copy of anything.
+        const bool dma_ok = (uint64_t)m2.ld * 32u * 4u < (1ull << 31) && (uint64_t)m1.ld * 64u * 4u < (1ull << 31);
+        if (dma_ok) return wgk_gemm_f32_skinny(ctx, true, N, M, K, nmats, out, 1u, out_batch, m2, m1, alpha, 0.f, out_ld, /*m2_kmajor=*/!trans);
+        // (leading dimensions beyond the kernel's 32-bit offsets: transposed copies and the general path)
         const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
         void *ws = nullptr;
         if (int rc = wg_ctx_pad_workspace(ctx, (size_t)((at_elems + ct_elems) * nmats * sizeof(float)), &ws)) return rc;

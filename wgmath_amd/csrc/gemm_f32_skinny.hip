@@ -29,6 +29,7 @@ struct SkinnyArgs {
     const float *b; uint32_t ldb; uint64_t b_batch;
     float *part;               // slabs [z][split][N][M] (nsplit > 1)
     float *c; uint32_t ldc; uint64_t c_batch; float alpha, beta; // the output view: written directly when nsplit == 1
+    uint32_t crs;              // element stride between consecutive ROWS of the output (1; != 1: the caller wants it transposed, beta == 0)
     uint32_t M, N, K;
     uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
 };
@@ -172,6 +173,11 @@ __global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
             if (direct) {
                 if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+                if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
+                    float *t = P + (uint64_t)col * ldp + (uint64_t)row * g.crs;
+                    t[0] = v.x; t[g.crs] = v.y; t[2u * g.crs] = v.z; t[3u * g.crs] = v.w;
+                    continue;
+                }
                 if (g.beta != 0.f) { // beta == 0 never reads the output
                     const float4 o = *dst;
                     v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
@@ -205,7 +211,9 @@ __device__ __forceinline__ void tr_dma(uint32_t voff, const void *sbase) {
 }
 __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst)); }
 
-template <bool TRANS_A, int NT>
+// B_KMAJ: m2 is given with its COLUMNS contiguous (element (k, n) at b[n + k * ldb]) -- the untransposed m1 of a few-row Gemm computed
+// transposed; its stage image is [32 k][32 n] per column tile, read like the column-major A image.
+template <bool TRANS_A, int NT, bool B_KMAJ = false>
 __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g) {
     constexpr int RING = NT == 1 ? 4 : 3;           // 128 / 144 KiB of LDS: one workgroup per CU
     constexpr int STAGE_BYTES = 4096 * (1 + NT);      // per wave: A 32 rows x 128 B, then B 32 NT columns x 128 B
@@ -223,7 +231,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
     const uint32_t last_chunks = (ke - kb - 32u * (nst - 1u)) / 4u; // valid 16-byte chunks of the last stage: 1 .. 8
 
     // ---- DMA addressing: piece q = rows 8 q .. 8 q + 7 of the wave's 32 (lane -> row 8 q + (lane >> 3), position lane & 7) ----
-    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda), *B = g.b + z * g.b_batch + kb;
+    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda);
+    const float *B = g.b + z * g.b_batch + (B_KMAJ ? (uint64_t)kb * g.ldb : (uint64_t)kb);
     uint32_t a_voff[4], b_voff[4 * NT], a_tail[4], b_tail[4 * NT]; // byte offsets; *_tail: the last stage, k clamped into the matrix
     const uint32_t kmax = g.K - 4u - kb - 32u * (nst - 1u);        // largest valid k offset (in floats) of a chunk in the last stage
 #pragma unroll
@@ -244,19 +253,27 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
     }
 #pragma unroll
     for (int q = 0; q < 4 * NT; ++q) {
+        if constexpr (B_KMAJ) { // piece q & 3 = k rows 8 (q & 3) .. + 7 of column tile q >> 2; 4 columns per lane (N % 4 == 0)
+            const uint32_t kr = 8u * (q & 3) + (lane >> 3);
+            const uint32_t col = min(32u * (q >> 2) + 4u * (lane & 7u), g.N - 4u);
+            b_voff[q] = (kr * g.ldb + col) * 4u + (TR_BIAS - 1024u * (q & 3));
+            b_tail[q] = (min(kr, kmax + 3u) * g.ldb + col) * 4u + (TR_BIAS - 1024u * (q & 3));
+            continue;
+        }
         const uint32_t cl = 8u * q + (lane >> 3);
         const uint32_t chunk = (lane & 7u) ^ ((cl >> 1) & 7u);
         const uint32_t col = min(cl, g.N - 1u);
         b_voff[q] = col * g.ldb * 4u + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
         b_tail[q] = col * g.ldb * 4u + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
     }
+    const uint64_t b_step = B_KMAJ ? (uint64_t)128u * g.ldb : 128u; // bytes per stage (32 k)
     const char *ga0 = (const char *)(TRANS_A ? A + (uint64_t)min(r0, g.M - 1u) * g.lda : A + min(r0, g.M - 4u)) - TR_BIAS;
     const uint64_t a_step = TRANS_A ? 128u : (uint64_t)128u * g.lda; // bytes per stage (32 k)
     const char *gb0 = (const char *)B - TR_BIAS;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (RING * STAGE_BYTES));
     auto issue = [&](uint32_t st) { // stage st -> ring slot st % RING
         const uint32_t dst = lds_wave + (st % RING) * STAGE_BYTES;
-        const char *ga = ga0 + (uint64_t)st * a_step, *gb = gb0 + (uint64_t)st * 128u;
+        const char *ga = ga0 + (uint64_t)st * a_step, *gb = gb0 + (uint64_t)st * b_step;
         const bool tail = st + 1u == nst; // wave-uniform
         tr_set_m0(dst);
         tr_dma<0>(tail ? a_tail[0] : a_voff[0], ga); tr_dma<1024>(tail ? a_tail[1] : a_voff[1], ga);
@@ -302,6 +319,10 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
             float4 bf[NT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
+                if constexpr (B_KMAJ) {
+                    const float *bk = reinterpret_cast<const float *>(sl + 4096u * (1 + u) + (4u * c) * 128u) + i;
+                    bf[u] = make_float4(bk[0], bk[32], bk[64], bk[96]);
+                } else
                 bf[u] = *reinterpret_cast<const float4 *>(sl + 4096u * (1 + u) + rd + ((c ^ sw) * 16u));
                 bf[u] = live ? bf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -330,6 +351,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
             float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
             if (direct) {
                 if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+                if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
+                    float *t = P + (uint64_t)col * ldp + (uint64_t)row * g.crs;
+                    t[0] = v.x; t[g.crs] = v.y; t[2u * g.crs] = v.z; t[3u * g.crs] = v.w;
+                    continue;
+                }
                 if (g.beta != 0.f) {
                     const float4 o = *dst;
                     v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
@@ -344,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
 
 // out = alpha * m1 * m2 + beta * out for N <= 64 (NN only). Returns WG_ERR_UNSUPPORTED-free: the caller checks applicability.
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
-                        wgk_mat m1, wgk_mat m2, float alpha, float beta) {
+                        wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride, bool m2_kmajor) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t row_blocks = (M + 127u) / 128u;
     // K splits: the count whose workgroups fill whole rounds of the CUs with the least k per round (11008 rows = 86 row blocks: 3 splits
@@ -368,7 +394,7 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     if (ns > 1)
         if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
     SkinnyArgs g;
-    g.c = out; g.ldc = out_ld; g.c_batch = out_batch; g.alpha = alpha; g.beta = beta;
+    g.c = out; g.ldc = out_ld; g.c_batch = out_batch; g.alpha = alpha; g.beta = beta; g.crs = out_row_stride;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
@@ -376,7 +402,10 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     // Gemm: the LDS-staged kernel as well (4096 x 64 x 4096 29 vs 38 us, 4096 x 16 x 4096 18.7 vs 20.1), except for one long chunk per row
     // block with <= 32 columns, where the register-streaming kernel is ahead (32000 x 16 x 4096: 110 vs 128 us)
     const bool staged = !(ns == 1 && N <= 32);
-    if (trans) {
+    if (m2_kmajor) { // GemmTr only (the few-row route)
+        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 2, true>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (trans) {
         if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 2>), grid, dim3(256), 0, ctx->stream, g);
     } else if (staged) {
@@ -386,5 +415,6 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (ns == 1) return WG_OK;
+    if (out_row_stride != 1u) return wg_splitk_reduce_strided(ctx, g.part, ns, M, N, nmats, out, out_row_stride, out_ld, out_batch, alpha);
     return wg_splitk_reduce(ctx, g.part, ns, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
 }

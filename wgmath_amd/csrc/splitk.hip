@@ -36,6 +36,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     }
 }
 
+// out[r * rs + c * cs] = alpha * sum_s part[s][c][r]: reads run along r (contiguous), writes are rs apart -- the outputs this serves are small
+__global__ __launch_bounds__(256) void splitk_reduce_strided_kernel(const float *__restrict__ part, uint32_t nsplit, uint32_t M, uint32_t N,
+                                                                    float *__restrict__ out, uint32_t rs, uint32_t cs, uint64_t c_batch, float alpha) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= M) return;
+    const uint32_t col = blockIdx.y, z = blockIdx.z;
+    const uint64_t slab = (uint64_t)M * N;
+    const float *p = part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M + r;
+    float s = p[0];
+    for (uint32_t i = 1; i < nsplit; ++i) s += p[(uint64_t)i * slab];
+    out[z * c_batch + (uint64_t)r * rs + (uint64_t)col * cs] = alpha != 1.f ? s * alpha : s;
+}
+
 } // namespace
 
 // How many K-splits to use (1 = none). `tiles` = output tiles x matrices, `slots` = workgroups the chip holds at once,
@@ -55,6 +68,15 @@ int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M
     const dim3 grid((M / 4u + 255u) / 256u, N, nmats), block(256);
     if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch, alpha, beta);
     else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch, alpha, beta);
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+int wg_splitk_reduce_strided(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, float *out,
+                             uint32_t row_stride, uint32_t col_stride, uint64_t c_batch, float alpha) {
+    if (N > 65535 || nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: N or nmats above 65535");
+    const dim3 grid((M + 255u) / 256u, N, nmats), block(256);
+    hipLaunchKernelGGL(splitk_reduce_strided_kernel, grid, block, 0, ctx->stream, part, nsplit, M, N, out, row_stride, col_stride, c_batch, alpha);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
