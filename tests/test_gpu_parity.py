@@ -746,6 +746,17 @@ def test_gemm_f32_fuzz_few_columns(gpu, seed):
     _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 4) == 0))
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_gemm_f32_fuzz_few_rows(gpu, seed):
+    """M <= 64 with many columns: computed transposed on the few-column GemmTr kernel (operands read in place, output written transposed by
+    the epilogue or the strided split-K reduce) -- both variants, padded views, batches, alpha; beta != 0 falls back to the tiles."""
+    rng = np.random.default_rng(5000 + seed)
+    M = 4 * int(rng.integers(1, 17))
+    N = 4 * int(rng.integers(128, 400)) if seed % 2 else 4 * int(rng.integers(8200, 8600))  # ~33 k columns: no K split
+    K = int(rng.choice([128, 132, 260, 1000, 2052]))
+    _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 2)))
+
+
 def _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, mats, tr):
     wg = _wg()
     ex = bool(rng.integers(0, 2))
