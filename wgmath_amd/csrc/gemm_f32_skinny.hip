@@ -384,7 +384,7 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     for (uint32_t c = 1; c <= max_split && (uint64_t)c * blocks <= 4ull * cus + blocks; ++c) {
         if ((uint64_t)c * M * N * nmats * 4u > (512ull << 20)) break;
         const uint64_t rounds = (blocks * c + cus - 1) / cus;
-        const uint64_t cost = rounds * ((K + c - 1) / c + 48u);
+        const uint64_t cost = rounds * ((K + c - 1) / c + 128u); // + pipeline fill, epilogue and slab per round (11008 x 32 x 4096: 5 splits 49 us, 11 splits 52)
         if (cost < best) { best = cost; ns = c; }
     }
     uint32_t kps = (((K + ns - 1) / ns) + 31u) & ~31u;
