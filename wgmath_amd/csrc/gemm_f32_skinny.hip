@@ -15,6 +15,7 @@
 // Bound: HBM (A is read exactly once: 4 * M * K bytes).
 #include "wg_internal.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 #ifndef WG_SKINNY_ABLATE
 #define WG_SKINNY_ABLATE 0 // experiments: 1 = no B loads, 2 = no MFMAs (results are garbage)
@@ -295,27 +296,20 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
     const uint32_t rd = (uint32_t)i * 128u, sw = (uint32_t)((i >> 1) & 7);
     const char *wbase = smem + wave * (RING * STAGE_BYTES);
     for (uint32_t st = 0; st < (uint32_t)(RING - 1) && st < nst; ++st) issue(st);
-    for (uint32_t st = 0; st < nst; ++st) {
-        // slot (st - 1) % RING was read in the previous trip (lgkmcnt(0) below): refill it with stage st + RING - 1
-        if (st + (uint32_t)(RING - 1) < nst) {
-            issue(st + RING - 1);
-            asm volatile("s_waitcnt vmcnt(%c0)" ::"i"((RING - 1) * PIECES) : "memory"); // stage st has landed
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last RING - 1 stages: nothing more is issued
-        }
-        const char *sl = wbase + (st % RING) * STAGE_BYTES;
-        const uint32_t valid = st + 1u == nst ? last_chunks : 8u;
+    // one stage's MFMAs on ring slot sl. TAIL (the last stage only): chunks at or past `valid` lie outside the K range -- they were fetched from
+    // clamped addresses and are zeroed here. The steady-state instance has no selects: as `live ? load : 0` hipcc sinks the LDS reads into
+    // branches, which costs the overlap of the next substep's reads with this substep's MFMAs.
+    auto compute = [&](const char *sl, auto tail_c, uint32_t valid) {
+        constexpr bool TAIL = decltype(tail_c)::value;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint32_t c = 2u * ks + h;
-            const bool live = c < valid;
             float4 af;
             if constexpr (TRANS_A) af = *reinterpret_cast<const float4 *>(sl + rd + ((c ^ sw) * 16u));
             else { // [k][32 m]: k = 4 c + s, one float per MFMA (lanes i consecutive: conflict-free)
                 const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + i;
                 af = make_float4(ak[0], ak[32], ak[64], ak[96]);
             }
-            af = live ? af : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 bf[NT];
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
@@ -324,7 +318,16 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
                     bf[u] = make_float4(bk[0], bk[32], bk[64], bk[96]);
                 } else
                 bf[u] = *reinterpret_cast<const float4 *>(sl + 4096u * (1 + u) + rd + ((c ^ sw) * 16u));
-                bf[u] = live ? bf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if constexpr (TAIL) {
+                const bool live = c < valid; // select on registers that are already loaded (the empty asm keeps the loads out of a branch)
+                asm volatile("" : "+v"(af.x), "+v"(af.y), "+v"(af.z), "+v"(af.w));
+                af = live ? af : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < NT; ++u) {
+                    asm volatile("" : "+v"(bf[u].x), "+v"(bf[u].y), "+v"(bf[u].z), "+v"(bf[u].w));
+                    bf[u] = live ? bf[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
 #pragma unroll
             for (int sidx = 0; sidx < 4; ++sidx)
@@ -332,8 +335,18 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g
                 for (int u = 0; u < NT; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp4(af, sidx), comp4(bf[u], sidx), acc[u], 0, 0, 0);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this slot's reads are done before the next trip's DMA refills it
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this slot's reads are done before a later trip's DMA refills it
+    };
+    uint32_t st = 0;
+    for (; st + (uint32_t)(RING - 1) < nst; ++st) { // steady state: stage st + RING - 1 exists, so stage st is never the last
+        // slot (st - 1) % RING was read in the previous trip: refill it with stage st + RING - 1, then wait for stage st
+        issue(st + RING - 1);
+        asm volatile("s_waitcnt vmcnt(%c0)" ::"i"((RING - 1) * PIECES) : "memory");
+        compute(wbase + (st % RING) * STAGE_BYTES, std::false_type{}, 8u);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the last <= RING - 1 stages: nothing more is issued
+    for (; st + 1u < nst; ++st) compute(wbase + (st % RING) * STAGE_BYTES, std::false_type{}, 8u);
+    compute(wbase + (st % RING) * STAGE_BYTES, std::true_type{}, last_chunks);
 
     // C/D map: lane (i, h), register e -> row (e&3) + 8 (e>>2) + 4 h of the wave's 32, column i: registers 4 gq .. 4 gq + 3 = 4 consecutive rows
     const bool direct = g.nsplit == 1;
