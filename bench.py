@@ -254,7 +254,7 @@ class FewColumnsGemmWorkload(GemmWorkload):
 
     def __init__(self, name, M, N, K):
         super().__init__(name, M, N, K, "f32")
-        self.kernel = "gemm_f32_skinny_kernel (+ splitk_reduce_kernel)"
+        self.kernel = "gemm_f32_skinny_kernel"
 
     def _bytes(self):
         return 4.0 * (self.M * self.K + self.K * self.N + self.M * self.N)

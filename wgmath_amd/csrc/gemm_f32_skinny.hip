@@ -1,25 +1,18 @@
-// f32 Gemm (NN) with few output columns (N <= 64): the small-batch shape of a matrix applied to a handful of vectors.
+// f32 Gemm / GemmTr with few output columns (N <= 64): the small-batch shape of a matrix applied to a handful of vectors. Few-row products
+// (M <= 64) are computed transposed on the same kernel (gemm_f32.hip, wgk_gemm_f32), and GEMVs with 9-64 right-hand sides land here too.
 //
 // The 256 x 128 tile of gemm_f32.hip spends 50-87 % of its MFMAs on columns that do not exist here (4096 x 16 x 4096: 41 us against
 // 18 us for the vendor's 32 x 16 tile), and the operation is not MFMA-bound anyway: every element of A is used N times, so it is
-// bound by streaming A from HBM like a GEMV. This kernel is built like the GEMV -- no LDS staging, every wave streams its own
-// rows straight from global memory into MFMA operands -- with v_mfma_f32_32x32x2_f32 doing the N dot products per row:
-//   * a workgroup owns 128 rows and one K chunk; its 4 waves take a quarter of the chunk each and are summed through LDS at the end
-//     (fixed order); chunks are further split over grid.y into f32 partial slabs that wg_splitk_reduce adds in ascending order
-//     (deterministic; alpha / beta / output view applied there);
-//   * operands in the layout of gemm_f32.hip: per 8 k, half-wave h takes k = k0 + 4 h + s (s = 0..3); a lane loads, for each s, the
-//     float4 of rows 4 i .. 4 i + 3 of A at that k (512 contiguous bytes per half-wave) -- its components feed four M-tiles, M-tile t
-//     holding rows {4 i + t} -- and one float4 of B (4 consecutive k of column i, k-contiguous) per 32 columns;
-//   * 16 * NT MFMAs per 8 k and wave (NT = 1 or 2 column tiles of 32; columns >= N are zero operands), against 4 + NT 16-byte loads
-//     per lane: the loads run 4 groups of 8 k ahead of the MFMAs (register ring).
-// Bound: HBM (A is read exactly once: 4 * M * K bytes).
+// bound by streaming A from HBM like a GEMV. The kernel below is built for that: every wave owns 32 rows for the whole K range and streams
+// them -- and its own copy of the small B -- through a wave-private LDS ring by LDS-DMA: no barrier, no cross-wave sum. K is split over
+// grid.y into f32 partial slabs that wg_splitk_reduce adds in ascending order (deterministic; alpha / beta / output view applied there);
+// with a single chunk the kernel writes the output itself.
+// History (profiles/r01_evidence.md section 14): a first kernel streamed A straight from global memory into MFMA operands (register ring,
+// 4 waves splitting K, LDS sum) -- 20-40 % slower than this one once its loads overlapped the MFMAs; a shared B stage with one barrier per
+// stage was 50-70 % slower (the waves drift with memory latency); a 16-wide MFMA variant for N <= 16 changed nothing (stream-bound).
 #include "wg_internal.hpp"
 #include <cstdlib>
 #include <type_traits>
-
-#ifndef WG_SKINNY_ABLATE
-#define WG_SKINNY_ABLATE 0 // experiments: 1 = no B loads, 2 = no MFMAs (results are garbage)
-#endif
 
 namespace {
 
@@ -37,160 +30,8 @@ struct SkinnyArgs {
 
 __device__ __forceinline__ float comp4(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
-template <int NT>
-__global__ __launch_bounds__(256) void gemm_f32_skinny_kernel(SkinnyArgs g) {
-    __shared__ floatx16 red[2][4 * NT][64]; // two waves' accumulators
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 31, h = lane >> 5;
-    const uint32_t r0 = blockIdx.x * 128u;
-    const uint32_t z = blockIdx.z, split = blockIdx.y;
-    // this wave's k range: a quarter (multiple of 8) of the workgroup's chunk, clipped to K
-    const uint32_t kq = g.k_per_split / 4u;
-    const uint32_t kb = split * g.k_per_split + wave * kq;
-    const uint32_t ke = min(kb + kq, g.K);
-    // No predicated loads in the loop (hipcc turns `ok ? *p : 0` into a branch around every load): addresses are clamped instead. Rows
-    // past M and columns past N only feed outputs that are never stored; k past the wave's range is loaded (from valid memory) but never
-    // multiplied, except in the one half-filled group at the end of a range, whose missing half is zeroed by selects.
-    const float *A = g.a + z * g.a_batch + min(r0 + 4u * i, g.M - 4u); // M % 4 == 0
-    const float *B = g.b + z * g.b_batch;
-    const uint32_t bcol[2] = { min((uint32_t)i, g.N - 1u), min(32u + (uint32_t)i, g.N - 1u) };
-
-    floatx16 acc[4][NT];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
-
-    auto load = [&](uint32_t k0, float4 (&af)[4], float4 (&bf)[NT]) { // fragments of the 8 k starting at k0 (this half-wave: k0 + 4 h ..)
-        const uint32_t kh = k0 + 4u * h;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) af[s] = wg_ld_nt(reinterpret_cast<const float4 *>(A + (uint64_t)min(kh + s, g.K - 1u) * g.lda));
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-#if WG_SKINNY_ABLATE & 1
-            bf[u] = make_float4(1.f, 2.f, 3.f, (float)kh);
-#else
-            bf[u] = *reinterpret_cast<const float4 *>(B + (uint64_t)bcol[u] * g.ldb + min(kh, g.K - 4u)); // K % 4 == 0
-#endif
-        }
-    };
-    auto mul = [&](const float4 (&af)[4], const float4 (&bf)[NT]) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int u = 0; u < NT; ++u) {
-#if WG_SKINNY_ABLATE & 2
-                    if (s == 0 && t == 0) acc[t][u][0] += comp4(af[s], t) + af[1].y + af[2].z + af[3].w + comp4(bf[u], s);
-#else
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp4(af[s], t), comp4(bf[u], s), acc[t][u], 0, 0, 0);
-#endif
-                }
-    };
-
-    // DEPTH groups of 8 k in flight per wave: with one wave per SIMD a group's MFMAs take ~0.5 us against ~2 us of HBM latency
-#ifndef WG_SKINNY_DEPTH
-#define WG_SKINNY_DEPTH 4
-#endif
-    constexpr int DEPTH = WG_SKINNY_DEPTH;
-    if (kb < ke) {
-        const uint32_t full = (ke - kb) / 8u, half = (ke - kb) & 4u; // whole groups; 4 more k (first half-wave only) or none
-        float4 af[DEPTH][4], bf[DEPTH][NT];
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) load(kb + 8u * d, af[d], bf[d]);
-        // steady state: straight-line code, no condition between a group's MFMAs and the loads that refill its slot -- with branches in
-        // the body hipcc's wait-count pass falls back to vmcnt(0) at every join, and the loads stop overlapping the MFMAs (measured: the
-        // kernel took exactly loads-only + MFMA-only time)
-        uint32_t gidx = 0;
-        for (; gidx + DEPTH <= full; gidx += DEPTH) {
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                mul(af[d], bf[d]);
-                load(kb + 8u * (gidx + d + DEPTH), af[d], bf[d]); // past the range: clamped addresses, values never used
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            if (gidx + d < full) mul(af[d], bf[d]); // the last < DEPTH whole groups are already in the ring (wave-uniform conditions)
-        if (half) { // group `full` sits in ring slot full % DEPTH; its second half-wave's k are outside the range
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                if ((full % DEPTH) == (uint32_t)d) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) af[d][s] = h ? make_float4(0.f, 0.f, 0.f, 0.f) : af[d][s];
-#pragma unroll
-                    for (int u = 0; u < NT; ++u) bf[d][u] = h ? make_float4(0.f, 0.f, 0.f, 0.f) : bf[d][u];
-                    mul(af[d], bf[d]);
-                }
-            }
-        }
-    }
-
-    // sum the 4 waves in a fixed order: (w0 + w2) + (w1 + w3)
-    if (wave >= 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) red[wave - 2][t * NT + u][lane] = acc[t][u];
-    }
-    __syncthreads();
-    if (wave < 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) acc[t][u] += red[wave][t * NT + u][lane];
-    }
-    __syncthreads();
-    if (wave == 1) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) red[0][t * NT + u][lane] = acc[t][u];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    // C/D map of the 32x32 MFMA: lane (i, h), register e -> MFMA row (e&3) + 8 (e>>2) + 4 h, column i. M-tile t holds rows {4 row + t}:
-    // for one (e, u) the four tiles are 4 consecutive rows of column 32 u + i -> one float4 of the slab [col][M]
-    const bool direct = g.nsplit == 1; // one chunk covers K: no slab, alpha / beta and the output view applied here
-    float *P = direct ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
-    const uint32_t ldp = direct ? g.ldc : g.M;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const uint32_t col = 32u * u + i;
-        if (col >= g.N) continue;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const uint32_t row = r0 + 4u * ((e & 3) + 8 * (e >> 2) + 4 * h);
-            if (row >= g.M) continue;
-            const floatx16 *q = &red[0][0][lane];
-            float4 v;
-            v.x = acc[0][u][e] + q[(0 * NT + u) * 64][e];
-            v.y = acc[1][u][e] + q[(1 * NT + u) * 64][e];
-            v.z = acc[2][u][e] + q[(2 * NT + u) * 64][e];
-            v.w = acc[3][u][e] + q[(3 * NT + u) * 64][e];
-            float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
-            if (direct) {
-                if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
-                if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
-                    float *t = P + (uint64_t)col * ldp + (uint64_t)row * g.crs;
-                    t[0] = v.x; t[g.crs] = v.y; t[2u * g.crs] = v.z; t[3u * g.crs] = v.w;
-                    continue;
-                }
-                if (g.beta != 0.f) { // beta == 0 never reads the output
-                    const float4 o = *dst;
-                    v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
-                }
-            }
-            *dst = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
-// The LDS-staged few-column kernel (TRANS_A = true: GemmTr; false: Gemm, see the launcher for when it replaces the streaming kernel above).
+// TRANS_A = true: GemmTr; false: Gemm.
 // GemmTr with few columns (m1 stored K x M: every output row is a k-contiguous column, like the columns of m2). Lanes reading float4s
 // along k of 32 different columns straight from global memory touch 32 cache lines per instruction (measured: no better than the
 // tiles), so here the rows go through LDS, fetched as WHOLE 128-byte lines by LDS-DMA -- and, since every wave owns its own 32 rows for
@@ -215,7 +56,7 @@ __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mo
 // B_KMAJ: m2 is given with its COLUMNS contiguous (element (k, n) at b[n + k * ldb]) -- the untransposed m1 of a few-row Gemm computed
 // transposed; its stage image is [32 k][32 n] per column tile, read like the column-major A image.
 template <bool TRANS_A, int NT, bool B_KMAJ = false>
-__global__ __launch_bounds__(256, 1) void gemm_f32_skinny_tr_kernel(SkinnyArgs g) {
+__global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     constexpr int RING = NT == 1 ? 4 : 3;           // 128 / 144 KiB of LDS: one workgroup per CU
     constexpr int STAGE_BYTES = 4096 * (1 + NT);      // per wave: A 32 rows x 128 B, then B 32 NT columns x 128 B
     constexpr int PIECES = 4 * (1 + NT);              // DMA pieces per wave and stage
@@ -412,20 +253,14 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
     const dim3 grid(row_blocks, ns, nmats);
-    // Gemm: the LDS-staged kernel as well (4096 x 64 x 4096 29 vs 38 us, 4096 x 16 x 4096 18.7 vs 20.1), except for one long chunk per row
-    // block with <= 32 columns, where the register-streaming kernel is ahead (32000 x 16 x 4096: 110 vs 128 us)
-    const bool staged = !(ns == 1 && N <= 32);
     if (m2_kmajor) { // GemmTr only (the few-row route)
-        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
-        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 2, true>), grid, dim3(256), 0, ctx->stream, g);
+        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2, true>), grid, dim3(256), 0, ctx->stream, g);
     } else if (trans) {
-        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
-        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<true, 2>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (staged) {
-        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<false, 1>), grid, dim3(256), 0, ctx->stream, g);
-        else hipLaunchKernelGGL((gemm_f32_skinny_tr_kernel<false, 2>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (N <= 32) hipLaunchKernelGGL(gemm_f32_skinny_kernel<1>, grid, dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL(gemm_f32_skinny_kernel<2>, grid, dim3(256), 0, ctx->stream, g);
+        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 1>), grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 2>), grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (ns == 1) return WG_OK;
     if (out_row_stride != 1u) return wg_splitk_reduce_strided(ctx, g.part, ns, M, N, nmats, out, out_row_stride, out_ld, out_batch, alpha);
