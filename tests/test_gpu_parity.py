@@ -746,6 +746,20 @@ def test_gemm_f32_fuzz_few_columns(gpu, seed):
     _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 4) == 0))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_f32_fuzz_column_panels(gpu, seed):
+    """64-column panels of the few-column kernel (what small squares run on), forced for ragged sizes, batches, both variants, alpha / beta."""
+    import os
+    rng = np.random.default_rng(6000 + seed)
+    M, N = 4 * int(rng.integers(32, 300)), 4 * int(rng.integers(17, 200))
+    K = int(rng.choice([128, 132, 516, 1024]))
+    os.environ["WG_F32_PANELS"] = "1"
+    try:
+        _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 2)))
+    finally:
+        os.environ.pop("WG_F32_PANELS", None)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_gemm_f32_fuzz_few_rows(gpu, seed):
     """M <= 64 with many columns: computed transposed on the few-column GemmTr kernel (operands read in place, output written transposed by

@@ -23,6 +23,7 @@ struct SkinnyArgs {
     const float *b; uint32_t ldb; uint64_t b_batch;
     float *part;               // slabs [z][split][N][M] (nsplit > 1)
     float *c; uint32_t ldc; uint64_t c_batch; float alpha, beta; // the output view: written directly when nsplit == 1
+    uint32_t npanels;          // blockIdx.z = matrix * npanels + column panel of 32 NT columns (1: the whole of a few-column output)
     uint32_t crs;              // element stride between consecutive ROWS of the output (1; != 1: the caller wants it transposed, beta == 0)
     uint32_t M, N, K;
     uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     const uint32_t r0 = blockIdx.x * 128u + 32u * wave;
-    const uint32_t z = blockIdx.z, split = blockIdx.y;
+    const uint32_t z = blockIdx.z / g.npanels, col0 = (blockIdx.z % g.npanels) * (32u * NT), split = blockIdx.y;
     const uint32_t kb = split * g.k_per_split;             // multiple of 32
     const uint32_t ke = min(kb + g.k_per_split, g.K);
     if (kb >= ke) return;                                   // (the launcher leaves no empty split)
@@ -97,21 +98,21 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     for (int q = 0; q < 4 * NT; ++q) {
         if constexpr (B_KMAJ) { // piece q & 3 = k rows 8 (q & 3) .. + 7 of column tile q >> 2; 4 columns per lane (N % 4 == 0)
             const uint32_t kr = 8u * (q & 3) + (lane >> 3);
-            const uint32_t col = min(32u * (q >> 2) + 4u * (lane & 7u), g.N - 4u);
+            const uint32_t col = min(col0 + 32u * (q >> 2) + 4u * (lane & 7u), g.N - 4u);
             b_voff[q] = (kr * g.ldb + col) * 4u + (TR_BIAS - 1024u * (q & 3));
             b_tail[q] = (min(kr, kmax + 3u) * g.ldb + col) * 4u + (TR_BIAS - 1024u * (q & 3));
             continue;
         }
         const uint32_t cl = 8u * q + (lane >> 3);
         const uint32_t chunk = (lane & 7u) ^ ((cl >> 1) & 7u);
-        const uint32_t col = min(cl, g.N - 1u);
+        const uint32_t col = min(cl, g.N - 1u - col0); // relative to the panel's first column (gb0 below)
         b_voff[q] = col * g.ldb * 4u + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
         b_tail[q] = col * g.ldb * 4u + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
     }
     const uint64_t b_step = B_KMAJ ? (uint64_t)128u * g.ldb : 128u; // bytes per stage (32 k)
     const char *ga0 = (const char *)(TRANS_A ? A + (uint64_t)min(r0, g.M - 1u) * g.lda : A + min(r0, g.M - 4u)) - TR_BIAS;
     const uint64_t a_step = TRANS_A ? 128u : (uint64_t)128u * g.lda; // bytes per stage (32 k)
-    const char *gb0 = (const char *)B - TR_BIAS;
+    const char *gb0 = (const char *)(B_KMAJ ? B : B + (uint64_t)col0 * g.ldb) - TR_BIAS;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (RING * STAGE_BYTES));
     auto issue = [&](uint32_t st) { // stage st -> ring slot st % RING
         const uint32_t dst = lds_wave + (st % RING) * STAGE_BYTES;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     const uint32_t ldp = direct ? g.ldc : g.M;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const uint32_t col = 32u * u + i;
+        const uint32_t col = col0 + 32u * u + i;
         if (col >= g.N) continue;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
 
 // out = alpha * m1 * m2 + beta * out for N <= 64 (NN only). Returns WG_ERR_UNSUPPORTED-free: the caller checks applicability.
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
-                        wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride, bool m2_kmajor) {
+                        wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride, bool m2_kmajor, uint32_t ns_force) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t row_blocks = (M + 127u) / 128u;
     // K splits: the count whose workgroups fill whole rounds of the CUs with the least k per round (11008 rows = 86 row blocks: 3 splits
@@ -232,7 +233,10 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     // per CU beats several short ones (4096 x 16 x 4096: 24 us with 256 workgroups, 32 us with 1024), so ties go to fewer splits and
     // every extra split is charged the k-equivalent of its slab + epilogue.
     const uint32_t max_split = (K + 127u) / 128u; // >= 128 k per workgroup
-    const uint64_t blocks = (uint64_t)row_blocks * nmats;
+    // more than 64 columns (small squares, see wgk_gemm_f32): 64-column panels over grid.z, every panel streaming A from L2
+    const uint32_t npanels = N > 64u ? (N + 63u) / 64u : 1u;
+    if ((uint64_t)nmats * npanels > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many matrices x column panels");
+    const uint64_t blocks = (uint64_t)row_blocks * nmats * npanels;
     uint32_t ns = 1;
     uint64_t best = ~0ull;
     for (uint32_t c = 1; c <= max_split && (uint64_t)c * blocks <= 4ull * cus + blocks; ++c) {
@@ -241,6 +245,7 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
         const uint64_t cost = rounds * ((K + c - 1) / c + 128u); // + pipeline fill, epilogue and slab per round (11008 x 32 x 4096: 5 splits 49 us, 11 splits 52)
         if (cost < best) { best = cost; ns = c; }
     }
+    if (ns_force) ns = ns_force > max_split ? max_split : ns_force;
     uint32_t kps = (((K + ns - 1) / ns) + 31u) & ~31u;
     ns = (K + kps - 1) / kps;
     if (ns > 65535u || nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many splits or matrices for the skinny path");
@@ -251,8 +256,8 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.c = out; g.ldc = out_ld; g.c_batch = out_batch; g.alpha = alpha; g.beta = beta; g.crs = out_row_stride;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
-    g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps;
-    const dim3 grid(row_blocks, ns, nmats);
+    g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = npanels;
+    const dim3 grid(row_blocks, ns, nmats * npanels);
     if (m2_kmajor) { // GemmTr only (the few-row route)
         if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2, true>), grid, dim3(256), 0, ctx->stream, g);

@@ -98,7 +98,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
-                        wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false);
+                        wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 
