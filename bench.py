@@ -75,6 +75,29 @@ def device_random(wg, gpu, shape, dtype, seed):
 # ------------------------------------------------------------------------------------------------------------
 # workloads
 # ------------------------------------------------------------------------------------------------------------
+DIST = None  # set by main() for multi-rank runs: {"comm": Comm, "mode": "rccl"|"peer", "barrier": fn, "all_gather_object": fn}
+
+
+def plan_panel_cols(Mg: int, N: int, cus: int, tile: int = 256, target_panels: int = 16) -> int:
+    """Width of the N-panels of the sharded Gemm: a whole number of rounds of `cus` workgroups per panel (a Gemm workgroup owns a CU,
+    so a panel of 1.3 rounds costs 2), as many panels as that allows up to `target_panels` (panel i's exchange hides under panel
+    i+1's Gemm; only the last one is exposed), at least 2 when N allows."""
+    tiles_m = max(1, -(-Mg // tile))
+    tcols = max(1, N // tile)
+    best = None
+    for c in range(1, tcols + 1):
+        npan = -(-tcols // c)
+        if npan < 2 and tcols >= 2:
+            break
+        t = tiles_m * c
+        waste = (-(-t // cus)) * cus / t  # launched rounds / useful rounds
+        score = (round(waste, 3), abs(npan - target_panels))
+        if best is None or score < best[0]:
+            best = (score, c)
+    c = best[1] if best else tcols
+    return min(N, c * tile)
+
+
 class Workload:
     name = ""
     dtype = "f32"
@@ -109,101 +132,76 @@ class GemmWorkload(Workload):
             self.kernel = "gemm_f32_kernel + splitk_reduce_kernel"
 
     def setup(self, wg, gpu, rank, world):
-        from wgmath_amd.sharded import MShardPlan, ShardedGemm
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
-        # N-panels: the all-gather of panel i overlaps the GEMM of panel i+1 (only meaningful with > 1 rank)
-        self.dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
-        # Panel count: enough panels to overlap the all-gather with compute, but >= ~512 output tiles (256 x 256) per launch:
-        # the f16 GEMM workgroup needs a whole CU, so CUs occupied by RCCL's copy kernels are unavailable to it and a panel of
-        # exactly 256 tiles (8 ranks: 4096 x 4096 per panel) would take two rounds instead of one.
-        tiles = (self.M // max(world, 1) // 256) * (self.N // 256)
-        npanels = 1 if not self.dist_mode else max(1, min(8, tiles // 512, self.N // 2048))
-        panel_cols = None
-        cus = int(gpu.adapter().get("stream_compute_units") or gpu.adapter()["compute_units"])
-        if self.dist_mode and self.np_dtype == np.float16 and self.M % (256 * world) == 0 and self.N % 256 == 0:
-            # The compute stream may use `cus` CUs (bench main(): the rest is left to RCCL's copy kernels). Size the panels to a whole
-            # number of rounds of `cus` workgroups (a 256 x 256 tile each): c tile-columns per panel with the least idle CUs in the
-            # last round, between ~1 and ~4 rounds per panel (enough panels to overlap, few enough launches), + one remainder panel.
-            tiles_m, tcols = self.M // world // 256, self.N // 256
-            best = None
-            for c in range(1, tcols + 1):
-                t = tiles_m * c
-                rounds = -(-t // cus)
-                if rounds > 8 or tcols // c < 2:
-                    continue
-                score = (round(rounds * cus / t, 6), abs(rounds - 2))  # least idle CUs first, then closest to 2 rounds per panel
-                if best is None or score < best[0]:
-                    best = (score, c)
-            if best is not None:
-                c = best[1]
-                cols = [256 * c] * (tcols // c) + ([256 * (tcols % c)] if tcols % c else [])
-                panel_cols, npanels = tuple(cols), len(cols)
-        self.plan = plan = MShardPlan(self.M, self.N, self.K, world, npanels, panel_cols)
-        self.Mg = plan.Mg  # this rank's rows: A_g = A[g*Mg:(g+1)*Mg, :], its own contiguous col-major tensor
+        # M-shard: rank g owns A_g = A[g*Mg:(g+1)*Mg, :] as its own contiguous col-major tensor, B is replicated, every rank ends with
+        # the full M x N column-major C (wgmath_amd/csrc/comm.hip). DIST is set by main() when the run has a communicator.
+        self.dist = DIST if (DIST is not None and DIST.get("comm") is not None) else None
+        if self.M % (4 * world):
+            raise ValueError(f"M={self.M} does not split into {world} vec4-aligned row blocks")
+        self.Mg = self.M // world
         self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
         self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
+        S = wg.BufferUsages
+        self.C = wg.TensorBuilder.matrix(self.M, self.N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(gpu.device(), self.np_dtype)
         self.gemm = wg.Gemm.from_device(gpu.device())
         self.shapes = wg.ViewShapeBuffers()
-        self.torch_out = None
-        S = wg.BufferUsages
-        if not self.dist_mode:
-            self.C = wg.TensorBuilder.vector(plan.gathered_elems(), S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
-        else:
-            import torch
-            tdt = torch.float32 if self.dtype == "f32" else torch.float16
-            # the gathered buffer [panel][rank][np*Mg]; per panel a GpuCube [Mg, np, world] (wgmath_amd/sharded.py)
-            self.torch_out = torch.empty(plan.gathered_elems(), dtype=tdt, device=f"cuda:{gpu._ctx.device_index}")
-            self.C = wg.GpuTensor.wrap(gpu.device(), self.torch_out.data_ptr(), (plan.gathered_elems(),), self.np_dtype,
-                                       keepalive=self.torch_out)
         self.enc = gpu.device().create_command_encoder()
         self.pass_ = self.enc.compute_pass("bench", None)
-        a_view = self.A.as_embedded_view(3)
+        self.variant = wg.GemmVariant.GemmTr if self.trans else wg.GemmVariant.Gemm
+        self.mode, self.panel_cols, self.npanels = None, 0, 1
+        if self.dist is not None:
+            self.set_mode(self.dist["mode"])
 
-        variant = wg.GemmVariant.GemmTr if self.trans else wg.GemmVariant.Gemm
-
-        def local_gemm(out_shape, a_shape, b_shape):
-            self.gemm.dispatch_generic(gpu.device(), self.shapes, self.pass_, wg.GpuTensorView(out_shape, self.C, 2), a_view,
-                                       wg.GpuTensorView(b_shape, self.B, 2), variant)
-
-        def all_gather(start, count, rk):
-            import torch
-            import torch.distributed as dist
-            ext = getattr(gpu, "_torch_ext_stream", None)
-            if ext is not None:  # the GEMMs run on the library's own (CU-masked) stream: the collective must wait for it
-                torch.cuda.current_stream().wait_stream(ext)
-            out = self.torch_out[start:start + world * count]
-            return dist.all_gather_into_tensor(out, out[rk * count:(rk + 1) * count], async_op=True)
-
-        self.driver = ShardedGemm(plan, rank, local_gemm, all_gather, wait=lambda w: w.wait(), always_gather=self.dist_mode)
+    def set_mode(self, mode):
+        """Exchange engine of the sharded run: "rccl" (staging cube + ncclAllGather + relayout) or "peer" (SDMA pushes)."""
+        from wgmath_amd.sharded import GatherMode
+        comm, world = self.dist["comm"], self.world
+        self.mode = mode
+        cus = int(self.gpu.adapter().get("stream_compute_units") or self.gpu.adapter()["compute_units"])
+        self.panel_cols = plan_panel_cols(self.Mg, self.N, cus, tile=256 if self.dtype == "f16" else 128)
+        self.npanels = -(-self.N // self.panel_cols)
+        self.gather_mode = GatherMode.PEER_COPY if mode == "peer" else GatherMode.RCCL
+        if mode == "peer" and world > 1 and not getattr(self, "_peers_registered", False):
+            handles = self.dist["all_gather_object"](comm.export_handle(self.C))
+            comm.register_peers(self.C, handles)
+            self._peers_registered = True
 
     def step(self):
-        self.driver.step()
-        ext = getattr(self.gpu, "_torch_ext_stream", None)
-        if ext is not None:
-            # a step is self-contained: the next step's GEMMs (library stream) start after this step's all-gathers (torch's stream,
-            # which step() just made wait for them) -- no overlap across steps
-            import torch
-            ext.wait_stream(torch.cuda.current_stream())
+        if self.dist is None:
+            self.gemm.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.C, self.A, self.B, self.variant)
+            return
+        comm = self.dist["comm"]
+        comm.sharded_gemm(self.C, self.A, self.B, int(self.variant), self.gather_mode, self.panel_cols)
+        if self.mode == "peer" and self.world > 1:
+            # a step is self-contained: every rank's pushes have landed before the next step's Gemms overwrite C
+            if comm.has_collectives:
+                comm.barrier()
+            else:
+                self.gpu.sync()
+                comm.flush()
+                self.dist["barrier"]()
 
     def units_per_step(self):
         return 2.0 * self.M * self.N * self.K
 
     def algorithmic_per_launch(self):
-        return 2.0 * self.Mg * self.N * self.K / self.plan.npanels  # mean over the launches of a step (one launch = one N-panel of this rank's row block)
+        return 2.0 * self.Mg * self.N * self.K / self.npanels  # mean over the launches of a step (one launch = one N-panel of this rank's row block)
 
     def launches_per_step(self):
-        return self.plan.npanels
+        return self.npanels
+
+    def gather_bytes_per_step(self):
+        """Payload this rank receives per step from the other ranks (the all-gather of C)."""
+        return (self.world - 1) * self.Mg * self.N * np.dtype(self.np_dtype).itemsize
 
     def check(self):
-        # sampled (row, column-block) entries of this rank's C_g against f64 on the host
-        gpu, pl = self.gpu, self.plan
+        # sampled entries of C against f64 on the host: this rank's own rows always; with a communicator also rows the OTHER ranks
+        # computed and pushed / gathered here (their A blocks are regenerated from the seed: device_random is deterministic)
+        gpu = self.gpu
         rng = np.random.default_rng(1)
-        rows = np.unique(rng.integers(0, self.Mg, 6))
         cols = np.unique(rng.integers(0, self.N, 24))
         item = np.dtype(self.np_dtype).itemsize
         from wgmath_amd._lib import check, lib
-        A = self.A.read(gpu.device())
-        A = (A.reshape(self.K, self.Mg, order="F").T if self.trans else A.reshape(self.Mg, self.K, order="F"))[rows].astype(np.float64)
 
         def read_range(t, start, n):
             out = np.empty(n, self.np_dtype)
@@ -211,14 +209,24 @@ class GemmWorkload(Workload):
             return out
 
         Bc = np.stack([read_range(self.B, c * self.K, self.K) for c in cols], axis=1).astype(np.float64)  # K x ncols
-        got = np.empty((rows.size, cols.size))
-        for jc, c in enumerate(cols):
-            colbuf = read_range(self.C, pl.element_index(self.rank * self.Mg, int(c)), self.Mg)
-            got[:, jc] = colbuf[rows]
-        truth, sabs = A @ Bc, np.abs(A) @ np.abs(Bc)
-        tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
-        err = np.abs(got - truth)
-        assert (err <= tol).all(), f"bench sanity check failed: worst err/tol {(err / tol).max():.3g}"
+        owners = [self.rank] if (self.dist is None or self.world == 1) else sorted({self.rank, (self.rank + 1) % self.world, (self.rank - 1) % self.world})
+        for g in owners:
+            rows = np.unique(rng.integers(0, self.Mg, 6))
+            if g == self.rank:
+                A = self.A.read(gpu.device())
+            else:  # the peer's row block, regenerated the way device_random filled it (one seeded block, tiled)
+                n = self.Mg * self.K
+                blk = rand_block(0xA000 + g, min(n, 1 << 24), self.np_dtype)
+                A = np.resize(blk, n)
+            A = (A.reshape(self.K, self.Mg, order="F").T if self.trans else A.reshape(self.Mg, self.K, order="F"))[rows].astype(np.float64)
+            got = np.empty((rows.size, cols.size))
+            for jc, c in enumerate(cols):
+                colbuf = read_range(self.C, int(c) * self.M + g * self.Mg, self.Mg)
+                got[:, jc] = colbuf[rows]
+            truth, sabs = A @ Bc, np.abs(A) @ np.abs(Bc)
+            tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
+            err = np.abs(got - truth)
+            assert (err <= tol).all(), f"bench sanity check failed (rows of rank {g} as seen on rank {self.rank}): worst err/tol {(err / tol).max():.3g}"
 
     def cpu_baseline(self, budget_s):
         # The reference's only GEMM is the f32 WGSL kernel; its CPU port is timed on a slice with the SAME K
@@ -523,7 +531,7 @@ def load_traffic(workload: str):
         return None
 
 
-def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0):
+def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0, keep=True):
     """Times EXACTLY `steps` steps (after `warmup` untimed ones). With min_seconds > 0 (secondary configs only) `steps` is raised
     so that the timed region lasts at least that long: millisecond kernels timed for a few tens of ms still see the clocks
     ramping (measured: f32 GEMM 140 TF over 30 ms vs 148 TF sustained)."""
@@ -554,7 +562,7 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     kernel_ms = (ev[1] - ev[0]) / (steps * launches)  # HIP events on the stream the kernels run on
     if not os.environ.get("WG_BENCH_NO_CHECK"):
         w.check()
-    res = {"workload": w, "elapsed": elapsed, "kernel_ms": kernel_ms, "steps": steps}
+    res = {"workload": w if keep else None, "elapsed": elapsed, "kernel_ms": kernel_ms, "steps": steps}
     res["cpu"] = w.cpu_baseline(cpu_budget) if (with_cpu and rank == 0 and world == 1) else None
     return res
 
@@ -572,6 +580,93 @@ def summarize(w, elapsed, kernel_ms, steps, world):
     return value, roof
 
 
+def free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one process per GPU) as CHILDREN of this process --
+    which has not touched the GPU and never will (no exec of a GPU-initialised process) -- relay rank 0's single JSON line,
+    and fail if any rank fails."""
+    import subprocess
+    if not args.dry_run:
+        import torch  # device_count() does not initialise the GPU on this image
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and os.environ.get("WG_BENCH_OVERSUBSCRIBE") != "1":
+            log(f"bench.py --gpus {args.gpus}: only {ndev} GPU(s) visible on this node; one process per GPU is required "
+                f"(WG_BENCH_OVERSUBSCRIBE=1 shares GPUs between ranks for plumbing tests: peer copies only, RCCL refuses it)")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL, hipIpcGetMemHandle)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching:", " ".join(cmd))
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)  # stderr passes through
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if r.returncode != 0 or not lines:
+        sys.stderr.write(r.stdout)
+        log(f"[bench] the {args.gpus}-rank run failed (rc {r.returncode})")
+        return r.returncode or 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+def dry_run(args, rank, world) -> None:
+    """--dry-run: the launcher / rendezvous / max-over-ranks / one-JSON-line plumbing of a multi-rank run WITHOUT a GPU (gloo, host
+    arithmetic): the M-shard planner and the pipelined all-gather driver (wgmath_amd/sharded.py) with a NumPy GEMM standing in for
+    the HIP kernel. Test infrastructure for tests/test_bench_launcher.py; its line says so and carries no roofline."""
+    import torch
+    import torch.distributed as dist
+    from wgmath_amd.sharded import MShardPlan, ShardedGemm  # loads the built library (no fallback), touches no GPU
+    dist.init_process_group("gloo")
+    M, N, K = 64 * world, 96, 32
+    pl = MShardPlan(M, N, K, world, npanels=3)
+    rng = np.random.default_rng(7)
+    A, B = rng.standard_normal((M, K)).astype(np.float32), rng.standard_normal((K, N)).astype(np.float32)
+    r0, nr = pl.a_rows(rank)
+    a_g, b_flat = np.ascontiguousarray(A[r0:r0 + nr].reshape(-1, order="F")), B.reshape(-1, order="F")
+    gathered = torch.zeros(pl.gathered_elems(), dtype=torch.float32)
+    g_np = gathered.numpy()
+
+    def idx(sh):
+        return sh.offset + np.arange(sh.size[0])[:, None] + np.arange(sh.size[1])[None, :] * sh.stride
+
+    def local_gemm(o, a, b):
+        g_np[idx(o)] = a_g[idx(a)] @ b_flat[idx(b)]
+
+    def all_gather(start, count, rk):
+        outs = [gathered[start + g * count:start + (g + 1) * count] for g in range(world)]
+        return dist.all_gather(outs, gathered[start + rk * count:start + (rk + 1) * count].clone(), async_op=True)
+
+    drv = ShardedGemm(pl, rank, local_gemm, all_gather, wait=lambda w: w.wait())
+    for _ in range(args.warmup):
+        drv.step()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.step()
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    C = A @ B
+    ok = all(abs(g_np[pl.element_index(r, c)] - C[r, c]) < 1e-3 for r in range(0, M, 7) for c in range(0, N, 5))
+    if not ok:
+        raise SystemExit("dry-run: gathered product is wrong")
+    if rank == 0:
+        elapsed = float(el.item())
+        print(json.dumps({"metric": "dry_run_gemm_tflops", "value": round(2.0 * M * N * K * args.steps / elapsed / 1e12, 9), "unit": "TFLOP/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                          "data": "dry-run: host arithmetic over gloo, no GPU (launcher plumbing test)",
+                          "config": {"workload": f"dry_run_{M}x{N}x{K}", "ranks": dist.get_world_size(),
+                                     "parallelism": f"m-shard x{world} + gloo all-gather (dry run)",
+                                     "all_gather_bytes_per_step": (world - 1) * pl.Mg * N * 4}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,18 +678,25 @@ def main():
     ap.add_argument("--skip", default="", help="comma-separated secondary workloads to skip (e.g. under rocprofv3)")
     ap.add_argument("--secondary-seconds", type=float, default=0.6, help="minimum timed duration of each secondary config")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
+    ap.add_argument("--gather", default=os.environ.get("WG_BENCH_GATHER", "auto"), choices=["auto", "rccl", "peer"],
+                    help="exchange engine of the M-sharded Gemm with N > 1 ranks: RCCL all-gather (+ relayout), SDMA peer copies, or "
+                         "auto = time both during warm-up and run the timed steps on the faster one")
+    ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing test without a GPU (gloo, host arithmetic)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))  # before anything touches the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs one process per GPU: launch with "
-                     f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py ...`")
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
-    # WG_BENCH_FORCE_DIST=1: take the torch.distributed/RCCL path even with one rank (single-GPU test of the N > 1 plumbing)
+    global DIST
+    # WG_BENCH_FORCE_DIST=1: take the communicator path even with one rank (single-GPU test of the N > 1 plumbing: RCCL with one rank)
     dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
     if dist_mode:
         # torch bundles its own ROCm runtime (same soname as /opt/rocm's): it must be loaded FIRST so that libwgebra_hip.so
@@ -602,6 +704,7 @@ def main():
         import torch  # noqa: F401
     import wgmath_amd as wg
 
+    oversub = False
     if dist_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -610,33 +713,56 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch
         import torch.distributed as dist
-        # CU partitioning between compute and communication. Every f16 GEMM workgroup needs a whole CU (160 KiB LDS, 512 registers per
-        # lane), so a copy kernel of the collective library, launched from a second queue while a GEMM grid is resident, only gets CUs
-        # when GEMM workgroups retire -- measured with tools/overlap_probe.py: its workgroups start ~0.75-1.4 ms late, i.e. the
-        # all-gather of panel i would barely overlap the GEMM of panel i+1. So the GEMM stream is CU-masked to leave `comm_cus` CUs
-        # free: the copy kernels (small workgroups, several fit on one CU) then start within ~20 us of their launch. 32 = one CU per
-        # shader engine of every XCD (a mask that is not a multiple of 32 unbalances the shader engines: 240 CUs ran 20 % slower than
-        # 224). Per tile the GEMM is ~4 % slower on 224 CUs than on 256 shared with a copy kernel (tools/overlap_probe2.py).
+        from wgmath_amd.sharded import Comm, new_unique_id
+        ndev = torch.cuda.device_count()
+        oversub = world > ndev  # WG_BENCH_OVERSUBSCRIBE: ranks share GPUs -- RCCL refuses that, so gloo is the control plane and the
+        dev_index = local_rank % max(ndev, 1)  # data plane is peer copies between the ranks' buffers on the shared device
+        torch.cuda.set_device(dev_index)
+        # torch.distributed is the CONTROL plane only (launch contract: rendezvous, barrier, max-over-ranks, shipping the unique id and
+        # the IPC handles); the data plane -- RCCL all-gather or SDMA peer copies -- is driven by libwgebra_hip.so itself (wg_comm_*)
+        if oversub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        total_cus = torch.cuda.get_device_properties(dev_index).multi_processor_count
+        gather = args.gather if not oversub else "peer"
+        # CU partitioning between compute and communication. Every f16 GEMM workgroup needs a whole CU (160 KiB
+        # LDS, 512 registers per lane), so RCCL's copy kernels, launched from a second queue while a GEMM grid is resident, only get CUs
+        # when GEMM workgroups retire (tools/overlap_probe.py: they start ~0.75-1.4 ms late). For the RCCL engine the GEMM stream is
+        # therefore CU-masked to leave `comm_cus` CUs free (32 = one per shader engine of every XCD; masks that are not a multiple of 32
+        # unbalance the shader engines). The peer-copy engine moves the blocks with the SDMA engines: no mask, all 256 CUs compute.
         comm_cus = int(os.environ.get("WG_BENCH_COMM_CUS", "32"))
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        total_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-        gpu = None
-        if comm_cus > 0 and total_cus > 2 * comm_cus:
-            try:
-                gpu = wg.GpuInstance.new(local_rank, cu_count=total_cus - comm_cus)
-                gpu._torch_ext_stream = torch.cuda.ExternalStream(gpu.stream(), device=torch.device(f"cuda:{local_rank}"))
-            except Exception as e:  # no CU-masked stream on this runtime: share torch's stream (the transport is unchanged)
-                log(f"[bench] CU-masked compute stream unavailable ({e}); sharing torch's stream")
-                gpu = None
-        if gpu is None:
-            # share torch's current stream so that the GEMM and the all-gather are ordered without extra events
-            gpu = wg.GpuInstance.new(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+        def make_gpu(masked):
+            if masked and comm_cus > 0 and total_cus > 2 * comm_cus:
+                try:
+                    return wg.GpuInstance.new(dev_index, cu_count=total_cus - comm_cus)
+                except Exception as e:  # no CU-masked stream on this runtime
+                    log(f"[bench] CU-masked compute stream unavailable ({e}); using an unmasked stream")
+            return wg.GpuInstance.new(dev_index)
+
+        def bcast_id():
+            box = [new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        def all_gather_object(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
 
         def barrier():
             gpu.sync()
             dist.barrier()
             torch.cuda.synchronize()
+
+        engines = {}  # mode -> (GpuInstance, Comm)
+        for mode in (["rccl", "peer"] if gather == "auto" else [gather]):
+            g = make_gpu(masked=(mode == "rccl" and world > 1))
+            engines[mode] = (g, Comm(g, world, rank, None if oversub else bcast_id()))
+        first = "rccl" if "rccl" in engines else "peer"
+        gpu, comm = engines[first]
+        DIST = {"comm": comm, "mode": first, "barrier": lambda: dist.barrier(), "all_gather_object": all_gather_object}
     else:
         gpu = wg.GpuInstance.new(local_rank)
 
@@ -647,13 +773,42 @@ def main():
     _pad = None
     if os.environ.get("WG_BENCH_PAD"):  # experiment hook: shift every later allocation by this many bytes
         _pad = wg.TensorBuilder.vector(int(os.environ["WG_BENCH_PAD"]) // 4, wg.BufferUsages.STORAGE).build(gpu.device(), np.float32)
+
+    dist_report = None
+    if dist_mode and len(engines) > 1:
+        # auto: a short untimed trial of both engines (warm-up steps each, max over ranks), then the contract's timed run on the faster;
+        # an engine that fails on this node (e.g. no peer mapping) is reported and skipped, never silently replaced
+        import torch
+        import torch.distributed as dist
+        trial = {}
+        for mode, (g, cm) in engines.items():
+            DIST.update(comm=cm, mode=mode)
+            gpu = g
+            try:
+                r = run_workload(wg, g, args.workload, max(2, args.warmup), 1, rank, world, barrier, False, 0.0, keep=False)
+                el = r["elapsed"] / r["steps"]
+                err = None
+            except Exception as e:
+                el, err = float("inf"), f"{type(e).__name__}: {e}"
+            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{dev_index}" if not oversub else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[mode] = {"ms_per_step": None if not np.isfinite(float(t.item())) else round(float(t.item()) * 1e3, 4), "error": err}
+        ok = {m: v["ms_per_step"] for m, v in trial.items() if v["ms_per_step"] is not None}
+        if not ok:
+            sys.exit(f"no exchange engine works on this node: {trial}")
+        best = min(ok, key=ok.get)
+        gpu, comm = engines[best]
+        DIST.update(comm=comm, mode=best)
+        dist_report = {"engine_trials": trial, "chosen": best}
+        info = gpu.adapter()
+
     main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
                             not args.no_cpu_baseline, args.cpu_budget)
     elapsed = main_res["elapsed"]
     if dist_mode:
         import torch
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversub else f"cuda:{dev_index}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     w = main_res["workload"]
@@ -662,9 +817,20 @@ def main():
     main_cpu = main_res["cpu"]
     main_res = None  # release the headline workload's buffers before the secondary configs allocate theirs
     w_name, w_metric, w_unit, w_dtype, w_is_gemm = w.name, w.metric, w.unit, w.dtype, isinstance(w, GemmWorkload)
+    par = f"replicas x{world}"
+    cfg_extra = {}
+    if dist_mode and w_is_gemm:
+        engine = {"rccl": "RCCL all-gather", "peer": f"peer-copy gather ({DIST['comm'].copy_engine})"}[DIST["mode"]]
+        par = f"m-shard x{world} + {engine}"
+        cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels,
+                     "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"])}
+        if dist_report:
+            cfg_extra.update(dist_report)
+        if oversub:
+            cfg_extra["oversubscribed"] = f"{world} ranks on {ndev} GPU(s): plumbing test, not a scaling number"
     w = None
     others = []
-    if world == 1 and not args.no_secondary:
+    if world == 1 and not dist_mode and not args.no_secondary:
         for name in SECONDARY:
             if name == args.workload or name in args.skip.split(","):
                 continue
@@ -677,10 +843,11 @@ def main():
             except Exception as e:  # a secondary config must never take the headline down with it
                 others.append({"workload": name, "error": f"{type(e).__name__}: {e}"})
 
-    if dist_mode and not args.no_secondary:
+    if dist_mode and not args.no_secondary and not oversub:
         import torch
         import torch.distributed as dist
-        gpu_all = wg.GpuInstance.new(local_rank)  # its own stream, all CUs: no collective runs next to these
+        saved, DIST = DIST, None  # the HBM-bound operators shard by independent units: no communicator
+        gpu_all = wg.GpuInstance.new(dev_index)  # its own stream, all CUs: no collective runs next to these
 
         def barrier_all():
             gpu_all.sync()
@@ -696,7 +863,7 @@ def main():
                 el = r["elapsed"]
             except Exception as e:
                 err, el = f"{type(e).__name__}: {e}", float("inf")
-            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local_rank}")
+            t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{dev_index}")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)  # every rank takes part, also one whose run failed
             if not np.isfinite(float(t.item())):
                 others.append({"workload": name, "error": err or "failed on another rank"})
@@ -706,20 +873,23 @@ def main():
                            "dtype": r["workload"].dtype, "steps": r["steps"], "n_gpus": world, "scaling": "weak",
                            "parallelism": f"row-sharded x{world}, no collective", "roofline": rf})
             r = None
+        DIST = saved
 
     if rank == 0:
         line = {
             "metric": w_metric, "value": round(value, 3), "unit": w_unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "strong" if w_is_gemm else "weak", "vs_baseline": None, "dtype": w_dtype,
-            "data": "synthetic (seeded U[-1,1), resident in HBM before the timed region)",
-            "config": {"workload": w_name, "device": info["name"], "compute_units": info["compute_units"],
-                       "parallelism": f"m-shard x{world} + RCCL all-gather" if (world > 1 and w_is_gemm) else f"replicas x{world}"},
+            "data": "synthetic (seeded U[-1,1): one 16 Mi-element random block tiled over each operand, resident in HBM before the timed region)",
+            "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra),
             "roofline": roof, "cpu_baseline": main_cpu, "others": others,
         }
         print(json.dumps(line), flush=True)
     if dist_mode:
         import torch.distributed as dist
+        DIST = None
+        for g, cm in engines.values():
+            cm.close()
         dist.destroy_process_group()
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WGEBRA_HIP_ABI_VERSION 1
+#define WGEBRA_HIP_ABI_VERSION 2
 
 /* ------------------------------------------------------------------------------------------------ */
 /* status codes                                                                                      */
@@ -48,7 +48,9 @@ typedef enum wg_status {
     WG_ERR_OUT_OF_BOUNDS = 4, /* the view addresses elements past the end of its buffer                       */
     WG_ERR_HIP = 5,           /* a HIP runtime call failed; message carries hipGetErrorString                 */
     WG_ERR_UNSUPPORTED = 6,   /* dtype/variant combination not implemented                                    */
-    WG_ERR_NO_DEVICE = 7      /* no gfx950 device visible (GpuInstance::new() -> Err, gpu.rs:24-58)           */
+    WG_ERR_NO_DEVICE = 7,     /* no gfx950 device visible (GpuInstance::new() -> Err, gpu.rs:24-58)           */
+    WG_ERR_WORKSPACE = 8      /* a context scratch region would have to grow while recording (allocation cannot be
+                                 captured): run the call once eagerly, or wg_ctx_reserve_workspace, then record    */
 } wg_status;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -140,7 +142,9 @@ int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in
  */
 int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_ticks);
 
-/* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. */
+/* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. An operator that would
+ * have to grow a scratch region inside a recording returns WG_ERR_WORKSPACE. Scratch regions that a live command buffer may
+ * replay into are never freed before that command buffer is destroyed. */
 int wg_ctx_reserve_workspace(wg_ctx *ctx, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -269,6 +273,61 @@ int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype,
  * (as `y += x` / `y -= x`) bit for bit. Same indexing, errors and skips as wg_op_assign. f16: computed in f32, rounded once.
  */
 int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y_shape, const wg_buf *x, wg_view_shape x_shape);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* multi-GPU: the M-sharded Gemm of the north star. The reference has one wgpu::Device + Queue       */
+/* (wgcore gpu.rs:7-12) and nothing to replace here; what is kept is its tensor model: every rank's   */
+/* operands and the gathered result are plain column-major tensors addressed by ViewShape, and each   */
+/* rank's local product is Gemm::dispatch_generic (gemm.rs:65-127) on views of them.                  */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct wg_comm wg_comm; /* one rank of a group of contexts (one context = one GPU); not thread-safe, like its context */
+#define WG_COMM_ID_BYTES 128   /* == sizeof(ncclUniqueId) */
+#define WG_IPC_HANDLE_BYTES 96
+typedef enum wg_gather_mode {
+    WG_GATHER_RCCL = 0,      /* per N-panel: Gemm into a staging cube [M/P, np, P], in-place ncclAllGather (RCCL over xGMI) on the
+                                communicator's stream beside the next panel's Gemm, then an HBM-bound relayout into columns of C */
+    WG_GATHER_PEER_COPY = 1, /* per N-panel: Gemm straight into this rank's rows of C, then the SDMA engines push that strided block
+                                into every peer's C (no compute units, no relayout); completion: wg_comm_flush + a barrier */
+    WG_GATHER_NONE = 2       /* this rank's rows of C only */
+} wg_gather_mode;
+
+/* ncclGetUniqueId: call on one rank, ship the WG_COMM_ID_BYTES bytes to the others out of band (env, file, MPI, a torch store). */
+int wg_comm_unique_id(void *id);
+/* Rank `rank` of `nranks`, bound to `ctx` (its device, its stream). id != NULL: ncclCommInitRank (collective: every rank must call).
+ * id == NULL: no collective library -- peer copies only, the caller brings its own barrier. librccl / libhsa-runtime64 are bound
+ * at run time; the library itself links only the HIP runtime. */
+int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **out);
+int wg_comm_destroy(wg_comm *comm);
+int wg_comm_rank(const wg_comm *comm);
+int wg_comm_size(const wg_comm *comm);
+int wg_comm_has_collectives(const wg_comm *comm);
+const char *wg_comm_copy_engine(const wg_comm *comm); /* "sdma-rect" | "hip2d" | "none" */
+uint64_t wg_comm_bytes_sent(const wg_comm *comm);     /* payload bytes this rank contributed / pushed so far */
+/* In-place all-gather of elements [first, first + nranks*per_rank) of `buf` (rank r owns [first + r*per_rank, +per_rank)) on the
+ * communicator's stream, ordered after the work already enqueued on the context; the context does not wait (wg_comm_join). */
+int wg_all_gather(wg_comm *comm, wg_dtype dtype, wg_buf *buf, uint64_t first_elem, uint64_t elems_per_rank);
+int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collectives in flight */
+int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */
+int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined into the context: all ranks' earlier exchanges are complete */
+/* One process per GPU: export a device buffer / map a peer's (hipIpcGetMemHandle / hipIpcOpenMemHandle; needs the dmabuf IPC mode,
+ * HSA_ENABLE_IPC_MODE_LEGACY=0, on this platform). The mapped buffer is released by wg_buf_destroy. */
+int wg_buf_ipc_export(const wg_buf *buf, void *handle /* WG_IPC_HANDLE_BYTES */);
+int wg_buf_ipc_open(wg_ctx *ctx, const void *handle, wg_buf **out);
+/* Relayout of a gathered GpuCube [M/P, np, P] (dense) into the (M x np) column-major view `out`: out[g*M/P + i, j] = cube[i, j, g].
+ * HBM-bound: 2 * sizeof(T) * M * np bytes. (What WG_GATHER_RCCL runs per panel; exported for callers that gather themselves.) */
+int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_shape cube_shape, wg_buf *out, wg_view_shape out_shape);
+/*
+ * out (M x N, one matrix, on EVERY rank) = op(A) * B with A sharded on M: `a_rows` is this rank's row block of op(A)
+ * (M/P x K; WG_GEMM_TR*: stored K x M/P), `b` (K x N) is replicated. N is cut into panels of `panel_cols` columns (0 = default)
+ * and panel i's exchange overlaps panel i+1's Gemm. peer_out[r] (WG_GATHER_PEER_COPY only) is rank r's `out` buffer as addressable
+ * from this process (wg_buf_ipc_open, or the buffer itself when the ranks share a process); peer_out[rank] is ignored.
+ * On return everything is enqueued: WG_GATHER_RCCL -- `out` is complete in context-stream order; WG_GATHER_PEER_COPY -- this rank's
+ * rows are complete in stream order, the peers' rows after every rank's wg_comm_flush + a barrier (wg_comm_barrier does both), which
+ * must also separate two calls that write the same `out`. DIM_MISMATCH as Gemm (gemm.rs:91-95) with M = P * rows(a_rows).
+ */
+int wg_gemm_sharded(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols,
+                    wg_buf *out, wg_view_shape out_shape, wg_buf *const *peer_out,
+                    const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* record / replay: CommandEncoder -> finish() -> CommandBuffer -> Queue::submit, as a hipGraph      */

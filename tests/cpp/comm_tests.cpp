@@ -1,0 +1,192 @@
+// The multi-GPU entry points of the C ABI (include/wgebra_hip.h, "multi-GPU" section), driven from plain C++ with no torch in the
+// process -- what a Rust caller of the boundary would do:
+//   1. a 1-rank RCCL communicator: unique id -> wg_comm_create -> wg_all_gather round trip -> wg_gemm_sharded(WG_GATHER_RCCL), i.e.
+//      staging cube + ncclAllGather + cube_to_matrix relayout, against a host f64 product;
+//   2. two ranks in ONE process on one device (two contexts, two communicators without a collective library), WG_GATHER_PEER_COPY:
+//      each rank's Gemm writes its rows of its own C and the copy engine pushes them into the other rank's C; both results must be
+//      the plain M x N product. (RCCL refuses two ranks on one device, so the 2-rank collective itself needs a multi-GPU node.)
+//   3. wg_cube_to_matrix on a hand-made cube (exact), wg_buf_ipc_export on a wrapped interior pointer (offset carried).
+// f32 and f16, Gemm and GemmTr, ragged last panel. Exit code 0 and "ALL OK" on success.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "wgebra_hip.h"
+
+static int failures = 0;
+#define EXPECT(cond, ...) do { if (!(cond)) { ++failures; std::printf("FAIL %s:%d: ", __FILE__, __LINE__); std::printf(__VA_ARGS__); std::printf("\n"); } } while (0)
+#define CK(x) do { int rc_ = (x); if (rc_ != WG_OK) { std::printf("FAIL %s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #x, rc_, wg_last_error_string()); ++failures; return; } } while (0)
+
+static const uint32_t USAGE = WG_USAGE_STORAGE | WG_USAGE_COPY_SRC | WG_USAGE_COPY_DST;
+
+template <typename T> struct dt;
+template <> struct dt<float> { static constexpr wg_dtype v = WG_F32; };
+template <> struct dt<_Float16> { static constexpr wg_dtype v = WG_F16; };
+
+template <typename T> static std::vector<T> rnd(size_t n, uint32_t seed) {
+    std::mt19937 rng(seed);
+    std::uniform_real_distribution<float> d(-1.f, 1.f);
+    std::vector<T> v(n);
+    for (auto &x : v) x = (T)d(rng);
+    return v;
+}
+
+// |got - truth| <= 2 sqrt(K) 2^-24 sum|a||b| (+ half an f16 ulp of the result for f16): tests/_util.py
+template <typename T>
+static void check_product(const char *what, const std::vector<T> &got, const std::vector<T> &A, bool tr, const std::vector<T> &B, uint32_t M, uint32_t N, uint32_t K) {
+    double worst = 0;
+    for (uint32_t j = 0; j < N; ++j)
+        for (uint32_t i = 0; i < M; ++i) {
+            double t = 0, s = 0;
+            for (uint32_t k = 0; k < K; ++k) {
+                const double a = tr ? (double)A[(size_t)i * K + k] : (double)A[(size_t)k * M + i], b = (double)B[(size_t)j * K + k];
+                t += a * b;
+                s += std::fabs(a * b);
+            }
+            double tol = 2.0 * std::sqrt((double)K) * std::ldexp(1.0, -24) * s + 1e-30;
+            if (sizeof(T) == 2) tol += std::ldexp(1.0, -11) * std::fabs(t) + std::ldexp(1.0, -25);
+            const double e = std::fabs((double)got[(size_t)j * M + i] - t) / tol;
+            if (e > worst) worst = e;
+        }
+    EXPECT(worst <= 1.0, "%s: worst err/tol %.3g", what, worst);
+}
+
+static wg_view_shape mat(uint32_t r, uint32_t c) { return wg_view_shape{ { r, c, 1 }, r, r * c, 0 }; }
+
+// rank g's row block of op(A) as its own dense tensor
+template <typename T> static std::vector<T> row_block(const std::vector<T> &A, bool tr, uint32_t M, uint32_t K, uint32_t g, uint32_t mg) {
+    std::vector<T> out((size_t)mg * K);
+    if (tr) { // stored K x M: columns g*mg .. are contiguous
+        std::memcpy(out.data(), A.data() + (size_t)g * mg * K, out.size() * sizeof(T));
+    } else {
+        for (uint32_t k = 0; k < K; ++k)
+            for (uint32_t i = 0; i < mg; ++i) out[(size_t)k * mg + i] = A[(size_t)k * M + g * mg + i];
+    }
+    return out;
+}
+
+template <typename T> static void rccl_one_rank(wg_ctx *ctx, wg_comm *comm, bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel) {
+    auto A = rnd<T>((size_t)M * K, 11), B = rnd<T>((size_t)K * N, 12);
+    wg_buf *a = nullptr, *b = nullptr, *c = nullptr;
+    CK(wg_buf_create_init(ctx, A.data(), A.size() * sizeof(T), USAGE, &a));
+    CK(wg_buf_create_init(ctx, B.data(), B.size() * sizeof(T), USAGE, &b));
+    CK(wg_buf_create(ctx, (size_t)M * N * sizeof(T), USAGE, &c));
+    CK(wg_buf_fill_zero(ctx, c));
+    const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
+    CK(wg_gemm_sharded(comm, v, dt<T>::v, WG_GATHER_RCCL, panel, c, mat(M, N), nullptr, a, tr ? mat(K, M) : mat(M, K), b, mat(K, N)));
+    std::vector<T> got((size_t)M * N);
+    CK(wg_buf_read(ctx, c, 0, got.data(), got.size() * sizeof(T)));
+    char what[128];
+    std::snprintf(what, sizeof what, "rccl 1-rank %s %s %ux%ux%u panel %u", sizeof(T) == 2 ? "f16" : "f32", tr ? "GemmTr" : "Gemm", M, N, K, panel);
+    check_product(what, got, A, tr, B, M, N, K);
+    wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
+}
+
+template <typename T> static void peer_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel) {
+    const uint32_t P = 2, mg = M / P;
+    wg_ctx *ctx[2] = { nullptr, nullptr };
+    wg_comm *comm[2] = { nullptr, nullptr };
+    wg_buf *a[2] = {}, *b[2] = {}, *c[2] = {};
+    auto A = rnd<T>((size_t)M * K, 21), B = rnd<T>((size_t)K * N, 22);
+    for (uint32_t g = 0; g < P; ++g) {
+        CK(wg_ctx_create(0, &ctx[g]));
+        CK(wg_comm_create(ctx[g], P, g, nullptr, &comm[g]));
+        auto Ag = row_block(A, tr, M, K, g, mg);
+        CK(wg_buf_create_init(ctx[g], Ag.data(), Ag.size() * sizeof(T), USAGE, &a[g]));
+        CK(wg_buf_create_init(ctx[g], B.data(), B.size() * sizeof(T), USAGE, &b[g]));
+        CK(wg_buf_create(ctx[g], (size_t)M * N * sizeof(T), USAGE, &c[g]));
+        CK(wg_buf_fill_zero(ctx[g], c[g]));
+        CK(wg_ctx_sync(ctx[g]));
+    }
+    const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
+    for (int rep = 0; rep < 2; ++rep) { // twice: the second call reuses events / signals and overwrites the same C
+        for (uint32_t g = 0; g < P; ++g) {
+            wg_buf *peers[2] = { c[0], c[1] };
+            CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_COPY, panel, c[g], mat(M, N), peers, a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
+        }
+        for (uint32_t g = 0; g < P; ++g) {
+            CK(wg_ctx_sync(ctx[g]));
+            CK(wg_comm_flush(comm[g])); // (the caller's barrier would follow here when the ranks are processes)
+        }
+    }
+    for (uint32_t g = 0; g < P; ++g) {
+        std::vector<T> got((size_t)M * N);
+        CK(wg_buf_read(ctx[g], c[g], 0, got.data(), got.size() * sizeof(T)));
+        char what[160];
+        std::snprintf(what, sizeof what, "peer-copy (%s) rank %u of 2 %s %s %ux%ux%u panel %u", wg_comm_copy_engine(comm[g]), g, sizeof(T) == 2 ? "f16" : "f32",
+                      tr ? "GemmTr" : "Gemm", M, N, K, panel);
+        check_product(what, got, A, tr, B, M, N, K);
+        EXPECT(wg_comm_bytes_sent(comm[g]) == 2ull * mg * N * sizeof(T), "bytes_sent %llu", (unsigned long long)wg_comm_bytes_sent(comm[g]));
+    }
+    for (uint32_t g = 0; g < P; ++g) {
+        wg_comm_destroy(comm[g]);
+        wg_buf_destroy(a[g]); wg_buf_destroy(b[g]); wg_buf_destroy(c[g]);
+        wg_ctx_destroy(ctx[g]);
+    }
+}
+
+static void cube_relayout(wg_ctx *ctx) {
+    const uint32_t mg = 12, np = 8, P = 3, M = mg * P, ld = M + 4; // f16, 24-byte row blocks: the 8-byte vector path
+    std::vector<_Float16> cube((size_t)mg * np * P), out((size_t)ld * np + 8, (_Float16)-1.f);
+    for (size_t i = 0; i < cube.size(); ++i) cube[i] = (_Float16)(float)(i % 2048);
+    wg_buf *bc = nullptr, *bo = nullptr;
+    CK(wg_buf_create_init(ctx, cube.data(), cube.size() * 2, USAGE, &bc));
+    CK(wg_buf_create_init(ctx, out.data(), out.size() * 2, USAGE, &bo));
+    wg_view_shape cs = { { mg, np, P }, mg, mg * np, 0 }, os = { { M, np, 1 }, ld, ld * np, 4 };
+    CK(wg_cube_to_matrix(ctx, WG_F16, bc, cs, bo, os));
+    std::vector<_Float16> got(out.size());
+    CK(wg_buf_read(ctx, bo, 0, got.data(), got.size() * 2));
+    size_t bad = 0;
+    for (uint32_t g = 0; g < P; ++g)
+        for (uint32_t j = 0; j < np; ++j)
+            for (uint32_t i = 0; i < mg; ++i) bad += got[4 + (size_t)j * ld + g * mg + i] != cube[((size_t)g * np + j) * mg + i];
+    for (uint32_t j = 0; j < np; ++j)
+        for (uint32_t i = M; i < ld; ++i) bad += got[4 + (size_t)j * ld + i] != (_Float16)-1.f; // the gap between columns is untouched
+    EXPECT(bad == 0, "cube_to_matrix: %zu wrong elements", bad);
+    wg_view_shape wrong = os;
+    wrong.size[0] = M + 4;
+    EXPECT(wg_cube_to_matrix(ctx, WG_F16, bc, cs, bo, wrong) == WG_ERR_DIM_MISMATCH, "cube_to_matrix accepted mismatching shapes");
+    wg_buf_destroy(bc); wg_buf_destroy(bo);
+}
+
+int main() {
+    wg_ctx *ctx = nullptr;
+    if (wg_ctx_create(0, &ctx) != WG_OK) { std::printf("no device: %s\n", wg_last_error_string()); return 2; }
+    cube_relayout(ctx);
+
+    unsigned char id[WG_COMM_ID_BYTES];
+    wg_comm *comm = nullptr;
+    if (wg_comm_unique_id(id) != WG_OK || wg_comm_create(ctx, 1, 0, id, &comm) != WG_OK) {
+        std::printf("FAIL: RCCL communicator: %s\n", wg_last_error_string());
+        return 1;
+    }
+    EXPECT(wg_comm_has_collectives(comm) == 1 && wg_comm_size(comm) == 1 && wg_comm_rank(comm) == 0, "communicator facts");
+    { // all-gather round trip with one rank: in place, the range must survive; then a barrier
+        std::vector<float> v(4096);
+        for (size_t i = 0; i < v.size(); ++i) v[i] = (float)i;
+        wg_buf *b = nullptr;
+        if (wg_buf_create_init(ctx, v.data(), v.size() * 4, USAGE, &b) == WG_OK) {
+            EXPECT(wg_all_gather(comm, WG_F32, b, 1024, 2048) == WG_OK, "wg_all_gather: %s", wg_last_error_string());
+            EXPECT(wg_all_gather(comm, WG_F32, b, 1024, 4096) == WG_ERR_OUT_OF_BOUNDS, "wg_all_gather accepted a range past the buffer");
+            EXPECT(wg_comm_join(comm) == WG_OK && wg_comm_barrier(comm) == WG_OK, "join/barrier: %s", wg_last_error_string());
+            std::vector<float> back(v.size());
+            EXPECT(wg_buf_read(ctx, b, 0, back.data(), back.size() * 4) == WG_OK && back == v, "all-gather round trip changed the data");
+            wg_buf_destroy(b);
+        }
+    }
+    rccl_one_rank<float>(ctx, comm, false, 512, 768, 256, 256);
+    rccl_one_rank<float>(ctx, comm, true, 512, 768, 256, 512); // ragged last panel
+    rccl_one_rank<_Float16>(ctx, comm, false, 1024, 1280, 512, 512);
+    rccl_one_rank<_Float16>(ctx, comm, true, 1024, 1280, 512, 0);
+    wg_comm_destroy(comm);
+
+    peer_two_ranks<float>(false, 512, 768, 256, 256);
+    peer_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
+    peer_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
+    wg_ctx_destroy(ctx);
+    if (failures == 0) std::printf("ALL OK\n");
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,61 @@
+"""bench.py's multi-rank launch contract on CPU: `python bench.py --gpus N` must start its own ranks (one process per GPU) from a
+parent that never touches the GPU, relay ONE JSON line, and fail cleanly when the node has fewer GPUs than ranks. The ranks run
+`--dry-run` here (gloo, host arithmetic through the same M-shard planner / pipelined all-gather driver): no GPU in this container."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _run(*argv, env=None):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_self_launch_two_ranks_dry_run():
+    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # exactly one JSON line on stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["config"]["ranks"] == 2 and "m-shard x2" in line["config"]["parallelism"]
+    assert line["config"]["all_gather_bytes_per_step"] == 64 * 96 * 4
+    assert line["scaling"] == "strong" and line["higher_is_better"] is True
+    assert "dry-run" in line["data"]
+
+
+def test_self_launch_fails_cleanly_without_enough_gpus():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return  # a multi-GPU box: the real launch is what runs there
+    r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary")
+    assert r.returncode == 2, r.stdout + r.stderr
+    assert "GPU(s) visible" in r.stderr and "Traceback" not in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_failing_rank_fails_the_launch():
+    # a rank that dies (here: an impossible world/--gpus combination inside the children) must surface as a non-zero exit, no line
+    r = _run("--gpus", "2", "--dry-run", "--steps", "0", "--warmup", "0")  # steps 0 -> division by zero in every rank
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_panel_planner_whole_rounds():
+    import bench
+    # 4 ranks of the 32768^3 problem on 256 CUs: 32 tile rows -> 8 tile columns (2048) fill exactly one round; 16 panels
+    assert bench.plan_panel_cols(8192, 32768, 256) == 2048
+    # 8 ranks: 16 tile rows -> 16 tile columns per round -> 4096-column panels, 8 of them
+    assert bench.plan_panel_cols(4096, 32768, 256) == 4096
+    # CU-masked stream (224 CUs): 32 tile rows x 7 tile columns = one round
+    assert bench.plan_panel_cols(8192, 32768, 224) % (7 * 256) == 0
+    # tiny problems: at least two panels when N allows, never wider than N
+    assert bench.plan_panel_cols(256, 512, 256) == 256
+    assert bench.plan_panel_cols(256, 256, 256) == 256

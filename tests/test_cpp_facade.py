@@ -17,6 +17,33 @@ def build():
                     f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
 
 
+COMM_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "comm_tests")
+
+
+def build_comm():
+    """tests/cpp/comm_tests.cpp: the multi-GPU entry points through the plain C ABI (clang++: _Float16 on the host)."""
+    os.makedirs(os.path.dirname(COMM_EXE), exist_ok=True)
+    lib_dir = os.path.join(ROOT, "wgmath_amd")
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "comm_tests.cpp"), "-o", COMM_EXE, "-L", lib_dir, "-lwgebra_hip",
+                    f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
+
+
+def test_cpp_comm_tests_compile_and_link():
+    build_comm()
+    assert os.path.exists(COMM_EXE)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["sdma", "hip2d"])
+def test_cpp_comm_tests_on_gpu(engine):
+    """1-rank RCCL round trip + sharded Gemm through the C ABI, and the 2-rank peer-copy gather on both copy engines (no torch)."""
+    build_comm()
+    env = dict(os.environ, WG_PEER_COPY_ENGINE=engine, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([COMM_EXE], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_cpp_facade_compiles_and_links():
     build()
     assert os.path.exists(EXE)

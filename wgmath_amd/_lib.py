@@ -13,7 +13,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "wgebra_hip.h")
 
 # status codes (wg_status)
 WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_OF_BOUNDS, WG_ERR_HIP, \
-    WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE = range(8)
+    WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE, WG_ERR_WORKSPACE = range(9)
+WG_GATHER_RCCL, WG_GATHER_PEER_COPY, WG_GATHER_NONE = 0, 1, 2
+WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
 WG_F32, WG_F16 = 0, 1
 
 
@@ -44,6 +46,10 @@ class PreconditionFailed(WgError, AssertionError):
 
 class NoDevice(WgError):
     pass
+
+
+class WorkspaceMustGrow(WgError):
+    """A context scratch region would have to grow inside a recording (WG_ERR_WORKSPACE): run the call once eagerly first."""
 
 
 def declared_symbols(header_path: str = HEADER_PATH) -> list[str]:
@@ -98,6 +104,22 @@ def _load() -> ctypes.CDLL:
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
         "wg_axpy": (ci, [vp, ctypes.c_float, ci, vp, S, vp, S]),
+        "wg_comm_unique_id": (ci, [vp]),
+        "wg_comm_create": (ci, [vp, ci, ci, vp, pvp]),
+        "wg_comm_destroy": (ci, [vp]),
+        "wg_comm_rank": (ci, [vp]),
+        "wg_comm_size": (ci, [vp]),
+        "wg_comm_has_collectives": (ci, [vp]),
+        "wg_comm_copy_engine": (cp, [vp]),
+        "wg_comm_bytes_sent": (u64, [vp]),
+        "wg_all_gather": (ci, [vp, ci, vp, u64, u64]),
+        "wg_comm_join": (ci, [vp]),
+        "wg_comm_flush": (ci, [vp]),
+        "wg_comm_barrier": (ci, [vp]),
+        "wg_buf_ipc_export": (ci, [vp, vp]),
+        "wg_buf_ipc_open": (ci, [vp, vp, pvp]),
+        "wg_cube_to_matrix": (ci, [vp, ci, vp, S, vp, S]),
+        "wg_gemm_sharded": (ci, [vp, ci, ci, ci, u32, vp, S, pvp, vp, S, vp, S]),
         "wg_encoder_begin": (ci, [vp]),
         "wg_encoder_finish": (ci, [vp, pvp]),
         "wg_queue_submit": (ci, [vp, vp]),
@@ -142,7 +164,7 @@ def assert_single_hip_runtime() -> None:
 
 lib = _load()
 
-_EXC = {WG_ERR_DIM_MISMATCH: DimensionMismatch, WG_ERR_PRECONDITION: PreconditionFailed, WG_ERR_NO_DEVICE: NoDevice}
+_EXC = {WG_ERR_DIM_MISMATCH: DimensionMismatch, WG_ERR_PRECONDITION: PreconditionFailed, WG_ERR_NO_DEVICE: NoDevice, WG_ERR_WORKSPACE: WorkspaceMustGrow}
 
 
 def check(status: int) -> None:

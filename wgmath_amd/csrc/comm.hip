@@ -1,0 +1,662 @@
+// Multi-GPU half of the boundary: the north star's M-sharded Gemm. The reference has ONE wgpu::Device and one Queue
+// (crates/wgcore/src/gpu.rs:7-12) and no multi-device path; what is kept from it is the tensor model -- every rank's operands and the
+// gathered result are ordinary column-major GpuMatrix tensors (tensor.rs:47-48) addressed by ViewShape (shapes.rs:9-21), and the local
+// product of every rank is exactly Gemm::dispatch_generic (gemm.rs:65-127) on views of them.
+//
+//   rank g of P owns A_g = A[g*M/P .. (g+1)*M/P, :] (its own dense tensor), B is replicated, every rank ends with the full M x N C.
+//   N is cut into column panels; panel i's exchange runs while panel i+1 computes. Two exchange engines:
+//
+//   WG_GATHER_RCCL       the north star's primary. A row block of a column-major C is strided, a collective wants contiguous
+//                        ranges: the panel Gemm writes slot g of a staging cube [M/P, np, P] (GpuCube, stride_mat = M/P*np), one
+//                        in-place ncclAllGather per panel fills the other slots on the communicator's stream, and an HBM-bound
+//                        relayout kernel (cube_to_matrix) scatters the cube into columns [c0, c0+np) of C. RCCL's copy kernels need
+//                        compute units; every f16 Gemm workgroup needs a whole one (so the caller may give the Gemm a CU-masked
+//                        context: wg_ctx_create_with_cu_count).
+//   WG_GATHER_PEER_COPY  no compute units and no relayout: the panel Gemm writes its row block straight into C (a strided view), and
+//                        the SDMA engines push that (M/P x np) block into every peer's C (hsa_amd_memory_async_copy_rect, the only
+//                        engine that copies strided blocks without a blit kernel: tools/cpp/sdma_probe.cpp), issued by a helper thread
+//                        as soon as the panel's event fires. ~60 GB/s per engine, one engine per peer: about the xGMI link rate.
+//
+// RCCL and the HSA runtime are resolved at run time (dlopen): the library links only libamdhip64, and a process that already
+// loaded torch's bundled copies binds to those.
+#include "wg_internal.hpp"
+
+#include <dlfcn.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+#include <rccl/rccl.h> // types and enums only
+
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// run-time bindings
+// ---------------------------------------------------------------------------------------------------------------
+void *open_lib(const char *env, const char *const *names) {
+    if (const char *p = getenv(env)) {
+        if (void *h = dlopen(p, RTLD_NOW | RTLD_GLOBAL)) return h;
+    }
+    for (int pass = 0; pass < 2; ++pass) // first whatever this process already mapped (e.g. torch's bundled copy), then the system's
+        for (const char *const *n = names; *n; ++n)
+            if (void *h = dlopen(*n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0))) return h;
+    return nullptr;
+}
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi &rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        static const char *const names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", nullptr };
+        a.h = open_lib("WG_RCCL_LIB", names);
+        if (!a.h) return a;
+        a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
+        a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
+        a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+        a.AllGather = (decltype(a.AllGather))dlsym(a.h, "ncclAllGather");
+        a.AllReduce = (decltype(a.AllReduce))dlsym(a.h, "ncclAllReduce");
+        a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+
+struct HsaApi {
+    void *h = nullptr;
+    hsa_status_t (*init)() = nullptr;
+    hsa_status_t (*signal_create)(hsa_signal_value_t, uint32_t, const hsa_agent_t *, hsa_signal_t *) = nullptr;
+    hsa_status_t (*signal_destroy)(hsa_signal_t) = nullptr;
+    void (*signal_store)(hsa_signal_t, hsa_signal_value_t) = nullptr;
+    hsa_signal_value_t (*signal_wait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
+    hsa_status_t (*copy_rect)(const hsa_pitched_ptr_t *, const hsa_dim3_t *, const hsa_pitched_ptr_t *, const hsa_dim3_t *, const hsa_dim3_t *,
+                              hsa_agent_t, hsa_amd_copy_direction_t, uint32_t, const hsa_signal_t *, hsa_signal_t) = nullptr;
+    hsa_status_t (*pointer_info)(const void *, hsa_amd_pointer_info_t *, void *(*)(size_t), uint32_t *, hsa_agent_t **) = nullptr;
+    hsa_status_t (*status_string)(hsa_status_t, const char **) = nullptr;
+    bool ok = false;
+};
+HsaApi &hsa() {
+    static HsaApi api = [] {
+        HsaApi a;
+        static const char *const names[] = { "libhsa-runtime64.so.1", "libhsa-runtime64.so", "/opt/rocm/lib/libhsa-runtime64.so.1", nullptr };
+        a.h = open_lib("WG_HSA_LIB", names);
+        if (!a.h) return a;
+        a.init = (decltype(a.init))dlsym(a.h, "hsa_init");
+        a.signal_create = (decltype(a.signal_create))dlsym(a.h, "hsa_signal_create");
+        a.signal_destroy = (decltype(a.signal_destroy))dlsym(a.h, "hsa_signal_destroy");
+        a.signal_store = (decltype(a.signal_store))dlsym(a.h, "hsa_signal_store_relaxed");
+        a.signal_wait = (decltype(a.signal_wait))dlsym(a.h, "hsa_signal_wait_scacquire");
+        a.copy_rect = (decltype(a.copy_rect))dlsym(a.h, "hsa_amd_memory_async_copy_rect");
+        a.pointer_info = (decltype(a.pointer_info))dlsym(a.h, "hsa_amd_pointer_info");
+        a.status_string = (decltype(a.status_string))dlsym(a.h, "hsa_status_string");
+        a.ok = a.init && a.signal_create && a.signal_destroy && a.signal_store && a.signal_wait && a.copy_rect && a.pointer_info && a.status_string;
+        if (a.ok && a.init() != HSA_STATUS_SUCCESS) a.ok = false; // reference-counted: HIP already initialised the same runtime
+        return a;
+    }();
+    return api;
+}
+
+struct Rect { // a strided block: `rows` pieces of `width` bytes, `pitch` bytes apart (a "row" of the copy is a matrix COLUMN)
+    void *dst;
+    size_t dpitch;
+    const void *src;
+    size_t spitch, width, rows;
+};
+struct CopyJob {
+    hipEvent_t after = nullptr; // issue once this event (recorded on the context's stream) has fired; nullptr = flush marker
+    std::vector<Rect> rects;
+};
+
+} // namespace
+
+struct wg_comm {
+    wg_ctx *ctx = nullptr;
+    int nranks = 1, rank = 0;
+    ncclComm_t nccl = nullptr;
+    hipStream_t stream = nullptr; // the collective library's stream
+    hipEvent_t ev_ctx = nullptr, ev_comm = nullptr;
+    std::vector<hipEvent_t> ev_panel; // per-panel events (grown on demand)
+    void *stage = nullptr;            // RCCL mode: two staging cubes
+    size_t stage_bytes = 0;
+    float *token = nullptr; // 1 float for the barrier's all-reduce
+    // peer copies
+    bool use_sdma = false;
+    hsa_agent_t agent = {};
+    hipStream_t copy_stream = nullptr; // fallback engine: hipMemcpy2DAsync (a blit kernel)
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<CopyJob> jobs;
+    bool stop = false, busy = false;
+    uint64_t flushes_done = 0, flushes_asked = 0;
+    std::vector<hsa_signal_t> free_signals, inflight;
+    std::vector<hipEvent_t> free_events, used_events;
+    int async_status = WG_OK;
+    std::string async_error;
+    uint64_t bytes_sent = 0; // payload this rank pushed or contributed since creation (diagnostics: wg_comm_bytes_sent)
+};
+
+namespace {
+
+void worker_fail(wg_comm *c, int status, const std::string &msg) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->async_status == WG_OK) {
+        c->async_status = status;
+        c->async_error = msg;
+    }
+}
+
+void worker_main(wg_comm *c) {
+    (void)hipSetDevice(c->ctx->device);
+    HsaApi &H = hsa();
+    for (;;) {
+        CopyJob job;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv_work.wait(lk, [&] { return c->stop || !c->jobs.empty(); });
+            if (c->jobs.empty()) return; // stop requested and nothing left
+            job = std::move(c->jobs.front());
+            c->jobs.pop_front();
+            c->busy = true;
+        }
+        if (job.after) {
+            hipError_t e = hipEventSynchronize(job.after);
+            if (e != hipSuccess) worker_fail(c, WG_ERR_HIP, std::string("peer copy: hipEventSynchronize failed: ") + hipGetErrorString(e));
+            for (const Rect &r : job.rects) {
+                hsa_signal_t sig;
+                {
+                    std::lock_guard<std::mutex> lk(c->mu);
+                    if (c->free_signals.empty()) {
+                        sig.handle = 0;
+                    } else {
+                        sig = c->free_signals.back();
+                        c->free_signals.pop_back();
+                    }
+                }
+                if (sig.handle == 0 && H.signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) {
+                    worker_fail(c, WG_ERR_HIP, "peer copy: hsa_signal_create failed");
+                    continue;
+                }
+                H.signal_store(sig, 1);
+                hsa_pitched_ptr_t d = { r.dst, r.dpitch, r.dpitch * r.rows }, s = { (void *)r.src, r.spitch, r.spitch * r.rows };
+                hsa_dim3_t off = { 0, 0, 0 }, range = { (uint32_t)r.width, (uint32_t)r.rows, 1 };
+                hsa_status_t st = H.copy_rect(&d, &off, &s, &off, &range, c->agent, hsaDeviceToDevice, 0, nullptr, sig);
+                if (st != HSA_STATUS_SUCCESS) {
+                    const char *m = nullptr;
+                    H.status_string(st, &m);
+                    worker_fail(c, WG_ERR_HIP, std::string("peer copy: hsa_amd_memory_async_copy_rect failed: ") + (m ? m : "?"));
+                    std::lock_guard<std::mutex> lk(c->mu);
+                    c->free_signals.push_back(sig);
+                    continue;
+                }
+                std::lock_guard<std::mutex> lk(c->mu);
+                c->inflight.push_back(sig);
+            }
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->busy = false;
+        } else { // flush: every copy issued so far has landed
+            std::vector<hsa_signal_t> w;
+            {
+                std::lock_guard<std::mutex> lk(c->mu);
+                w.swap(c->inflight);
+            }
+            for (hsa_signal_t s : w)
+                while (H.signal_wait(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
+            std::lock_guard<std::mutex> lk(c->mu);
+            for (hsa_signal_t s : w) c->free_signals.push_back(s);
+            c->busy = false;
+            c->flushes_done++;
+            c->cv_done.notify_all();
+        }
+    }
+}
+
+int nccl_fail(const char *what, ncclResult_t r) {
+    return wg_set_error(WG_ERR_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+}
+
+// cube [mg, np, P] (contiguous slots) -> columns of a column-major matrix: c[(j)*ldc + g*mg + i] = stage[(g*np + j)*mg + i], in units of V
+template <typename V>
+__global__ __launch_bounds__(256) void cube_to_matrix_kernel(const V *__restrict__ stage, V *__restrict__ c, uint32_t mg_v, uint32_t np, uint64_t ldc_v) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, g = blockIdx.z;
+    if (i >= mg_v) return;
+    for (uint32_t j = blockIdx.y; j < np; j += gridDim.y) {
+        const V v = __builtin_nontemporal_load(stage + ((uint64_t)g * np + j) * mg_v + i);
+        __builtin_nontemporal_store(v, c + (uint64_t)j * ldc_v + (uint64_t)g * mg_v + i);
+    }
+}
+
+typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
+typedef uint32_t wg_u2 __attribute__((ext_vector_type(2)));
+
+int launch_cube_to_matrix(wg_ctx *ctx, const void *stage, void *c_col0, uint32_t mg, uint32_t np, uint32_t nranks, uint64_t ldc, size_t es) {
+    if (mg == 0 || np == 0) return WG_OK;
+    const size_t row_bytes = (size_t)mg * es, ld_bytes = (size_t)ldc * es;
+    const uintptr_t align = (uintptr_t)stage | (uintptr_t)c_col0 | row_bytes | ld_bytes;
+    const uint32_t gy = np < 65535u ? np : 65535u;
+    if (align % 16 == 0) {
+        const uint32_t mv = (uint32_t)(row_bytes / 16);
+        hipLaunchKernelGGL(cube_to_matrix_kernel<wg_u4>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const wg_u4 *)stage, (wg_u4 *)c_col0, mv,
+                           np, (uint64_t)(ld_bytes / 16));
+    } else if (align % 8 == 0) {
+        const uint32_t mv = (uint32_t)(row_bytes / 8);
+        hipLaunchKernelGGL(cube_to_matrix_kernel<wg_u2>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const wg_u2 *)stage, (wg_u2 *)c_col0, mv,
+                           np, (uint64_t)(ld_bytes / 8));
+    } else if (align % 4 == 0) {
+        const uint32_t mv = (uint32_t)(row_bytes / 4);
+        hipLaunchKernelGGL(cube_to_matrix_kernel<uint32_t>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const uint32_t *)stage,
+                           (uint32_t *)c_col0, mv, np, (uint64_t)(ld_bytes / 4));
+    } else {
+        return wg_set_error(WG_ERR_PRECONDITION, "cube_to_matrix: row blocks are not 4-byte aligned");
+    }
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+hipEvent_t take_event(wg_comm *c) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    hipEvent_t e = nullptr;
+    if (!c->free_events.empty()) {
+        e = c->free_events.back();
+        c->free_events.pop_back();
+    }
+    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    c->used_events.push_back(e);
+    return e;
+}
+
+int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far has landed
+    if (c->nranks > 1 && c->use_sdma && c->worker.joinable()) {
+        std::unique_lock<std::mutex> lk(c->mu);
+        c->jobs.push_back(CopyJob());
+        const uint64_t want = ++c->flushes_asked;
+        c->cv_work.notify_one();
+        c->cv_done.wait(lk, [&] { return c->flushes_done >= want; });
+        for (hipEvent_t e : c->used_events) c->free_events.push_back(e);
+        c->used_events.clear();
+        if (c->async_status != WG_OK) {
+            const int st = c->async_status;
+            const std::string msg = c->async_error;
+            c->async_status = WG_OK;
+            c->async_error.clear();
+            lk.unlock();
+            return wg_set_error(st, "%s", msg.c_str());
+        }
+    } else if (c->copy_stream) {
+        WG_HIP_TRY(hipStreamSynchronize(c->copy_stream));
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (hipEvent_t e : c->used_events) c->free_events.push_back(e);
+        c->used_events.clear();
+    }
+    return WG_OK;
+}
+
+struct IpcHandle { // WG_IPC_HANDLE_BYTES
+    hipIpcMemHandle_t h;
+    uint64_t offset, bytes;
+};
+static_assert(sizeof(IpcHandle) <= WG_IPC_HANDLE_BYTES, "WG_IPC_HANDLE_BYTES too small");
+
+} // namespace
+
+extern "C" {
+
+int wg_comm_unique_id(void *id) {
+    if (!id) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_unique_id: id is NULL");
+    static_assert(sizeof(ncclUniqueId) == WG_COMM_ID_BYTES, "WG_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+    RcclApi &R = rccl();
+    if (!R.ok) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+    ncclUniqueId u;
+    ncclResult_t r = R.GetUniqueId(&u);
+    if (r != ncclSuccess) return nccl_fail("ncclGetUniqueId", r);
+    memcpy(id, &u, sizeof u);
+    return WG_OK;
+}
+
+int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **out) {
+    if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_create: NULL argument");
+    *out = nullptr;
+    if (nranks < 1 || rank < 0 || rank >= nranks) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_create: rank %d not in [0,%d)", rank, nranks);
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_create: cannot create a communicator while recording");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    wg_comm *c = new (std::nothrow) wg_comm();
+    if (!c) return wg_set_error(WG_ERR_HIP, "out of host memory");
+    c->ctx = ctx;
+    c->nranks = nranks;
+    c->rank = rank;
+    auto fail = [&](int rc) {
+        wg_comm_destroy(c);
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_ctx, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming) != hipSuccess || hipMalloc(&c->token, 256) != hipSuccess)
+        return fail(wg_set_error(WG_ERR_HIP, "wg_comm_create: stream / event creation failed"));
+    if (id) {
+        RcclApi &R = rccl();
+        if (!R.ok) return fail(wg_set_error(WG_ERR_UNSUPPORTED, "wg_comm_create: librccl.so.1 could not be loaded"));
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof u);
+        ncclResult_t r = R.CommInitRank(&c->nccl, nranks, u, rank);
+        if (r != ncclSuccess) return fail(nccl_fail("ncclCommInitRank", r));
+    }
+    // peer-copy engine: SDMA rect copies through the HSA runtime unless WG_PEER_COPY_ENGINE=hip2d (or HSA cannot be bound)
+    const char *eng = getenv("WG_PEER_COPY_ENGINE");
+    if (nranks > 1 && !(eng && strcmp(eng, "hip2d") == 0)) {
+        HsaApi &H = hsa();
+        if (H.ok) {
+            hsa_amd_pointer_info_t info;
+            memset(&info, 0, sizeof info);
+            info.size = sizeof info;
+            if (H.pointer_info(c->token, &info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && info.agentOwner.handle != 0) {
+                c->agent = info.agentOwner;
+                c->use_sdma = true;
+                c->worker = std::thread(worker_main, c);
+            }
+        }
+    }
+    if (nranks > 1 && !c->use_sdma && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(wg_set_error(WG_ERR_HIP, "wg_comm_create: copy stream creation failed"));
+    *out = c;
+    return WG_OK;
+}
+
+int wg_comm_destroy(wg_comm *c) {
+    if (!c) return WG_OK;
+    (void)hipSetDevice(c->ctx->device);
+    if (c->worker.joinable()) {
+        (void)comm_flush(c);
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            c->stop = true;
+        }
+        c->cv_work.notify_all();
+        c->worker.join();
+    }
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamDestroy(c->copy_stream);
+    }
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->nccl) (void)rccl().CommDestroy(c->nccl);
+    for (hsa_signal_t s : c->free_signals) (void)hsa().signal_destroy(s);
+    for (hsa_signal_t s : c->inflight) (void)hsa().signal_destroy(s);
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->used_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
+    if (c->ev_ctx) (void)hipEventDestroy(c->ev_ctx);
+    if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->token) (void)hipFree(c->token);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return WG_OK;
+}
+
+int wg_comm_rank(const wg_comm *c) { return c ? c->rank : -1; }
+int wg_comm_size(const wg_comm *c) { return c ? c->nranks : 0; }
+int wg_comm_has_collectives(const wg_comm *c) { return c && c->nccl ? 1 : 0; }
+const char *wg_comm_copy_engine(const wg_comm *c) { return !c || c->nranks < 2 ? "none" : (c->use_sdma ? "sdma-rect" : "hip2d"); }
+uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
+
+// In-place all-gather of the element range [first, first + nranks*per_rank) of `buf`: rank r contributes [first + r*per_rank, +per_rank).
+// Runs on the communicator's stream, ordered after everything enqueued on the context's stream so far; the context's stream does NOT
+// wait for it (wg_comm_join does), so later Gemms overlap it.
+int wg_all_gather(wg_comm *c, wg_dtype dtype, wg_buf *buf, uint64_t first_elem, uint64_t elems_per_rank) {
+    if (!c || !buf) return wg_set_error(WG_ERR_INVALID_ARG, "wg_all_gather: NULL argument");
+    if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "wg_all_gather: unknown dtype %d", (int)dtype);
+    if (!c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_all_gather: this communicator was created without a collective library (id == NULL)");
+    if (c->ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_all_gather: collectives cannot be recorded");
+    const size_t es = wg_dtype_size(dtype);
+    const uint64_t have = buf->bytes / es;
+    if (first_elem > have || elems_per_rank * (uint64_t)c->nranks > have - first_elem)
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "wg_all_gather: range [%llu, %llu) exceeds the buffer's %llu elements", (unsigned long long)first_elem,
+                            (unsigned long long)(first_elem + elems_per_rank * c->nranks), (unsigned long long)have);
+    if (elems_per_rank == 0) return WG_OK;
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    WG_HIP_TRY(hipEventRecord(c->ev_ctx, c->ctx->stream));
+    WG_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ctx, 0));
+    char *base = (char *)buf->ptr + first_elem * es;
+    ncclResult_t r = rccl().AllGather(base + (size_t)c->rank * elems_per_rank * es, base, elems_per_rank, dtype == WG_F16 ? ncclFloat16 : ncclFloat32, c->nccl, c->stream);
+    if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
+    c->bytes_sent += elems_per_rank * es;
+    return WG_OK;
+}
+
+// The context's stream waits for everything in flight on the communicator's stream (collectives).
+int wg_comm_join(wg_comm *c) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_join: comm is NULL");
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    WG_HIP_TRY(hipEventRecord(c->ev_comm, c->stream));
+    WG_HIP_TRY(hipStreamWaitEvent(c->ctx->stream, c->ev_comm, 0));
+    return WG_OK;
+}
+
+// Host-blocking: every peer copy this rank issued has landed in the peers' memory.
+int wg_comm_flush(wg_comm *c) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_flush: comm is NULL");
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    return comm_flush(c);
+}
+
+// Cross-rank barrier: flush this rank's peer copies, then a one-element all-reduce on the communicator's stream, joined into the
+// context's stream: work enqueued afterwards on ANY rank's context sees every rank's earlier copies and collectives complete.
+int wg_comm_barrier(wg_comm *c) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_barrier: comm is NULL");
+    if (!c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_comm_barrier: no collective library on this communicator; flush and use the caller's own barrier");
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    WG_HIP_TRY(hipStreamSynchronize(c->ctx->stream)); // the panel events the copies wait for have been recorded and will fire
+    if (int rc = comm_flush(c)) return rc;
+    ncclResult_t r = rccl().AllReduce(c->token, c->token, 1, ncclFloat32, ncclSum, c->nccl, c->stream);
+    if (r != ncclSuccess) return nccl_fail("ncclAllReduce", r);
+    return wg_comm_join(c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// buffers across processes (one process per GPU): export / open a device allocation
+// ---------------------------------------------------------------------------------------------------------------
+int wg_buf_ipc_export(const wg_buf *buf, void *handle) {
+    if (!buf || !handle) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_ipc_export: NULL argument");
+    if (buf->host_pinned || !buf->ptr) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_ipc_export: only non-empty device buffers can be exported");
+    WG_HIP_TRY(hipSetDevice(buf->ctx->device));
+    IpcHandle h;
+    memset(&h, 0, sizeof h);
+    hipDeviceptr_t base = nullptr;
+    size_t range = 0;
+    WG_HIP_TRY(hipMemGetAddressRange(&base, &range, (hipDeviceptr_t)buf->ptr)); // a wrapped pointer may sit inside a larger allocation
+    WG_HIP_TRY(hipIpcGetMemHandle(&h.h, base));
+    h.offset = (uint64_t)((char *)buf->ptr - (char *)base);
+    h.bytes = buf->bytes;
+    memset(handle, 0, WG_IPC_HANDLE_BYTES);
+    memcpy(handle, &h, sizeof h);
+    return WG_OK;
+}
+
+int wg_buf_ipc_open(wg_ctx *ctx, const void *handle, wg_buf **out) {
+    if (!ctx || !handle || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_buf_ipc_open: NULL argument");
+    *out = nullptr;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    IpcHandle h;
+    memcpy(&h, handle, sizeof h);
+    void *base = nullptr;
+    WG_HIP_TRY(hipIpcOpenMemHandle(&base, h.h, hipIpcMemLazyEnablePeerAccess));
+    wg_buf *b = new (std::nothrow) wg_buf();
+    if (!b) {
+        (void)hipIpcCloseMemHandle(base);
+        return wg_set_error(WG_ERR_HIP, "out of host memory");
+    }
+    b->ctx = ctx;
+    b->ptr = (char *)base + h.offset;
+    b->bytes = (size_t)h.bytes;
+    b->usage = WG_USAGE_STORAGE | WG_USAGE_COPY_SRC | WG_USAGE_COPY_DST;
+    b->owned = false;
+    b->ipc_base = base;
+    *out = b;
+    return WG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// relayout: gathered cube -> columns of the M x N matrix (RCCL mode; also exported for callers that all-gather themselves)
+// ---------------------------------------------------------------------------------------------------------------
+int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_shape cube_shape, wg_buf *out, wg_view_shape out_shape) {
+    if (!ctx || !cube || !out) return wg_set_error(WG_ERR_INVALID_ARG, "cube_to_matrix: NULL argument");
+    if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "cube_to_matrix: unknown dtype %d", (int)dtype);
+    const uint32_t mg = cube_shape.size[0], np = cube_shape.size[1], P = cube_shape.size[2];
+    if (out_shape.size[0] != mg * P || out_shape.size[1] != np || out_shape.size[2] != 1)
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "cube_to_matrix: dimension mismatch. (cube [%u,%u,%u] -> out [%u,%u,%u])", mg, np, P, out_shape.size[0],
+                            out_shape.size[1], out_shape.size[2]);
+    if (mg == 0 || np == 0 || P == 0) return WG_OK;
+    if (cube_shape.stride != mg || (P > 1 && cube_shape.stride_mat != mg * np))
+        return wg_set_error(WG_ERR_PRECONDITION, "cube_to_matrix: the cube must be dense (stride == rows, stride_mat == rows*cols)");
+    const size_t es = wg_dtype_size(dtype);
+    const uint64_t need_c = (uint64_t)cube_shape.offset + (uint64_t)mg * np * P;
+    const uint64_t need_o = (uint64_t)out_shape.offset + (uint64_t)(np - 1) * out_shape.stride + (uint64_t)mg * P;
+    if (need_c > cube->bytes / es || need_o > out->bytes / es) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "cube_to_matrix: a view exceeds its buffer");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return launch_cube_to_matrix(ctx, (const char *)cube->ptr + (size_t)cube_shape.offset * es, (char *)out->ptr + (size_t)out_shape.offset * es, mg, np, P,
+                                 out_shape.stride, es);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the M-sharded Gemm
+// ---------------------------------------------------------------------------------------------------------------
+int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols, wg_buf *out, wg_view_shape out_shape,
+                    wg_buf *const *peer_out, const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
+    if (!c || !out || !a_rows || !b) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): NULL argument");
+    if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown dtype %d", (int)dtype);
+    if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
+    if ((int)mode < 0 || (int)mode > 2) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown gather mode %d", (int)mode);
+    wg_ctx *ctx = c->ctx;
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): cannot be recorded");
+    const bool tr = variant == WG_GEMM_TR || variant == WG_GEMM_TR_FAST;
+    const uint32_t P = (uint32_t)c->nranks, g = (uint32_t)c->rank;
+    const uint32_t M = out_shape.size[0], N = out_shape.size[1];
+    const uint32_t mg = tr ? a_shape.size[1] : a_shape.size[0], K = tr ? a_shape.size[0] : a_shape.size[1];
+    // gemm.rs:91-95 on the sharded operands: rank g's rows of op(A) times B is rank g's row block of C
+    if ((uint64_t)mg * P != M || b_shape.size[0] != K || b_shape.size[1] != N || out_shape.size[2] != 1 || a_shape.size[2] != 1 || b_shape.size[2] != 1)
+        return wg_set_error(WG_ERR_DIM_MISMATCH, "Gemm: dimension mismatch. (sharded over %u ranks: out [%u,%u,%u], m1 row block [%u,%u,%u]%s, m2 [%u,%u,%u])", P, M, N,
+                            out_shape.size[2], a_shape.size[0], a_shape.size[1], a_shape.size[2], tr ? "^T" : "", b_shape.size[0], b_shape.size[1], b_shape.size[2]);
+    if (M == 0 || N == 0) return WG_OK;
+    if (mg % 4 || N % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): the row block (%u rows) and N=%u must be multiples of 4 (vec4 views, shape.wgsl:64-66)", mg, N);
+    if (mode == WG_GATHER_RCCL && P > 1 && !c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): WG_GATHER_RCCL needs a communicator created with a unique id");
+    if (mode == WG_GATHER_PEER_COPY && P > 1) {
+        if (!peer_out) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_COPY needs peer_out[rank] for every other rank");
+        for (uint32_t r = 0; r < P; ++r)
+            if (r != g && (!peer_out[r] || peer_out[r]->bytes < out->bytes))
+                return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): peer_out[%u] is missing or smaller than `out`", r);
+    }
+    if (panel_cols == 0) { // default: ~8 panels of whole 256-column tiles, so that all but the last exchange hides under a Gemm
+        panel_cols = N >= 2048 ? ((N / 8 + 255u) / 256u) * 256u : N;
+    }
+    if (panel_cols % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): panel_cols=%u must be a multiple of 4", panel_cols);
+    if (panel_cols > N) panel_cols = N;
+    const uint32_t npanels = (N + panel_cols - 1) / panel_cols;
+    const size_t es = wg_dtype_size(dtype);
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+
+    const bool staged = mode == WG_GATHER_RCCL && c->nccl != nullptr; // a 1-rank communicator still runs the whole path (tests)
+    wg_buf stage_buf;
+    if (staged) {
+        const size_t need = 2 * (size_t)M * panel_cols * es;
+        if (need > c->stage_bytes) {
+            WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            WG_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->stage) WG_HIP_TRY(hipFree(c->stage));
+            c->stage = nullptr;
+            c->stage_bytes = 0;
+            WG_HIP_TRY(hipMalloc(&c->stage, need));
+            c->stage_bytes = need;
+        }
+        stage_buf.ctx = ctx; stage_buf.ptr = c->stage; stage_buf.bytes = c->stage_bytes; stage_buf.usage = 0; stage_buf.owned = false; stage_buf.host_pinned = false;
+        while (c->ev_panel.size() < npanels) {
+            hipEvent_t e = nullptr;
+            WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_panel.push_back(e);
+        }
+    }
+
+    auto relayout = [&](uint32_t p) -> int { // panel p's cube -> columns of `out`, once its all-gather is done
+        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+        WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, c->ev_panel[p], 0));
+        const char *src = (const char *)c->stage + (size_t)(p & 1u) * M * panel_cols * es;
+        char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
+        return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es);
+    };
+
+    for (uint32_t p = 0; p < npanels; ++p) {
+        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+        wg_view_shape bs = b_shape;
+        bs.size[1] = np;
+        bs.offset = b_shape.offset + c0 * b_shape.stride;
+        wg_view_shape os;
+        os.size[0] = mg; os.size[1] = np; os.size[2] = 1;
+        if (staged) { // slot g of the staging cube of this panel
+            const uint64_t slot0 = (uint64_t)(p & 1u) * M * panel_cols;
+            os.stride = mg; os.stride_mat = mg * np; os.offset = (uint32_t)(slot0 + (uint64_t)g * mg * np);
+            if (slot0 + (uint64_t)M * np >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): staging cube exceeds u32 element indexing; use narrower panels");
+            if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, &stage_buf, os, a_rows, a_shape, b, bs)) return rc;
+            WG_HIP_TRY(hipEventRecord(c->ev_ctx, ctx->stream));
+            WG_HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_ctx, 0));
+            char *base = (char *)c->stage + slot0 * es;
+            ncclResult_t r = rccl().AllGather(base + (size_t)g * mg * np * es, base, (size_t)mg * np, dtype == WG_F16 ? ncclFloat16 : ncclFloat32, c->nccl, c->stream);
+            if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
+            c->bytes_sent += (uint64_t)mg * np * es;
+            WG_HIP_TRY(hipEventRecord(c->ev_panel[p], c->stream));
+            if (p > 0)
+                if (int rc = relayout(p - 1)) return rc; // after this panel's Gemm: the previous panel's gather ran beside it
+        } else { // straight into this rank's rows of C
+            os.stride = out_shape.stride; os.stride_mat = out_shape.stride_mat;
+            const uint64_t off = (uint64_t)out_shape.offset + (uint64_t)c0 * out_shape.stride + (uint64_t)g * mg;
+            if (off >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): output view exceeds u32 element indexing");
+            os.offset = (uint32_t)off;
+            if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, out, os, a_rows, a_shape, b, bs)) return rc;
+            if (mode == WG_GATHER_PEER_COPY && P > 1) {
+                hipEvent_t ev = take_event(c);
+                if (!ev) return wg_set_error(WG_ERR_HIP, "Gemm (sharded): event creation failed");
+                WG_HIP_TRY(hipEventRecord(ev, ctx->stream));
+                const size_t blk = off * es, pitch = (size_t)out_shape.stride * es, width = (size_t)mg * es;
+                if (c->use_sdma) {
+                    CopyJob job;
+                    job.after = ev;
+                    for (uint32_t r = 1; r < P; ++r) { // start with the next rank: every peer's link is busy from the first job on
+                        const uint32_t peer = (g + r) % P;
+                        job.rects.push_back(Rect{ (char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np });
+                    }
+                    {
+                        std::lock_guard<std::mutex> lk(c->mu);
+                        c->jobs.push_back(std::move(job));
+                    }
+                    c->cv_work.notify_one();
+                } else {
+                    WG_HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
+                    for (uint32_t r = 1; r < P; ++r) {
+                        const uint32_t peer = (g + r) % P;
+                        WG_HIP_TRY(hipMemcpy2DAsync((char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np, hipMemcpyDeviceToDevice,
+                                                    c->copy_stream));
+                    }
+                }
+                c->bytes_sent += (uint64_t)(P - 1) * width * np;
+            }
+        }
+    }
+    if (staged) return relayout(npanels - 1); // the only exposed exchange
+    return WG_OK;
+}
+
+} // extern "C"

@@ -24,54 +24,36 @@ int wg_set_error(int status, const char *fmt, ...) {
 }
 void wg_clear_error() { g_last_error.clear(); }
 
-int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->workspace_bytes) {
+// Grow-only scratch regions. A recorded command buffer (hipGraphExec) has the scratch pointer of its kernels baked in and may be
+// submitted many times (wgebra_hip.h, wg_queue_submit), so a region that a live command buffer may reference is never freed on regrow:
+// it is retired and released when the last command buffer of the context is destroyed (or with the context).
+static int grow_scratch(wg_ctx *ctx, void **region, size_t *region_bytes, size_t bytes, const char *what, void **out) {
+    if (bytes > *region_bytes) {
         if (ctx->recording)
-            return wg_set_error(WG_ERR_INVALID_ARG, "workspace of %zu bytes needed while recording: call wg_ctx_reserve_workspace first", bytes);
+            return wg_set_error(WG_ERR_WORKSPACE, "%s of %zu bytes needed while recording: run the call once outside the recording first "
+                                "(or wg_ctx_reserve_workspace)", what, bytes);
         WG_HIP_TRY(hipSetDevice(ctx->device));
-        // in-order stream: earlier users of the old workspace must be done before it is freed
+        // in-order stream: earlier users of the old region must be done before it is freed
         WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->workspace) WG_HIP_TRY(hipFree(ctx->workspace));
-        ctx->workspace = nullptr;
-        ctx->workspace_bytes = 0;
+        if (*region) {
+            if (ctx->live_cmdbufs > 0) ctx->retired_scratch.push_back(*region);
+            else WG_HIP_TRY(hipFree(*region));
+        }
+        *region = nullptr;
+        *region_bytes = 0;
         size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-        WG_HIP_TRY(hipMalloc(&ctx->workspace, want));
-        ctx->workspace_bytes = want;
+        WG_HIP_TRY(hipMalloc(region, want));
+        *region_bytes = want;
     }
-    *out = ctx->workspace;
+    *out = *region;
     return WG_OK;
 }
+int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out) { return grow_scratch(ctx, &ctx->workspace, &ctx->workspace_bytes, bytes, "workspace", out); }
 int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->tr_workspace_bytes) {
-        if (ctx->recording)
-            return wg_set_error(WG_ERR_INVALID_ARG, "transpose workspace of %zu bytes needed while recording: run the call once outside the recording first", bytes);
-        WG_HIP_TRY(hipSetDevice(ctx->device));
-        WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->tr_workspace) WG_HIP_TRY(hipFree(ctx->tr_workspace));
-        ctx->tr_workspace = nullptr;
-        ctx->tr_workspace_bytes = 0;
-        size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-        WG_HIP_TRY(hipMalloc(&ctx->tr_workspace, want));
-        ctx->tr_workspace_bytes = want;
-    }
-    *out = ctx->tr_workspace;
-    return WG_OK;
+    return grow_scratch(ctx, &ctx->tr_workspace, &ctx->tr_workspace_bytes, bytes, "transpose workspace", out);
 }
 int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out) {
-    if (bytes > ctx->pad_workspace_bytes) {
-        if (ctx->recording)
-            return wg_set_error(WG_ERR_INVALID_ARG, "padding workspace of %zu bytes needed while recording: run the call once outside the recording first", bytes);
-        WG_HIP_TRY(hipSetDevice(ctx->device));
-        WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->pad_workspace) WG_HIP_TRY(hipFree(ctx->pad_workspace));
-        ctx->pad_workspace = nullptr;
-        ctx->pad_workspace_bytes = 0;
-        size_t want = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-        WG_HIP_TRY(hipMalloc(&ctx->pad_workspace, want));
-        ctx->pad_workspace_bytes = want;
-    }
-    *out = ctx->pad_workspace;
-    return WG_OK;
+    return grow_scratch(ctx, &ctx->pad_workspace, &ctx->pad_workspace_bytes, bytes, "padding workspace", out);
 }
 extern "C" {
 
@@ -157,6 +139,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->tr_workspace) (void)hipFree(ctx->tr_workspace);
     if (ctx->pad_workspace) (void)hipFree(ctx->pad_workspace);
+    for (void *p : ctx->retired_scratch) (void)hipFree(p);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;
@@ -275,6 +258,11 @@ int wg_buf_destroy(wg_buf *buf) {
         hipError_t e = buf->host_pinned ? hipHostFree(buf->ptr) : hipFree(buf->ptr);
         if (e != hipSuccess) rc = wg_set_error(WG_ERR_HIP, "free failed: %s", hipGetErrorString(e));
     }
+    if (buf->ipc_base) { // a peer's allocation mapped by wg_buf_ipc_open
+        (void)hipSetDevice(buf->ctx->device);
+        (void)hipStreamSynchronize(buf->ctx->stream);
+        (void)hipIpcCloseMemHandle(buf->ipc_base);
+    }
     delete buf;
     return rc;
 }
@@ -361,6 +349,7 @@ int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out) {
     cb->ctx = ctx;
     cb->graph = graph;
     cb->exec = exec;
+    ctx->live_cmdbufs++;
     *out = cb;
     return WG_OK;
 }
@@ -380,6 +369,11 @@ int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf) {
     (void)hipStreamSynchronize(cmdbuf->ctx->stream);
     if (cmdbuf->exec) (void)hipGraphExecDestroy(cmdbuf->exec);
     if (cmdbuf->graph) (void)hipGraphDestroy(cmdbuf->graph);
+    wg_ctx *ctx = cmdbuf->ctx;
+    if (ctx->live_cmdbufs > 0 && --ctx->live_cmdbufs == 0) { // nothing can replay the retired scratch regions any more
+        for (void *p : ctx->retired_scratch) (void)hipFree(p);
+        ctx->retired_scratch.clear();
+    }
     delete cmdbuf;
     return WG_OK;
 }

@@ -24,6 +24,8 @@ struct wg_ctx {
     void *pad_workspace = nullptr; // third scratch: zero-padded operand copies of f16 GEMMs whose shapes the MFMA kernels do not take as they are
     size_t pad_workspace_bytes = 0;
     int compute_units = 0;
+    int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
+    std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
 };
 
 struct wg_buf {
@@ -33,6 +35,7 @@ struct wg_buf {
     uint32_t usage = 0;
     bool owned = true;
     bool host_pinned = false;
+    void *ipc_base = nullptr; // wg_buf_ipc_open: base of the mapped peer allocation (closed with the buffer)
 };
 
 struct wg_cmdbuf {

@@ -1,4 +1,12 @@
-"""M-sharded GEMM across the GPUs of one node: one process per GPU, RCCL all-gather over xGMI (torch.distributed "nccl").
+"""M-sharded GEMM across the GPUs of one node: one process per GPU, RCCL all-gather over xGMI.
+
+Two layers:
+  * `Comm` / `sharded_gemm` -- the product path: thin ctypes callers of the C ABI's multi-GPU section (include/wgebra_hip.h:
+    wg_comm_*, wg_gemm_sharded). RCCL is driven by the library itself (no torch needed); every rank ends with a plain M x N
+    column-major GpuMatrix. Exchange engines: RCCL all-gather of a staging cube + relayout, or SDMA peer copies of the strided
+    row blocks straight into every peer's C (csrc/comm.hip).
+  * `MShardPlan` / `ShardedGemm` -- the planner and the cube-layout driver with injected GEMM / collective (pure host arithmetic,
+    runs under gloo in the CPU tests): the gathered result stays a GpuCube per panel, no relayout.
 
 The reference has no multi-device path (one wgpu::Device + one Queue, crates/wgcore/src/gpu.rs:7-12); this is the
 north-star's addition, expressed in the reference's own tensor model:
@@ -21,6 +29,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Callable, List, Optional, Tuple
+
+import ctypes
 
 from .wgcore import ViewShape
 
@@ -149,3 +159,114 @@ class ShardedGemm:
                 handles.append(self._gather(start, pl.slot_elems_of(p), self.rank))
         for h in handles:
             self._wait(h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# product path: the C ABI's communicator and M-sharded Gemm
+# ---------------------------------------------------------------------------------------------------------------------
+class GatherMode:
+    RCCL = 0       # staging cube + in-place ncclAllGather per panel + relayout into C (wg_gather_mode WG_GATHER_RCCL)
+    PEER_COPY = 1  # Gemm straight into C's rows, SDMA pushes the strided block to every peer's C (WG_GATHER_PEER_COPY)
+    NONE = 2
+
+
+def new_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI (rank 0 calls this and ships the bytes to the other ranks out of band)."""
+    from . import _lib
+    buf = ctypes.create_string_buffer(_lib.WG_COMM_ID_BYTES)
+    _lib.check(_lib.lib.wg_comm_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """wg_comm: one rank of a group of GpuInstances (one per GPU). `unique_id=None` creates a communicator without a collective
+    library (peer copies only; the caller brings its own barrier -- e.g. two ranks sharing one GPU in the tests)."""
+
+    def __init__(self, gpu, nranks: int, rank: int, unique_id: Optional[bytes]):
+        from . import _lib
+        self._lib, self.gpu, self.nranks, self.rank = _lib, gpu, nranks, rank
+        h = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(unique_id, _lib.WG_COMM_ID_BYTES) if unique_id is not None else None
+        _lib.check(_lib.lib.wg_comm_create(gpu._ctx.handle, nranks, rank, idbuf, ctypes.byref(h)))
+        self._h = h
+        self._peers = {}  # id(tensor) -> (ctypes array of wg_buf*, keepalive)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            for _, opened in self._peers.values():
+                for b in opened:
+                    self._lib.lib.wg_buf_destroy(b)
+            self._peers = {}
+            if self.gpu._ctx.handle:
+                self._lib.lib.wg_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def copy_engine(self) -> str:
+        return self._lib.lib.wg_comm_copy_engine(self._h).decode()
+
+    @property
+    def has_collectives(self) -> bool:
+        return bool(self._lib.lib.wg_comm_has_collectives(self._h))
+
+    @property
+    def bytes_sent(self) -> int:
+        return int(self._lib.lib.wg_comm_bytes_sent(self._h))
+
+    def all_gather(self, tensor, first_elem: int, elems_per_rank: int) -> None:
+        from .wgcore import wg_dtype
+        self._lib.check(self._lib.lib.wg_all_gather(self._h, wg_dtype(tensor.dtype), tensor._h, first_elem, elems_per_rank))
+
+    def join(self) -> None:
+        self._lib.check(self._lib.lib.wg_comm_join(self._h))
+
+    def flush(self) -> None:
+        self._lib.check(self._lib.lib.wg_comm_flush(self._h))
+
+    def barrier(self) -> None:
+        self._lib.check(self._lib.lib.wg_comm_barrier(self._h))
+
+    # -- peer buffers (one process per GPU): export mine, open everyone else's ---------------------------------------
+    def export_handle(self, tensor) -> bytes:
+        buf = ctypes.create_string_buffer(self._lib.WG_IPC_HANDLE_BYTES)
+        self._lib.check(self._lib.lib.wg_buf_ipc_export(tensor._h, buf))
+        return buf.raw
+
+    def register_peers(self, tensor, handles: List[bytes]) -> None:
+        """handles[r] = rank r's export_handle(its output tensor) (handles[self.rank] is ignored). After this, `tensor` can be the
+        output of sharded_gemm(..., mode=GatherMode.PEER_COPY)."""
+        arr = (ctypes.c_void_p * self.nranks)()
+        opened = []
+        for r, hb in enumerate(handles):
+            if r == self.rank:
+                arr[r] = tensor._h.value
+                continue
+            b = ctypes.c_void_p()
+            self._lib.check(self._lib.lib.wg_buf_ipc_open(self.gpu._ctx.handle, ctypes.create_string_buffer(hb, self._lib.WG_IPC_HANDLE_BYTES), ctypes.byref(b)))
+            arr[r] = b.value
+            opened.append(b)
+        self._peers[id(tensor)] = (arr, opened)
+
+    def register_local_peers(self, tensor, tensors) -> None:
+        """The ranks share this process (tests): peer r's output is `tensors[r]` itself."""
+        arr = (ctypes.c_void_p * self.nranks)()
+        for r, t in enumerate(tensors):
+            arr[r] = t._h.value
+        self._peers[id(tensor)] = (arr, [])
+
+    def sharded_gemm(self, out, a_rows, b, variant=0, mode: int = GatherMode.RCCL, panel_cols: int = 0) -> None:
+        """out (M x N GpuMatrix, on every rank) = op(A) * B with A sharded on M: `a_rows` is this rank's row block (M/P x K, or
+        K x M/P for the GemmTr variants), `b` (K x N) replicated. Views or tensors; enqueues and returns (see wg_gemm_sharded for
+        when `out` is complete)."""
+        from .wgcore import as_view, wg_dtype
+        ov, av, bv = as_view(out), as_view(a_rows), as_view(b)
+        peers = None
+        if mode == GatherMode.PEER_COPY and self.nranks > 1:
+            ent = self._peers.get(id(ov.buffer()))
+            if ent is None:
+                raise ValueError("PEER_COPY: call register_peers(out, handles) first")
+            peers = ent[0]
+        self._lib.check(self._lib.lib.wg_gemm_sharded(self._h, int(variant), wg_dtype(ov.dtype), int(mode), int(panel_cols), ov.buffer()._h, ov.shape().to_c(),
+                                                      peers, av.buffer()._h, av.shape().to_c(), bv.buffer()._h, bv.shape().to_c()))
