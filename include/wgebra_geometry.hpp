@@ -23,7 +23,7 @@
 #include <math.h>
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define WGG_FN __host__ __device__ inline
 #else
 #define WGG_FN inline

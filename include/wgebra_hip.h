@@ -214,7 +214,8 @@ int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
  * the vec4 precondition becomes cols, stride, stride_mat, offset % 4 == 0 (shape.wgsl:54-56). Same dimension checks
  * and messages as wg_gemm / wg_gemv. A row-major view is the column-major view of the transpose, so WG_GEMM runs the
  * column-major kernel with the operands swapped (no copy); WG_GEMM_TR needs m1 transposed in memory first (one HBM-bound
- * pass into a context-owned scratch buffer). wg_gemv_rm supports single right-hand-side vectors (ncols == 1).
+ * pass into a context-owned scratch buffer). wg_gemv_rm with several right-hand-side columns (ncols % 4 == 0, the row-major
+ * vec4 precondition) runs as the row-major Gemm / GemmTr it is.
  */
 int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype,
                wg_buf *out, wg_view_shape out_shape,
@@ -235,9 +236,10 @@ int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
               const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
 
 /*
- * Extension: result[0] = reduce(op, op(m) * v) in one call -- Gemv into a context-owned scratch vector, then
- * Reduce in the reference order on the same stream (e.g. SqNorm for |m v|^2, Max for the largest entry). Bit-identical to
- * wg_gemv followed by wg_reduce; `m` is one matrix, `v` one vector.
+ * Extension: result[0] = reduce(op, op(m) * v) in one call (e.g. SqNorm for |m v|^2, Max for the largest entry).
+ * Launch-bound sizes (Gemv, rows * cols <= 4 Mi, rows >= 128) run as ONE kernel: the last workgroup to finish folds the product
+ * vector in the reference order (reduce.wgsl:68-87); everything else is Gemv into a context-owned scratch vector, then Reduce, on the
+ * same stream. Either way bit-identical to wg_gemv followed by wg_reduce; `m` is one matrix, `v` one vector.
  */
 int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dtype dtype, wg_buf *result,
                    const wg_buf *m, wg_view_shape m_shape, const wg_buf *v, wg_view_shape v_shape);

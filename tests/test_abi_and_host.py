@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"include/wgebra_hip.h declares symbols the library does not export: {missing}"
     assert set(declared) == set(_lib.lib._wg_signatures), "the ctypes binding and the header disagree on the entry points"
-    assert _lib.lib.wg_abi_version() == 1
+    assert _lib.lib.wg_abi_version() == 2  # 2: + WG_ERR_WORKSPACE, the multi-GPU section (wg_comm_*, wg_gemm_sharded)
 
 
 def test_exported_symbols_are_plain_c():

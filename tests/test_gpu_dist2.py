@@ -98,3 +98,78 @@ def test_sharded_gemm_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=60)
     assert all(ok for _, ok, _ in results), results
+
+
+# --------------------------------------------------------------------------------------------------------
+# The product path of the multi-rank run, two processes on ONE GPU: wg_comm (no collective library: RCCL refuses two ranks on one
+# device), the output buffers exchanged as IPC handles (wg_buf_ipc_export / _open), wg_gemm_sharded(WG_GATHER_PEER_COPY): every rank's
+# Gemm writes its rows of its own M x N C and the copy engine pushes them into the peer's C. Both ranks must hold the plain
+# column-major product -- a GpuMatrix any Gemm::dispatch operand can consume (gemm.rs:65-74), which is then fed to one.
+# --------------------------------------------------------------------------------------------------------
+def _peer_worker(rank, world, port, engine, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["WG_PEER_COPY_ENGINE"] = engine
+        import torch  # first: one HIP runtime per process
+        import torch.distributed as dist
+        import wgmath_amd as wg
+        from wgmath_amd.sharded import Comm, GatherMode
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        M, N, K = 1024, 1536, 512
+        Mg = M // world
+        gpu = wg.GpuInstance.new(0)
+        dev, S = gpu.device(), wg.BufferUsages
+        rng = np.random.default_rng(99)
+        A = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        B = (rng.random((K, N), dtype=np.float32) * 2 - 1).astype(np.float16)
+        ta = wg.TensorBuilder.matrix(Mg, K, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(A[rank * Mg:(rank + 1) * Mg].reshape(-1, order="F")))
+        tb = wg.TensorBuilder.matrix(K, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(B.reshape(-1, order="F")))
+        tc = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.full(M * N, np.nan, np.float16))
+        comm = Comm(gpu, world, rank, None)
+        handles = [None] * world
+        dist.all_gather_object(handles, comm.export_handle(tc))
+        comm.register_peers(tc, handles)
+        dist.barrier()  # every rank's C is allocated, initialised and mapped before anyone pushes into it
+        for _ in range(2):
+            comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_COPY, 512)
+            gpu.sync()
+            comm.flush()
+            dist.barrier()
+        got = tc.read(dev).reshape(M, N, order="F").astype(np.float64)
+        A64, B64 = A.astype(np.float64), B.astype(np.float64)
+        truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
+        tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        ok = bool((np.abs(got - truth) <= tol).all())
+        # the gathered C is an ordinary GpuMatrix: use it as the m1 of another Gemm (C^T C would overflow f16: scale by a thin m2)
+        thin = (rng.random((N, 8), dtype=np.float32) / N).astype(np.float16)
+        tt = wg.TensorBuilder.matrix(N, 8, S.STORAGE | S.COPY_DST).build_init(dev, np.ascontiguousarray(thin.reshape(-1, order="F")))
+        to = wg.TensorBuilder.matrix(M, 8, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.zeros(M * 8, np.float16))
+        p = dev.create_command_encoder().compute_pass("use", None)
+        wg.Gemm.from_device(dev).dispatch(dev, wg.ViewShapeBuffers(), p, to, tc, tt)
+        used = to.read(dev).reshape(M, 8, order="F").astype(np.float64)
+        ref = tc.read(dev).reshape(M, N, order="F").astype(np.float64) @ thin.astype(np.float64)
+        ok2 = bool(np.abs(used - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3)
+        dist.barrier()
+        q.put((rank, ok and ok2, f"engine {comm.copy_engine}, sent {comm.bytes_sent} B, product ok={ok}, consumable ok={ok2}"))
+        comm.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(e)))
+
+
+@pytest.mark.parametrize("engine", ["sdma", "hip2d"])
+def test_two_ranks_one_gpu_peer_copy_gives_a_plain_matrix(engine):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, engine, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"
+    assert any(("sdma-rect" if engine == "sdma" else "hip2d") in m for _, _, m in res)

@@ -193,3 +193,58 @@ def test_addressing_beyond_4GiB(gpu):
     sums = res.read(gpu.device())
     assert np.array_equal(sums, np.tile(sums[:BLK // R], reps)), "columns past 4 GiB do not repeat the block's sums bit for bit"
     assert np.allclose(sums[:BLK // R], Mb.sum(0), rtol=0, atol=R * 2.0 ** -24 * np.abs(Mb).sum(0).max())
+
+
+# --------------------------------------------------------------------------------------------------------
+# config 5: f16 GEMM 32768^3 through the M-sharded entry point (wg_gemm_sharded). One GPU here, so one rank -- but the whole
+# path: a real RCCL communicator created through the C ABI, staging cube + ncclAllGather + cube_to_matrix relayout per N-panel
+# (WG_GATHER_RCCL), on the unmasked 256-CU stream and on the 224-CU masked stream the multi-rank bench gives that engine, and the
+# panel-wise strided-output path of the peer-copy engine (WG_GATHER_PEER_COPY). >= 64 sampled rows x 512 columns against f64.
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("peer", None)])
+def test_config5_gemm_f16_32768_sharded_entry_point(engine, cus):
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import bench
+    wg = _wg()
+    from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
+    from wgmath_amd._lib import check, lib
+    n = 32768
+    inst = wg.GpuInstance.new(0, cu_count=cus) if cus else wg.GpuInstance.new(0)
+    dev = inst.device()
+    comm = Comm(inst, 1, 0, new_unique_id())
+    assert comm.has_collectives
+    A = bench.device_random(wg, inst, (n, n), np.float16, 0xA000)
+    B = bench.device_random(wg, inst, (n, n), np.float16, 0xB000)
+    C = wg.TensorBuilder.matrix(n, n, S_ALL).build(dev, np.float16)
+    panel = bench.plan_panel_cols(n, n, cus or 256)
+    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.PEER_COPY
+    comm.sharded_gemm(C, A, B, 0, mode, panel)
+    comm.barrier()  # flush + 1-element all-reduce joined into the stream (what separates two steps of the bench)
+    inst.sync()
+    rng = np.random.default_rng(5)
+    rows = np.unique(rng.integers(0, n, 80))[:72]
+    cols = np.unique(rng.integers(0, n, 600))[:512]
+    assert rows.size >= 64 and cols.size == 512
+
+    def read_range(t, start, count):
+        out = np.empty(count, np.float16)
+        check(lib.wg_buf_read(inst._ctx.handle, t._h, start * 2, out.ctypes.data, count * 2))
+        return out
+
+    # rows of A: the operand is one 16 Mi-element block tiled (bench.device_random), column k starts at k*n
+    blk = bench.rand_block(0xA000, 1 << 24, np.float16)
+    a_rows = np.empty((rows.size, n), np.float64)
+    for k in range(n):
+        a_rows[:, k] = blk[(k * n + rows) % (1 << 24)]
+    bc = np.stack([read_range(B, int(c) * n, n) for c in cols], axis=1).astype(np.float64)
+    got = np.stack([read_range(C, int(c) * n, n)[rows] for c in cols], axis=1).astype(np.float64)
+    truth, sabs = a_rows @ bc, np.abs(a_rows) @ np.abs(bc)
+    tol = U.f32_gate(n, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+    err = np.abs(got - truth)
+    assert (err <= tol).all(), f"config 5 via {engine} (CUs {cus}): worst err/tol {(err / tol).max():.3g}"
+    # spot-check that device_random really is the tiled block the host side assumed
+    assert np.array_equal(read_range(A, 5 * n + 100, 64), blk[(5 * n + 100) % (1 << 24):][:64])
+    comm.close()
+    del A, B, C
+    inst.close()

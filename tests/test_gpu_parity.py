@@ -621,6 +621,32 @@ def test_gemv_row_major(gpu, tr, R, Cn):
     assert (np.abs(got - truth) <= U.f32_gate(vlen, sabs)).all()
 
 
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("R,Cn,nrhs,mats", [(64, 256, 4, 1), (1024, 512, 8, 1), (260, 72, 12, 2), (2048, 640, 32, 1)])
+def test_gemv_row_major_multi_rhs(gpu, tr, R, Cn, nrhs, mats):
+    """Row-major Gemv with several right-hand-side columns (shape.wgsl:49-57 `im` x grid.y of gemv.wgsl:40,46,62): out[:, y, z] =
+    op(m[:, :, z]) v[:, y, z] with every view row-major. Checked against f64 per (matrix, column)."""
+    wg = _wg()
+    rng = np.random.default_rng(R + Cn + nrhs + tr)
+    m = rng.random((mats, R, Cn), dtype=np.float32) * 2 - 1          # [z][i][j]: row-major matrices, stride = Cn
+    vlen, olen = (R, Cn) if tr else (Cn, R)
+    v = rng.random((mats, vlen, nrhs), dtype=np.float32) * 2 - 1     # row-major (vlen x nrhs): stride = nrhs
+    tm, tv = upload(gpu, (m.size,), m.reshape(-1), np.float32), upload(gpu, (v.size,), v.reshape(-1), np.float32)
+    to = upload(gpu, (mats * olen * nrhs,), np.full(mats * olen * nrhs, np.nan, np.float32), np.float32)
+    gemv = wg.Gemv.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    mv = wg.GpuTensorView(wg.ViewShape([R, Cn, mats], Cn, R * Cn, 0), tm, 3)
+    vv = wg.GpuTensorView(wg.ViewShape([vlen, nrhs, mats], nrhs, vlen * nrhs, 0), tv, 3)
+    ov = wg.GpuTensorView(wg.ViewShape([olen, nrhs, mats], nrhs, olen * nrhs, 0), to, 3)
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, ov, mv, vv, variant))
+    got = to.read(gpu.device()).astype(np.float64).reshape(mats, olen, nrhs)
+    for z in range(mats):
+        m64 = (m[z].T if tr else m[z]).astype(np.float64)
+        truth, sabs = m64 @ v[z].astype(np.float64), np.abs(m64) @ np.abs(v[z]).astype(np.float64)
+        assert (np.abs(got[z] - truth) <= U.f32_gate(vlen, sabs)).all(), f"row-major Gemv x{nrhs}: matrix {z}"
+
+
 # --------------------------------------------------------------------------------------------------------
 # seeded fuzz over the f16 MFMA paths: random ragged sizes, strides, offsets, batches, both variants, alpha/beta
 # --------------------------------------------------------------------------------------------------------
@@ -858,6 +884,47 @@ def test_record_replay_gemm_chain(gpu):
     assert np.abs(T2 - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3
 
 
+def test_scratch_regrow_keeps_recorded_command_buffers_valid():
+    """A recorded command buffer has the context's scratch pointer baked into its graph and may be submitted many times. (1) An
+    operator that would have to GROW the scratch inside a recording returns the distinct WG_ERR_WORKSPACE status (allocation cannot
+    be captured) and the recording stays usable. (2) Growing the scratch AFTER a recording must not free the region the old command
+    buffer replays into: the region is retired, so a buffer allocated afterwards can never alias it (canary), and the replay is right."""
+    wg = _wg()
+    inst = wg.GpuInstance.new(0)  # a fresh context: empty scratch
+    dev, shapes = inst.device(), wg.ViewShapeBuffers()
+    R, Cn = 4096, 16384  # split over grid.y: partial sums go through the scratch
+    rng = np.random.default_rng(5)
+    m, v = rng.random(R * Cn, dtype=np.float32), rng.random(Cn, dtype=np.float32)
+    S = wg.BufferUsages
+    mk = lambda shape, flat: wg.TensorBuilder.tensor(shape, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, flat)
+    tm, tv, to = mk((R, Cn), m), mk((Cn,), v), mk((R,), np.zeros(R, np.float32))
+    gemv = wg.Gemv.from_device(dev)
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("too early", None) as p:
+        with pytest.raises(wg.WorkspaceMustGrow) as ei:
+            gemv.dispatch(dev, shapes, p, to, tm, tv)
+        assert ei.value.status == 8 and "while recording" in str(ei.value)
+    enc.finish()  # the recording itself is still well-formed (it holds nothing)
+    p = dev.create_command_encoder().compute_pass("eager", None)
+    gemv.dispatch(dev, shapes, p, to, tm, tv)  # eager once: sizes the scratch
+    expect = to.read(dev).copy()
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p2:
+        gemv.dispatch(dev, shapes, p2, to, tm, tv)
+    cb = enc.finish()
+    dev.reserve_workspace(96 << 20)  # a later, larger need: the scratch regrows while `cb` is alive
+    canaries = [mk(((1 << 20) * k // 4,), np.full((1 << 20) * k // 4, 7.0, np.float32)) for k in (1, 1, 2, 2, 4, 4, 8)]  # would reuse a freed region
+    wg.OpAssign.new(dev, wg.OpAssignVariant.Sub).dispatch(dev, shapes, p, to, to)
+    assert not to.read(dev).any()
+    for _ in range(3):
+        inst.queue().submit([cb])
+    assert np.array_equal(to.read(dev), expect)
+    for c in canaries:
+        assert (c.read(dev) == 7.0).all(), "a replayed command buffer wrote into memory that was freed and reallocated"
+    del cb, canaries
+    inst.close()
+
+
 # --------------------------------------------------------------------------------------------------------
 # two-pass multi-workgroup reduce (extension, SURVEY 8(f) N3): Min/Max bit-identical, Sum/Prod/SqNorm within the re-association bound
 # --------------------------------------------------------------------------------------------------------
@@ -917,3 +984,38 @@ def test_gemv_reduce(gpu, tr):
         run_pass(gpu, two)
         run_pass(gpu, lambda p: wg.gemv_reduce(p, op, r2, tm, tv, variant))
         assert r1.read(gpu.device()).tobytes() == r2.read(gpu.device()).tobytes()
+
+
+@pytest.mark.parametrize("R,Cn", [(128, 4096), (260, 512), (1024, 1024), (4096, 1024), (132, 8), (8192, 1024)])
+def test_gemv_reduce_fused_single_launch(gpu, R, Cn):
+    """The launch-bound family runs Gemv + Reduce as ONE kernel (last workgroup folds y in the reference order; gemv.hip): same bits as
+    the two dispatches for all five operators, on repeated calls (the arrival counter re-arms itself), from a strided / offset matrix
+    view, and when replayed from a recorded command buffer. (8192 x 1024 exceeds 4 Mi elements: the two-launch path, same bits.)"""
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    rng = np.random.default_rng(R * 7 + Cn)
+    ld = R + 8
+    m = (rng.random(ld * Cn + 16, dtype=np.float32) * 2 - 1).astype(np.float32)
+    v = (rng.random(Cn, dtype=np.float32) + 0.5).astype(np.float32)
+    tm, tv = upload(gpu, (m.size,), m), upload(gpu, (Cn,), v)
+    mv = wg.GpuTensorView(wg.ViewShape([R, Cn, 1], ld, ld * Cn, 8), tm, 2)  # offset 8, leading dimension R + 8
+    to = upload(gpu, (R,), np.zeros(R, np.float32))
+    gemv = wg.Gemv.from_device(dev)
+    for op in (wg.ReduceOp.Min, wg.ReduceOp.Max, wg.ReduceOp.Sum, wg.ReduceOp.Prod, wg.ReduceOp.SqNorm):
+        r1, r2 = upload(gpu, (), np.zeros(1, np.float32)), upload(gpu, (), np.full(1, np.nan, np.float32))
+        red = wg.Reduce.new(dev, op)
+        run_pass(gpu, lambda p: (gemv.dispatch(dev, shapes, p, to, mv, tv), red.dispatch(dev, shapes, p, to, r1)))
+        for _ in range(3):
+            run_pass(gpu, lambda p: wg.gemv_reduce(p, op, r2, mv, tv, wg.GemvVariant.Gemv))
+            assert r1.read(dev).tobytes() == r2.read(dev).tobytes(), f"{op.name} {R}x{Cn}"
+    # recorded: the fused launch replays (its scratch and counter exist: it ran eagerly above)
+    r3 = upload(gpu, (), np.full(1, np.nan, np.float32))
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("rec", None) as p:
+        wg.gemv_reduce(p, wg.ReduceOp.Sum, r3, mv, tv, wg.GemvVariant.Gemv)
+    cb = enc.finish()
+    rs = upload(gpu, (), np.zeros(1, np.float32))
+    run_pass(gpu, lambda p: (gemv.dispatch(dev, shapes, p, to, mv, tv), wg.Reduce.new(dev, wg.ReduceOp.Sum).dispatch(dev, shapes, p, to, rs)))
+    for _ in range(2):
+        gpu.queue().submit([cb])
+    assert r3.read(dev).tobytes() == rs.read(dev).tobytes()

@@ -179,6 +179,24 @@ int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dty
     const uint32_t out_rows = tr ? mm.cols : mm.rows;
     void *ws = nullptr;
     if (int rc = wg_ctx_tr_workspace(ctx, (size_t)(out_rows ? out_rows : 4) * sizeof(float), &ws)) return rc;
+    // Launch-bound sizes (the single-kernel Gemv family): ONE launch -- the last workgroup to finish folds y in the reference order
+    // (gemv.hip, gemv_n_small_reduce_kernel). Same checks as wg_gemv would make; everything else falls through to the two launches.
+    if (!tr && dtype == WG_F32 && mm.cols == vv.rows && out_rows >= 128u && out_rows % 4u == 0 && mm.cols % 4u == 0 && mm.cols > 0 &&
+        m->bytes && v->bytes && mm.offset % 4u == 0 && vv.offset % 4u == 0 && (mm.cols == 1 || mm.stride % 4u == 0) &&
+        (uint64_t)out_rows * mm.cols <= (4ull << 20)) {
+        const View m_eff = { mm.rows, mm.cols, 1, mm.stride, mm.stride_mat, mm.offset }, v_eff = { vv.rows, 1, 1, vv.stride, vv.stride_mat, vv.offset };
+        if (int rc = check_bounds("Gemv", "m", m_eff, m, dtype)) return rc;
+        if (int rc = check_bounds("Gemv", "v", v_eff, v, dtype)) return rc;
+        if (!ctx->flags) {
+            if (ctx->recording) return wg_set_error(WG_ERR_WORKSPACE, "gemv_reduce: arrival counter needed while recording: run the call once outside the recording first");
+            WG_HIP_TRY(hipSetDevice(ctx->device));
+            WG_HIP_TRY(hipMalloc((void **)&ctx->flags, 256));
+            WG_HIP_TRY(hipMemsetAsync(ctx->flags, 0, 256, ctx->stream));
+        }
+        wgk_mat M = { elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat }, V = { elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat };
+        const int rc = wgk_gemv_small_reduce(ctx, (int)op, out_rows, mm.cols, (float *)ws, M, V, ctx->flags, (float *)result->ptr);
+        if (rc != WG_ERR_UNSUPPORTED) return rc;
+    }
     wg_buf tmp;
     tmp.ctx = ctx; tmp.ptr = ws; tmp.bytes = (size_t)(out_rows ? out_rows : 4) * sizeof(float); tmp.usage = 0; tmp.owned = false; tmp.host_pinned = false;
     wg_view_shape os;
@@ -303,10 +321,17 @@ int wg_gemv_rm(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out
     if ((variant == WG_GEMV_FAST || variant == WG_GEMV_TR_FAST) && o.rows % 4u != 0)
         return wg_set_error(WG_ERR_PRECONDITION, "Gemv: assertion `left == right` failed (out_nrows %% 4 == 0, gemv.rs:122): out has %u rows",
                             o.rows);
-    // a row-major matrix of right-hand sides has its columns strided by 1 element: only single vectors map onto the kernels
-    if (o.cols > 1 || vv.cols > 1)
-        return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv (row-major): %u right-hand-side columns; only vectors (ncols == 1) are supported",
-                            o.cols > vv.cols ? o.cols : vv.cols);
+    // Several right-hand sides (grid.y of gemv.wgsl:40,46,62 with the row-major `im`, shape.wgsl:49-57): a row-major matrix of
+    // right-hand sides has its columns 1 element apart, which no GEMV kernel streams -- but out (R x n) = op(m) * v (C x n) on row-major
+    // views IS the row-major Gemm / GemmTr, i.e. the column-major product out^T (n x R) = v^T * op(m)^T with few rows (the few-row and
+    // few-column MFMA kernels). The matrix is shared by the columns and the batch count comes from `out`, as in wg_gemv.
+    if (o.cols > 1 || vv.cols > 1) {
+        wg_view_shape os = out_shape, ms = m_shape, vs = v_shape;
+        ms.size[2] = o.mats;
+        vs.size[1] = o.cols;
+        vs.size[2] = o.mats;
+        return wg_gemm_rm(ctx, tr ? WG_GEMM_TR : WG_GEMM, dtype, out, os, m, ms, v, vs);
+    }
     return wg_gemv(ctx, tr ? WG_GEMV : WG_GEMV_TR, dtype, out, out_shape, m, relabel(m_shape), v, v_shape);
 }
 

@@ -536,8 +536,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     }
     // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. WG_F32_SKINNY=0 disables
     // it (experiments / tests of the tiled kernel on these shapes).
-    // (GemmTr: 32-bit DMA offsets within a 32-row block and within B)
-    if (N <= 64 && M >= 512 && K >= 128 && (!trans || ((uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)))) {
+    // (32-bit DMA offsets within a 32-row / 32-k block of m1 and within the 64 columns of m2: both variants build them)
+    if (N <= 64 && M >= 512 && K >= 128 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
         const char *e = getenv("WG_F32_SKINNY");
         if (!(e && atoi(e) == 0)) return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }

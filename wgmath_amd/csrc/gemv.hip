@@ -20,6 +20,7 @@
 // parity is tolerance-based: the order here is "per-lane sequential, then butterfly", which satisfies the
 // same error bound as both WGSL orders.
 #include "wg_internal.hpp"
+#include "reduce_ops.hpp"
 #include <cstdlib>
 
 namespace {
@@ -301,6 +302,78 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fused Gemv + Reduce for the launch-bound sizes (reduce.rs:100-113 after gemv.rs:64-137 in ONE launch): the body of
+// gemv_n_small_kernel writes y = m v into a scratch vector; the LAST workgroup to finish (one agent-scope release fence + one
+// atomic per workgroup -- a few dozen workgroups here; the same protocol lost on the big GEMVs, profiles/r01_evidence.md section 7) then
+// folds y in the reference's order: 128 virtual lanes, lane t takes y[t], y[t+128], ... ascending, then the 64..1 tree
+// (reduce.wgsl:68-87), mapped onto 32 lanes x float4 exactly like reduce_rows4 -- so the result has the bits of Gemv followed by Reduce.
+// ------------------------------------------------------------------------------------------------------
+template <int OP>
+__global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs a, unsigned *__restrict__ counter, float *__restrict__ result) {
+    __shared__ float4 part[32][8];
+    __shared__ unsigned is_last;
+    const uint32_t rl = threadIdx.x & 7u, g = threadIdx.x >> 3;
+    const uint32_t row = blockIdx.x * 32u + 4u * rl;
+    const bool row_ok = row < a.rows_out;
+    const float *mp = a.m + (row_ok ? row : 0u);
+    const float *vp = a.v;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t c = g;
+    for (; c + 96u < a.k; c += 128u) {
+        const float4 m0 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm));
+        const float4 m1 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 32u) * a.ldm));
+        const float4 m2 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 64u) * a.ldm));
+        const float4 m3 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 96u) * a.ldm));
+        fma4(acc, m0, vp[c]); fma4(acc, m1, vp[c + 32u]); fma4(acc, m2, vp[c + 64u]); fma4(acc, m3, vp[c + 96u]);
+    }
+    for (; c < a.k; c += 32u) fma4(acc, ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm)), vp[c]);
+    part[g][rl] = acc;
+    __syncthreads();
+    if (g == 0 && row_ok) { // the same summation as gemv_n_small_kernel: y has the bits wg_gemv would have produced
+        float4 s = part[0][rl];
+#pragma unroll
+        for (int i = 1; i < 32; ++i) {
+            const float4 p = part[i][rl];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        *reinterpret_cast<float4 *>(a.dst + row) = s;
+        __threadfence(); // release: this workgroup's rows of y are visible device-wide (other XCDs' L2 included) before it is counted
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(counter, 1u);
+        is_last = prev == gridDim.x - 1u;
+        if (is_last) *counter = 0u; // ready for the next launch on this stream (launches of one context are ordered)
+    }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 32u) return;
+    __threadfence(); // acquire: every other workgroup's y
+    const uint32_t p = threadIdx.x, n = a.rows_out; // n % 4 == 0 (vec4 precondition), y is 16-byte aligned scratch
+    const float *y = a.dst;
+    float r[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
+    const uint32_t full_rows = n / 128u;
+    for (uint32_t q = 0; q < full_rows; ++q) {
+        const float4 v = wg_ld_nt(reinterpret_cast<const float4 *>(y) + (uint64_t)q * 32u + p);
+        r[0] = r_ws<OP>(r[0], v.x); r[1] = r_ws<OP>(r[1], v.y); r[2] = r_ws<OP>(r[2], v.z); r[3] = r_ws<OP>(r[3], v.w);
+    }
+    {
+        const uint32_t i0 = full_rows * 128u + 4u * p;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            if (i0 + cc < n) r[cc] = r_ws<OP>(r[cc], __builtin_nontemporal_load(y + i0 + cc));
+    }
+#pragma unroll
+    for (int s = 16; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) r[cc] = r_red<OP>(r[cc], __shfl_down(r[cc], s, 32));
+    }
+    r[0] = r_red<OP>(r[0], r[2]);
+    r[1] = r_red<OP>(r[1], r[3]);
+    r[0] = r_red<OP>(r[0], r[1]);
+    if (p == 0) result[0] = r[0];
+}
+
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); }
 
 } // namespace
@@ -310,9 +383,9 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: only f32 is implemented (the reference kernel is f32: gemv.wgsl:9-14)");
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
     // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
-    // one GEMV pass per 8 columns. (GemvTr: m is the K x M operand of a GemmTr; the 32-bit DMA offsets of that kernel must suffice.)
+    // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
     if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
-        (!trans || ((uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))))
+        (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
         return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
@@ -334,6 +407,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     uint32_t nsplit = want > max_split ? max_split : want;
     if (nsplit < 1u) nsplit = 1u;
     if (nsplit > 65535u) nsplit = 65535u;
+    if (nrhs > 65535u) nsplit = 1u; // the combine pass puts the right-hand sides on grid.y; that many columns fill the chip unsplit
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
 
@@ -390,5 +464,26 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
                            nsplit, rows_out, nrhs, (float *)out, out_ld, out_batch);
         WG_HIP_TRY(hipGetLastError());
     }
+    return WG_OK;
+}
+
+// One launch for result = reduce(op, m v) when the Gemv is launch-bound (the single-kernel shape family of wgk_gemv); WG_ERR_UNSUPPORTED
+// tells the caller to run Gemv and Reduce as two launches. `y` is a scratch vector of rows_out floats, `counter` a zeroed device word.
+int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, float *y, wgk_mat m, wgk_mat v, unsigned *counter, float *result) {
+    if (!(GEMV_SMALL && (uint64_t)rows_out * k <= (4ull << 20) && rows_out >= 128u && k >= 4u)) return WG_ERR_UNSUPPORTED;
+    GemvArgs a;
+    a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = 0;
+    a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = 0;
+    a.rows_out = rows_out; a.k = k; a.nrhs = 1; a.k_per_split = k;
+    a.dst = y; a.ld_dst = rows_out; a.dst_split = 0; a.dst_batch = 0;
+    const dim3 grid(ceil_div(rows_out, 32u)), block(kThreads);
+    switch (op) {
+    case R_MIN: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_MIN>, grid, block, 0, ctx->stream, a, counter, result); break;
+    case R_MAX: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_MAX>, grid, block, 0, ctx->stream, a, counter, result); break;
+    case R_SUM: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_SUM>, grid, block, 0, ctx->stream, a, counter, result); break;
+    case R_PROD: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_PROD>, grid, block, 0, ctx->stream, a, counter, result); break;
+    default: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_SQNORM>, grid, block, 0, ctx->stream, a, counter, result); break;
+    }
+    WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

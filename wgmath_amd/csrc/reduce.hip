@@ -14,37 +14,9 @@
 // HBM-bound: 4 bytes per element read, 4 bytes per vector written.
 // Vectors whose base is not 16-byte aligned take the scalar twin (128 lanes x 4-byte loads, same tree).
 #include "wg_internal.hpp"
+#include "reduce_ops.hpp"
 
 namespace {
-
-enum { R_MIN = 0, R_MAX = 1, R_SUM = 2, R_PROD = 3, R_SQNORM = 4 };
-
-template <int OP>
-__device__ __forceinline__ float r_init() {
-    if constexpr (OP == R_MIN) return 3.4e38f;        // init_max_f32 (reduce.wgsl:40-42) -- not FLT_MAX
-    else if constexpr (OP == R_MAX) return -3.4e38f;  // init_min_f32 (reduce.wgsl:44-46)
-    else if constexpr (OP == R_PROD) return 1.0f;
-    else return 0.0f;
-}
-template <int OP>
-__device__ __forceinline__ float r_ws(float acc, float x) { // workspace_fn
-    if constexpr (OP == R_MIN) return fminf(acc, x);
-    else if constexpr (OP == R_MAX) return fmaxf(acc, x);
-    else if constexpr (OP == R_SUM) return __fadd_rn(acc, x);
-    else if constexpr (OP == R_PROD) return __fmul_rn(acc, x);
-    else {
-        float sq = __fmul_rn(x, x);
-        asm volatile("" : "+v"(sq)); // the product is rounded on its own (reduce_sqnorm_f32 as restated by the oracle): never an FMA
-        return __fadd_rn(acc, sq);
-    }
-}
-template <int OP>
-__device__ __forceinline__ float r_red(float a, float b) { // reduce_fn
-    if constexpr (OP == R_MIN) return fminf(a, b);
-    else if constexpr (OP == R_MAX) return fmaxf(a, b);
-    else if constexpr (OP == R_PROD) return __fmul_rn(a, b);
-    else return __fadd_rn(a, b); // Sum and SqNorm (reduce.rs:55)
-}
 
 #ifndef RED_UNROLL
 #define RED_UNROLL 16 // rows (float4 loads) in flight per lane: 8 -> 6.21 TB/s, 16 -> 6.60, 32 -> 6.60 (4096 x 65536)

@@ -140,6 +140,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     if (ctx->tr_workspace) (void)hipFree(ctx->tr_workspace);
     if (ctx->pad_workspace) (void)hipFree(ctx->pad_workspace);
     for (void *p : ctx->retired_scratch) (void)hipFree(p);
+    if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;

@@ -11,8 +11,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
                                                             OUT *__restrict__ out, uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
     const uint32_t m4 = blockIdx.x * 256u + threadIdx.x; // float4 index within a column (M % 4 == 0)
     if (m4 * 4u >= M) return;
-    const uint32_t col = blockIdx.y, z = blockIdx.z;
+    const uint32_t z = blockIdx.z;
     const uint64_t slab = (uint64_t)M * N;
+    for (uint32_t col = blockIdx.y; col < N; col += gridDim.y) { // grid.y is capped at 65535: wider outputs loop
     const float4 *p = reinterpret_cast<const float4 *>(part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M) + m4;
     float4 s = p[0];
     for (uint32_t i = 1; i < nsplit; ++i) {
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         h4 r = { { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w } };
         *reinterpret_cast<h4 *>(o) = r;
     }
+    }
 }
 
 // out[r * rs + c * cs] = alpha * sum_s part[s][c][r]: reads run along r (contiguous), writes are rs apart -- the outputs this serves are small
@@ -41,12 +43,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_strided_kernel(const float 
                                                                     float *__restrict__ out, uint32_t rs, uint32_t cs, uint64_t c_batch, float alpha) {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= M) return;
-    const uint32_t col = blockIdx.y, z = blockIdx.z;
+    const uint32_t z = blockIdx.z;
     const uint64_t slab = (uint64_t)M * N;
-    const float *p = part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M + r;
-    float s = p[0];
-    for (uint32_t i = 1; i < nsplit; ++i) s += p[(uint64_t)i * slab];
-    out[z * c_batch + (uint64_t)r * rs + (uint64_t)col * cs] = alpha != 1.f ? s * alpha : s;
+    for (uint32_t col = blockIdx.y; col < N; col += gridDim.y) {
+        const float *p = part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M + r;
+        float s = p[0];
+        for (uint32_t i = 1; i < nsplit; ++i) s += p[(uint64_t)i * slab];
+        out[z * c_batch + (uint64_t)r * rs + (uint64_t)col * cs] = alpha != 1.f ? s * alpha : s;
+    }
 }
 
 } // namespace
@@ -64,8 +68,8 @@ uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32
 
 int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
                      uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
-    if (N > 65535 || nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: N or nmats above 65535");
-    const dim3 grid((M / 4u + 255u) / 256u, N, nmats), block(256);
+    if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: more than 65535 matrices");
+    const dim3 grid((M / 4u + 255u) / 256u, N < 65535u ? N : 65535u, nmats), block(256);
     if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch, alpha, beta);
     else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch, alpha, beta);
     WG_HIP_TRY(hipGetLastError());
@@ -74,8 +78,8 @@ int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M
 
 int wg_splitk_reduce_strided(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, float *out,
                              uint32_t row_stride, uint32_t col_stride, uint64_t c_batch, float alpha) {
-    if (N > 65535 || nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: N or nmats above 65535");
-    const dim3 grid((M + 255u) / 256u, N, nmats), block(256);
+    if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: more than 65535 matrices");
+    const dim3 grid((M + 255u) / 256u, N < 65535u ? N : 65535u, nmats), block(256);
     hipLaunchKernelGGL(splitk_reduce_strided_kernel, grid, block, 0, ctx->stream, part, nsplit, M, N, out, row_stride, col_stride, c_batch, alpha);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;

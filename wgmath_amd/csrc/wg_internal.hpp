@@ -24,6 +24,7 @@ struct wg_ctx {
     void *pad_workspace = nullptr; // third scratch: zero-padded operand copies of f16 GEMMs whose shapes the MFMA kernels do not take as they are
     size_t pad_workspace_bytes = 0;
     int compute_units = 0;
+    unsigned *flags = nullptr;           // a few zeroed device words (arrival counters of fused epilogues), created on first use
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
 };
@@ -98,6 +99,9 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v);
 
 // out (M x N) = op(m1) (M x K) * m2 (K x N); trans: m1 stored K x M
+// fused Gemv + Reduce (one launch) for launch-bound sizes; WG_ERR_UNSUPPORTED (no error message) = not that shape family
+int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, float *y, wgk_mat m, wgk_mat v, unsigned *counter, float *result);
+
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
