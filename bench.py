@@ -293,6 +293,7 @@ class GemvWorkload(Workload):
         # graph_batch > 0: the dispatch is launch-bound (a few MB): record `graph_batch` dispatches into ONE command buffer
         # (a hipGraph) and replay it -- a step is then one Queue::submit of that buffer
         self.graph_batch = graph_batch
+        self.launch_bound = R * C <= (4 << 20)
 
     def setup(self, wg, gpu, rank, world):
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
@@ -513,7 +514,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
@@ -529,6 +530,25 @@ def load_traffic(workload: str):
         return json.load(open(path)).get(workload, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def load_pmc(workload: str):
+    """Counter-derived facts of the workload's dominant kernel from the tracked rocprofv3 summary (profiles/r02_pmc.csv, written by
+    tools/pmc_r02.sh): MFMA utilisation in cycles and the effective clock of the PROFILED run (profiled passes clock lower)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r02_pmc.csv")
+    try:
+        with open(path) as f:
+            for r in csv.DictReader(ln for ln in f if not ln.startswith("#")):
+                if r["workload"] == workload:
+                    out = {}
+                    for k_out, k_in in (("mfma_util", "mfma_util"), ("clock_ghz", "clock_ghz"), ("l2_hit_rate", "l2_hit_rate"), ("lds_bank_conflict", "lds_bank_conflict")):
+                        if r.get(k_in, "") != "":
+                            out[k_out] = float(r[k_in])
+                    return out
+    except Exception:
+        pass
+    return {}
 
 
 def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0, keep=True):
@@ -577,6 +597,16 @@ def summarize(w, elapsed, kernel_ms, steps, world):
     traffic = load_traffic(w.name) if (world == 1 and launches in (1, getattr(w, "graph_batch", 0))) else None
     roof = {"bound": w.bound, "kernel": w.kernel, "achieved": round(achieved, 3), "peak": peak, "unit": w.unit,
             "frac": round(achieved / peak, 4), "kernel_ms": round(kernel_ms, 5), "traffic": traffic}
+    if world == 1:
+        pmc = load_pmc(w.name)
+        if w.bound == "mfma" and "mfma_util" in pmc:
+            roof["mfma_util"] = pmc["mfma_util"]  # SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x cycles), profiles/r02_pmc.csv
+        if "clock_ghz" in pmc:
+            roof["clock_ghz_profiled"] = pmc["clock_ghz"]
+        if "l2_hit_rate" in pmc:
+            roof["l2_hit_rate"] = pmc["l2_hit_rate"]
+    if getattr(w, "launch_bound", False):
+        roof["dispatch_us"] = round(kernel_ms * 1e3, 2)  # launch-bound: wall time per dispatch on the stream, eager or replayed
     return value, roof
 
 

@@ -49,18 +49,23 @@ template <> struct dtype_of<float> { static constexpr wg_dtype value = WG_F32; }
 template <> struct dtype_of<_Float16> { static constexpr wg_dtype value = WG_F16; };
 #endif
 
+// Everything that owns a handle created on a context (tensors, command buffers) shares ownership of that context: wg_buf_destroy /
+// wg_cmdbuf_destroy dereference it, so it must be destroyed last -- like wgpu buffers keep their wgpu::Device alive.
+using CtxPtr = std::shared_ptr<wg_ctx>;
+
 class Device {
   public:
-    explicit Device(wg_ctx *c) : ctx_(c) {}
-    wg_ctx *raw() const { return ctx_; }
+    explicit Device(CtxPtr c) : ctx_(std::move(c)) {}
+    wg_ctx *raw() const { return ctx_.get(); }
+    const CtxPtr &shared() const { return ctx_; }
   private:
-    wg_ctx *ctx_;
+    CtxPtr ctx_;
 };
 
 class CommandBuffer {
   public:
     CommandBuffer() = default;
-    explicit CommandBuffer(wg_cmdbuf *cb) : cb_(cb, [](wg_cmdbuf *p) { wg_cmdbuf_destroy(p); }) {}
+    CommandBuffer(wg_cmdbuf *cb, CtxPtr ctx) : cb_(cb, [ctx](wg_cmdbuf *p) { wg_cmdbuf_destroy(p); }) {}
     wg_cmdbuf *raw() const { return cb_.get(); }
   private:
     std::shared_ptr<wg_cmdbuf> cb_;
@@ -78,17 +83,17 @@ class ComputePass {
 // wgpu::CommandEncoder + CommandEncoderExt::compute_pass (kernel.rs:15-27). record == false: work is enqueued as encoded.
 class CommandEncoder {
   public:
-    CommandEncoder(wg_ctx *c, bool record) : ctx_(c), record_(record) { if (record_) check(wg_encoder_begin(ctx_)); }
-    ComputePass compute_pass(const char * /*label*/, std::nullptr_t = nullptr) { return ComputePass(ctx_); }
+    CommandEncoder(CtxPtr c, bool record) : ctx_(std::move(c)), record_(record) { if (record_) check(wg_encoder_begin(ctx_.get())); }
+    ComputePass compute_pass(const char * /*label*/, std::nullptr_t = nullptr) { return ComputePass(ctx_.get()); }
     CommandBuffer finish() {
         if (!record_) return CommandBuffer();
         wg_cmdbuf *cb = nullptr;
-        check(wg_encoder_finish(ctx_, &cb));
-        return CommandBuffer(cb);
+        check(wg_encoder_finish(ctx_.get(), &cb));
+        return CommandBuffer(cb, ctx_);
     }
-    wg_ctx *ctx() const { return ctx_; }
+    wg_ctx *ctx() const { return ctx_.get(); }
   private:
-    wg_ctx *ctx_;
+    CtxPtr ctx_;
     bool record_;
 };
 
@@ -110,11 +115,11 @@ class GpuInstance {
     }
     const Device &device() const { return device_; }
     const Queue &queue() const { return queue_; }
-    CommandEncoder create_command_encoder(bool record = false) const { return CommandEncoder(ctx_.get(), record); }
+    CommandEncoder create_command_encoder(bool record = false) const { return CommandEncoder(ctx_, record); }
     void poll_wait() const { check(wg_ctx_sync(ctx_.get())); }
   private:
-    explicit GpuInstance(wg_ctx *c) : ctx_(c, [](wg_ctx *p) { wg_ctx_destroy(p); }), device_(c), queue_(c) {}
-    std::shared_ptr<wg_ctx> ctx_;
+    explicit GpuInstance(wg_ctx *c) : ctx_(c, [](wg_ctx *p) { wg_ctx_destroy(p); }), device_(ctx_), queue_(c) {}
+    CtxPtr ctx_; // declared first: device_ copies it
     Device device_;
     Queue queue_;
 };
@@ -159,8 +164,8 @@ class GpuTensorView {
 template <typename T>
 class GpuTensor {
   public:
-    GpuTensor(wg_ctx *ctx, wg_buf *b, std::vector<uint32_t> shape)
-        : ctx_(ctx), buf_(b, [](wg_buf *p) { wg_buf_destroy(p); }), shape_(std::move(shape)) {}
+    GpuTensor(CtxPtr ctx, wg_buf *b, std::vector<uint32_t> shape)
+        : ctx_(std::move(ctx)), buf_(b, [](wg_buf *p) { wg_buf_destroy(p); }), shape_(std::move(shape)) {}
     uint64_t len() const { uint64_t n = 1; for (auto s : shape_) n *= s; return n; }
     uint64_t bytes_len() const { return sizeof(T) * len(); }
     const std::vector<uint32_t> &shape() const { return shape_; }
@@ -185,7 +190,7 @@ class GpuTensor {
     }
     operator GpuTensorView<T>() const { return as_embedded_view(); } // From<&GpuTensor> (tensor.rs:403-409)
   private:
-    wg_ctx *ctx_;
+    CtxPtr ctx_;                  // declared before buf_: members are destroyed in reverse order, so the buffer goes first
     std::shared_ptr<wg_buf> buf_;
     std::vector<uint32_t> shape_;
 };
@@ -206,7 +211,7 @@ class TensorBuilder {
     template <typename T> GpuTensor<T> build(const Device &dev) const {
         wg_buf *b = nullptr;
         check(wg_buf_create(dev.raw(), sizeof(T) * len(), usage_, &b));
-        return GpuTensor<T>(dev.raw(), b, shape_);
+        return GpuTensor<T>(dev.shared(), b, shape_);
     }
     template <typename T> GpuTensor<T> build_init(const Device &dev, const std::vector<T> &data) const {
         if (data.size() < len()) // tensor.rs:176-182
@@ -214,7 +219,7 @@ class TensorBuilder {
                                                  std::to_string(len()) + ", found " + std::to_string(data.size()));
         wg_buf *b = nullptr;
         check(wg_buf_create_init(dev.raw(), data.data(), sizeof(T) * len(), usage_, &b));
-        return GpuTensor<T>(dev.raw(), b, shape_);
+        return GpuTensor<T>(dev.shared(), b, shape_);
     }
   private:
     TensorBuilder(std::vector<uint32_t> shape, uint32_t usage) : shape_(std::move(shape)), usage_(usage) {}

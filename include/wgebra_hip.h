@@ -201,6 +201,7 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
  *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).
  *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122), vec4 alignment.
  *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
+ * dtype WG_F16 (extension): the f16 Gemm contract (f16 operands, f32 accumulation, one rounding) on the f16 Gemm kernels.
  */
 int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
             wg_buf *out, wg_view_shape out_shape,
@@ -231,6 +232,8 @@ int wg_gemv_rm(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
  * `result` is the GpuScalar's buffer (>= 4 bytes). The summation ORDER is the reference's (128 strided lanes,
  * then the 64..1 tree; reduce.wgsl:68-87), so Min/Max/Sum/Prod are bit-identical to it; n == 0 gives the init
  * value (0, 1, +3.4e38, -3.4e38).
+ * dtype WG_F16 (extension): `value` and `result` are f16; elements are converted to f32 (exact), folded in the same order in f32,
+ * and the result is rounded once (RNE) to f16. (wg_reduce_batched likewise: one f16 result per vector; wg_reduce_fast is f32 only.)
  */
 int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
               const wg_buf *value, wg_view_shape value_shape, wg_buf *result);
@@ -256,7 +259,7 @@ int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
 /*
  * Extension (BASELINE config 4): one launch for many vectors. Column c of matrix t of the
  * column-major view is reduced exactly as wg_reduce would reduce the vector view at
- * offset + c*stride + t*stride_mat; results[c + t*size[1]] (f32 each).
+ * offset + c*stride + t*stride_mat; results[c + t*size[1]] (one element of `dtype` each).
  */
 int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
                       const wg_buf *values, wg_view_shape values_shape, wg_buf *results);

@@ -141,8 +141,28 @@ static void panics(const GpuInstance &gpu) {
     EXPECT(threw, "dimension mismatch must panic with the reference's message");
 }
 
+// A tensor and a recorded command buffer that outlive the GpuInstance they were created on: their deleters (wg_buf_destroy,
+// wg_cmdbuf_destroy) dereference the context, so they share its ownership -- like wgpu buffers keep their Device alive.
+static void handles_outlive_the_instance() {
+    std::vector<float> data(1024, 2.5f);
+    auto make = [&]() {
+        auto gpu = GpuInstance::create();
+        auto t = TensorBuilder::vector(1024, BufferUsages::STORAGE | BufferUsages::COPY_SRC).build_init(gpu.device(), data);
+        auto enc = gpu.create_command_encoder(/*record=*/true);
+        auto pass = enc.compute_pass("rec", nullptr);
+        OpAssign::create(gpu.device(), OpAssignVariant::Add).dispatch<float>(gpu.device(), ViewShapeBuffers::create(), pass, t, t);
+        auto cb = enc.finish();
+        gpu.queue().submit(cb);
+        gpu.poll_wait();
+        return std::make_pair(std::move(t), std::move(cb));
+    };
+    auto kept = make(); // the GpuInstance is gone; the context lives on through the tensor and the command buffer
+    EXPECT(kept.first.len() == 1024, "tensor survived");
+} // both destroyed here, then the context
+
 int main() {
     try {
+        handles_outlive_the_instance();
         auto gpu = GpuInstance::create();
         gpu_gemm(gpu);
         gpu_gemv(gpu);

@@ -32,8 +32,8 @@ def test_self_launch_two_ranks_dry_run():
 
 
 def test_self_launch_fails_cleanly_without_enough_gpus():
-    import torch
-    if torch.cuda.device_count() >= 2:
+    ndev = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True).stdout.strip() or 0)
+    if ndev >= 2:  # (counted in a child: the pytest process must not load torch's bundled HIP runtime next to the library's)
         return  # a multi-GPU box: the real launch is what runs there
     r = _run("--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-secondary")
     assert r.returncode == 2, r.stdout + r.stderr

@@ -87,7 +87,7 @@ def _worker(rank, world, port, q):
 
 
 def test_sharded_gemm_two_ranks_one_gpu():
-    import torch.multiprocessing as mp
+    import multiprocessing as mp  # not torch.multiprocessing: the pytest process must not load torch's bundled HIP runtime next to the library's
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

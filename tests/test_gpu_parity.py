@@ -1019,3 +1019,60 @@ def test_gemv_reduce_fused_single_launch(gpu, R, Cn):
     for _ in range(2):
         gpu.queue().submit([cb])
     assert r3.read(dev).tobytes() == rs.read(dev).tobytes()
+
+
+# --------------------------------------------------------------------------------------------------------
+# f16 Gemv / Reduce (extension: `T: Pod` is a parameter of every reference operator, the kernels are f32). Contract = the f16 Gemm's:
+# f16 elements, f32 arithmetic, one rounding. Reduce keeps the reference ORDER, so it is bit-exact against the f32 oracle run on the
+# (exactly converted) inputs and rounded once.
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("R,Cn,nrhs,mats", [(1024, 2048, 1, 1), (256, 512, 3, 2), (4096, 8192, 1, 1), (132, 260, 2, 1)])
+def test_gemv_f16(gpu, tr, R, Cn, nrhs, mats):
+    wg = _wg()
+    rng = np.random.default_rng(R + Cn + nrhs + tr)
+    m = (rng.random((mats, Cn, R), dtype=np.float32) * 2 - 1).astype(np.float16)       # [z][col][row]: column-major R x Cn
+    vlen, olen = (R, Cn) if tr else (Cn, R)
+    v = (rng.random((mats, nrhs, vlen), dtype=np.float32) * 2 - 1).astype(np.float16)  # [z][rhs][i]
+    tm, tv = upload(gpu, (R, Cn, mats), m.reshape(-1), np.float16), upload(gpu, (vlen, nrhs, mats), v.reshape(-1), np.float16)
+    to = upload(gpu, (olen, nrhs, mats), np.full(mats * nrhs * olen, np.nan, np.float16), np.float16)
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, to, tm, tv, variant))
+    got = to.read(gpu.device()).astype(np.float64).reshape(mats, nrhs, olen)
+    for z in range(mats):
+        M64 = m[z].astype(np.float64).T  # R x Cn
+        M64 = M64.T if tr else M64
+        truth, sabs = M64 @ v[z].astype(np.float64).T, np.abs(M64) @ np.abs(v[z].astype(np.float64)).T
+        tol = U.f32_gate(vlen, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        assert (np.abs(got[z].T - truth) <= tol).all(), f"f16 Gemv tr={tr} matrix {z}: worst {(np.abs(got[z].T - truth) / tol).max():.3g}"
+
+
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (127, 0), (128, 4), (129, 1), (345, 3), (65536, 0), (100003, 8)])
+def test_reduce_f16_bit_exact(gpu, oracle_c, n, off):
+    wg = _wg()
+    from oracle import wgsl_oracle as wo
+    rng = np.random.default_rng(n + off)
+    x = (rng.random(n + off + 8, dtype=np.float32) * 0.5 + 0.75).astype(np.float16)  # around 1: products stay finite
+    tx = upload(gpu, (x.size,), x, np.float16)
+    view = wg.GpuTensorView(wg.ViewShape([n, 1, 1], max(n, 1), max(n, 1), off), tx, 1)
+    for op, o in ((wg.ReduceOp.Min, wo.MIN), (wg.ReduceOp.Max, wo.MAX), (wg.ReduceOp.Sum, wo.SUM), (wg.ReduceOp.Prod, wo.PROD), (wg.ReduceOp.SqNorm, wo.SQNORM)):
+        if op == wg.ReduceOp.Prod and n > 2000:
+            continue  # overflows f16 either way
+        res = upload(gpu, (), np.zeros(1, np.float16), np.float16)
+        run_pass(gpu, lambda p: wg.Reduce.new(gpu.device(), op).dispatch(gpu.device(), wg.ViewShapeBuffers(), p, view, res))
+        exp32 = np.float32(oracle_c.reduce(o, x.astype(np.float32), wo.Shape(n, 1, 1, max(n, 1), max(n, 1), off)))
+        with np.errstate(over="ignore"):
+            exp = np.float16(exp32)
+        assert res.read(gpu.device())[0].tobytes() == exp.tobytes(), f"f16 reduce {op.name} n={n} off={off}"
+    # batched: one f16 result per column
+    if n >= 128:
+        cols = 5
+        xm = (rng.random(n * cols, dtype=np.float32) - 0.5).astype(np.float16)
+        tm = upload(gpu, (n, cols), xm, np.float16)
+        rs = upload(gpu, (cols,), np.zeros(cols, np.float16), np.float16)
+        run_pass(gpu, lambda p: wg.Reduce.new(gpu.device(), wg.ReduceOp.Sum).dispatch_batched(gpu.device(), wg.ViewShapeBuffers(), p, tm, rs))
+        got = rs.read(gpu.device())
+        for c in range(cols):
+            e = np.float16(np.float32(oracle_c.reduce(wo.SUM, xm.astype(np.float32), wo.Shape(n, 1, 1, n, n, c * n))))
+            assert got[c].tobytes() == e.tobytes()

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""What ONE rank of a P-rank M-sharded f16 Gemm 32768^3 does, emulated on one GPU -- the measured inputs of DESIGN.md section 6's
+expected multi-GPU speed-up. Rank 0 of P computes its (M/P x N) row block panel by panel on all 256 CUs; with the peer-copy engine its
+SDMA engines push every panel's block into P-1 peer buffers -- here P-1 other buffers of the SAME device, so the local HBM sees the reads
+of the outgoing copies plus writes standing in for the incoming ones (the link is the part a single GPU cannot show: a same-device SDMA
+rect copy runs at ~60 GB/s, about the xGMI per-direction rate). Reports, per P: ms per step with no exchange, with the exchange, the
+exposed tail after the last Gemm, and the copy rate. Usage: python tools/rank_emulation.py [P ...] > gpurun_out/rank_emulation.json"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+
+import bench
+import wgmath_amd as wg
+from wgmath_amd.sharded import Comm, GatherMode
+
+N = K = M = 32768
+Ps = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+STEPS = int(os.environ.get("STEPS", "6"))
+out = {"problem": "f16 32768^3, M-sharded; one rank emulated on one GPU", "steps": STEPS, "ranks": {}}
+for P in Ps:
+    gpu = wg.GpuInstance.new(0)
+    dev, S = gpu.device(), wg.BufferUsages
+    Mg = M // P
+    A = bench.device_random(wg, gpu, (Mg, K), np.float16, 0xA000)
+    B = bench.device_random(wg, gpu, (K, N), np.float16, 0xB000)
+    C = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(dev, np.float16)
+    npeers = min(P - 1, 3)  # 3 stand-in buffers are enough to keep 3 engines busy; more peers reuse them round-robin
+    peers = [wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_DST).build(dev, np.float16) for _ in range(npeers)]
+    comm = Comm(gpu, P, 0, None)
+    if P > 1:
+        comm.register_local_peers(C, [C] + [peers[i % npeers] for i in range(P - 1)])
+    panel = bench.plan_panel_cols(Mg, N, 256)
+    res = {"rows_per_rank": Mg, "panel_cols": panel, "panels": -(-N // panel), "copy_engine": comm.copy_engine}
+    for mode, name in ((GatherMode.NONE, "no_exchange"), (GatherMode.PEER_COPY, "peer_copy")):
+        if P == 1 and mode == GatherMode.PEER_COPY:
+            continue
+        for _ in range(2):
+            comm.sharded_gemm(C, A, B, 0, mode, panel)
+            gpu.sync(); comm.flush()
+        t0 = time.perf_counter()
+        tails = []
+        for _ in range(STEPS):
+            comm.sharded_gemm(C, A, B, 0, mode, panel)
+            gpu.sync()
+            t1 = time.perf_counter()
+            comm.flush()  # the copies still in flight after the last Gemm: the exposed part of the exchange
+            tails.append(time.perf_counter() - t1)
+        dt = (time.perf_counter() - t0) / STEPS
+        res[name] = {"ms_per_step": round(dt * 1e3, 3), "exposed_tail_ms": round(float(np.mean(tails)) * 1e3, 3),
+                     "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1)}
+        if mode == GatherMode.PEER_COPY:
+            sent = (P - 1) * Mg * N * 2
+            res[name]["bytes_pushed_per_step"] = sent
+            res[name]["aggregate_push_gbs_if_fully_overlapped"] = round(sent / dt / 1e9, 1)
+    out["ranks"][str(P)] = res
+    comm.close()
+    del A, B, C, peers
+    gpu.close()
+t1 = out["ranks"].get("1", {}).get("no_exchange", {}).get("ms_per_step")
+if t1:
+    for P, r in out["ranks"].items():
+        if "peer_copy" in r:
+            r["expected_speedup_vs_1_gpu"] = round(t1 / r["peer_copy"]["ms_per_step"], 3)
+print(json.dumps(out, indent=1))

@@ -143,12 +143,12 @@ int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *value,
     if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;
     if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
     if (value->bytes == 0 || result->bytes == 0) return WG_OK; // kernel.rs:111-123
-    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    if (result->bytes < wg_dtype_size(dtype)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one element");
     // reduce.wgsl:71-72: input[offset + i], i < nrows; stride / ncols / nmats are ignored
     const View vec = { value_shape.size[0], 1, 1, 1, 1, value_shape.offset };
     if (int rc = check_bounds("Reduce", "value", vec, value, dtype)) return rc;
     WG_HIP_TRY(hipSetDevice(ctx->device));
-    return wgk_reduce(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, 1, 1, 0, 0, (float *)result->ptr);
+    return wgk_reduce(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, 1, 1, 0, 0, result->ptr);
 }
 
 int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *value, wg_view_shape value_shape, wg_buf *result) {
@@ -171,7 +171,7 @@ int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dty
     if (int rc = check_common("Gemv", ctx, dtype, bufs, 3)) return rc;
     if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
     if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemv: unknown variant %d", (int)variant);
-    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    if (result->bytes < wg_dtype_size(dtype)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one element");
     const bool tr = variant == WG_GEMV_TR || variant == WG_GEMV_TR_FAST;
     const View mm = mk(m_shape), vv = mk(v_shape);
     if (vv.cols != 1 || vv.mats != 1 || mm.mats != 1)
@@ -212,14 +212,14 @@ int wg_reduce_batched(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf
     const View v = mk(values_shape);
     const uint64_t nvec = (uint64_t)v.cols * v.mats;
     if (nvec == 0 || results->bytes == 0) return WG_OK;
-    if (results->bytes / sizeof(float) < nvec)
-        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: results buffer holds %zu f32 but %llu vectors are reduced",
-                            results->bytes / sizeof(float), (unsigned long long)nvec);
+    if (results->bytes / wg_dtype_size(dtype) < nvec)
+        return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: results buffer holds %zu elements but %llu vectors are reduced",
+                            results->bytes / wg_dtype_size(dtype), (unsigned long long)nvec);
     if (values->bytes == 0 && v.rows != 0) return WG_OK;
     if (int rc = check_bounds("Reduce", "values", v, values, dtype)) return rc;
     WG_HIP_TRY(hipSetDevice(ctx->device));
     return wgk_reduce(ctx, (int)op, dtype, elem_ptr(values, v.offset, dtype), v.rows, v.cols, v.mats, v.stride, v.stride_mat,
-                      (float *)results->ptr);
+                      results->ptr);
 }
 
 int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype, wg_buf *a, wg_view_shape a_shape, const wg_buf *b,

@@ -374,26 +374,13 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs 
     if (p == 0) result[0] = r[0];
 }
 
+#ifndef GEMV_SMALL
+#define GEMV_SMALL 1
+#endif
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); }
 
-} // namespace
-
-int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
-             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
-    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: only f32 is implemented (the reference kernel is f32: gemv.wgsl:9-14)");
-    if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
-    // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
-    // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
-    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
-        (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
-        return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
-    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
-    const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
-    const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
-    if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/8) = %llu exceeds 65535", (unsigned long long)gz64);
-    const uint32_t gz = (uint32_t)gz64;
-
-    // blocks along the output, and how finely the contraction must be split to give every CU ~4 workgroups
+// blocks along the output, and how finely the contraction must be split to give every CU ~4 workgroups
+static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t gz) {
     const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
     const uint64_t blocks_xy = (uint64_t)gx * gz;
@@ -408,6 +395,35 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     if (nsplit < 1u) nsplit = 1u;
     if (nsplit > 65535u) nsplit = 65535u;
     if (nrhs > 65535u) nsplit = 1u; // the combine pass puts the right-hand sides on grid.y; that many columns fill the chip unsplit
+    return nsplit;
+}
+// wgk_gemv runs launch-bound Gemvs as ONE kernel without partials (gemv_n_small_kernel); the fused Gemv+Reduce must pick exactly those
+static bool uses_small_kernel(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nsplit) {
+    return GEMV_SMALL && !trans && nsplit > 1 && (uint64_t)rows_out * k <= (4ull << 20) && rows_out >= 128u && nrhs <= 65535u;
+}
+
+} // namespace
+
+int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
+             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
+    if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
+    // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): a Gemv is a Gemm with `nrhs` columns, and the f16 Gemm kernels take
+    // any column count (B rows are clamped, the epilogue is predicated) -- one pass over the matrix on the matrix cores, f16 operands,
+    // f32 accumulation, one rounding: the f16 Gemm contract. Not an HBM-roofline kernel (the MFMA tiles are 256 or 128 columns wide).
+    if (dtype == WG_F16) return wgk_gemm_f16(ctx, trans, rows_out, nrhs, k, nmats, (__half *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+    // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
+    // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
+    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
+        (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
+        return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
+    const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
+    if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/8) = %llu exceeds 65535", (unsigned long long)gz64);
+    const uint32_t gz = (uint32_t)gz64;
+
+    const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
+    uint32_t nsplit = plan_nsplit(cus, trans, rows_out, k, nrhs, gz);
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
 
@@ -432,11 +448,8 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
         a.dst_batch = out_batch;
     }
 
-#ifndef GEMV_SMALL
-#define GEMV_SMALL 1
-#endif
     // launch-bound sizes: one kernel without partials beats split + combine (1024 x 1024: 12.6 -> ~9 us per eager dispatch)
-    if (GEMV_SMALL && !trans && nsplit > 1 && (uint64_t)rows_out * k <= (4ull << 20) && rows_out >= 128u && nrhs <= 65535u) {
+    if (uses_small_kernel(cus, trans, rows_out, k, nrhs, nsplit)) {
         a.dst = (float *)out; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
         hipLaunchKernelGGL(gemv_n_small_kernel, dim3(ceil_div(rows_out, 32u), nrhs, nmats), dim3(kThreads), 0, ctx->stream, a);
         WG_HIP_TRY(hipGetLastError());
@@ -470,7 +483,8 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 // One launch for result = reduce(op, m v) when the Gemv is launch-bound (the single-kernel shape family of wgk_gemv); WG_ERR_UNSUPPORTED
 // tells the caller to run Gemv and Reduce as two launches. `y` is a scratch vector of rows_out floats, `counter` a zeroed device word.
 int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, float *y, wgk_mat m, wgk_mat v, unsigned *counter, float *result) {
-    if (!(GEMV_SMALL && (uint64_t)rows_out * k <= (4ull << 20) && rows_out >= 128u && k >= 4u)) return WG_ERR_UNSUPPORTED;
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    if (k < 4u || !uses_small_kernel(cus, false, rows_out, k, 1, plan_nsplit(cus, false, rows_out, k, 1, 1))) return WG_ERR_UNSUPPORTED;
     GemvArgs a;
     a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = 0;
     a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = 0;

@@ -27,22 +27,31 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kUnroll = RED_UNROLL;
 
-__device__ __forceinline__ const float *vector_base(const float *base, uint32_t q, uint32_t ncols, uint32_t stride,
+template <typename T>
+__device__ __forceinline__ const T *vector_base(const T *base, uint32_t q, uint32_t ncols, uint32_t stride,
                                                     uint32_t stride_mat) {
     const uint32_t c = q % ncols, t = q / ncols;
     return base + (uint64_t)c * stride + (uint64_t)t * stride_mat;
 }
 
-// 32 physical lanes x float4 per vector; requires every vector base 16-byte aligned.
-template <int OP>
-__global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict__ base, uint32_t n, uint32_t ncols,
+// Element types: f32 (the reference's), and f16 as this build's extension -- f16 elements are converted to f32 (exact), folded in the
+// reference's order in f32, and the result is rounded once (RNE) to f16. Four consecutive elements of a row, as floats:
+__device__ __forceinline__ float4 load4(const float *p, bool nt) { return nt ? wg_ld_nt(reinterpret_cast<const float4 *>(p)) : *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load4(const _Float16 *p, bool nt) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 v = nt ? __builtin_nontemporal_load(reinterpret_cast<const h4 *>(p)) : *reinterpret_cast<const h4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+
+// 32 physical lanes x 4 elements per vector; requires every vector base aligned to 4 elements (16 bytes f32, 8 bytes f16).
+template <int OP, typename T>
+__global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ base, uint32_t n, uint32_t ncols,
                                                          uint32_t nvec, uint32_t stride, uint32_t stride_mat,
-                                                         float *__restrict__ results) {
+                                                         T *__restrict__ results) {
     const uint32_t q = blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
     const uint32_t p = threadIdx.x & 31;
     if (q >= nvec) return; // whole 32-lane half leaves together; shuffles below never cross halves
-    const float *x = vector_base(base, q, ncols, stride, stride_mat);
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const T *x = vector_base(base, q, ncols, stride, stride_mat);
 
     float acc[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
     const uint32_t full_rows = n / 128u;
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict
     for (; r + kUnroll <= full_rows; r += kUnroll) {
         float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = RED_NT ? wg_ld_nt(&x4[(uint64_t)(r + u) * 32u + p]) : x4[(uint64_t)(r + u) * 32u + p];
+        for (int u = 0; u < kUnroll; ++u) v[u] = load4(x + ((uint64_t)(r + u) * 32u + p) * 4u, RED_NT);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) { // rows in ascending order: the per-lane chain of reduce.wgsl:71-74
             acc[0] = r_ws<OP>(acc[0], v[u].x);
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict
         }
     }
     for (; r < full_rows; ++r) {
-        float4 v = x4[(uint64_t)r * 32u + p];
+        float4 v = load4(x + ((uint64_t)r * 32u + p) * 4u, false);
         acc[0] = r_ws<OP>(acc[0], v.x);
         acc[1] = r_ws<OP>(acc[1], v.y);
         acc[2] = r_ws<OP>(acc[2], v.z);
@@ -70,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict
         const uint32_t i0 = full_rows * 128u + 4u * p;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (i0 + c < n) acc[c] = r_ws<OP>(acc[c], x[i0 + c]);
+            if (i0 + c < n) acc[c] = r_ws<OP>(acc[c], (float)x[i0 + c]);
     }
     // tree, virtual strides 64,32,16,8,4 == physical 16,8,4,2,1 (lanes >= stride compute garbage nobody reads)
 #pragma unroll
@@ -82,31 +91,31 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const float *__restrict
     acc[0] = r_red<OP>(acc[0], acc[2]);
     acc[1] = r_red<OP>(acc[1], acc[3]);
     acc[0] = r_red<OP>(acc[0], acc[1]);
-    if (p == 0) results[q] = acc[0];
+    if (p == 0) results[q] = (T)acc[0];
 }
 
 // 128 physical lanes per vector, any alignment; 2 vectors per workgroup.
-template <int OP>
-__global__ __launch_bounds__(kThreads) void reduce_rows1(const float *__restrict__ base, uint32_t n, uint32_t ncols,
+template <int OP, typename T>
+__global__ __launch_bounds__(kThreads) void reduce_rows1(const T *__restrict__ base, uint32_t n, uint32_t ncols,
                                                          uint32_t nvec, uint32_t stride, uint32_t stride_mat,
-                                                         float *__restrict__ results) {
+                                                         T *__restrict__ results) {
     __shared__ float upper[2][64];
     const uint32_t half = threadIdx.x >> 7; // which vector of the workgroup
     const uint32_t t = threadIdx.x & 127;
     const uint32_t q = blockIdx.x * 2 + half;
     float acc = r_init<OP>();
     if (q < nvec) {
-        const float *x = vector_base(base, q, ncols, stride, stride_mat);
+        const T *x = vector_base(base, q, ncols, stride, stride_mat);
         uint32_t i = t;
         for (; (uint64_t)i + 128u * (kUnroll - 1) < n; i += 128u * kUnroll) {
             float v[kUnroll];
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = x[i + 128u * u];
+            for (int u = 0; u < kUnroll; ++u) v[u] = (float)x[i + 128u * u];
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) acc = r_ws<OP>(acc, v[u]);
         }
         for (; i < n; i += 128u) {
-            acc = r_ws<OP>(acc, x[i]);
+            acc = r_ws<OP>(acc, (float)x[i]);
             if (i + 128u < i) break;
         }
     }
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows1(const float *__restrict
         acc = r_red<OP>(acc, upper[half][t]);
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) acc = r_red<OP>(acc, __shfl_down(acc, s, 64));
-        if (t == 0 && q < nvec) results[q] = acc;
+        if (t == 0 && q < nvec) results[q] = (T)acc;
     }
 }
 
@@ -220,22 +229,27 @@ __global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restr
     if (p == 0) results[q] = acc[0];
 }
 
-template <int OP>
-int launch(wg_ctx *ctx, const float *base, uint32_t n, uint32_t ncols, uint32_t nmats, uint32_t stride,
-           uint32_t stride_mat, float *results) {
+template <int OP, typename T>
+int launch(wg_ctx *ctx, const T *base, uint32_t n, uint32_t ncols, uint32_t nmats, uint32_t stride,
+           uint32_t stride_mat, T *results) {
     const uint64_t nvec64 = (uint64_t)ncols * nmats;
     if (nvec64 == 0) return WG_OK;
     if (nvec64 > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: more than 2^31 vectors in one call");
     const uint32_t nvec = (uint32_t)nvec64;
-    const bool aligned = ((uintptr_t)base % 16 == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
-    if (aligned && n >= 65536u && nvec <= 256u) { // long vectors, fewer than there are CUs: one 8-wave workgroup each
-        hipLaunchKernelGGL(reduce_long<OP>, dim3(nvec), dim3(kLongThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
-    } else if (aligned) {
+    const bool aligned = ((uintptr_t)base % (4 * sizeof(T)) == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
+    if constexpr (sizeof(T) == 4) {
+        if (aligned && n >= 65536u && nvec <= 256u) { // long vectors, fewer than there are CUs: one 8-wave workgroup each
+            hipLaunchKernelGGL(reduce_long<OP>, dim3(nvec), dim3(kLongThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
+            WG_HIP_TRY(hipGetLastError());
+            return WG_OK;
+        }
+    }
+    if (aligned) {
         const uint32_t per_block = kThreads / 32;
-        hipLaunchKernelGGL(reduce_rows4<OP>, dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n,
+        hipLaunchKernelGGL((reduce_rows4<OP, T>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n,
                            ncols, nvec, stride, stride_mat, results);
     } else {
-        hipLaunchKernelGGL(reduce_rows1<OP>, dim3((nvec + 1) / 2), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride,
+        hipLaunchKernelGGL((reduce_rows1<OP, T>), dim3((nvec + 1) / 2), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride,
                            stride_mat, results);
     }
     WG_HIP_TRY(hipGetLastError());
@@ -327,7 +341,7 @@ int launch_fast(wg_ctx *ctx, const float *x, uint32_t n, float *result) {
 } // namespace
 
 int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, float *result) {
-    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: only f32 is implemented (the reference kernel is f32: reduce.wgsl:5-8)");
+    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce (fast): only f32 is implemented; f16 vectors take wg_reduce / wg_reduce_batched");
     const float *b = (const float *)base;
     switch (op) {
     case R_MIN: return launch_fast<R_MIN>(ctx, b, n, result);
@@ -339,10 +353,8 @@ int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint3
     return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", op);
 }
 
-int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
-               uint32_t stride, uint32_t stride_mat, float *results) {
-    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: only f32 is implemented (the reference kernel is f32: reduce.wgsl:5-8)");
-    const float *b = (const float *)base;
+template <typename T>
+static int reduce_dispatch(wg_ctx *ctx, int op, const T *b, uint32_t n, uint32_t ncols, uint32_t nmats, uint32_t stride, uint32_t stride_mat, T *results) {
     switch (op) {
     case R_MIN: return launch<R_MIN>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
     case R_MAX: return launch<R_MAX>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
@@ -351,4 +363,11 @@ int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n
     case R_SQNORM: return launch<R_SQNORM>(ctx, b, n, ncols, nmats, stride, stride_mat, results);
     }
     return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", op);
+}
+
+// `results` has the element type of the input (Reduce::dispatch(value: GpuVectorView<T>, result: &GpuScalar<T>), reduce.rs:100-107)
+int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
+               uint32_t stride, uint32_t stride_mat, void *results) {
+    if (dtype == WG_F16) return reduce_dispatch(ctx, op, (const _Float16 *)base, n, ncols, nmats, stride, stride_mat, (_Float16 *)results);
+    return reduce_dispatch(ctx, op, (const float *)base, n, ncols, nmats, stride, stride_mat, (float *)results);
 }

@@ -92,7 +92,7 @@ int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, u
 
 int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, float *result);
 int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
-               uint32_t stride, uint32_t stride_mat, float *results);
+               uint32_t stride, uint32_t stride_mat, void *results); // results: one element of `dtype` per vector
 
 // out[rows_out, nrhs, nmats]; trans == false: out = m * v, m is (rows_out x k); trans: out = m^T v, m is (k x rows_out)
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,

@@ -58,7 +58,11 @@ class ViewShape:
     offset: int
 
     def to_c(self) -> ViewShapeC:
-        return ViewShapeC((ctypes.c_uint32 * 3)(*self.size), self.stride, self.stride_mat, self.offset)
+        c = self.__dict__.get("_c")  # built once per shape object (a dispatch costs microseconds: keep the host side out of it)
+        if c is None:
+            c = ViewShapeC((ctypes.c_uint32 * 3)(*self.size), self.stride, self.stride_mat, self.offset)
+            object.__setattr__(self, "_c", c)
+        return c
 
     def f32_to_vec4(self, column_major: bool = True) -> "ViewShape":
         """shapes.rs:25-38 (floor division, unlike the WGSL twin's ceil)."""
@@ -443,9 +447,13 @@ class GpuTensor:
 
     def as_embedded_view(self, dim2: int = 3) -> "GpuTensorView":
         assert dim2 >= self.DIM, "Can only embed into a higher-order tensor view."
-        embedded = [1] * dim2
-        embedded[:self.DIM] = self._shape
-        return self.reshape(embedded, None, None)
+        cache = self.__dict__.setdefault("_embedded", {})  # views are immutable values: one per dimension is enough
+        v = cache.get(dim2)
+        if v is None:
+            embedded = [1] * dim2
+            embedded[:self.DIM] = self._shape
+            v = cache[dim2] = self.reshape(embedded, None, None)
+        return v
 
     def reshape(self, shape: Sequence[int], stride: Optional[int] = None, stride_mat: Optional[int] = None) -> "GpuTensorView":
         shape = [int(s) for s in shape]

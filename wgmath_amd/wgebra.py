@@ -51,9 +51,9 @@ class OpAssignVariant(enum.IntEnum):  # op_assign.rs:12-26
 
 
 def _common_dtype(*views: GpuTensorView):
-    dt = views[0].dtype
+    dt = views[0]._tensor.dtype
     for v in views[1:]:
-        if v.dtype != dt:
+        if v._tensor.dtype is not dt and v._tensor.dtype != dt:
             raise TypeError(f"operands must share one element type, got {[str(x.dtype) for x in views]}")
     return wg_dtype(dt)
 
