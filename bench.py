@@ -50,6 +50,8 @@ def rand_block(seed: int, n: int, dtype) -> np.ndarray:
     rng = np.random.default_rng(seed)
     if os.environ.get("WG_BENCH_VALUES") == "u01":  # the reference tests' distribution (`new_random`: U[0,1)); experiments only
         return rng.random(n, dtype=np.float32).astype(dtype)
+    if os.environ.get("WG_BENCH_VALUES") == "zero":  # experiments only: zero operands take the chip off its power cap, so the clock pins at
+        return np.zeros(n, dtype)                     # its maximum and kernel time measures CYCLES (schedule quality), not energy per flop
     return (rng.random(n, dtype=np.float32) * np.float32(2) - np.float32(1)).astype(dtype)
 
 
@@ -153,18 +155,23 @@ class GemmWorkload(Workload):
             self.set_mode(self.dist["mode"])
 
     def set_mode(self, mode):
-        """Exchange engine of the sharded run: "rccl" (staging cube + ncclAllGather + relayout) or "peer" (SDMA pushes)."""
+        """Exchange engine of the sharded run: "rccl" (staging cube + ncclAllGather + relayout), "peer" (SDMA rect pushes straight into C:
+        one rect-capable engine per GPU, enough for 2 ranks) or "staged" (contiguous copies on one SDMA engine per link + relayout)."""
         from wgmath_amd.sharded import GatherMode
         comm, world = self.dist["comm"], self.world
         self.mode = mode
         cus = int(self.gpu.adapter().get("stream_compute_units") or self.gpu.adapter()["compute_units"])
         self.panel_cols = plan_panel_cols(self.Mg, self.N, cus, tile=256 if self.dtype == "f16" else 128)
         self.npanels = -(-self.N // self.panel_cols)
-        self.gather_mode = GatherMode.PEER_COPY if mode == "peer" else GatherMode.RCCL
+        self.gather_mode = {"peer": GatherMode.PEER_COPY, "staged": GatherMode.PEER_STAGED}.get(mode, GatherMode.RCCL)
         if mode == "peer" and world > 1 and not getattr(self, "_peers_registered", False):
             handles = self.dist["all_gather_object"](comm.export_handle(self.C))
             comm.register_peers(self.C, handles)
             self._peers_registered = True
+        if mode == "staged":  # two staging cubes (step parity) + flag array, exported to every peer
+            pair = comm.stage_export(2 * self.M * self.N * np.dtype(self.np_dtype).itemsize)
+            if world > 1:
+                comm.set_peer_stages(self.dist["all_gather_object"](pair))
 
     def step(self):
         if self.dist is None:
@@ -631,6 +638,9 @@ def self_launch(args) -> int:
             return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL, hipIpcGetMemHandle)
+    # HIP multiplexes a process's streams onto 4 hardware queues by default; a rank has its compute stream, the collective's stream and one
+    # copy stream per peer: give every stream its own queue, or copies queue up behind Gemms instead of running beside them
+    env.setdefault("GPU_MAX_HW_QUEUES", "16")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     log("[bench] launching:", " ".join(cmd))
@@ -708,9 +718,9 @@ def main():
     ap.add_argument("--skip", default="", help="comma-separated secondary workloads to skip (e.g. under rocprofv3)")
     ap.add_argument("--secondary-seconds", type=float, default=0.6, help="minimum timed duration of each secondary config")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
-    ap.add_argument("--gather", default=os.environ.get("WG_BENCH_GATHER", "auto"), choices=["auto", "rccl", "peer"],
-                    help="exchange engine of the M-sharded Gemm with N > 1 ranks: RCCL all-gather (+ relayout), SDMA peer copies, or "
-                         "auto = time both during warm-up and run the timed steps on the faster one")
+    ap.add_argument("--gather", default=os.environ.get("WG_BENCH_GATHER", "auto"), choices=["auto", "rccl", "peer", "staged"],
+                    help="exchange engine of the M-sharded Gemm with N > 1 ranks: RCCL all-gather (+ relayout), SDMA rect pushes straight into C, "
+                         "staged contiguous peer copies (+ relayout), or auto = time all of them during warm-up and run the timed steps on the fastest")
     ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing test without a GPU (gloo, host arithmetic)")
     args = ap.parse_args()
 
@@ -735,7 +745,13 @@ def main():
     import wgmath_amd as wg
 
     oversub = False
+    saved_stdout = None
     if dist_mode:
+        # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to stdout when its first communicator is created --
+        # send everything the libraries print during the run to stderr, and give stdout back just before the line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -755,7 +771,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
         total_cus = torch.cuda.get_device_properties(dev_index).multi_processor_count
-        gather = args.gather if not oversub else "peer"
+        gather = args.gather if not oversub else (args.gather if args.gather in ("peer", "staged") else "staged")
         # CU partitioning between compute and communication. Every f16 GEMM workgroup needs a whole CU (160 KiB
         # LDS, 512 registers per lane), so RCCL's copy kernels, launched from a second queue while a GEMM grid is resident, only get CUs
         # when GEMM workgroups retire (tools/overlap_probe.py: they start ~0.75-1.4 ms late). For the RCCL engine the GEMM stream is
@@ -787,10 +803,10 @@ def main():
             torch.cuda.synchronize()
 
         engines = {}  # mode -> (GpuInstance, Comm)
-        for mode in (["rccl", "peer"] if gather == "auto" else [gather]):
+        for mode in (["rccl", "staged", "peer"] if gather == "auto" else [gather]):
             g = make_gpu(masked=(mode == "rccl" and world > 1))
             engines[mode] = (g, Comm(g, world, rank, None if oversub else bcast_id()))
-        first = "rccl" if "rccl" in engines else "peer"
+        first = next(iter(engines))
         gpu, comm = engines[first]
         DIST = {"comm": comm, "mode": first, "barrier": lambda: dist.barrier(), "all_gather_object": all_gather_object}
     else:
@@ -850,7 +866,8 @@ def main():
     par = f"replicas x{world}"
     cfg_extra = {}
     if dist_mode and w_is_gemm:
-        engine = {"rccl": "RCCL all-gather", "peer": f"peer-copy gather ({DIST['comm'].copy_engine})"}[DIST["mode"]]
+        engine = {"rccl": "RCCL all-gather", "peer": f"peer-copy gather ({DIST['comm'].copy_engine})",
+                  "staged": "staged peer-copy gather (one SDMA engine per link + relayout)"}[DIST["mode"]]
         par = f"m-shard x{world} + {engine}"
         cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels,
                      "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"])}
@@ -914,6 +931,9 @@ def main():
             "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra),
             "roofline": roof, "cpu_baseline": main_cpu, "others": others,
         }
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
     if dist_mode:
         import torch.distributed as dist

@@ -293,7 +293,12 @@ typedef enum wg_gather_mode {
                                 communicator's stream beside the next panel's Gemm, then an HBM-bound relayout into columns of C */
     WG_GATHER_PEER_COPY = 1, /* per N-panel: Gemm straight into this rank's rows of C, then the SDMA engines push that strided block
                                 into every peer's C (no compute units, no relayout); completion: wg_comm_flush + a barrier */
-    WG_GATHER_NONE = 2       /* this rank's rows of C only */
+    WG_GATHER_NONE = 2,      /* this rank's rows of C only */
+    WG_GATHER_PEER_STAGED = 3 /* per N-panel: Gemm into slot g of this rank's staging cube, one CONTIGUOUS copy per peer (the runtime's
+                                peer-to-peer path: that link's own SDMA engine, no compute units) into the same slot of the peer's cube + a
+                                sequence-number flag; the receiver's stream waits on the flags (one-wave kernel) and relayouts the panel into
+                                C. Stream-ordered end to end, no barrier: the cubes are double-buffered by step parity. Needs
+                                wg_comm_stage_reserve + wg_comm_set_peer_stages. The engine for P > 2 (one rect-capable SDMA queue per GPU) */
 } wg_gather_mode;
 
 /* ncclGetUniqueId: call on one rank, ship the WG_COMM_ID_BYTES bytes to the others out of band (env, file, MPI, a torch store). */
@@ -318,6 +323,12 @@ int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined i
  * HSA_ENABLE_IPC_MODE_LEGACY=0, on this platform). The mapped buffer is released by wg_buf_destroy. */
 int wg_buf_ipc_export(const wg_buf *buf, void *handle /* WG_IPC_HANDLE_BYTES */);
 int wg_buf_ipc_open(wg_ctx *ctx, const void *handle, wg_buf **out);
+/* WG_GATHER_PEER_STAGED: make the communicator's staging cubes (>= 2 * sizeof(T) * M * N bytes: two steps in flight) and its flag array
+ * exist and return them (owned by the communicator) so that the caller can export them (wg_buf_ipc_export) to the peers; then register
+ * every peer's pair as addressable from here (wg_buf_ipc_open, or the buffers themselves when the ranks share a process). Growing the
+ * cubes invalidates the registration on every rank. */
+int wg_comm_stage_reserve(wg_comm *comm, size_t bytes, wg_buf **stage, wg_buf **flags);
+int wg_comm_set_peer_stages(wg_comm *comm, wg_buf *const *peer_stage, wg_buf *const *peer_flags);
 /* Relayout of a gathered GpuCube [M/P, np, P] (dense) into the (M x np) column-major view `out`: out[g*M/P + i, j] = cube[i, j, g].
  * HBM-bound: 2 * sizeof(T) * M * np bytes. (What WG_GATHER_RCCL runs per panel; exported for callers that gather themselves.) */
 int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_shape cube_shape, wg_buf *out, wg_view_shape out_shape);
@@ -326,7 +337,7 @@ int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_s
  * (M/P x K; WG_GEMM_TR*: stored K x M/P), `b` (K x N) is replicated. N is cut into panels of `panel_cols` columns (0 = default)
  * and panel i's exchange overlaps panel i+1's Gemm. peer_out[r] (WG_GATHER_PEER_COPY only) is rank r's `out` buffer as addressable
  * from this process (wg_buf_ipc_open, or the buffer itself when the ranks share a process); peer_out[rank] is ignored.
- * On return everything is enqueued: WG_GATHER_RCCL -- `out` is complete in context-stream order; WG_GATHER_PEER_COPY -- this rank's
+ * On return everything is enqueued: WG_GATHER_RCCL and WG_GATHER_PEER_STAGED -- `out` is complete in context-stream order; WG_GATHER_PEER_COPY -- this rank's
  * rows are complete in stream order, the peers' rows after every rank's wg_comm_flush + a barrier (wg_comm_barrier does both), which
  * must also separate two calls that write the same `out`. DIM_MISMATCH as Gemm (gemm.rs:91-95) with M = P * rows(a_rows).
  */

@@ -128,6 +128,54 @@ template <typename T> static void peer_two_ranks(bool tr, uint32_t M, uint32_t N
     }
 }
 
+// two ranks in one process, WG_GATHER_PEER_STAGED: staging cubes + contiguous per-peer copies + flags + wait kernel + relayout, three steps
+// back to back WITHOUT any host synchronisation or barrier in between (the engine is stream-ordered and double-buffered by step parity)
+template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel) {
+    const uint32_t P = 2, mg = M / P;
+    wg_ctx *ctx[2] = { nullptr, nullptr };
+    wg_comm *comm[2] = { nullptr, nullptr };
+    wg_buf *a[2] = {}, *b[2] = {}, *c[2] = {}, *st[2] = {}, *fl[2] = {};
+    auto A = rnd<T>((size_t)M * K, 31), B = rnd<T>((size_t)K * N, 32);
+    for (uint32_t g = 0; g < P; ++g) {
+        CK(wg_ctx_create(0, &ctx[g]));
+        CK(wg_comm_create(ctx[g], P, g, nullptr, &comm[g]));
+        auto Ag = row_block(A, tr, M, K, g, mg);
+        CK(wg_buf_create_init(ctx[g], Ag.data(), Ag.size() * sizeof(T), USAGE, &a[g]));
+        CK(wg_buf_create_init(ctx[g], B.data(), B.size() * sizeof(T), USAGE, &b[g]));
+        CK(wg_buf_create(ctx[g], (size_t)M * N * sizeof(T), USAGE, &c[g]));
+        CK(wg_comm_stage_reserve(comm[g], 2 * (size_t)M * N * sizeof(T), &st[g], &fl[g]));
+    }
+    for (uint32_t g = 0; g < P; ++g) CK(wg_comm_set_peer_stages(comm[g], st, fl));
+    const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
+    for (int rep = 0; rep < 3; ++rep) {
+        for (uint32_t g = 0; g < P; ++g) {
+            CK(wg_buf_fill_zero(ctx[g], c[g]));
+            CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[g], mat(M, N), nullptr, a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
+        }
+    }
+    for (uint32_t g = 0; g < P; ++g) {
+        std::vector<T> got((size_t)M * N);
+        CK(wg_buf_read(ctx[g], c[g], 0, got.data(), got.size() * sizeof(T))); // stream order is all it takes
+        char what[160];
+        std::snprintf(what, sizeof what, "peer-staged rank %u of 2 %s %s %ux%ux%u panel %u", g, sizeof(T) == 2 ? "f16" : "f32", tr ? "GemmTr" : "Gemm", M, N, K, panel);
+        check_product(what, got, A, tr, B, M, N, K);
+        EXPECT(wg_comm_flush(comm[g]) == WG_OK, "flush: %s", wg_last_error_string());
+        EXPECT(wg_comm_bytes_sent(comm[g]) == 3ull * mg * N * sizeof(T), "bytes_sent %llu", (unsigned long long)wg_comm_bytes_sent(comm[g]));
+    }
+    { // unregistered peers are an error, not a hang
+        wg_comm *lone = nullptr;
+        CK(wg_comm_create(ctx[0], P, 0, nullptr, &lone));
+        EXPECT(wg_gemm_sharded(lone, v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[0], mat(M, N), nullptr, a[0], tr ? mat(K, mg) : mat(mg, K), b[0], mat(K, N)) == WG_ERR_INVALID_ARG,
+               "PEER_STAGED without staging cubes must be rejected");
+        wg_comm_destroy(lone);
+    }
+    for (uint32_t g = 0; g < P; ++g) {
+        wg_comm_destroy(comm[g]);
+        wg_buf_destroy(a[g]); wg_buf_destroy(b[g]); wg_buf_destroy(c[g]);
+        wg_ctx_destroy(ctx[g]);
+    }
+}
+
 static void cube_relayout(wg_ctx *ctx) {
     const uint32_t mg = 12, np = 8, P = 3, M = mg * P, ld = M + 4; // f16, 24-byte row blocks: the 8-byte vector path
     std::vector<_Float16> cube((size_t)mg * np * P), out((size_t)ld * np + 8, (_Float16)-1.f);
@@ -186,6 +234,9 @@ int main() {
     peer_two_ranks<float>(false, 512, 768, 256, 256);
     peer_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
     peer_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
+    staged_two_ranks<float>(false, 512, 768, 256, 256);
+    staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
+    staged_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
     wg_ctx_destroy(ctx);
     if (failures == 0) std::printf("ALL OK\n");
     return failures ? 1 : 0;

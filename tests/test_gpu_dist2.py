@@ -173,3 +173,64 @@ def test_two_ranks_one_gpu_peer_copy_gives_a_plain_matrix(engine):
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
     assert any(("sdma-rect" if engine == "sdma" else "hip2d") in m for _, _, m in res)
+
+
+# --------------------------------------------------------------------------------------------------------
+# The engine for more than two ranks (WG_GATHER_PEER_STAGED), two processes on one GPU: staging cubes + flag arrays exchanged as IPC
+# handles, contiguous per-peer copies + sequence-number flags, wait kernel + relayout on the receiving stream -- and NO host
+# synchronisation or barrier between three back-to-back steps (stream-ordered, double-buffered by step parity).
+# --------------------------------------------------------------------------------------------------------
+def _staged_worker(rank, world, port, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"  # one hardware queue per stream: copies run beside the Gemms, not behind them
+        import torch  # first: one HIP runtime per process
+        import torch.distributed as dist
+        import wgmath_amd as wg
+        from wgmath_amd.sharded import Comm, GatherMode
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        M, N, K = 1024, 1536, 512
+        Mg = M // world
+        gpu = wg.GpuInstance.new(0)
+        dev, S = gpu.device(), wg.BufferUsages
+        rng = np.random.default_rng(77)
+        A = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        B = (rng.random((K, N), dtype=np.float32) * 2 - 1).astype(np.float16)
+        ta = wg.TensorBuilder.matrix(Mg, K, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(A[rank * Mg:(rank + 1) * Mg].reshape(-1, order="F")))
+        tb = wg.TensorBuilder.matrix(K, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(B.reshape(-1, order="F")))
+        tc = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.full(M * N, np.nan, np.float16))
+        comm = Comm(gpu, world, rank, None)
+        pairs = [None] * world
+        dist.all_gather_object(pairs, comm.stage_export(2 * M * N * 2))
+        comm.set_peer_stages(pairs)
+        dist.barrier()  # every rank's cubes and flags exist and are mapped before anyone pushes
+        for _ in range(3):
+            comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, 512)
+        got = tc.read(dev).reshape(M, N, order="F").astype(np.float64)  # stream order is all it takes
+        A64, B64 = A.astype(np.float64), B.astype(np.float64)
+        truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
+        tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        ok = bool((np.abs(got - truth) <= tol).all())
+        comm.flush()
+        dist.barrier()
+        q.put((rank, ok, f"sent {comm.bytes_sent} B, product ok={ok}"))
+        comm.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(e)))
+
+
+def test_two_ranks_one_gpu_staged_peer_copies():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_staged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

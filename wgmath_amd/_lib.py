@@ -14,7 +14,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "wgebra_hip.h")
 # status codes (wg_status)
 WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_OF_BOUNDS, WG_ERR_HIP, \
     WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE, WG_ERR_WORKSPACE = range(9)
-WG_GATHER_RCCL, WG_GATHER_PEER_COPY, WG_GATHER_NONE = 0, 1, 2
+WG_GATHER_RCCL, WG_GATHER_PEER_COPY, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 1, 2, 3
 WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
 WG_F32, WG_F16 = 0, 1
 
@@ -118,6 +118,8 @@ def _load() -> ctypes.CDLL:
         "wg_comm_barrier": (ci, [vp]),
         "wg_buf_ipc_export": (ci, [vp, vp]),
         "wg_buf_ipc_open": (ci, [vp, vp, pvp]),
+        "wg_comm_stage_reserve": (ci, [vp, sz, pvp, pvp]),
+        "wg_comm_set_peer_stages": (ci, [vp, pvp, pvp]),
         "wg_cube_to_matrix": (ci, [vp, ci, vp, S, vp, S]),
         "wg_gemm_sharded": (ci, [vp, ci, ci, ci, u32, vp, S, pvp, vp, S, vp, S]),
         "wg_encoder_begin": (ci, [vp]),

@@ -17,6 +17,16 @@
 //                        engine that copies strided blocks without a blit kernel: tools/cpp/sdma_probe.cpp), issued by a helper thread
 //                        as soon as the panel's event fires. ~60 GB/s per engine, one engine per peer: about the xGMI link rate.
 //
+//   WG_GATHER_PEER_STAGED  what P > 2 needs: ONE rect-capable SDMA queue per direction flag is all the HSA API exposes (measured: every
+//                        rect copy of an agent shares ~60 GB/s, tools/rank_emulation.py), but contiguous peer copies go to an SDMA engine
+//                        PER LINK (16 engines, 60.7 GB/s each, 7 at once 330 GB/s, Gemm beside 3 / 7 busy engines +2.3 % / +4.8 %:
+//                        tools/cpp/sdma_probe2.cpp). So: the panel Gemm writes slot g of a staging cube (as in RCCL mode), one contiguous
+//                        hipMemcpyAsync per peer (its own stream: the runtime's peer-to-peer path = that link's SDMA engine, no compute
+//                        units) pushes the slot into the SAME slot of the peer's staging cube, followed by a 4-byte sequence-number copy
+//                        into the peer's flag array; the receiver's context stream runs a one-wave wait kernel on those flags and then the
+//                        relayout of that panel -- everything stream-ordered, no helper thread, no barrier: the staging cube is double-
+//                        buffered by step parity, and a rank cannot be more than one step ahead of a peer whose data it needs.
+//
 // RCCL and the HSA runtime are resolved at run time (dlopen): the library links only libamdhip64, and a process that already
 // loaded torch's bundled copies binds to those.
 #include "wg_internal.hpp"
@@ -150,6 +160,18 @@ struct wg_comm {
     int async_status = WG_OK;
     std::string async_error;
     uint64_t bytes_sent = 0; // payload this rank pushed or contributed since creation (diagnostics: wg_comm_bytes_sent)
+    // staged peer copies (WG_GATHER_PEER_STAGED)
+    void *pstage = nullptr;          // two staging cubes of the whole step (step parity), caller-sized: wg_comm_stage_reserve
+    size_t pstage_bytes = 0;
+    uint32_t *pflags = nullptr;      // flags[sender][panel] = sequence number of the last step whose slot has landed (uncached memory)
+    wg_buf stage_buf, flags_buf;     // non-owning views handed to the caller for export
+    std::vector<wg_buf *> peer_stage, peer_flags; // the peers' staging cubes / flag arrays as addressable from here
+    std::vector<hipStream_t> peer_stream;         // one copy stream per peer
+    std::vector<hipEvent_t> sent_ev;              // [parity][panel][peer]: my slot of that panel has left for that peer
+    uint32_t *seq_src = nullptr;     // device word holding the current step's sequence number (source of the flag copies)
+    uint32_t *seq_host = nullptr;    // pinned ring of sequence numbers (source of seq_src's update)
+    uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout
+    uint32_t step = 0;
 };
 
 namespace {
@@ -269,6 +291,26 @@ int launch_cube_to_matrix(wg_ctx *ctx, const void *stage, void *c_col0, uint32_t
     return WG_OK;
 }
 
+constexpr uint32_t kMaxPanels = 1024, kMaxRanks = 16;
+constexpr size_t kFlagBytes = (size_t)kMaxRanks * kMaxPanels * sizeof(uint32_t);
+
+// One wave: lane r waits until rank r's slot of `panel` carries sequence number >= seq (wrap-safe). The flags live in uncached device
+// memory written by the peers' copy engines; system-scope loads. Gives up after ~4 s (100 MHz ticks) and raises *err instead of hanging
+// the queue: a missing peer is then reported by the next call instead of wedging the GPU.
+__global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32_t self, uint32_t panel, uint32_t seq, uint32_t *err) {
+    const uint32_t r = threadIdx.x;
+    if (r >= nranks || r == self) return;
+    const uint32_t *f = flags + (size_t)r * kMaxPanels + panel;
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+        __builtin_amdgcn_s_sleep(64);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+            __hip_atomic_store(err, 1u + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+    }
+}
+
 hipEvent_t take_event(wg_comm *c) {
     std::lock_guard<std::mutex> lk(c->mu);
     hipEvent_t e = nullptr;
@@ -282,6 +324,13 @@ hipEvent_t take_event(wg_comm *c) {
 }
 
 int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far has landed
+    for (hipStream_t st : c->peer_stream)
+        if (st) WG_HIP_TRY(hipStreamSynchronize(st));
+    if (c->wait_err && *c->wait_err) {
+        const uint32_t r = *c->wait_err - 1u;
+        *c->wait_err = 0;
+        return wg_set_error(WG_ERR_HIP, "Gemm (sharded): rank %u's slot did not arrive within 4 s (peer gone, or peer buffers not registered on it)", r);
+    }
     if (c->nranks > 1 && c->use_sdma && c->worker.joinable()) {
         std::unique_lock<std::mutex> lk(c->mu);
         c->jobs.push_back(CopyJob());
@@ -402,6 +451,15 @@ int wg_comm_destroy(wg_comm *c) {
     for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
     if (c->ev_ctx) (void)hipEventDestroy(c->ev_ctx);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
+    for (hipStream_t st : c->peer_stream)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : c->sent_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->pstage) (void)hipFree(c->pstage);
+    if (c->pflags) (void)hipFree(c->pflags);
+    if (c->seq_src) (void)hipFree(c->seq_src);
+    if (c->seq_host) (void)hipHostFree(c->seq_host);
+    if (c->wait_err) (void)hipHostFree(c->wait_err);
     if (c->stage) (void)hipFree(c->stage);
     if (c->token) (void)hipFree(c->token);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -512,6 +570,63 @@ int wg_buf_ipc_open(wg_ctx *ctx, const void *handle, wg_buf **out) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// staged peer copies: the communicator's staging cube + flag array, to be exported to / imported from the peers by the caller
+// ---------------------------------------------------------------------------------------------------------------
+int wg_comm_stage_reserve(wg_comm *c, size_t bytes, wg_buf **stage, wg_buf **flags) {
+    if (!c || !stage || !flags) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_stage_reserve: NULL argument");
+    if (c->ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_stage_reserve: cannot allocate while recording");
+    if (c->nranks > (int)kMaxRanks) return wg_set_error(WG_ERR_UNSUPPORTED, "staged peer copies support up to %u ranks", kMaxRanks);
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    if (bytes > c->pstage_bytes) {
+        WG_HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        if (int rc = comm_flush(c)) return rc;
+        if (c->pstage) WG_HIP_TRY(hipFree(c->pstage));
+        c->pstage = nullptr;
+        c->pstage_bytes = 0;
+        WG_HIP_TRY(hipMalloc(&c->pstage, bytes));
+        c->pstage_bytes = bytes;
+        c->peer_stage.clear(); // the peers' mappings of the old cube are stale for them too: re-exchange
+    }
+    if (!c->pflags) {
+        // uncached device memory: written by the peers' copy engines, polled by the wait kernel
+        hipError_t e = hipExtMallocWithFlags((void **)&c->pflags, kFlagBytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            WG_HIP_TRY(hipExtMallocWithFlags((void **)&c->pflags, kFlagBytes, hipDeviceMallocFinegrained));
+        }
+        WG_HIP_TRY(hipMemset(c->pflags, 0, kFlagBytes));
+        WG_HIP_TRY(hipMalloc((void **)&c->seq_src, 256));
+        WG_HIP_TRY(hipHostMalloc((void **)&c->seq_host, 64 * sizeof(uint32_t), hipHostMallocDefault));
+        WG_HIP_TRY(hipHostMalloc((void **)&c->wait_err, 64, hipHostMallocDefault));
+        *c->wait_err = 0;
+    }
+    c->stage_buf.ctx = c->ctx; c->stage_buf.ptr = c->pstage; c->stage_buf.bytes = c->pstage_bytes; c->stage_buf.usage = WG_USAGE_STORAGE; c->stage_buf.owned = false;
+    c->flags_buf.ctx = c->ctx; c->flags_buf.ptr = c->pflags; c->flags_buf.bytes = kFlagBytes; c->flags_buf.usage = WG_USAGE_STORAGE; c->flags_buf.owned = false;
+    *stage = &c->stage_buf;
+    *flags = &c->flags_buf;
+    return WG_OK;
+}
+
+int wg_comm_set_peer_stages(wg_comm *c, wg_buf *const *peer_stage, wg_buf *const *peer_flags) {
+    if (!c || !peer_stage || !peer_flags) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: NULL argument");
+    if (!c->pstage) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: call wg_comm_stage_reserve first");
+    for (int r = 0; r < c->nranks; ++r) {
+        if (r == c->rank) continue;
+        if (!peer_stage[r] || !peer_flags[r] || peer_stage[r]->bytes < c->pstage_bytes || peer_flags[r]->bytes < kFlagBytes)
+            return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: rank %d's staging cube / flag array is missing or smaller than this rank's", r);
+    }
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    c->peer_stage.assign(peer_stage, peer_stage + c->nranks);
+    c->peer_flags.assign(peer_flags, peer_flags + c->nranks);
+    while ((int)c->peer_stream.size() < c->nranks) {
+        hipStream_t st = nullptr;
+        WG_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->peer_stream.push_back(st);
+    }
+    return WG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // relayout: gathered cube -> columns of the M x N matrix (RCCL mode; also exported for callers that all-gather themselves)
 // ---------------------------------------------------------------------------------------------------------------
 int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_shape cube_shape, wg_buf *out, wg_view_shape out_shape) {
@@ -541,7 +656,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     if (!c || !out || !a_rows || !b) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): NULL argument");
     if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown dtype %d", (int)dtype);
     if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
-    if ((int)mode < 0 || (int)mode > 2) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown gather mode %d", (int)mode);
+    if ((int)mode < 0 || (int)mode > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown gather mode %d", (int)mode);
     wg_ctx *ctx = c->ctx;
     if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): cannot be recorded");
     const bool tr = variant == WG_GEMM_TR || variant == WG_GEMM_TR_FAST;
@@ -569,6 +684,76 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     const uint32_t npanels = (N + panel_cols - 1) / panel_cols;
     const size_t es = wg_dtype_size(dtype);
     WG_HIP_TRY(hipSetDevice(ctx->device));
+
+    if (mode == WG_GATHER_PEER_STAGED) {
+        // ---- contiguous per-link copies into the peers' staging cubes + flag, wait kernel + relayout on the receiving side ----
+        if (npanels > kMaxPanels) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): more than %u panels", kMaxPanels);
+        const size_t cube_bytes = (size_t)M * N * es;
+        if (!c->pstage || c->pstage_bytes < 2 * cube_bytes)
+            return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_STAGED needs wg_comm_stage_reserve(>= %zu bytes) and, with > 1 rank, wg_comm_set_peer_stages", 2 * cube_bytes);
+        if (P > 1 && (int)c->peer_stage.size() != c->nranks)
+            return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_STAGED: peers' staging cubes are not registered (wg_comm_set_peer_stages)");
+        if (2ull * M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
+        if (c->wait_err && *c->wait_err) {
+            const uint32_t r = *c->wait_err - 1u;
+            *c->wait_err = 0;
+            return wg_set_error(WG_ERR_HIP, "Gemm (sharded): rank %u's slot did not arrive within 4 s in an earlier step", r);
+        }
+        const uint32_t seq = ++c->step, parity = seq & 1u;
+        // the sequence number the flag copies carry: pinned ring entry -> device word, on the context's stream ahead of this step's Gemms
+        c->seq_host[seq % 64u] = seq;
+        WG_HIP_TRY(hipMemcpyAsync(c->seq_src + (seq % 64u), c->seq_host + (seq % 64u), sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        const size_t nev = 2 * (size_t)kMaxPanels; // sent_ev[parity][panel]: recorded on every peer stream -> one event per (parity, panel, peer)
+        (void)nev;
+        while (c->sent_ev.size() < (size_t)2 * npanels * P) c->sent_ev.push_back(nullptr);
+        wg_buf sbuf;
+        sbuf.ctx = ctx; sbuf.ptr = c->pstage; sbuf.bytes = c->pstage_bytes; sbuf.usage = 0; sbuf.owned = false; sbuf.host_pinned = false;
+        auto slot_elem = [&](uint32_t c0, uint32_t np, uint32_t r) { return (uint64_t)parity * M * N + (uint64_t)c0 * M + (uint64_t)r * mg * np; };
+        auto finish_panel = [&](uint32_t p) -> int { // wait for the peers' slots of panel p, then relayout it into columns of `out`
+            const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            if (P > 1) {
+                hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err);
+                WG_HIP_TRY(hipGetLastError());
+            }
+            const char *src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
+            char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
+            return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es);
+        };
+        for (uint32_t p = 0; p < npanels; ++p) {
+            const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            wg_view_shape bs = b_shape;
+            bs.size[1] = np;
+            bs.offset = b_shape.offset + c0 * b_shape.stride;
+            wg_view_shape os;
+            os.size[0] = mg; os.size[1] = np; os.size[2] = 1; os.stride = mg; os.stride_mat = mg * np;
+            os.offset = (uint32_t)slot_elem(c0, np, g);
+            // this slot last left for the peers two steps ago (same parity): those copies must be done before the Gemm overwrites it
+            for (uint32_t r = 0; r < P; ++r) {
+                hipEvent_t e = c->sent_ev[((size_t)parity * npanels + p) * P + r];
+                if (r != g && e) WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, e, 0));
+            }
+            if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, &sbuf, os, a_rows, a_shape, b, bs)) return rc;
+            if (P > 1) {
+                WG_HIP_TRY(hipEventRecord(c->ev_ctx, ctx->stream));
+                const size_t off = slot_elem(c0, np, g) * es, bytes = (size_t)mg * np * es;
+                for (uint32_t i = 1; i < P; ++i) { // start with the next rank: every link is busy from the first panel on
+                    const uint32_t r = (g + i) % P;
+                    hipStream_t st = c->peer_stream[r];
+                    WG_HIP_TRY(hipStreamWaitEvent(st, c->ev_ctx, 0));
+                    WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_stage[r]->ptr + off, (const char *)c->pstage + off, bytes, hipMemcpyDeviceToDevice, st));
+                    WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_flags[r]->ptr + ((size_t)g * kMaxPanels + p) * sizeof(uint32_t), c->seq_src + (seq % 64u),
+                                              sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                    hipEvent_t &e = c->sent_ev[((size_t)parity * npanels + p) * P + r];
+                    if (!e) WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                    WG_HIP_TRY(hipEventRecord(e, st));
+                }
+                c->bytes_sent += (uint64_t)(P - 1) * bytes;
+            }
+            if (p > 0)
+                if (int rc = finish_panel(p - 1)) return rc; // after this panel's Gemm: the previous panel's slots travelled beside it
+        }
+        return finish_panel(npanels - 1);
+    }
 
     const bool staged = mode == WG_GATHER_RCCL && c->nccl != nullptr; // a 1-rank communicator still runs the whole path (tests)
     wg_buf stage_buf;

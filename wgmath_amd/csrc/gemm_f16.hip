@@ -38,6 +38,24 @@ namespace {
 // start of H / of 2s+1. During H: A(H+4) -> A slot H&3; B: the first half of B(s+3) during odd H, the second half of B(s+2)
 // during even H -> B slot (stage % 3). Everything a barrier must publish was issued >= 2 half-steps before it.
 // ===============================================================================================================
+#ifndef WG_NN_RDENSE
+#define WG_NN_RDENSE 0
+#endif
+#ifndef WG_NN_DSTRIDE
+#define WG_NN_DSTRIDE 8 // NN: a DMA piece every this many MFMA slots (>= 2) ...
+#endif
+#ifndef WG_NN_DOFF
+#define WG_NN_DOFF 3    // ... starting at this slot (>= 1): 4 A pieces, then 4 B pieces
+#endif
+#ifndef WG_TN_RSTRIDE
+#define WG_TN_RSTRIDE 4 // TN: a fragment read every this many MFMA slots
+#endif
+#ifndef WG_TN_DSTRIDE
+#define WG_TN_DSTRIDE 4 // TN: a DMA piece every this many slots ...
+#endif
+#ifndef WG_TN_DOFF
+#define WG_TN_DOFF 2    // ... starting at this slot (>= 1)
+#endif
 #ifndef WG_F16_NN_SWAP
 #define WG_F16_NN_SWAP 1 // NN A reads: 1 = conflict-free transpose reads + v_permlane16_swap, 0 = direct reads (2-way bank conflicts)
 #endif
@@ -55,6 +73,7 @@ constexpr int M16_A_RING = 4, M16_B_RING = 3;
 constexpr int M16_BS_BYTES = BN * 64 * 2;              // one full stage of B: 256 rows x 128 bytes = 32 KiB
 constexpr int M16_B_BASE = M16_A_RING * HA_BYTES;      // 64 KiB
 static_assert(M16_B_BASE + M16_B_RING * M16_BS_BYTES == 160 * 1024, "LDS plan");
+static_assert(WG_TN_DSTRIDE >= 2 && WG_TN_DOFF >= 1, "M0 of a group is set one slot before its first piece and after the previous group's last");
 
 __device__ __forceinline__ void m16_set_m0(uint32_t lds_dst) {
     if (WG_ABLATE & 2) return;
@@ -62,10 +81,19 @@ __device__ __forceinline__ void m16_set_m0(uint32_t lds_dst) {
 }
 // LDS destination = M0 + IMM + 16 * lane; the instruction's immediate offset moves the GLOBAL address too, so the per-piece
 // voff registers are biased by -IMM (see M16_BIAS). Needs >= 1 instruction since m16_set_m0.
+#ifndef WG_F16_DMA_MUBUF
+#define WG_F16_DMA_MUBUF 0 // 1: buffer_load_dwordx4 ... offen lds (descriptor + 32-bit offset) instead of global_load_lds_dwordx4 (64-bit scalar base)
+#endif
 template <int IMM>
 __device__ __forceinline__ void m16_dma_imm(uint32_t voff, const void *sbase) {
     if (WG_ABLATE & 2) return;
-    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
+    if constexpr (WG_F16_DMA_MUBUF) {
+        // raw buffer descriptor over "everything from sbase on": stride 0, num_records 2^32 - 1 (offsets stay below 2^31: off_ok), gfx9 raw-buffer flags
+        const uintx4 srd = { (uint32_t)(uintptr_t)sbase, (uint32_t)((uintptr_t)sbase >> 32) & 0xffffu, 0xffffffffu, 0x00020000u };
+        asm volatile("buffer_load_dwordx4 %0, %1, 0 offen offset:%c2 lds" ::"v"(voff), "s"(srd), "i"(IMM));
+    } else {
+        asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
+    }
 }
 __device__ __forceinline__ void m16_dma(int q, uint32_t voff, const void *sbase) { // piece q (0..3) of a group of four
     if (q == 0) m16_dma_imm<0>(voff, sbase);
@@ -272,32 +300,35 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
             if constexpr (decltype(has_next)::value) {
                 if constexpr (TRANS_A) {
-                    // one fragment read every 4 slots (every 2 or 3, leaving slack before the end-of-half-step wait: no faster)
-                    if constexpr ((j & 3) == 0) frag_op(sa, sb, j >> 2, HS ^ 1, HS ^ 1);
+                    // one fragment read every WG_TN_RSTRIDE slots
+                    if constexpr ((j % WG_TN_RSTRIDE) == 0 && (j / WG_TN_RSTRIDE) < 16) frag_op(sa, sb, j / WG_TN_RSTRIDE, HS ^ 1, HS ^ 1);
                 } else {
-                    if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1, HS ^ 1);
+                    if constexpr (WG_NN_RDENSE) { // one fragment op in every slot from the start: all issued by slot kOps, the rest of the half-step is slack
+                        if constexpr (j < kOps) frag_op(sa, sb, j, HS ^ 1, HS ^ 1);
+                    } else if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1, HS ^ 1);
                 }
             }
             if constexpr (!TRANS_A) {
-                constexpr int pi = j >> 3, q = pi & 3;
-                if constexpr (pi < 4 ? ADMA : BDMA) {
-                    if constexpr (j == 1) m16_set_m0(la);
-                    if constexpr (j == 33) m16_set_m0(lb);
-                    if constexpr ((j & 7) == 3) {
-                        if constexpr (pi < 4) m16_dma_imm<1024 * q>(a_voff[q], ga);
-                        else m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb);
-                    }
+                // piece p (0..3: A, 4..7: B) at slot WG_NN_DOFF + WG_NN_DSTRIDE p; M0 one slot before the first piece of each group of four
+                constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
+                if constexpr (ADMA && j == DO - 1) m16_set_m0(la);
+                if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(lb);
+                if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
+                    constexpr int pi = (j - DO) / DS, q = pi & 3;
+                    if constexpr (pi < 4) { if constexpr (ADMA) m16_dma_imm<1024 * q>(a_voff[q], ga); }
+                    else { if constexpr (BDMA) m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb); }
                 }
             } else {
-                // piece list of this half-step: [A0..A7 if ADMA] + [B0..B3 if BDMA]; piece n is issued at slot 4 n + 2
+                // piece list of this half-step: [A0..A7 if ADMA] + [B0..B3 if BDMA]; piece n is issued at slot WG_TN_DSTRIDE n + WG_TN_DOFF,
+                // M0 (one per group of four pieces) one slot before the group's first piece
                 constexpr int nA = ADMA ? 8 : 0, nB = BDMA ? 4 : 0;
-                if constexpr ((j & 3) == 0 && (j >> 2) < nA + nB && ((j >> 2) & 3) == 0 ) {
-                    // group start (pieces j>>2 .. j>>2 + 3): M0 two slots before the group's first DMA
-                    constexpr int n = j >> 2;
+                constexpr int DS = WG_TN_DSTRIDE, DO = WG_TN_DOFF;
+                if constexpr (j + 1 >= DO && ((j + 1 - DO) % DS) == 0 && ((j + 1 - DO) / DS) < nA + nB && (((j + 1 - DO) / DS) & 3) == 0) {
+                    constexpr int n = (j + 1 - DO) / DS;
                     if constexpr (n < nA) m16_set_m0(la + (n >> 2) * 4096); else m16_set_m0(lb);
                 }
-                if constexpr ((j & 3) == 2 && (j >> 2) < nA + nB) {
-                    constexpr int n = j >> 2;
+                if constexpr (j >= DO && ((j - DO) % DS) == 0 && ((j - DO) / DS) < nA + nB) {
+                    constexpr int n = (j - DO) / DS;
                     if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], ga);
                     else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
                 }

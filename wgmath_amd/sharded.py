@@ -168,6 +168,7 @@ class GatherMode:
     RCCL = 0       # staging cube + in-place ncclAllGather per panel + relayout into C (wg_gather_mode WG_GATHER_RCCL)
     PEER_COPY = 1  # Gemm straight into C's rows, SDMA pushes the strided block to every peer's C (WG_GATHER_PEER_COPY)
     NONE = 2
+    PEER_STAGED = 3  # Gemm into a staging cube, one contiguous copy per peer link + flag, wait kernel + relayout on the receiver (WG_GATHER_PEER_STAGED)
 
 
 def new_unique_id() -> bytes:
@@ -255,6 +256,48 @@ class Comm:
         for r, t in enumerate(tensors):
             arr[r] = t._h.value
         self._peers[id(tensor)] = (arr, [])
+
+    # -- staged peer copies (GatherMode.PEER_STAGED): the communicator's staging cubes + flag array ---------------------------
+    def stage_reserve(self, nbytes: int):
+        """Make the staging cubes (>= 2 * itemsize * M * N bytes) and the flag array exist; returns their two wg_buf handles."""
+        st, fl = ctypes.c_void_p(), ctypes.c_void_p()
+        self._lib.check(self._lib.lib.wg_comm_stage_reserve(self._h, int(nbytes), ctypes.byref(st), ctypes.byref(fl)))
+        self._stage = (st, fl)
+        return st, fl
+
+    def stage_export(self, nbytes: int):
+        """(stage handle bytes, flags handle bytes) to ship to every peer."""
+        st, fl = self.stage_reserve(nbytes)
+        out = []
+        for b in (st, fl):
+            buf = ctypes.create_string_buffer(self._lib.WG_IPC_HANDLE_BYTES)
+            self._lib.check(self._lib.lib.wg_buf_ipc_export(b, buf))
+            out.append(buf.raw)
+        return tuple(out)
+
+    def set_peer_stages(self, handles) -> None:
+        """handles[r] = rank r's stage_export() pair (handles[self.rank] is ignored)."""
+        sa, fa = (ctypes.c_void_p * self.nranks)(), (ctypes.c_void_p * self.nranks)()
+        opened = []
+        for r, pair in enumerate(handles):
+            if r == self.rank:
+                sa[r], fa[r] = self._stage[0].value, self._stage[1].value
+                continue
+            for arr, hb in ((sa, pair[0]), (fa, pair[1])):
+                b = ctypes.c_void_p()
+                self._lib.check(self._lib.lib.wg_buf_ipc_open(self.gpu._ctx.handle, ctypes.create_string_buffer(hb, self._lib.WG_IPC_HANDLE_BYTES), ctypes.byref(b)))
+                arr[r] = b.value
+                opened.append(b)
+        self._lib.check(self._lib.lib.wg_comm_set_peer_stages(self._h, sa, fa))
+        self._peers["__stages__"] = ((sa, fa), opened)
+
+    def set_local_peer_stages(self, comms) -> None:
+        """The ranks share this process (tests): comms[r] is rank r's Comm (each already stage_reserve()d)."""
+        sa, fa = (ctypes.c_void_p * self.nranks)(), (ctypes.c_void_p * self.nranks)()
+        for r, cm in enumerate(comms):
+            sa[r], fa[r] = cm._stage[0].value, cm._stage[1].value
+        self._lib.check(self._lib.lib.wg_comm_set_peer_stages(self._h, sa, fa))
+        self._peers["__stages__"] = ((sa, fa), [])
 
     def sharded_gemm(self, out, a_rows, b, variant=0, mode: int = GatherMode.RCCL, panel_cols: int = 0) -> None:
         """out (M x N GpuMatrix, on every rank) = op(A) * B with A sharded on M: `a_rows` is this rank's row block (M/P x K, or
