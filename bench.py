@@ -558,12 +558,23 @@ def load_pmc(workload: str):
     return {}
 
 
-def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0, keep=True):
+def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, cpu_budget, min_seconds=0.0, keep=True, agree=None):
     """Times EXACTLY `steps` steps (after `warmup` untimed ones). With min_seconds > 0 (secondary configs only) `steps` is raised
     so that the timed region lasts at least that long: millisecond kernels timed for a few tens of ms still see the clocks
     ramping (measured: f32 GEMM 140 TF over 30 ms vs 148 TF sustained)."""
     w = WORKLOADS[name]()
-    w.setup(wg, gpu, rank, world)
+    setup_err = None
+    try:
+        w.setup(wg, gpu, rank, world)
+    except Exception as e:
+        if agree is None:
+            raise
+        setup_err = e
+    if agree is not None:
+        # multi-rank: a rank whose set-up failed (no peer mapping, out of memory, ...) must not leave the others waiting inside a
+        # collective or on its flags -- everybody learns about it here and skips the run together
+        if not agree(setup_err is None):
+            raise RuntimeError(f"set-up failed on {'this' if setup_err is not None else 'another'} rank" + (f": {type(setup_err).__name__}: {setup_err}" if setup_err else ""))
     t_w = time.perf_counter()
     for _ in range(max(warmup, 1)):
         w.step()
@@ -736,6 +747,10 @@ def main():
         return dry_run(args, rank, world)
 
     global DIST
+    if world > 1:
+        # before the HIP runtime initialises: one hardware queue per stream (compute, collective, one copy stream per peer), or the copies of
+        # the exchange queue up behind the Gemms instead of running beside them (HIP's default folds all streams onto 4 queues)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     # WG_BENCH_FORCE_DIST=1: take the communicator path even with one rank (single-GPU test of the N > 1 plumbing: RCCL with one rank)
     dist_mode = world > 1 or os.environ.get("WG_BENCH_FORCE_DIST") == "1"
     if dist_mode:
@@ -802,6 +817,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+        def agree(ok: bool) -> bool:  # True iff every rank says ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if oversub else f"cuda:{dev_index}")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
         engines = {}  # mode -> (GpuInstance, Comm)
         for mode in (["rccl", "staged", "peer"] if gather == "auto" else [gather]):
             g = make_gpu(masked=(mode == "rccl" and world > 1))
@@ -831,7 +851,7 @@ def main():
             DIST.update(comm=cm, mode=mode)
             gpu = g
             try:
-                r = run_workload(wg, g, args.workload, max(2, args.warmup), 1, rank, world, barrier, False, 0.0, keep=False)
+                r = run_workload(wg, g, args.workload, max(2, args.warmup), 1, rank, world, barrier, False, 0.0, keep=False, agree=agree)
                 el = r["elapsed"] / r["steps"]
                 err = None
             except Exception as e:
@@ -849,7 +869,7 @@ def main():
         info = gpu.adapter()
 
     main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
-                            not args.no_cpu_baseline, args.cpu_budget)
+                            not args.no_cpu_baseline, args.cpu_budget, agree=agree if dist_mode else None)
     elapsed = main_res["elapsed"]
     if dist_mode:
         import torch

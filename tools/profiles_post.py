@@ -11,14 +11,14 @@ def find(pattern):
 # 1. kernel stats + durations by (kernel, grid)
 stats = find("kt/**/*kernel_stats.csv")
 if stats:
-    shutil.copy(stats[0], os.path.join(out, "r01_bench_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(out, "r02_bench_kernel_stats.csv"))
 rows = collections.defaultdict(list)
 for f in find("kt/**/*kernel_trace.csv"):
     for r in csv.DictReader(open(f)):
         grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
         rows[(r["Kernel_Name"], grid)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-with open(os.path.join(out, "r01_kernel_durations_by_grid.csv"), "w") as fo:
-    fo.write("# derived from rocprofv3 --kernel-trace (same run as r01_bench_kernel_stats.csv: tools/make_profiles.sh step 1).\n")
+with open(os.path.join(out, "r02_kernel_durations_by_grid.csv"), "w") as fo:
+    fo.write("# derived from rocprofv3 --kernel-trace (same run as r02_bench_kernel_stats.csv: tools/make_profiles.sh step 1).\n")
     fo.write("# mean duration per kernel AND grid size in threads (one kernel name can serve several workloads). Microseconds.\n")
     fo.write("kernel,grid_size,calls,mean_us,min_us,max_us\n")
     for (k, g), v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
@@ -51,6 +51,7 @@ work = {
     "gemm_f16_32768": pick("gemm_f16_m16_kernel<false>", grid=16384 * 256) or pick("gemm_f16_m16_kernel<false>", 0),
     "gemm_f16_8192": pick("gemm_f16_m16_kernel<false>", grid=1024 * 256) or pick("gemm_f16_m16_kernel<false>", 2),
     "gemm_f16_ts_131072x1024x8192": pick("gemm_f16_m16_kernel<false>", grid=2048 * 256),
+    "gemmtr_f16_8192": pick("gemm_f16_m16_kernel<true>", grid=1024 * 256),
     "gemm_f16_2048": pick("gemm_f16_t128_kernel<false>", grid=256 * 256),
     "gemm_f32_4096": pick("gemm_f32_kernel<false>", grid=512 * 256) or pick("gemm_f32", grid=512 * 256),
     "gemm_f32_ts_65536x512x4096": pick("gemm_f32_kernel<false>", grid=1024 * 256) or pick("gemm_f32", grid=1024 * 256),

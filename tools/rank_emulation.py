@@ -57,13 +57,44 @@ for P in Ps:
             sent = (P - 1) * Mg * N * 2
             res[name]["bytes_pushed_per_step"] = sent
             res[name]["aggregate_push_gbs_if_fully_overlapped"] = round(sent / dt / 1e9, 1)
+    # the staged engine's compute side: panel Gemms into the staging cube + the relayout of every panel, copies switched off
+    # (WG_STAGED_NO_COPY) and the flags pre-set so that the wait kernels pass: what the contiguous per-link copies run BESIDE
+    if P > 1:
+        os.environ["WG_STAGED_NO_COPY"] = "1"
+        from wgmath_amd._lib import check, lib
+        st, fl = comm.stage_reserve(2 * M * N * 2)
+        ones = np.full(16 * 1024, 0x3fffffff, np.uint32)
+        check(lib.wg_buf_write(gpu._ctx.handle, fl, 0, ones.ctypes.data, ones.nbytes))
+        comm._stage = (st, fl)
+        comm.set_local_peer_stages([comm] * P)
+        for _ in range(2):
+            comm.sharded_gemm(C, A, B, 0, GatherMode.PEER_STAGED, panel)
+        gpu.sync()
+        t0 = time.perf_counter()
+        for _ in range(STEPS):
+            comm.sharded_gemm(C, A, B, 0, GatherMode.PEER_STAGED, panel)
+        gpu.sync()
+        dt = (time.perf_counter() - t0) / STEPS
+        last = Mg * min(panel, N) * 2
+        res["staged_compute_and_relayout"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1),
+                                              "last_panel_bytes_per_peer": last}
     out["ranks"][str(P)] = res
     comm.close()
     del A, B, C, peers
     gpu.close()
 t1 = out["ranks"].get("1", {}).get("no_exchange", {}).get("ms_per_step")
+# measured beside busy SDMA engines (tools/cpp/sdma_probe2.cpp): Gemm slowdown with 1 / 3 / 7 engines at 60.7 GB/s each
+SLOW = {2: 1.006, 4: 1.023, 8: 1.048}
+ENGINE_GBS = 60.7
 if t1:
     for P, r in out["ranks"].items():
         if "peer_copy" in r:
-            r["expected_speedup_vs_1_gpu"] = round(t1 / r["peer_copy"]["ms_per_step"], 3)
+            r["expected_speedup_rect_engine"] = round(t1 / r["peer_copy"]["ms_per_step"], 3)
+        if "staged_compute_and_relayout" in r:
+            sc = r["staged_compute_and_relayout"]
+            tail = sc["last_panel_bytes_per_peer"] / (ENGINE_GBS * 1e6)  # ms: the last panel's slot on one link, nothing left to hide it under
+            steady = (int(P) - 1) and (r["rows_per_rank"] * N * 2 / (ENGINE_GBS * 1e6))  # ms per step one link needs at the engine rate
+            t = max(sc["ms_per_step"] * SLOW.get(int(P), 1.05), steady) + tail
+            r["expected_staged"] = {"ms_per_step": round(t, 3), "link_ms_per_step_at_engine_rate": round(steady, 3), "exposed_tail_ms": round(tail, 3),
+                                    "gemm_slowdown_beside_engines": SLOW.get(int(P), 1.05), "speedup_vs_1_gpu": round(t1 / t, 3)}
 print(json.dumps(out, indent=1))

@@ -733,7 +733,8 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 if (r != g && e) WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, e, 0));
             }
             if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, &sbuf, os, a_rows, a_shape, b, bs)) return rc;
-            if (P > 1) {
+            static const bool no_copy = getenv("WG_STAGED_NO_COPY") != nullptr; // tools/rank_emulation.py: one rank's compute + relayout alone
+            if (P > 1 && !no_copy) {
                 WG_HIP_TRY(hipEventRecord(c->ev_ctx, ctx->stream));
                 const size_t off = slot_elem(c0, np, g) * es, bytes = (size_t)mg * np * es;
                 for (uint32_t i = 1; i < P; ++i) { // start with the next rank: every link is busy from the first panel on

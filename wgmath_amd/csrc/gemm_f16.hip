@@ -41,6 +41,9 @@ namespace {
 #ifndef WG_NN_RDENSE
 #define WG_NN_RDENSE 0
 #endif
+#ifndef WG_NN_STAGGER
+#define WG_NN_STAGGER 0 // NN: wave w issues its DMA pieces this many slots later than wave w-1 (0: all four waves in the same slots)
+#endif
 #ifndef WG_NN_DSTRIDE
 #define WG_NN_DSTRIDE 8 // NN: a DMA piece every this many MFMA slots (>= 2) ...
 #endif
@@ -276,8 +279,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // first half of B(st+3)). TN: even H only B; odd H the 8 pieces of the full stage A(st+2) first (its slot held A(st), read
     // out by now; it must land by the end of the NEXT half-step, so it goes ahead of B in the in-order vmcnt queue), then B:
     // 12 pieces at slots 4 i + 2. M0 is set once per group of four pieces, two slots ahead.
-    auto half_step = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next) {
+    auto half_step = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto wsel) {
         constexpr int HS = decltype(hs_c)::value;
+        constexpr int WSEL = decltype(wsel)::value; // wave-specific DMA slot shift (WG_NN_STAGGER slots per wave index)
         constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
         const uint32_t H = 2u * st + HS;
         const char *sa;
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
             }
             if constexpr (!TRANS_A) {
                 // piece p (0..3: A, 4..7: B) at slot WG_NN_DOFF + WG_NN_DSTRIDE p; M0 one slot before the first piece of each group of four
-                constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
+                constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF + WG_NN_STAGGER * WSEL;
                 if constexpr (ADMA && j == DO - 1) m16_set_m0(la);
                 if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(lb);
                 if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
@@ -400,20 +404,29 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
     // because they issue fewer (then no) DMA pieces.
     using k8 = std::integral_constant<int, 8>;
+    using W0 = std::integral_constant<int, 0>;
     if constexpr (!TRANS_A) {
-        while (st + 3 < S) { // st advances in next_stage()
-            half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{});
-            half_step(c1{}, yes{}, yes{}, yes{}); advance(k16{});
-            next_stage();
-        }
-        half_step(c0{}, yes{}, yes{}, yes{}); advance(k16{}); // stage S-3: A(2S-2), second half of B(S-1)
-        half_step(c1{}, yes{}, no{}, yes{});  advance(k12{}); //            A(2S-1)
+        auto steady = [&](auto wsel) {
+            while (st + 3 < S) { // st advances in next_stage()
+                half_step(c0{}, yes{}, yes{}, yes{}, wsel); advance(k16{});
+                half_step(c1{}, yes{}, yes{}, yes{}, wsel); advance(k16{});
+                next_stage();
+            }
+        };
+        if constexpr (WG_NN_STAGGER != 0) { // one copy of the steady-state loop per wave: its DMA pieces sit in that wave's own slots
+            if (wave == 0) steady(std::integral_constant<int, 0>{});
+            else if (wave == 1) steady(std::integral_constant<int, 1>{});
+            else if (wave == 2) steady(std::integral_constant<int, 2>{});
+            else steady(std::integral_constant<int, 3>{});
+        } else steady(W0{});
+        half_step(c0{}, yes{}, yes{}, yes{}, W0{}); advance(k16{}); // stage S-3: A(2S-2), second half of B(S-1)
+        half_step(c1{}, yes{}, no{}, yes{}, W0{});  advance(k12{}); //            A(2S-1)
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); advance(k4{});    // stage S-2
-        half_step(c1{}, no{}, no{}, yes{}); advance(k0{});
+        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k4{});    // stage S-2
+        half_step(c1{}, no{}, no{}, yes{}, W0{}); advance(k0{});
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-1
-        half_step(c1{}, no{}, no{}, no{});
+        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k0{});    // stage S-1
+        half_step(c1{}, no{}, no{}, no{}, W0{});
     } else {
         // TN: both operands live in full-stage slots, so ONE wait + barrier per stage suffices, at the end of the EVEN half-step:
         // it publishes stage st+1 (read by the odd half-step that follows and by the even one after it) and releases the slots of
@@ -422,18 +435,18 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         // without any synchronisation (lgkmcnt(0) only: see advance()).
         auto soft = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); };
         while (st + 3 < S) {
-            half_step(c0{}, no{}, yes{}, yes{});  advance(k8{});
-            half_step(c1{}, yes{}, yes{}, yes{}); soft();
+            half_step(c0{}, no{}, yes{}, yes{}, W0{});  advance(k8{});
+            half_step(c1{}, yes{}, yes{}, yes{}, W0{}); soft();
             next_stage();
         }
-        half_step(c0{}, no{}, yes{}, yes{}); advance(k8{});   // stage S-3: second half of B(S-1)
-        half_step(c1{}, yes{}, no{}, yes{}); soft();          //            A(S-1)
+        half_step(c0{}, no{}, yes{}, yes{}, W0{}); advance(k8{});   // stage S-3: second half of B(S-1)
+        half_step(c1{}, yes{}, no{}, yes{}, W0{}); soft();          //            A(S-1)
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); advance(k0{});    // stage S-2: A(S-1), B(S-1) must have landed
-        half_step(c1{}, no{}, no{}, yes{}); soft();
+        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k0{});    // stage S-2: A(S-1), B(S-1) must have landed
+        half_step(c1{}, no{}, no{}, yes{}, W0{}); soft();
         next_stage();
-        half_step(c0{}, no{}, no{}, yes{}); soft();           // stage S-1
-        half_step(c1{}, no{}, no{}, no{});
+        half_step(c0{}, no{}, no{}, yes{}, W0{}); soft();           // stage S-1
+        half_step(c1{}, no{}, no{}, no{}, W0{});
     }
     WG_TRACE_POINT(2);
 
