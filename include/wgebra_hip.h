@@ -298,7 +298,10 @@ typedef enum wg_gather_mode {
                                 peer-to-peer path: that link's own SDMA engine, no compute units) into the same slot of the peer's cube + a
                                 sequence-number flag; the receiver's stream waits on the flags (one-wave kernel) and relayouts the panel into
                                 C. Stream-ordered end to end, no barrier: the cubes are double-buffered by step parity. Needs
-                                wg_comm_stage_reserve + wg_comm_set_peer_stages. The engine for P > 2 (one rect-capable SDMA queue per GPU) */
+                                wg_comm_stage_reserve + wg_comm_set_peer_stages. The engine for P > 2 (one rect-capable SDMA queue per GPU).
+                                The HIP runtime folds a process's streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise: give
+                                a rank's process >= 3 + P of them, or its copies queue up behind its Gemms instead of running beside them
+                                (correct either way; two ranks driven from ONE thread on one device need it for progress) */
 } wg_gather_mode;
 
 /* ncclGetUniqueId: call on one rank, ship the WG_COMM_ID_BYTES bytes to the others out of band (env, file, MPI, a torch store). */

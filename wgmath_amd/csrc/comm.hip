@@ -127,6 +127,8 @@ struct Rect { // a strided block: `rows` pieces of `width` bytes, `pitch` bytes 
     size_t dpitch;
     const void *src;
     size_t spitch, width, rows;
+    int queue; // the HSA rect-copy API runs "host-to-device" and "device-to-host" copies on two different SDMA queues (60 GB/s each,
+               // concurrently: tools/cpp/sdma_probe2.cpp); device-to-device shares one of them. Peers alternate between the two.
 };
 struct CopyJob {
     hipEvent_t after = nullptr; // issue once this event (recorded on the context's stream) has fired; nullptr = flush marker
@@ -218,7 +220,7 @@ void worker_main(wg_comm *c) {
                 H.signal_store(sig, 1);
                 hsa_pitched_ptr_t d = { r.dst, r.dpitch, r.dpitch * r.rows }, s = { (void *)r.src, r.spitch, r.spitch * r.rows };
                 hsa_dim3_t off = { 0, 0, 0 }, range = { (uint32_t)r.width, (uint32_t)r.rows, 1 };
-                hsa_status_t st = H.copy_rect(&d, &off, &s, &off, &range, c->agent, hsaDeviceToDevice, 0, nullptr, sig);
+                hsa_status_t st = H.copy_rect(&d, &off, &s, &off, &range, c->agent, (r.queue & 1) ? hsaHostToDevice : hsaDeviceToHost, 0, nullptr, sig);
                 if (st != HSA_STATUS_SUCCESS) {
                     const char *m = nullptr;
                     H.status_string(st, &m);
@@ -822,7 +824,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                     job.after = ev;
                     for (uint32_t r = 1; r < P; ++r) { // start with the next rank: every peer's link is busy from the first job on
                         const uint32_t peer = (g + r) % P;
-                        job.rects.push_back(Rect{ (char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np });
+                        job.rects.push_back(Rect{ (char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np, (int)r });
                     }
                     {
                         std::lock_guard<std::mutex> lk(c->mu);
