@@ -187,3 +187,25 @@ def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):
         assert body.count("global_load_lds_dwordx4") >= min_dma
         loop = body[body.index("Inner Loop Header"):]
         assert "scratch_" not in loop[:loop.index("s_cbranch_scc1")], f"{name}: register spills inside the main loop"
+
+
+def test_multi_gpu_entry_points_reject_null_handles_without_a_device():
+    """The multi-GPU section of the ABI (wg_comm_*, wg_gemm_sharded, ...) validates its handles before touching HIP / RCCL: callable on a
+    machine without a GPU, status + message instead of a crash. (Compute paths need a GPU: tests/cpp/comm_tests.cpp, test_gpu_dist2.py.)"""
+    L, S = _lib.lib, _lib.ViewShapeC()
+    out = ctypes.c_void_p()
+    assert L.wg_comm_create(None, 2, 0, None, ctypes.byref(out)) == _lib.WG_ERR_INVALID_ARG and not out.value
+    assert L.wg_gemm_sharded(None, 0, 0, 0, 0, None, S, None, None, S, None, S) == _lib.WG_ERR_INVALID_ARG
+    assert b"NULL" in L.wg_last_error_string()
+    assert L.wg_all_gather(None, 0, None, 0, 0) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_cube_to_matrix(None, 0, None, S, None, S) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_comm_stage_reserve(None, 0, ctypes.byref(out), ctypes.byref(out)) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_comm_barrier(None) == _lib.WG_ERR_INVALID_ARG and L.wg_comm_flush(None) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_comm_size(None) == 0 and L.wg_comm_rank(None) == -1 and L.wg_comm_copy_engine(None) == b"none"
+    assert L.wg_comm_destroy(None) == _lib.WG_OK
+    # the gather modes the Python mirror names are the header's
+    from wgmath_amd.sharded import GatherMode
+    hdr = open(_lib.HEADER_PATH).read()
+    for name, val in (("WG_GATHER_RCCL", GatherMode.RCCL), ("WG_GATHER_PEER_COPY", GatherMode.PEER_COPY), ("WG_GATHER_NONE", GatherMode.NONE),
+                      ("WG_GATHER_PEER_STAGED", GatherMode.PEER_STAGED)):
+        assert f"{name} = {val}" in hdr
