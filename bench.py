@@ -188,6 +188,12 @@ class GemmWorkload(Workload):
                 comm.flush()
                 self.dist["barrier"]()
 
+    def close(self):
+        """Multi-rank: unmap the peers' C buffers before their owners free them (called after the run's closing barrier)."""
+        if self.dist is not None and getattr(self, "_peers_registered", False):
+            self.dist["comm"].release_peers(self.C)
+            self._peers_registered = False
+
     def units_per_step(self):
         return 2.0 * self.M * self.N * self.K
 
@@ -600,6 +606,11 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     kernel_ms = (ev[1] - ev[0]) / (steps * launches)  # HIP events on the stream the kernels run on
     if not os.environ.get("WG_BENCH_NO_CHECK"):
         w.check()
+    if agree is not None:
+        barrier()  # every rank is past its checks: nobody reads a peer's buffers any more
+        if hasattr(w, "close") and not keep:
+            w.close()
+        barrier()  # ... and nobody frees a buffer a peer still has mapped for copying
     res = {"workload": w if keep else None, "elapsed": elapsed, "kernel_ms": kernel_ms, "steps": steps}
     res["cpu"] = w.cpu_baseline(cpu_budget) if (with_cpu and rank == 0 and world == 1) else None
     return res
@@ -895,6 +906,10 @@ def main():
             cfg_extra.update(dist_report)
         if oversub:
             cfg_extra["oversubscribed"] = f"{world} ranks on {ndev} GPU(s): plumbing test, not a scaling number"
+    if dist_mode and hasattr(w, "close"):
+        barrier()
+        w.close()  # unmap the peers' buffers before anyone frees them
+        barrier()
     w = None
     others = []
     if world == 1 and not dist_mode and not args.no_secondary:
@@ -955,6 +970,8 @@ def main():
         if saved_stdout is not None:
             os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)
+        if saved_stdout is not None:
+            os.dup2(2, 1)  # whatever the libraries print while tearing down goes to stderr as well
     if dist_mode:
         import torch.distributed as dist
         DIST = None

@@ -194,8 +194,10 @@ class Comm:
 
     def close(self):
         if getattr(self, "_h", None):
-            for _, opened in self._peers.values():
-                for b in opened:
+            for k, v in self._peers.items():
+                if k == "__stages_key__":
+                    continue
+                for b in v[1]:
                     self._lib.lib.wg_buf_destroy(b)
             self._peers = {}
             if self.gpu._ctx.handle:
@@ -250,6 +252,13 @@ class Comm:
             opened.append(b)
         self._peers[id(tensor)] = (arr, opened)
 
+    def release_peers(self, tensor) -> None:
+        """Unmap the peers' buffers registered for `tensor` (call before the owners free them; every rank's copies must be done: flush + barrier)."""
+        ent = self._peers.pop(id(tensor), None)
+        if ent is not None:
+            for b in ent[1]:
+                self._lib.lib.wg_buf_destroy(b)
+
     def register_local_peers(self, tensor, tensors) -> None:
         """The ranks share this process (tests): peer r's output is `tensors[r]` itself."""
         arr = (ctypes.c_void_p * self.nranks)()
@@ -276,7 +285,15 @@ class Comm:
         return tuple(out)
 
     def set_peer_stages(self, handles) -> None:
-        """handles[r] = rank r's stage_export() pair (handles[self.rank] is ignored)."""
+        """handles[r] = rank r's stage_export() pair (handles[self.rank] is ignored). Idempotent: the same pairs again (a second workload on
+        the same communicator) keep the existing mappings -- an allocation is opened once per process."""
+        key = tuple(tuple(p) if p is not None else None for p in handles)
+        if self._peers.get("__stages_key__") == key:
+            return
+        old = self._peers.pop("__stages__", None)
+        if old is not None:  # the peers re-allocated their cubes: drop the stale mappings
+            for b in old[1]:
+                self._lib.lib.wg_buf_destroy(b)
         sa, fa = (ctypes.c_void_p * self.nranks)(), (ctypes.c_void_p * self.nranks)()
         opened = []
         for r, pair in enumerate(handles):
@@ -290,6 +307,7 @@ class Comm:
                 opened.append(b)
         self._lib.check(self._lib.lib.wg_comm_set_peer_stages(self._h, sa, fa))
         self._peers["__stages__"] = ((sa, fa), opened)
+        self._peers["__stages_key__"] = key
 
     def set_local_peer_stages(self, comms) -> None:
         """The ranks share this process (tests): comms[r] is rank r's Comm (each already stage_reserve()d)."""
