@@ -298,8 +298,10 @@ class GemvWorkload(Workload):
     metric = "gemv_gbs"
     unit = "GB/s"
 
-    def __init__(self, name, R, C, trans, graph_batch=0, nrhs=1):
+    def __init__(self, name, R, C, trans, graph_batch=0, nrhs=1, dtype="f32"):
         self.name, self.R, self.C, self.trans = name, R, C, trans
+        self.dtype = dtype  # "f16": this build's extension (f16 elements, f32 accumulation, one rounding); the reference kernel is f32
+        self.np_dtype = np.float32 if dtype == "f32" else np.float16
         self.nrhs = nrhs  # right-hand-side columns (`out_ncols` of the reference: grid.y of gemv.wgsl); the matrix is read ONCE for up to 8
         # launch-bound sizes take the one-kernel path (gemv.hip: rows * cols <= 4 Mi, wgk_gemv)
         self.kernel = "gemv_t_kernel" if trans else ("gemv_n_small_kernel" if R * C <= (4 << 20) and R >= 128 else "gemv_n_kernel")
@@ -311,15 +313,15 @@ class GemvWorkload(Workload):
     def setup(self, wg, gpu, rank, world):
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
         R, C = self.R, self.C
-        self.m = device_random(wg, gpu, (R, C), np.float32, 0xC000 + rank)
+        self.m = device_random(wg, gpu, (R, C), self.np_dtype, 0xC000 + rank)
         vlen, olen = (R, C) if self.trans else (C, R)
         S = wg.BufferUsages
         if self.nrhs == 1:
-            self.v = device_random(wg, gpu, (vlen,), np.float32, 0xD000)
-            self.out = wg.TensorBuilder.vector(olen, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+            self.v = device_random(wg, gpu, (vlen,), self.np_dtype, 0xD000)
+            self.out = wg.TensorBuilder.vector(olen, S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
         else:
-            self.v = device_random(wg, gpu, (vlen, self.nrhs), np.float32, 0xD000)
-            self.out = wg.TensorBuilder.matrix(olen, self.nrhs, S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
+            self.v = device_random(wg, gpu, (vlen, self.nrhs), self.np_dtype, 0xD000)
+            self.out = wg.TensorBuilder.matrix(olen, self.nrhs, S.STORAGE | S.COPY_SRC).build(gpu.device(), self.np_dtype)
         self.gemv = wg.Gemv.from_device(gpu.device())
         self.shapes = wg.ViewShapeBuffers()
         self.enc = gpu.device().create_command_encoder()
@@ -342,7 +344,7 @@ class GemvWorkload(Workload):
             self.gemv.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.out, self.m, self.v, self.variant)
 
     def _bytes(self):
-        return 4.0 * (self.R * self.C + self.nrhs * (self.R + self.C))  # matrix + vector(s) + result(s)
+        return np.dtype(self.np_dtype).itemsize * float(self.R * self.C + self.nrhs * (self.R + self.C))  # matrix + vector(s) + result(s)
 
     def units_per_step(self):
         return self._bytes() * self.world * max(self.graph_batch, 1)  # every rank streams its own matrix (no collective)
@@ -362,7 +364,7 @@ class GemvWorkload(Workload):
         idx = np.unique(np.random.default_rng(2).integers(0, olen, 64))
         a = (m[:, idx].T if self.trans else m[idx, :]).astype(np.float64)
         truth, sabs = a @ v, np.abs(a) @ np.abs(v)
-        tol = 2 * np.sqrt(vlen) * 2.0 ** -24 * sabs
+        tol = 2 * np.sqrt(vlen) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
         assert (np.abs(got[idx] - truth) <= tol).all(), "bench sanity check failed (gemv)"
 
     def cpu_baseline(self, budget_s):
@@ -386,7 +388,7 @@ class GemvWorkload(Workload):
         dt = (time.perf_counter() - t0) / reps
         return {"value": 4.0 * (Rs * Cs + Rs + Cs) / dt / 1e9, "unit": "GB/s", "cores": C.num_threads(), "kind": "port",
                 "sample": f"oracle/wgsl_oracle.c `{'gemv_tr' if self.trans else 'gemv'}` on a {Rs}x{Cs} slice (1/{scale} of the matrix), "
-                          f"mean of {reps} runs, {dt * 1e3:.1f} ms each"}
+                          f"mean of {reps} runs, {dt * 1e3:.1f} ms each" + (" (the f32 port: the reference has no f16 kernel)" if self.dtype == "f16" else "")}
 
 
 class ReduceWorkload(Workload):
@@ -519,6 +521,8 @@ WORKLOADS = {
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
     "gemv_f32_4096x65536_rhs8": lambda: GemvWorkload("gemv_f32_4096x65536_rhs8", 4096, 65536, False, nrhs=8),
+    "gemv_f16_4096x65536": lambda: GemvWorkload("gemv_f16_4096x65536", 4096, 65536, False, dtype="f16"),
+    "gemvtr_f16_65536x4096": lambda: GemvWorkload("gemvtr_f16_65536x4096", 65536, 4096, True, dtype="f16"),
     "gemv_f32_1024": lambda: GemvWorkload("gemv_f32_1024", 1024, 1024, False),
     "gemv_f32_1024_graph": lambda: GemvWorkload("gemv_f32_1024_graph", 1024, 1024, False, graph_batch=64),
     "reduce_f32_4096x65536": lambda: ReduceWorkload("reduce_f32_4096x65536", 4096, 65536),
@@ -527,7 +531,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 

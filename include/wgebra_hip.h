@@ -201,7 +201,8 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
  *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).
  *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122), vec4 alignment.
  *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
- * dtype WG_F16 (extension): the f16 Gemm contract (f16 operands, f32 accumulation, one rounding) on the f16 Gemm kernels.
+ * dtype WG_F16 (extension): f16 elements, f32 accumulation, one rounding at the store -- the same HBM-bound kernels (> 8 right-hand
+ * sides: the f16 Gemm kernels).
  */
 int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
             wg_buf *out, wg_view_shape out_shape,

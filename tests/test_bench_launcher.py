@@ -59,3 +59,24 @@ def test_panel_planner_whole_rounds():
     # tiny problems: at least two panels when N allows, never wider than N
     assert bench.plan_panel_cols(256, 512, 256) == 256
     assert bench.plan_panel_cols(256, 256, 256) == 256
+
+
+def test_panel_planner_properties():
+    """plan_panel_cols over a sweep of shard heights / widths / CU counts: panels are whole tiles, never wider than N, at least two when N
+    allows, and no candidate with fewer idle CUs in its last round was passed over."""
+    import bench
+    for tile in (128, 256):
+        for cus in (224, 248, 256):
+            for mg in (256, 1024, 4096, 8192, 16384, 32768, 5000):
+                for n in (256, 512, 2048, 8192, 32768, 12800):
+                    pc = bench.plan_panel_cols(mg, n, cus, tile=tile)
+                    assert 0 < pc <= n and (pc % tile == 0 or pc == n), (mg, n, cus, tile, pc)
+                    if n >= 2 * tile:
+                        assert -(-n // pc) >= 2
+                    tiles_m = -(-mg // tile)
+
+                    def waste(c):
+                        t = tiles_m * c
+                        return (-(-t // cus)) * cus / t
+                    best = min(round(waste(c), 3) for c in range(1, n // tile + 1) if -(-(n // tile) // c) >= 2 or n // tile < 2)
+                    assert round(waste(pc // tile), 3) <= best + 1e-9, (mg, n, cus, tile, pc)

@@ -35,6 +35,9 @@ constexpr int kMaxRhs = 8; // RHS columns handled per pass over the matrix (m is
 #ifndef GEMV_NU
 #define GEMV_NU 4 // N kernel: columns (float4 loads) in flight per lane (4: 6.45 TB/s, 8/16: 6.40 at 4096 x 65536)
 #endif
+#ifndef WG_GEMV_TS_F16
+#define WG_GEMV_TS_F16 2
+#endif
 #ifndef GEMV_TS
 #define GEMV_TS 1 // T kernel: row-steps (4 float4 each) in flight per lane (1: 6.40 TB/s, 2/4: 6.34)
 #endif
@@ -48,17 +51,37 @@ __device__ __forceinline__ void fma4(float4 &acc, float4 a, float s) {
     acc.z = fmaf(a.z, s, acc.z);
     acc.w = fmaf(a.w, s, acc.w);
 }
+// Element types: f32 (the reference's), and f16 as this build's extension (f16 matrix / vectors, f32 accumulation in the same per-lane +
+// butterfly order, one rounding when the result is stored; split partials stay f32). Four consecutive elements as floats:
+typedef _Float16 wg_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4s(const float *p) { return ld_stream(reinterpret_cast<const float4 *>(p)); } // streaming (matrix)
+__device__ __forceinline__ float4 load4s(const _Float16 *p) {
+    const wg_h4 v = GEMV_NT ? __builtin_nontemporal_load(reinterpret_cast<const wg_h4 *>(p)) : *reinterpret_cast<const wg_h4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); } // cached (vector)
+__device__ __forceinline__ float4 load4(const _Float16 *p) {
+    const wg_h4 v = *reinterpret_cast<const wg_h4 *>(p);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void store4(float *d, float4 s) { *reinterpret_cast<float4 *>(d) = s; }
+__device__ __forceinline__ void store4(_Float16 *d, float4 s) {
+    const wg_h4 v = { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w };
+    *reinterpret_cast<wg_h4 *>(d) = v;
+}
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) x += __shfl_xor(x, s, 64);
     return x;
 }
 
-struct GemvArgs {
-    const float *m; uint32_t ldm; uint64_t m_batch;
-    const float *v; uint32_t ldv; uint64_t v_batch;
-    float *dst;      // out, or the partials buffer when nsplit > 1
-    uint32_t ld_dst; // elements between RHS columns of dst
+template <typename T>
+struct GemvArgsT {
+    const T *m; uint32_t ldm; uint64_t m_batch;
+    const T *v; uint32_t ldv; uint64_t v_batch;
+    T *out;          // the result (written when part == nullptr) ...
+    float *part;     // ... or the f32 partials buffer when nsplit > 1
+    uint32_t ld_dst; // elements between RHS columns of the destination
     uint64_t dst_batch;
     uint64_t dst_split; // elements between splits (partials only)
     uint32_t rows_out;  // length of out
@@ -66,13 +89,14 @@ struct GemvArgs {
     uint32_t nrhs;      // total RHS columns
     uint32_t k_per_split;
 };
+using GemvArgs = GemvArgsT<float>;
 
 // ------------------------------------------------------------------------------------------------------
 // N: dst[r] = sum_c m[r, c] v[c],  r in this block's 256 rows, c in this split's column range
 // grid = (row blocks, splits, nmats * rhs groups)
 // ------------------------------------------------------------------------------------------------------
-template <int NRHS>
-__global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
+template <int NRHS, typename T>
+__global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgsT<T> a) {
     __shared__ float4 part[kWaves][NRHS][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,8 +113,8 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
     const uint32_t w_begin = min(c_end, c_begin + wave * per_wave);
     const uint32_t w_end = min(c_end, w_begin + per_wave);
 
-    const float *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
-    const float *vp = a.v + z * a.v_batch;
+    const T *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
+    const T *vp = a.v + z * a.v_batch;
 
     float4 acc[NRHS];
 #pragma unroll
@@ -101,15 +125,15 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
         float vv[NRHS];
 #pragma unroll
         for (int y = 0; y < NRHS; ++y)
-            vv[y] = (cb + lane < w_end && y0 + y < a.nrhs) ? vp[(uint64_t)(y0 + y) * a.ldv + cb + lane] : 0.f;
-        const float4 *col = reinterpret_cast<const float4 *>(mp + (uint64_t)cb * a.ldm);
-        const uint64_t ld4 = a.ldm / 4u;
+            vv[y] = (cb + lane < w_end && y0 + y < a.nrhs) ? (float)vp[(uint64_t)(y0 + y) * a.ldv + cb + lane] : 0.f;
+        const T *col = mp + (uint64_t)cb * a.ldm;
+        const uint64_t ld4 = a.ldm; // elements between columns
         if (cb + 64u <= w_end) {
 #pragma unroll
             for (int u8 = 0; u8 < 64; u8 += GEMV_NU) {
                 float4 mv[GEMV_NU];
 #pragma unroll
-                for (int u = 0; u < GEMV_NU; ++u) mv[u] = ld_stream(col + (uint64_t)(u8 + u) * ld4);
+                for (int u = 0; u < GEMV_NU; ++u) mv[u] = load4s(col + (uint64_t)(u8 + u) * ld4);
 #pragma unroll
                 for (int u = 0; u < GEMV_NU; ++u)
 #pragma unroll
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
         } else {
             const int rem = (int)(w_end - cb); // wave-uniform
             for (int u = 0; u < rem; ++u) { // < 64 columns left in this wave's range
-                float4 mv = ld_stream(col + (uint64_t)u * ld4);
+                float4 mv = load4s(col + (uint64_t)u * ld4);
 #pragma unroll
                 for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv, __shfl(vv[y], u, 64));
             }
@@ -138,8 +162,8 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
                 float4 p = part[w][y][lane];
                 s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
             }
-            float *d = a.dst + z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + row;
-            *reinterpret_cast<float4 *>(d) = s;
+            const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + row;
+            if (a.part) store4(a.part + off, s); else store4(a.out + off, s);
         }
     }
 }
@@ -148,8 +172,8 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgs a) {
 // T: dst[c] = sum_r m[r, c] v[r],  4 columns per wave, rows of this split
 // grid = (column groups of 16, splits, nmats * rhs groups)
 // ------------------------------------------------------------------------------------------------------
-template <int NRHS>
-__global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
+template <int NRHS, typename T>
+__global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgsT<T> a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t rhs_groups = (a.nrhs + kMaxRhs - 1) / kMaxRhs;
@@ -160,9 +184,9 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
     const uint32_t r_begin = blockIdx.y * a.k_per_split;
     const uint32_t r_end = min(a.k, r_begin + a.k_per_split);
 
-    const float *mp = a.m + z * a.m_batch + (uint64_t)col0 * a.ldm;
-    const float *vp = a.v + z * a.v_batch;
-    const uint64_t ld4 = a.ldm / 4u;
+    const T *mp = a.m + z * a.m_batch + (uint64_t)col0 * a.ldm;
+    const T *vp = a.v + z * a.v_batch;
+    const uint64_t ld4 = a.ldm; // elements between columns
 
     float acc[4][NRHS];
 #pragma unroll
@@ -171,14 +195,14 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
         for (int y = 0; y < NRHS; ++y) acc[c][y] = 0.f;
 
     auto step = [&](uint32_t r) { // r: this lane's first row (multiple of 4), r < r_end
-        const float4 *m4 = reinterpret_cast<const float4 *>(mp + r);
+        const T *m4 = mp + r;
         float4 mv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mv[c] = ld_stream(m4 + c * ld4);
+        for (int c = 0; c < 4; ++c) mv[c] = load4s(m4 + c * ld4);
 #pragma unroll
         for (int y = 0; y < NRHS; ++y) {
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (y0 + y < a.nrhs) x = *reinterpret_cast<const float4 *>(vp + (uint64_t)(y0 + y) * a.ldv + r);
+            if (y0 + y < a.nrhs) x = load4(vp + (uint64_t)(y0 + y) * a.ldv + r);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]);
@@ -189,11 +213,12 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
         }
     };
 
-    uint32_t r = r_begin + 4u * lane;
-    // GEMV_TS row-steps per trip: 4*GEMV_TS matrix float4 (+ vector float4) in flight per lane
-    for (; (uint64_t)r + 256u * (GEMV_TS - 1) < r_end; r += 256u * GEMV_TS) {
+    uint32_t r = r_begin + 4u * lane; // (f16: 8-byte loads of 4 rows; a 16-byte / 8-row variant measured slower: 5.1 vs 5.7 TB/s at 65536 x 4096)
+    // TS row-steps per trip: 4*TS matrix loads (+ vector loads) in flight per lane; f16 loads are 8 bytes: twice as many keep the same bytes in flight
+    constexpr int TS = (sizeof(T) == 2 ? WG_GEMV_TS_F16 : 1) * GEMV_TS;
+    for (; (uint64_t)r + 256u * (TS - 1) < r_end; r += 256u * TS) {
 #pragma unroll
-        for (int t = 0; t < GEMV_TS; ++t) step(r + 256u * t);
+        for (int t = 0; t < TS; ++t) step(r + 256u * t);
     }
     for (; r < r_end; r += 256u) step(r);
 
@@ -206,8 +231,8 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
         s.z = wave_sum(acc[2][y]);
         s.w = wave_sum(acc[3][y]);
         if (lane == 0) {
-            float *d = a.dst + z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + col0;
-            *reinterpret_cast<float4 *>(d) = s;
+            const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)(y0 + y) * a.ld_dst + col0;
+            if (a.part) store4(a.part + off, s); else store4(a.out + off, s);
         }
     }
 }
@@ -220,8 +245,9 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgs a) {
 // (Folding the partials in the producing kernel -- last-arriver protocol with device-scope stores and one atomic per
 // workgroup -- was measured and rejected: same-address atomics serialise, 64 x 2^20 went to 120 us and 4096^2 from 15 to
 // 27 us; it only won 1-2 us on the launch-bound 1024^2 case.)
+template <typename T>
 __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__restrict__ partial, uint32_t nsplit, uint32_t rows_out,
-                                                                 uint32_t nrhs, float *__restrict__ out, uint32_t ld_out,
+                                                                 uint32_t nrhs, T *__restrict__ out, uint32_t ld_out,
                                                                  uint64_t out_batch) {
     __shared__ float4 red[kWaves][4];
     const uint32_t rl = threadIdx.x & 3, sl = threadIdx.x >> 2;
@@ -262,7 +288,7 @@ __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__r
             float4 q = red[w][rl];
             s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
         }
-        *reinterpret_cast<float4 *>(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4) = s;
+        store4(out + z * out_batch + (uint64_t)y * ld_out + 4u * r4, s);
     }
 }
 
@@ -271,24 +297,25 @@ __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__r
 // row segments) and all columns: its 32 lane groups take columns g, g + 32, ... and are summed through LDS in a fixed order.
 // 1024 x 1024 (BASELINE config 1): 32 workgroups, one launch instead of split + combine.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgs a) {
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgsT<T> a) {
     __shared__ float4 part[32][8];
     const uint32_t rl = threadIdx.x & 7u, g = threadIdx.x >> 3; // row lane, column group
     const uint32_t z = blockIdx.z, y = blockIdx.y;
     const uint32_t row = blockIdx.x * 32u + 4u * rl;
     const bool row_ok = row < a.rows_out;
-    const float *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
-    const float *vp = a.v + z * a.v_batch + (uint64_t)y * a.ldv;
+    const T *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
+    const T *vp = a.v + z * a.v_batch + (uint64_t)y * a.ldv;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t c = g;
     for (; c + 96u < a.k; c += 128u) { // 4 columns in flight per lane
-        const float4 m0 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm));
-        const float4 m1 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 32u) * a.ldm));
-        const float4 m2 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 64u) * a.ldm));
-        const float4 m3 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 96u) * a.ldm));
-        fma4(acc, m0, vp[c]); fma4(acc, m1, vp[c + 32u]); fma4(acc, m2, vp[c + 64u]); fma4(acc, m3, vp[c + 96u]);
+        const float4 m0 = load4s(mp + (uint64_t)c * a.ldm);
+        const float4 m1 = load4s(mp + (uint64_t)(c + 32u) * a.ldm);
+        const float4 m2 = load4s(mp + (uint64_t)(c + 64u) * a.ldm);
+        const float4 m3 = load4s(mp + (uint64_t)(c + 96u) * a.ldm);
+        fma4(acc, m0, (float)vp[c]); fma4(acc, m1, (float)vp[c + 32u]); fma4(acc, m2, (float)vp[c + 64u]); fma4(acc, m3, (float)vp[c + 96u]);
     }
-    for (; c < a.k; c += 32u) fma4(acc, ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm)), vp[c]);
+    for (; c < a.k; c += 32u) fma4(acc, load4s(mp + (uint64_t)c * a.ldm), (float)vp[c]);
     part[g][rl] = acc;
     __syncthreads();
     if (g == 0 && row_ok) {
@@ -298,7 +325,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgs a) {
             const float4 p = part[i][rl];
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
-        *reinterpret_cast<float4 *>(a.dst + z * a.dst_batch + (uint64_t)y * a.ld_dst + row) = s;
+        store4(a.out + z * a.dst_batch + (uint64_t)y * a.ld_dst + row, s);
     }
 }
 
@@ -337,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs 
             const float4 p = part[i][rl];
             s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
         }
-        *reinterpret_cast<float4 *>(a.dst + row) = s;
+        *reinterpret_cast<float4 *>(a.out + row) = s;
         __threadfence(); // release: this workgroup's rows of y are visible device-wide (other XCDs' L2 included) before it is counted
     }
     __syncthreads();
@@ -350,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs 
     if (!is_last || threadIdx.x >= 32u) return;
     __threadfence(); // acquire: every other workgroup's y
     const uint32_t p = threadIdx.x, n = a.rows_out; // n % 4 == 0 (vec4 precondition), y is 16-byte aligned scratch
-    const float *y = a.dst;
+    const float *y = a.out;
     float r[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
     const uint32_t full_rows = n / 128u;
     for (uint32_t q = 0; q < full_rows; ++q) {
@@ -404,18 +431,9 @@ static bool uses_small_kernel(int cus, bool trans, uint32_t rows_out, uint32_t k
 
 } // namespace
 
-int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
-             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
-    if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
-    // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): a Gemv is a Gemm with `nrhs` columns, and the f16 Gemm kernels take
-    // any column count (B rows are clamped, the epilogue is predicated) -- one pass over the matrix on the matrix cores, f16 operands,
-    // f32 accumulation, one rounding: the f16 Gemm contract. Not an HBM-roofline kernel (the MFMA tiles are 256 or 128 columns wide).
-    if (dtype == WG_F16) return wgk_gemm_f16(ctx, trans, rows_out, nrhs, k, nmats, (__half *)out, out_ld, out_batch, m, v, 1.f, 0.f);
-    // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
-    // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
-    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
-        (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
-        return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+template <typename T>
+static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, T *out, uint32_t out_ld, uint64_t out_batch,
+                       wgk_mat m, wgk_mat v) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     const uint32_t rhs_groups = ceil_div(nrhs, kMaxRhs);
     const uint64_t gz64 = (uint64_t)nmats * rhs_groups;
@@ -427,22 +445,21 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
 
-    GemvArgs a;
-    a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = m.batch;
-    a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = v.batch;
+    GemvArgsT<T> a;
+    a.m = (const T *)m.ptr; a.ldm = m.ld; a.m_batch = m.batch;
+    a.v = (const T *)v.ptr; a.ldv = v.ld; a.v_batch = v.batch;
     a.rows_out = rows_out; a.k = k; a.nrhs = nrhs; a.k_per_split = k_per_split;
-    float *partial = nullptr;
-    if (nsplit > 1) {
+    a.out = out;
+    a.part = nullptr;
+    if (nsplit > 1) { // f32 partial sums whatever the element type
         size_t bytes = (size_t)nmats * nsplit * nrhs * rows_out * sizeof(float);
         void *ws = nullptr;
         if (int rc = wg_ctx_workspace(ctx, bytes, &ws)) return rc;
-        partial = (float *)ws;
-        a.dst = partial;
+        a.part = (float *)ws;
         a.ld_dst = rows_out;
         a.dst_split = (uint64_t)nrhs * rows_out;
         a.dst_batch = (uint64_t)nsplit * nrhs * rows_out;
     } else {
-        a.dst = (float *)out;
         a.ld_dst = out_ld;
         a.dst_split = 0;
         a.dst_batch = out_batch;
@@ -450,8 +467,8 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 
     // launch-bound sizes: one kernel without partials beats split + combine (1024 x 1024: 12.6 -> ~9 us per eager dispatch)
     if (uses_small_kernel(cus, trans, rows_out, k, nrhs, nsplit)) {
-        a.dst = (float *)out; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
-        hipLaunchKernelGGL(gemv_n_small_kernel, dim3(ceil_div(rows_out, 32u), nrhs, nmats), dim3(kThreads), 0, ctx->stream, a);
+        a.part = nullptr; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
+        hipLaunchKernelGGL(gemv_n_small_kernel<T>, dim3(ceil_div(rows_out, 32u), nrhs, nmats), dim3(kThreads), 0, ctx->stream, a);
         WG_HIP_TRY(hipGetLastError());
         return WG_OK;
     }
@@ -461,23 +478,41 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
     const uint32_t per_group = nrhs < (uint32_t)kMaxRhs ? nrhs : (uint32_t)kMaxRhs;
     const int tile = per_group > 4 ? 8 : (per_group > 2 ? 4 : (int)per_group);
     if (trans) {
-        if (tile == 1) hipLaunchKernelGGL(gemv_t_kernel<1>, grid, block, 0, ctx->stream, a);
-        else if (tile == 2) hipLaunchKernelGGL(gemv_t_kernel<2>, grid, block, 0, ctx->stream, a);
-        else if (tile == 4) hipLaunchKernelGGL(gemv_t_kernel<4>, grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL(gemv_t_kernel<8>, grid, block, 0, ctx->stream, a);
+        if (tile == 1) hipLaunchKernelGGL((gemv_t_kernel<1, T>), grid, block, 0, ctx->stream, a);
+        else if (tile == 2) hipLaunchKernelGGL((gemv_t_kernel<2, T>), grid, block, 0, ctx->stream, a);
+        else if (tile == 4) hipLaunchKernelGGL((gemv_t_kernel<4, T>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemv_t_kernel<8, T>), grid, block, 0, ctx->stream, a);
     } else {
-        if (tile == 1) hipLaunchKernelGGL(gemv_n_kernel<1>, grid, block, 0, ctx->stream, a);
-        else if (tile == 2) hipLaunchKernelGGL(gemv_n_kernel<2>, grid, block, 0, ctx->stream, a);
-        else if (tile == 4) hipLaunchKernelGGL(gemv_n_kernel<4>, grid, block, 0, ctx->stream, a);
-        else hipLaunchKernelGGL(gemv_n_kernel<8>, grid, block, 0, ctx->stream, a);
+        if (tile == 1) hipLaunchKernelGGL((gemv_n_kernel<1, T>), grid, block, 0, ctx->stream, a);
+        else if (tile == 2) hipLaunchKernelGGL((gemv_n_kernel<2, T>), grid, block, 0, ctx->stream, a);
+        else if (tile == 4) hipLaunchKernelGGL((gemv_n_kernel<4, T>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemv_n_kernel<8, T>), grid, block, 0, ctx->stream, a);
     }
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
-        hipLaunchKernelGGL(gemv_combine_kernel, dim3(ceil_div(rows_out / 4u, 4u), nrhs, nmats), block, 0, ctx->stream, partial,
-                           nsplit, rows_out, nrhs, (float *)out, out_ld, out_batch);
+        hipLaunchKernelGGL(gemv_combine_kernel<T>, dim3(ceil_div(rows_out / 4u, 4u), nrhs, nmats), block, 0, ctx->stream, a.part, nsplit, rows_out, nrhs, out,
+                           out_ld, out_batch);
         WG_HIP_TRY(hipGetLastError());
     }
     return WG_OK;
+}
+
+int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
+             void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
+    if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
+    if (dtype == WG_F16) {
+        // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): the same HBM-bound kernels on f16 elements (8-byte loads of 4 rows,
+        // f32 accumulation in the same order, one rounding at the store; split partials stay f32). More than 8 right-hand sides are a
+        // Gemm with few columns: the f16 Gemm kernels take any column count (one pass over the matrix on the matrix cores).
+        if (nrhs > (uint32_t)kMaxRhs) return wgk_gemm_f16(ctx, trans, rows_out, nrhs, k, nmats, (__half *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+        return gemv_launch<_Float16>(ctx, trans, rows_out, k, nrhs, nmats, (_Float16 *)out, out_ld, out_batch, m, v);
+    }
+    // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
+    // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
+    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
+        (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
+        return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+    return gemv_launch<float>(ctx, trans, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
 }
 
 // One launch for result = reduce(op, m v) when the Gemv is launch-bound (the single-kernel shape family of wgk_gemv); WG_ERR_UNSUPPORTED
@@ -489,7 +524,7 @@ int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, fl
     a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = 0;
     a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = 0;
     a.rows_out = rows_out; a.k = k; a.nrhs = 1; a.k_per_split = k;
-    a.dst = y; a.ld_dst = rows_out; a.dst_split = 0; a.dst_batch = 0;
+    a.out = y; a.part = nullptr; a.ld_dst = rows_out; a.dst_split = 0; a.dst_batch = 0;
     const dim3 grid(ceil_div(rows_out, 32u)), block(kThreads);
     switch (op) {
     case R_MIN: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_MIN>, grid, block, 0, ctx->stream, a, counter, result); break;
