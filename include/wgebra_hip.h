@@ -234,7 +234,7 @@ int wg_gemv_rm(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
  * then the 64..1 tree; reduce.wgsl:68-87), so Min/Max/Sum/Prod are bit-identical to it; n == 0 gives the init
  * value (0, 1, +3.4e38, -3.4e38).
  * dtype WG_F16 (extension): `value` and `result` are f16; elements are converted to f32 (exact), folded in the same order in f32,
- * and the result is rounded once (RNE) to f16. (wg_reduce_batched likewise: one f16 result per vector; wg_reduce_fast is f32 only.)
+ * and the result is rounded once (RNE) to f16. (wg_reduce_batched and wg_reduce_fast likewise.)
  */
 int wg_reduce(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype,
               const wg_buf *value, wg_view_shape value_shape, wg_buf *result);

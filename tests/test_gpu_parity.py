@@ -1076,3 +1076,27 @@ def test_reduce_f16_bit_exact(gpu, oracle_c, n, off):
         for c in range(cols):
             e = np.float16(np.float32(oracle_c.reduce(wo.SUM, xm.astype(np.float32), wo.Shape(n, 1, 1, n, n, c * n))))
             assert got[c].tobytes() == e.tobytes()
+
+
+@pytest.mark.parametrize("n,off", [(5, 3), (4097, 1), (65536, 0), (300007, 2)])
+def test_reduce_fast_f16(gpu, oracle_c, n, off):
+    """Two-pass reduce on f16 vectors: Min/Max have the bits of the reference-order Reduce; Sum/SqNorm are re-associated in f32 and rounded
+    once: within the f32 re-association bound + half an f16 ulp of the f64 truth."""
+    wg = _wg()
+    rng = np.random.default_rng(n + off)
+    x = (rng.random(n + off + 8, dtype=np.float32) - 0.5).astype(np.float16)
+    tx = upload(gpu, (x.size,), x, np.float16)
+    view = wg.GpuTensorView(wg.ViewShape([n, 1, 1], n, n, off), tx, 1)
+    xs = x[off:off + n].astype(np.float64)
+    for op in (wg.ReduceOp.Min, wg.ReduceOp.Max, wg.ReduceOp.Sum, wg.ReduceOp.SqNorm):
+        r_ref, r_fast = upload(gpu, (), np.zeros(1, np.float16), np.float16), upload(gpu, (), np.zeros(1, np.float16), np.float16)
+        red = wg.Reduce.new(gpu.device(), op)
+        run_pass(gpu, lambda p: (red.dispatch(gpu.device(), wg.ViewShapeBuffers(), p, view, r_ref), red.dispatch_fast(gpu.device(), wg.ViewShapeBuffers(), p, view, r_fast)))
+        a, b = r_ref.read(gpu.device())[0], r_fast.read(gpu.device())[0]
+        if op in (wg.ReduceOp.Min, wg.ReduceOp.Max):
+            assert a.tobytes() == b.tobytes()
+        else:
+            truth = xs.sum() if op == wg.ReduceOp.Sum else (xs * xs).sum()
+            sabs = np.abs(xs).sum() if op == wg.ReduceOp.Sum else (xs * xs).sum()
+            tol = n * 2.0 ** -24 * sabs + 2.0 ** -10 * abs(truth) + 2.0 ** -24
+            assert abs(float(b) - truth) <= tol and abs(float(a) - truth) <= tol, (op, float(a), float(b), truth)

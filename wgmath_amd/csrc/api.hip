@@ -156,11 +156,11 @@ int wg_reduce_fast(wg_ctx *ctx, wg_reduce_op op, wg_dtype dtype, const wg_buf *v
     if (int rc = check_common("Reduce", ctx, dtype, bufs, 2)) return rc;
     if ((int)op < 0 || (int)op > 4) return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", (int)op);
     if (value->bytes == 0 || result->bytes == 0) return WG_OK; // kernel.rs:111-123
-    if (result->bytes < sizeof(float)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one f32");
+    if (result->bytes < wg_dtype_size(dtype)) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "Reduce: result buffer smaller than one element");
     const View vec = { value_shape.size[0], 1, 1, 1, 1, value_shape.offset };
     if (int rc = check_bounds("Reduce", "value", vec, value, dtype)) return rc;
     WG_HIP_TRY(hipSetDevice(ctx->device));
-    return wgk_reduce_fast(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, (float *)result->ptr);
+    return wgk_reduce_fast(ctx, (int)op, dtype, elem_ptr(value, vec.offset, dtype), vec.rows, result->ptr);
 }
 
 int wg_gemv_reduce(wg_ctx *ctx, wg_gemv_variant variant, wg_reduce_op op, wg_dtype dtype, wg_buf *result, const wg_buf *m,

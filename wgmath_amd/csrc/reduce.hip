@@ -277,49 +277,49 @@ __device__ __forceinline__ float fast_block_fold(float acc) { // fold the 256 pe
     return r;
 }
 
-template <int OP>
-__global__ __launch_bounds__(kThreads) void reduce_fast_pass1(const float *__restrict__ x, uint32_t n, uint32_t chunk, float *__restrict__ partial) {
+template <int OP, typename T>
+__global__ __launch_bounds__(kThreads) void reduce_fast_pass1(const T *__restrict__ x, uint32_t n, uint32_t chunk, float *__restrict__ partial) {
     const uint64_t begin = (uint64_t)blockIdx.x * chunk; // chunk is a multiple of 4; x + begin keeps x's alignment class
     const uint32_t len = (uint32_t)min((uint64_t)chunk, (uint64_t)n - begin);
-    const float *p = x + begin;
+    const T *p = x + begin;
     float acc = r_init<OP>();
-    // scalar head up to 16-byte alignment, float4 body, scalar tail
-    const uint32_t mis = (uint32_t)(((uintptr_t)p >> 2) & 3u);
+    // scalar head up to 4-element alignment (16 bytes f32, 8 bytes f16), 4-element body, scalar tail
+    const uint32_t mis = (uint32_t)(((uintptr_t)p / sizeof(T)) & 3u);
     const uint32_t head = mis ? min(4u - mis, len) : 0u;
-    if (threadIdx.x < head) acc = r_ws<OP>(acc, p[threadIdx.x]);
-    const float4 *p4 = reinterpret_cast<const float4 *>(p + head);
+    if (threadIdx.x < head) acc = r_ws<OP>(acc, (float)p[threadIdx.x]);
+    const T *p4 = p + head; // indexed in units of 4 elements below
     const uint32_t n4 = (len - head) / 4u;
     uint32_t i = threadIdx.x;
     for (; (uint64_t)i + 7u * kThreads < n4; i += 8u * kThreads) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = wg_ld_nt(p4 + i + u * kThreads);
+        for (int u = 0; u < 8; ++u) v[u] = load4(p4 + 4ull * (i + u * kThreads), true);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             acc = r_ws<OP>(acc, v[u].x); acc = r_ws<OP>(acc, v[u].y); acc = r_ws<OP>(acc, v[u].z); acc = r_ws<OP>(acc, v[u].w);
         }
     }
     for (; i < n4; i += kThreads) {
-        const float4 v = wg_ld_nt(p4 + i);
+        const float4 v = load4(p4 + 4ull * i, true);
         acc = r_ws<OP>(acc, v.x); acc = r_ws<OP>(acc, v.y); acc = r_ws<OP>(acc, v.z); acc = r_ws<OP>(acc, v.w);
     }
     const uint32_t tail0 = head + n4 * 4u;
-    if (tail0 + threadIdx.x < len) acc = r_ws<OP>(acc, p[tail0 + threadIdx.x]);
+    if (tail0 + threadIdx.x < len) acc = r_ws<OP>(acc, (float)p[tail0 + threadIdx.x]);
     const float r = fast_block_fold<OP>(acc);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-template <int OP>
-__global__ __launch_bounds__(kThreads) void reduce_fast_pass2(const float *__restrict__ partial, uint32_t nparts, float *__restrict__ result) {
+template <int OP, typename T>
+__global__ __launch_bounds__(kThreads) void reduce_fast_pass2(const float *__restrict__ partial, uint32_t nparts, T *__restrict__ result) {
     // partials are already reduce_fn-domain values (sums of squares for SqNorm): fold with reduce_fn; the neutral start is the op's init
     float acc = r_init<OP>();
     for (uint32_t i = threadIdx.x; i < nparts; i += kThreads) acc = r_red<OP>(acc, partial[i]);
     const float r = fast_block_fold<OP>(acc);
-    if (threadIdx.x == 0) result[0] = r;
+    if (threadIdx.x == 0) result[0] = (T)r;
 }
 
-template <int OP>
-int launch_fast(wg_ctx *ctx, const float *x, uint32_t n, float *result) {
+template <int OP, typename T>
+int launch_fast(wg_ctx *ctx, const T *x, uint32_t n, T *result) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
     // >= 16 Ki elements per workgroup, at most 4 workgroups per CU
     const uint64_t want = ((uint64_t)n + 16383u) / 16384u, cap = (uint64_t)cus * 4u;
@@ -331,18 +331,17 @@ int launch_fast(wg_ctx *ctx, const float *x, uint32_t n, float *result) {
     if (nparts == 0) nparts = 1; // n == 0: one workgroup writes the init value, like the reference (reduce.wgsl with an empty loop)
     void *ws = nullptr;
     if (int rc = wg_ctx_workspace(ctx, (size_t)nparts * sizeof(float), &ws)) return rc;
-    hipLaunchKernelGGL(reduce_fast_pass1<OP>, dim3(nparts), dim3(kThreads), 0, ctx->stream, x, n, chunk, (float *)ws);
+    hipLaunchKernelGGL((reduce_fast_pass1<OP, T>), dim3(nparts), dim3(kThreads), 0, ctx->stream, x, n, chunk, (float *)ws);
     WG_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(reduce_fast_pass2<OP>, dim3(1), dim3(kThreads), 0, ctx->stream, (const float *)ws, nparts, result);
+    hipLaunchKernelGGL((reduce_fast_pass2<OP, T>), dim3(1), dim3(kThreads), 0, ctx->stream, (const float *)ws, nparts, result);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
 
 } // namespace
 
-int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, float *result) {
-    if (dtype != WG_F32) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce (fast): only f32 is implemented; f16 vectors take wg_reduce / wg_reduce_batched");
-    const float *b = (const float *)base;
+template <typename T>
+static int reduce_fast_dispatch(wg_ctx *ctx, int op, const T *b, uint32_t n, T *result) {
     switch (op) {
     case R_MIN: return launch_fast<R_MIN>(ctx, b, n, result);
     case R_MAX: return launch_fast<R_MAX>(ctx, b, n, result);
@@ -351,6 +350,11 @@ int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint3
     case R_SQNORM: return launch_fast<R_SQNORM>(ctx, b, n, result);
     }
     return wg_set_error(WG_ERR_INVALID_ARG, "Reduce: unknown op %d", op);
+}
+
+int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, void *result) {
+    if (dtype == WG_F16) return reduce_fast_dispatch(ctx, op, (const _Float16 *)base, n, (_Float16 *)result);
+    return reduce_fast_dispatch(ctx, op, (const float *)base, n, (float *)result);
 }
 
 template <typename T>

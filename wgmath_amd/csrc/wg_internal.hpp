@@ -90,7 +90,7 @@ struct wgk_mat {
 
 int wgk_op_assign(wg_ctx *ctx, int op, wg_dtype dtype, void *a, const void *b, uint32_t n, float alpha = 0.f); // op 5 = axpy
 
-int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, float *result);
+int wgk_reduce_fast(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, void *result);
 int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
                uint32_t stride, uint32_t stride_mat, void *results); // results: one element of `dtype` per vector
 
