@@ -303,6 +303,7 @@ __global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32
     const uint32_t r = threadIdx.x;
     if (r >= nranks || r == self) return;
     const uint32_t *f = flags + (size_t)r * kMaxPanels + panel;
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // an earlier wait of this step already gave up: fail fast
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
         __builtin_amdgcn_s_sleep(64);
