@@ -172,6 +172,9 @@ class GemmWorkload(Workload):
             pair = comm.stage_export(2 * self.M * self.N * np.dtype(self.np_dtype).itemsize)
             if world > 1:
                 comm.set_peer_stages(self.dist["all_gather_object"](pair))
+            # pipelined steps: a step's last panel (the one exchange nothing of its own step hides) completes under the next step's first
+            # Gemm; finish() joins, inside the timed region, so every step's C is complete when the clock stops
+            comm.set_pipelined(os.environ.get("WG_BENCH_PIPELINED", "1") != "0")
 
     def step(self):
         if self.dist is None:
@@ -187,6 +190,11 @@ class GemmWorkload(Workload):
                 self.gpu.sync()
                 comm.flush()
                 self.dist["barrier"]()
+
+    def finish(self):
+        """End of a run of steps (inside the timed region): complete what pipelined steps deferred."""
+        if self.dist is not None and self.mode == "staged":
+            self.dist["comm"].join()
 
     def close(self):
         """Multi-rank: unmap the peers' C buffers before their owners free them (called after the run's closing barrier)."""
@@ -588,6 +596,8 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     t_w = time.perf_counter()
     for _ in range(max(warmup, 1)):
         w.step()
+    if hasattr(w, "finish"):
+        w.finish()
     gpu.sync()
     if min_seconds > 0:
         per_step = max((time.perf_counter() - t_w) / max(warmup, 1), 1e-6)
@@ -601,6 +611,8 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     ts.write(gpu.device())
     for _ in range(steps):
         w.step()
+    if hasattr(w, "finish"):
+        w.finish()  # (pipelined multi-rank steps: the last step's deferred panel; no-op otherwise)
     ts.write(gpu.device())
     gpu.sync()
     barrier()
@@ -905,7 +917,8 @@ def main():
                   "staged": "staged peer-copy gather (one SDMA engine per link + relayout)"}[DIST["mode"]]
         par = f"m-shard x{world} + {engine}"
         cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels,
-                     "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"])}
+                     "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"]),
+                     "pipelined_steps": bool(DIST["mode"] == "staged" and os.environ.get("WG_BENCH_PIPELINED", "1") != "0")}
         if dist_report:
             cfg_extra.update(dist_report)
         if oversub:

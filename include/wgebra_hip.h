@@ -320,7 +320,11 @@ uint64_t wg_comm_bytes_sent(const wg_comm *comm);     /* payload bytes this rank
 /* In-place all-gather of elements [first, first + nranks*per_rank) of `buf` (rank r owns [first + r*per_rank, +per_rank)) on the
  * communicator's stream, ordered after the work already enqueued on the context; the context does not wait (wg_comm_join). */
 int wg_all_gather(wg_comm *comm, wg_dtype dtype, wg_buf *buf, uint64_t first_elem, uint64_t elems_per_rank);
-int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collectives in flight */
+int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collectives in flight (and completes a deferred last panel) */
+/* Pipelined steps (WG_GATHER_PEER_STAGED): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
+ * exchange nothing of its own call can hide -- to the next call on the communicator, which runs it right after enqueueing its first Gemm
+ * (wg_comm_join / _flush / _barrier / a call in another mode complete it too). `out` is then complete in stream order only after that. */
+int wg_comm_set_pipelined(wg_comm *comm, int on);
 int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */
 int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined into the context: all ranks' earlier exchanges are complete */
 /* One process per GPU: export a device buffer / map a peer's (hipIpcGetMemHandle / hipIpcOpenMemHandle; needs the dmabuf IPC mode,

@@ -131,7 +131,7 @@ template <typename T> static void peer_two_ranks(bool tr, uint32_t M, uint32_t N
 
 // two ranks in one process, WG_GATHER_PEER_STAGED: staging cubes + contiguous per-peer copies + flags + wait kernel + relayout, three steps
 // back to back WITHOUT any host synchronisation or barrier in between (the engine is stream-ordered and double-buffered by step parity)
-template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel) {
+template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel, bool pipelined = false) {
     const uint32_t P = 2, mg = M / P;
     wg_ctx *ctx[2] = { nullptr, nullptr };
     wg_comm *comm[2] = { nullptr, nullptr };
@@ -147,6 +147,7 @@ template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t
         CK(wg_comm_stage_reserve(comm[g], 2 * (size_t)M * N * sizeof(T), &st[g], &fl[g]));
     }
     for (uint32_t g = 0; g < P; ++g) CK(wg_comm_set_peer_stages(comm[g], st, fl));
+    for (uint32_t g = 0; g < P; ++g) CK(wg_comm_set_pipelined(comm[g], pipelined ? 1 : 0)); // last panel of a call deferred into the next call
     const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
     for (int rep = 0; rep < 3; ++rep) {
         for (uint32_t g = 0; g < P; ++g) {
@@ -154,6 +155,8 @@ template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t
             CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[g], mat(M, N), nullptr, a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
         }
     }
+    if (pipelined)
+        for (uint32_t g = 0; g < P; ++g) CK(wg_comm_join(comm[g])); // completes the deferred last panel of the last call
     for (uint32_t g = 0; g < P; ++g) {
         std::vector<T> got((size_t)M * N);
         CK(wg_buf_read(ctx[g], c[g], 0, got.data(), got.size() * sizeof(T))); // stream order is all it takes
@@ -238,6 +241,8 @@ int main() {
     staged_two_ranks<float>(false, 512, 768, 256, 256);
     staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
     staged_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
+    staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512, /*pipelined=*/true);
+    staged_two_ranks<float>(true, 512, 768, 256, 256, /*pipelined=*/true);
     wg_ctx_destroy(ctx);
     if (failures == 0) std::printf("ALL OK\n");
     return failures ? 1 : 0;

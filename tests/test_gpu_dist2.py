@@ -205,8 +205,11 @@ def _staged_worker(rank, world, port, q):
         dist.all_gather_object(pairs, comm.stage_export(2 * M * N * 2))
         comm.set_peer_stages(pairs)
         dist.barrier()  # every rank's cubes and flags exist and are mapped before anyone pushes
-        for _ in range(3):
-            comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, 512)
+        for pipelined in (False, True):
+            comm.set_pipelined(pipelined)  # True: each call's last panel completes inside the next call (or join)
+            for _ in range(3):
+                comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, 512)
+            comm.join()
         got = tc.read(dev).reshape(M, N, order="F").astype(np.float64)  # stream order is all it takes
         A64, B64 = A.astype(np.float64), B.astype(np.float64)
         truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)

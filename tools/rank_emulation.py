@@ -95,6 +95,9 @@ if t1:
             tail = sc["last_panel_bytes_per_peer"] / (ENGINE_GBS * 1e6)  # ms: the last panel's slot on one link, nothing left to hide it under
             steady = (int(P) - 1) and (r["rows_per_rank"] * N * 2 / (ENGINE_GBS * 1e6))  # ms per step one link needs at the engine rate
             t = max(sc["ms_per_step"] * SLOW.get(int(P), 1.05), steady) + tail
+            tp = max(sc["ms_per_step"] * SLOW.get(int(P), 1.05), steady)  # pipelined steps: the tail runs under the next step's first Gemm
+            r["expected_staged_pipelined"] = {"ms_per_step": round(tp, 3), "speedup_vs_1_gpu": round(t1 / tp, 3),
+                                              "note": "wg_comm_set_pipelined: only the last step of a run exposes its tail"}
             r["expected_staged"] = {"ms_per_step": round(t, 3), "link_ms_per_step_at_engine_rate": round(steady, 3), "exposed_tail_ms": round(tail, 3),
                                     "gemm_slowdown_beside_engines": SLOW.get(int(P), 1.05), "speedup_vs_1_gpu": round(t1 / t, 3)}
 print(json.dumps(out, indent=1))

@@ -174,6 +174,17 @@ struct wg_comm {
     uint32_t *seq_host = nullptr;    // pinned ring of sequence numbers (source of seq_src's update)
     uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout
     uint32_t step = 0;
+    // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
+    // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
+    bool pipelined = false;
+    struct Pending {
+        bool on = false;
+        uint32_t seq = 0, panel = 0, mg = 0, np = 0;
+        const char *src = nullptr;
+        char *dst = nullptr;
+        uint64_t ld = 0;
+        size_t es = 0;
+    } pending;
 };
 
 namespace {
@@ -359,6 +370,17 @@ int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far h
     return WG_OK;
 }
 
+int run_pending(wg_comm *c) { // the deferred last panel of the previous staged call: wait for its slots, relayout it
+    if (!c->pending.on) return WG_OK;
+    c->pending.on = false;
+    const wg_comm::Pending &q = c->pending;
+    if (c->nranks > 1) {
+        hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, c->ctx->stream, c->pflags, (uint32_t)c->nranks, (uint32_t)c->rank, q.panel, q.seq, c->wait_err);
+        WG_HIP_TRY(hipGetLastError());
+    }
+    return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es);
+}
+
 struct IpcHandle { // WG_IPC_HANDLE_BYTES
     hipIpcMemHandle_t h;
     uint64_t offset, bytes;
@@ -476,6 +498,16 @@ int wg_comm_has_collectives(const wg_comm *c) { return c && c->nccl ? 1 : 0; }
 const char *wg_comm_copy_engine(const wg_comm *c) { return !c || c->nranks < 2 ? "none" : (c->use_sdma ? "sdma-rect" : "hip2d"); }
 uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
 
+int wg_comm_set_pipelined(wg_comm *c, int on) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_pipelined: comm is NULL");
+    c->pipelined = on != 0;
+    if (!c->pipelined) {
+        WG_HIP_TRY(hipSetDevice(c->ctx->device));
+        return run_pending(c);
+    }
+    return WG_OK;
+}
+
 // In-place all-gather of the element range [first, first + nranks*per_rank) of `buf`: rank r contributes [first + r*per_rank, +per_rank).
 // Runs on the communicator's stream, ordered after everything enqueued on the context's stream so far; the context's stream does NOT
 // wait for it (wg_comm_join does), so later Gemms overlap it.
@@ -504,6 +536,7 @@ int wg_all_gather(wg_comm *c, wg_dtype dtype, wg_buf *buf, uint64_t first_elem, 
 int wg_comm_join(wg_comm *c) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_join: comm is NULL");
     WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    if (int rc = run_pending(c)) return rc;
     WG_HIP_TRY(hipEventRecord(c->ev_comm, c->stream));
     WG_HIP_TRY(hipStreamWaitEvent(c->ctx->stream, c->ev_comm, 0));
     return WG_OK;
@@ -513,6 +546,7 @@ int wg_comm_join(wg_comm *c) {
 int wg_comm_flush(wg_comm *c) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_flush: comm is NULL");
     WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    if (int rc = run_pending(c)) return rc;
     return comm_flush(c);
 }
 
@@ -522,6 +556,7 @@ int wg_comm_barrier(wg_comm *c) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_barrier: comm is NULL");
     if (!c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_comm_barrier: no collective library on this communicator; flush and use the caller's own barrier");
     WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    if (int rc = run_pending(c)) return rc;
     WG_HIP_TRY(hipStreamSynchronize(c->ctx->stream)); // the panel events the copies wait for have been recorded and will fire
     if (int rc = comm_flush(c)) return rc;
     ncclResult_t r = rccl().AllReduce(c->token, c->token, 1, ncclFloat32, ncclSum, c->nccl, c->stream);
@@ -688,6 +723,8 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     const size_t es = wg_dtype_size(dtype);
     WG_HIP_TRY(hipSetDevice(ctx->device));
 
+    if (mode != WG_GATHER_PEER_STAGED)
+        if (int rc = run_pending(c)) return rc;
     if (mode == WG_GATHER_PEER_STAGED) {
         // ---- contiguous per-link copies into the peers' staging cubes + flag, wait kernel + relayout on the receiving side ----
         if (npanels > kMaxPanels) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): more than %u panels", kMaxPanels);
@@ -753,8 +790,18 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 }
                 c->bytes_sent += (uint64_t)(P - 1) * bytes;
             }
-            if (p > 0)
+            if (p > 0) {
                 if (int rc = finish_panel(p - 1)) return rc; // after this panel's Gemm: the previous panel's slots travelled beside it
+            } else if (int rc = run_pending(c)) return rc;   // ... and the previous CALL's last panel beside this call's first Gemm (pipelined steps)
+        }
+        if (c->pipelined) { // leave the last panel to the next call (or wg_comm_join): nothing in this call can hide its exchange
+            const uint32_t p = npanels - 1, c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            c->pending.on = true;
+            c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
+            c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
+            c->pending.dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
+            c->pending.ld = out_shape.stride; c->pending.es = es;
+            return WG_OK;
         }
         return finish_panel(npanels - 1);
     }

@@ -222,6 +222,10 @@ class Comm:
         from .wgcore import wg_dtype
         self._lib.check(self._lib.lib.wg_all_gather(self._h, wg_dtype(tensor.dtype), tensor._h, first_elem, elems_per_rank))
 
+    def set_pipelined(self, on: bool) -> None:
+        """Staged engine: defer each call's last panel (wait + relayout) to the next call / join(), hiding its exchange under the next step."""
+        self._lib.check(self._lib.lib.wg_comm_set_pipelined(self._h, 1 if on else 0))
+
     def join(self) -> None:
         self._lib.check(self._lib.lib.wg_comm_join(self._h))
 
