@@ -106,10 +106,9 @@ __device__ __forceinline__ void m16_dma(int q, uint32_t voff, const void *sbase)
 }
 constexpr uint32_t M16_BIAS = 3072; // scalar bases are lowered by this many bytes, voff of piece q raised by BIAS - 1024 q
 
+// One 256 x 256 tile (tile id `bid`), K range of this workgroup's split. `smem` is the kernel's 160 KiB LDS array.
 template <bool TRANS_A>
-__global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
-
+__device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, char *const smem) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
 #define WG_TRACE_POINT(i) do { } while (0)
 #endif
     uint32_t tm, tn;
-    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split;
@@ -454,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
     const uint32_t row0 = m0 + 128u * wm + 8u * kg;
     if (g.tail_tiles > 0) { // tail split: raw f32 partial TILE (256 x 256, dense) of this split; gemm_f16_tail_reduce finishes the job
-        float *P = part + ((uint64_t)split * g.tail_tiles + blockIdx.x) * 65536u;
+        float *P = part + ((uint64_t)split * g.tail_tiles + bid) * 65536u;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const uint32_t cl = 128u * wn + 16u * u + i16; // column within the tile
@@ -519,13 +518,36 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     WG_TRACE_POINT(4);                       // all stores acknowledged
     if (threadIdx.x == 0 && g.nsplit == 1 && g.part) {
-        uint64_t *o = (uint64_t *)g.part + (uint64_t)blockIdx.x * 8u;
+        uint64_t *o = (uint64_t *)g.part + (uint64_t)bid * 8u;
         for (int i = 0; i < 5; ++i) o[i] = tr_t[i];
         o[5] = __builtin_amdgcn_s_getreg((3 << 0) | (0 << 6) | (31 << 11)); // HW_ID
         o[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID (gfx940+)
     }
 #endif
 }
+
+template <bool TRANS_A>
+__global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
+    m16_tile<TRANS_A>(g, blockIdx.x, smem);
+}
+
+#ifndef WG_F16_PERSIST
+#define WG_F16_PERSIST 0
+#endif
+#if WG_F16_PERSIST
+// Persistent form (experiment, -DWG_F16_PERSIST=1; measured 0.5-1 % SLOWER than letting the hardware re-dispatch a workgroup per tile:
+// profiles/r02_evidence.md section 3c): one workgroup per CU walks the tiles bid, bid + grid, ... itself instead of being
+// re-dispatched per tile (hardware deals ids round-robin to the XCDs and so does this walk: tile t stays on XCD t % 8).
+template <bool TRANS_A>
+__global__ __launch_bounds__(256, 1) void gemm_f16_m16p_kernel(GemmArgs g, uint32_t ntiles) {
+    __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        m16_tile<TRANS_A>(g, t, smem);
+        __syncthreads(); // every wave is done with the LDS before the next tile's prologue DMA lands in it
+    }
+}
+#endif
 
 // Tail split (tile quantisation): when the tile count is a little more than a multiple of the CU count, the last round would
 // run on a nearly empty chip for a full tile time. The launcher then runs the full rounds normally and cuts the few tail tiles
@@ -718,6 +740,13 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 WG_HIP_TRY(hipGetLastError());
                 return WG_OK;
             }
+#if WG_F16_PERSIST
+            if (nsplit == 1 && nmats == 1 && tiles >= 2ull * (uint64_t)cus) {
+                const dim3 pg((uint32_t)cus, 1);
+                if (trans) hipLaunchKernelGGL((gemm_f16_m16p_kernel<true>), pg, dim3(256), 0, ctx->stream, g, (uint32_t)tiles);
+                else hipLaunchKernelGGL((gemm_f16_m16p_kernel<false>), pg, dim3(256), 0, ctx->stream, g, (uint32_t)tiles);
+            } else
+#endif
             if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), grid, dim3(256), 0, ctx->stream, g);
             else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), grid, dim3(256), 0, ctx->stream, g);
 #ifdef WG_F16_TRACE
