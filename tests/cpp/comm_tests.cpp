@@ -204,10 +204,44 @@ static void cube_relayout(wg_ctx *ctx) {
     wg_buf_destroy(bc); wg_buf_destroy(bo);
 }
 
+// argument checking of the sharded entry point, and the IPC export of a buffer that wraps an INTERIOR pointer of an allocation
+static void errors_and_export(wg_ctx *ctx) {
+    wg_comm *comm = nullptr;
+    CK(wg_comm_create(ctx, 2, 0, nullptr, &comm)); // two ranks, no collective library, no peers registered
+    wg_buf *a = nullptr, *b = nullptr, *c = nullptr;
+    CK(wg_buf_create(ctx, 256 * 64 * 4, USAGE, &a));
+    CK(wg_buf_create(ctx, 64 * 128 * 4, USAGE, &b));
+    CK(wg_buf_create(ctx, 512 * 128 * 4, USAGE, &c));
+    // M = 2 * rows(a_rows) must hold; K and N must match (gemm.rs:91-95 on the sharded operands)
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(500, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_DIM_MISMATCH, "M != P * rows");
+    EXPECT(std::strstr(wg_last_error_string(), "Gemm: dimension mismatch.") != nullptr, "message: %s", wg_last_error_string());
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(60, 128)) == WG_ERR_DIM_MISMATCH, "K mismatch");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 6, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_PRECONDITION, "panel_cols not a multiple of 4");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_RCCL, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_UNSUPPORTED, "RCCL mode without a unique id");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_PEER_COPY, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "peer mode without peers");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, (wg_gather_mode)9, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "unknown mode");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_OK, "local-only mode: %s", wg_last_error_string());
+    EXPECT(wg_all_gather(comm, WG_F32, c, 0, 16) == WG_ERR_UNSUPPORTED && wg_comm_barrier(comm) == WG_ERR_UNSUPPORTED, "collectives without a library");
+    // export of a wrapped interior pointer: the handle names the base allocation and carries the offset
+    wg_buf *inner = nullptr;
+    CK(wg_buf_wrap(ctx, (char *)wg_buf_device_ptr(c) + 4096, 8192, &inner));
+    unsigned char h[WG_IPC_HANDLE_BYTES], h0[WG_IPC_HANDLE_BYTES];
+    CK(wg_buf_ipc_export(inner, h));
+    CK(wg_buf_ipc_export(c, h0));
+    uint64_t off = 0, bytes = 0, off0 = 1;
+    std::memcpy(&off, h + 64, 8); std::memcpy(&bytes, h + 72, 8); std::memcpy(&off0, h0 + 64, 8);
+    EXPECT(off - off0 == 4096 && bytes == 8192 && std::memcmp(h, h0, 64) == 0, "interior export: offset %llu (+%llu), bytes %llu", (unsigned long long)off, (unsigned long long)off0, (unsigned long long)bytes);
+    wg_buf_destroy(inner);
+    CK(wg_ctx_sync(ctx));
+    wg_comm_destroy(comm);
+    wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
+}
+
 int main() {
     wg_ctx *ctx = nullptr;
     if (wg_ctx_create(0, &ctx) != WG_OK) { std::printf("no device: %s\n", wg_last_error_string()); return 2; }
     cube_relayout(ctx);
+    errors_and_export(ctx);
 
     unsigned char id[WG_COMM_ID_BYTES];
     wg_comm *comm = nullptr;
