@@ -174,6 +174,7 @@ struct wg_comm {
     uint32_t *seq_host = nullptr;    // pinned ring of sequence numbers (source of seq_src's update)
     uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout
     uint32_t step = 0;
+    uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
@@ -640,6 +641,7 @@ int wg_comm_stage_reserve(wg_comm *c, size_t bytes, wg_buf **stage, wg_buf **fla
     }
     c->stage_buf.ctx = c->ctx; c->stage_buf.ptr = c->pstage; c->stage_buf.bytes = c->pstage_bytes; c->stage_buf.usage = WG_USAGE_STORAGE; c->stage_buf.owned = false;
     c->flags_buf.ctx = c->ctx; c->flags_buf.ptr = c->pflags; c->flags_buf.bytes = kFlagBytes; c->flags_buf.usage = WG_USAGE_STORAGE; c->flags_buf.owned = false;
+    c->stage_buf.borrowed = c->flags_buf.borrowed = true; // members of the communicator: wg_buf_destroy on them is a no-op
     *stage = &c->stage_buf;
     *flags = &c->flags_buf;
     return WG_OK;
@@ -738,6 +740,17 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             const uint32_t r = *c->wait_err - 1u;
             *c->wait_err = 0;
             return wg_set_error(WG_ERR_HIP, "Gemm (sharded): rank %u's slot did not arrive within 4 s in an earlier step", r);
+        }
+        const uint64_t geom[4] = { M, N, panel_cols, es };
+        if (memcmp(geom, c->staged_geom, sizeof geom) != 0) {
+            // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything that is
+            // still leaving the old layout finish before any Gemm writes the cubes (host-blocking, first call of a new shape only)
+            if (int rc = run_pending(c)) return rc;
+            for (hipStream_t st : c->peer_stream)
+                if (st) WG_HIP_TRY(hipStreamSynchronize(st));
+            for (hipEvent_t &e : c->sent_ev)
+                if (e) { (void)hipEventDestroy(e); e = nullptr; }
+            memcpy(c->staged_geom, geom, sizeof geom);
         }
         const uint32_t seq = ++c->step, parity = seq & 1u;
         // the sequence number the flag copies carry: pinned ring entry -> device word, on the context's stream ahead of this step's Gemms

@@ -249,7 +249,7 @@ int wg_buf_wrap(wg_ctx *ctx, void *device_ptr, size_t bytes, wg_buf **out) {
 }
 
 int wg_buf_destroy(wg_buf *buf) {
-    if (!buf) return WG_OK;
+    if (!buf || buf->borrowed) return WG_OK;
     int rc = WG_OK;
     if (buf->owned && buf->ptr) {
         (void)hipSetDevice(buf->ctx->device);

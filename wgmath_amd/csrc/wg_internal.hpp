@@ -37,6 +37,7 @@ struct wg_buf {
     bool owned = true;
     bool host_pinned = false;
     void *ipc_base = nullptr; // wg_buf_ipc_open: base of the mapped peer allocation (closed with the buffer)
+    bool borrowed = false;    // a view owned by another object (a communicator's staging cube): wg_buf_destroy leaves it alone
 };
 
 struct wg_cmdbuf {
