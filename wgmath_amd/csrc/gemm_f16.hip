@@ -41,6 +41,9 @@ namespace {
 #ifndef WG_NN_RDENSE
 #define WG_NN_RDENSE 0
 #endif
+#ifndef WG_NN_KEEP
+#define WG_NN_KEEP 16
+#endif
 #ifndef WG_NN_STAGGER
 #define WG_NN_STAGGER 0 // NN: wave w issues its DMA pieces this many slots later than wave w-1 (0: all four waves in the same slots)
 #endif
@@ -407,8 +410,11 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     if constexpr (!TRANS_A) {
         auto steady = [&](auto wsel) {
             while (st + 3 < S) { // st advances in next_stage()
-                half_step(c0{}, yes{}, yes{}, yes{}, wsel); advance(k16{});
-                half_step(c1{}, yes{}, yes{}, yes{}, wsel); advance(k16{});
+                // Counted wait: a half-step issues its 4 A pieces before its 4 B pieces, and B is needed one half-step later than A
+                // (A(H+4) is read during H+3, the B halves issued in H during H+4): at the end of a half-step only the A pieces issued two
+                // half-steps ago must have landed, their 4 B pieces may still fly -- keep 20, not 16 (WG_NN_KEEP; loads retire in order).
+                half_step(c0{}, yes{}, yes{}, yes{}, wsel); advance(std::integral_constant<int, WG_NN_KEEP>{});
+                half_step(c1{}, yes{}, yes{}, yes{}, wsel); advance(std::integral_constant<int, WG_NN_KEEP>{});
                 next_stage();
             }
         };
