@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Timing experiment (trace build of the library: make EXTRA=-DWG_F16_TRACE=1): per-workgroup timestamps of the f16 GEMM.
-usage: WGEBRA_HIP_LIB=.../libwg_trace.so python tools/f16_trace.py M K N"""
+usage: WGEBRA_HIP_LIB=.../libwgebra_hip_trace2.so python tools/f16_trace.py M K N [zero] [tn]
+-DWG_F16_TRACE=2 builds add, per wave, the split of every end-of-half-step into counted-DMA wait / barrier wait (shader cycles)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,14 +12,26 @@ M, K, N = (int(x) for x in sys.argv[1:4])
 gpu = wg.GpuInstance.new(0)
 dev, shapes = gpu.device(), wg.ViewShapeBuffers()
 S = wg.BufferUsages
-a = device_random(wg, gpu, (M, K), np.float16, 1)
-b = device_random(wg, gpu, (K, N), np.float16, 2)
+ZERO, TN = "zero" in sys.argv[4:], "tn" in sys.argv[4:]
+if ZERO:
+    a = wg.TensorBuilder.matrix(*((K, M) if TN else (M, K)), S.STORAGE).build(dev, np.float16)
+    b = wg.TensorBuilder.matrix(K, N, S.STORAGE).build(dev, np.float16)
+else:
+    a = device_random(wg, gpu, (K, M) if TN else (M, K), np.float16, 1)
+    b = device_random(wg, gpu, (K, N), np.float16, 2)
 c = wg.TensorBuilder.matrix(M, N, S.STORAGE).build(dev, np.float16)
 gemm = wg.Gemm.from_device(dev)
+variant = wg.GemmVariant.GemmTr if TN else wg.GemmVariant.Gemm
 enc = dev.create_command_encoder(); p = enc.compute_pass("t", None)
-for _ in range(6): gemm.dispatch(dev, shapes, p, c, a, b)
+for _ in range(6): gemm.dispatch_generic(dev, shapes, p, c, a, b, variant)
 gpu.sync()
-t = np.fromfile("/tmp/wg_f16_trace.bin", dtype=np.uint64).reshape(-1, 8)
+raw = np.fromfile("/tmp/wg_f16_trace.bin", dtype=np.uint64)
+ntile = (M // 256) * (N // 256)
+fine = None
+if len(raw) == ntile * 24:
+    fine = raw[ntile * 8:].view(np.uint32).reshape(ntile, 4, 8).astype(np.float64)
+    raw = raw[:ntile * 8]
+t = raw.reshape(-1, 8)
 ts = t[:, :5].astype(np.float64) * 0.01  # us (100 MHz)
 t0 = ts[:, 0].min()
 ts -= t0
@@ -44,3 +57,19 @@ if gaps:
     print(f"  gap: end of a workgroup -> start of the next on the same CU: mean {gaps.mean():.2f} us  min {gaps.min():.2f}  max {gaps.max():.2f}  (n={len(gaps)}, {len(np.unique(key))} CUs)")
 starts = np.sort(ts[:, 0])
 print("  start times of the first 8 and of workgroups 256..263:", np.round(starts[:8], 2), np.round(starts[256:264], 2) if len(starts) > 264 else "")
+
+if fine is not None:
+    loop, vm, bar, probe, mvm, mbar, nadv = (fine[:, :, i] for i in range(7))
+    n = nadv.mean()
+    hs = K // 32                      # half-steps per tile; each 64 MFMAs per wave = 1024 cycles at 16 cycles / MFMA
+    work = loop - vm - bar - probe    # cycles spent issuing the half-steps themselves
+    print(f"fine trace ({'zero' if ZERO else 'random'} operands, {'TN' if TN else 'NN'}): {hs} half-steps per tile, {n:.0f} instrumented ends; shader cycles per wave, mean over {ntile} tiles x 4 waves")
+    print(f"  loop span                {loop.mean():10.0f}   = {loop.mean()/hs:7.1f} per half-step (ideal 1024)")
+    print(f"  half-step bodies         {work.mean():10.0f}   = {work.mean()/hs:7.1f} per half-step  ({100*work.mean()/loop.mean():.1f} % of the loop)")
+    print(f"  counted-DMA wait (vmcnt) {vm.mean():10.0f}   = {vm.mean()/n:7.1f} per end   ({100*vm.mean()/loop.mean():.1f} %)   max single {mvm.max():.0f}, mean of per-wave max {mvm.mean():.0f}")
+    print(f"  barrier wait             {bar.mean():10.0f}   = {bar.mean()/n:7.1f} per end   ({100*bar.mean()/loop.mean():.1f} %)   max single {mbar.max():.0f}, mean of per-wave max {mbar.mean():.0f}")
+    print(f"  probe round trips        {probe.mean():10.0f}   = {probe.mean()/n:7.1f} per end   ({100*probe.mean()/loop.mean():.1f} %; not in the shipped kernel)")
+    for w in range(4):
+        print(f"    wave {w}: body {work[:, w].mean()/hs:7.1f}  vm {vm[:, w].mean()/n:6.1f}  barrier {bar[:, w].mean()/n:6.1f}")
+    d = ts[:, 2] - ts[:, 1]
+    print(f"  loop span in us (100 MHz clock) {d.mean():.2f} -> shader clock {loop.mean()/d.mean()/1000:.3f} GHz")

@@ -127,6 +127,11 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #else
 #define WG_TRACE_POINT(i) do { } while (0)
 #endif
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+    // fine trace: every wave splits each end-of-half-step into counted-DMA wait / barrier wait / probe latency (shader cycles, s_memtime);
+    // the sums + the loop's span go to the second 64 bytes of the tile's trace record (see tools/f16_trace.py)
+    uint32_t q_a = 0, q_b = 0, q_c = 0, q_d = 0, s_vm = 0, s_bar = 0, s_probe = 0, m_vm = 0, m_bar = 0, n_adv = 0, loop_t0 = 0, loop_t1 = 0;
+#endif
     uint32_t tm, tn;
     tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
@@ -339,16 +344,39 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                     else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
                 }
             }
+#if defined(WG_EXP_NOPS_SPREAD)
+            if constexpr (!TRANS_A && (j == 53 || j == 54 || j == 55 || j == 56 || j == 57 || j == 58 || j == 60 || j == 61)) asm volatile("s_nop 0"); // issue-model probe: one extra slot in each of 8 empty gaps
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
+#if defined(WG_EXP_NOPS_BOUNDARY)
+        asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0"); // issue-model probe: the same 8 extra slots in the boundary gap
+#endif
     };
     // end of a half-step: all fragment reads done (also tells the compiler's wait-count pass that no LDS read is pending
     // across the loop back-edge -- otherwise it opens each iteration with lgkmcnt(0) AFTER new reads were issued), at most
     // KEEP DMA pieces (those issued in this and the previous half-step) still in flight, publish.
     auto advance = [&](auto keep_c) {
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+        q_a = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         wait_dma_keep<decltype(keep_c)::value>();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+        q_b = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+        q_c = (uint32_t)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xc07f); // the three timestamps have returned: no scalar load is pending during the next half-step
+        q_d = (uint32_t)__builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        {
+            const uint32_t dv = q_b - q_a, db = q_c - q_b;
+            s_vm += dv; s_bar += db; s_probe += 2u * (q_d - q_c); // two round trips of the probe itself sit inside the half-step that follows
+            m_vm = dv > m_vm ? dv : m_vm; m_bar = db > m_bar ? db : m_bar; ++n_adv;
+        }
+#endif
     };
     auto next_stage = [&]() {
         ++st;
@@ -401,6 +429,10 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier(); // every wave has read A(0): half-step 0 may overwrite its slot with A(4)
     __builtin_amdgcn_sched_barrier(0);
     WG_TRACE_POINT(1);
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+    loop_t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
 
     // No parity branches (two accumulator-modifying arms merging in a loop make the register allocator shuffle all 256
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
@@ -454,6 +486,10 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         half_step(c1{}, no{}, no{}, no{}, W0{});
     }
     WG_TRACE_POINT(2);
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+    loop_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#endif
 
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
@@ -529,6 +565,12 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         o[5] = __builtin_amdgcn_s_getreg((3 << 0) | (0 << 6) | (31 << 11)); // HW_ID
         o[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID (gfx940+)
     }
+#if WG_F16_TRACE >= 2
+    if (lane == 0 && g.nsplit == 1 && g.part) {
+        uint32_t *o = (uint32_t *)((uint64_t *)g.part + (uint64_t)g.trace_tiles * 8u) + ((uint64_t)bid * 4u + wave) * 8u;
+        o[0] = loop_t1 - loop_t0; o[1] = s_vm; o[2] = s_bar; o[3] = s_probe; o[4] = m_vm; o[5] = m_bar; o[6] = n_adv; o[7] = 0;
+    }
+#endif
 #endif
 }
 
@@ -708,8 +750,10 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifdef WG_F16_TRACE
             uint64_t *trace = nullptr;
             if (nsplit == 1) {
-                WG_HIP_TRY(hipMalloc((void **)&trace, tiles * nmats * 64));
+                WG_HIP_TRY(hipMalloc((void **)&trace, tiles * nmats * 192));
+                WG_HIP_TRY(hipMemset(trace, 0, tiles * nmats * 192));
                 g.part = (float *)trace;
+                g.trace_tiles = (uint32_t)(tiles * nmats);
             }
 #endif
             // tail split: full rounds as they are, the few tiles of a nearly empty last round cut along K over the idle CUs
@@ -758,7 +802,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifdef WG_F16_TRACE
             if (trace) {
                 WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-                std::vector<uint64_t> h(tiles * nmats * 8);
+                std::vector<uint64_t> h(tiles * nmats * 24); // 8 u64 per tile, then 4 waves x 8 u32 per tile
                 WG_HIP_TRY(hipMemcpy(h.data(), trace, h.size() * 8, hipMemcpyDeviceToHost));
                 if (FILE *f = fopen("/tmp/wg_f16_trace.bin", "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
                 (void)hipFree(trace);
