@@ -62,6 +62,18 @@ namespace {
 #ifndef WG_TN_DOFF
 #define WG_TN_DOFF 2    // ... starting at this slot (>= 1)
 #endif
+#ifndef WG_NN_SPREAD
+#define WG_NN_SPREAD 1  // NN: ring / address bookkeeping and the end-of-half-step synchronisation sit in otherwise empty MFMA gaps (see half_step_nn)
+#endif
+#ifndef WG_TN_SPREAD
+#define WG_TN_SPREAD 1
+#endif
+#ifndef WG_TN_SYNC_SLOT
+#define WG_TN_SYNC_SLOT 56
+#endif
+#ifndef WG_NN_SYNC_SLOT
+#define WG_NN_SYNC_SLOT 60 // NN (WG_NN_SPREAD): lgkmcnt(0) + counted vmcnt + barrier after this MFMA slot (> the last DMA piece's and the last LDS read's slot)
+#endif
 #ifndef WG_F16_NN_SWAP
 #define WG_F16_NN_SWAP 1 // NN A reads: 1 = conflict-free transpose reads + v_permlane16_swap, 0 = direct reads (2-way bank conflicts)
 #endif
@@ -353,6 +365,179 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0"); // issue-model probe: the same 8 extra slots in the boundary gap
 #endif
     };
+    // ---- NN, WG_NN_SPREAD: the same half-step with its bookkeeping spread out ---------------------------------------------------
+    // Measured (profiles/r02_evidence.md 3d): one wave per SIMD hides up to ~3 single-issue instructions in the 16 cycles of a
+    // 16x16x32 MFMA; every instruction beyond that costs ~4.8 cycles. The form above recomputes ring slots, DMA bases and LDS read
+    // addresses at the top of each half-step, right after the waits and the barrier: ~18 instructions in two gaps, ~80 cycles of
+    // 1190 per half-step. Here every quantity is a running value updated IN PLACE, in a gap of its own after its last use:
+    //   rD  A ring offset DMA'd this half-step   (H & 3) << 14          += 16 KiB mod 64 KiB at slot 6   (M0 set at slot 2)
+    //   vb  B read address (VGPR)                 base[parity] + oR      at slot 27 (last B read: slot 25); oR moves on at slot 26 of even H
+    //   ga  global base of A(H+4)                 += 32 k rows           at slot 30 (last A piece: slot 27)
+    //   oD  B ring offset DMA'd this half-step    moves on at slot 38 of even H (M0 set at slot 34)
+    //   va  A read address (VGPR)                 baseA + rR             at slots 47/54 (last A read: slot 41)
+    //   gb  global base of the B stage            += 64 k at slot 61 of even H (last B piece: slot 59)
+    // and lgkmcnt(0) + counted vmcnt + barrier sit after slot WG_NN_SYNC_SLOT: all LDS reads were issued by slot 41, all 8 pieces by
+    // slot 59, so the counts mean what they meant at the end of the half-step; MFMAs 61..63 only touch registers.
+    uint32_t nn_rD = 0, nn_rR = 1u << 14, nn_oR = 0, nn_oD = 2u * M16_BS_BYTES;
+    const char *nn_ga = nullptr, *nn_gb = nullptr;
+    uint32_t nn_lb = 0;
+    uint32_t nn_va = 0, nn_vb = 0, nn_vbaseA = 0, nn_vbaseB0 = 0, nn_vbaseB1 = 0;
+    uint64_t nn_astep = 0;
+    if constexpr (!TRANS_A) {
+        nn_ga = (const char *)a_src(4u); nn_gb = (const char *)b_src(2u);
+        nn_astep = (uint64_t)BKH * g.lda * 2u;
+        nn_vbaseA = lds_base + a_off[0]; nn_vbaseB0 = lds_base + b_off[0]; nn_vbaseB1 = lds_base + b_off[1];
+        nn_va = nn_vbaseA + nn_rR; nn_vb = nn_vbaseB1 + nn_oR;
+    }
+    auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
+    auto frag_nn = [&](int op, int set) {
+        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(nn_vb + u * 2048); };
+        auto tr = [&](int p, int i) {
+            const int h = i >> 1, ins = i & 1;
+            const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at(nn_va + (2 * ins + h) * 2048 + p * 256));
+            a_r[set][2 * p + ins][2 * h] = v[0];
+            a_r[set][2 * p + ins][2 * h + 1] = v[1];
+        };
+        auto sw = [&](int p, int i) {
+            if (WG_ABLATE & 16) return;
+            const uintx2 r = __builtin_amdgcn_permlane16_swap(a_r[set][2 * p][i], a_r[set][2 * p + 1][i], false, false);
+            a_r[set][2 * p][i] = r[0];
+            a_r[set][2 * p + 1][i] = r[1];
+        };
+        if (op < 4) tr(0, op);
+        else if (op < 8) rb(op - 4);
+        else if (op < 12) tr(1, op - 8);
+        else if (op < 16) sw(0, op - 12);
+        else if (op < 20) rb(op - 12);
+        else if (op < 24) tr(2, op - 20);
+        else if (op < 28) sw(1, op - 24);
+        else if (op < 32) tr(3, op - 28);
+        else if (op < 36) sw(2, op - 32);
+        else sw(3, op - 36);
+    };
+    // sync_c: >= 0: counted wait keeping that many pieces + barrier at WG_NN_SYNC_SLOT; -1: none (the last half-step of the tile)
+    auto half_step_nn = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto sync_c) {
+        constexpr int HS = decltype(hs_c)::value, SYNC = decltype(sync_c)::value;
+        constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
+        static_assert(WG_F16_NN_SWAP && !WG_NN_RDENSE && WG_NN_STAGGER == 0, "the spread form implements the shipped read schedule only");
+        static_assert(WG_NN_DOFF + 7 * WG_NN_DSTRIDE < WG_NN_SYNC_SLOT && WG_NN_SYNC_SLOT < 64, "all pieces are issued before the counted wait");
+        static_for<64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 3, u = j & 7;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
+            if constexpr (decltype(has_next)::value) {
+                if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < 40) frag_nn(3 * (j >> 2) + (j & 3), HS ^ 1);
+            }
+            constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
+            if constexpr (ADMA && j == DO - 1) m16_set_m0(lds_a_wave + nn_rD);
+            if constexpr (BDMA && j == DO + 4 * DS - 4) { nn_lb = lds_b_wave + nn_oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(nn_lb)); }
+            if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(nn_lb);
+            if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
+                constexpr int pi = (j - DO) / DS, q = pi & 3;
+                if constexpr (pi < 4) { if constexpr (ADMA) m16_dma_imm<1024 * q>(a_voff[q], nn_ga); }
+                else { if constexpr (BDMA) m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], nn_gb); }
+            }
+            // bookkeeping, each in its own gap after the value's last use in this half-step
+            if constexpr (j == DO + 3) { nn_rD = (nn_rD + 0x4000u) & 0xffffu; asm volatile("" : "+s"(nn_rD)); }
+            if constexpr (j == 26 && HS == 0) { nn_oR = ring3(nn_oR); asm volatile("" : "+s"(nn_oR)); }
+            if constexpr (j == 27) { nn_vb = (HS == 0 ? nn_vbaseB0 : nn_vbaseB1) + nn_oR; asm volatile("" : "+v"(nn_vb)); }
+            if constexpr (j == DO + 3 * DS + 3) { nn_ga += nn_astep; asm volatile("" : "+s"(nn_ga)); }
+            if constexpr (j == DO + 4 * DS + 3 && HS == 0) { nn_oD = ring3(nn_oD); asm volatile("" : "+s"(nn_oD)); }
+            if constexpr (j == 47) { nn_rR = (nn_rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(nn_rR)); }
+            if constexpr (j == 54) { nn_va = nn_vbaseA + nn_rR; asm volatile("" : "+v"(nn_va)); }
+            if constexpr (j == 56 && HS == 1) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (j == WG_NN_SYNC_SLOT && SYNC >= 0) {
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): every fragment read of this half-step has returned
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+                q_a = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+                wait_dma_keep<(SYNC >= 0 ? SYNC : 0)>();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+                q_b = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+                if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+                q_c = (uint32_t)__builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                q_d = (uint32_t)__builtin_amdgcn_s_memtime();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                {
+                    const uint32_t dv = q_b - q_a, db = q_c - q_b;
+                    s_vm += dv; s_bar += db; s_probe += 2u * (q_d - q_c);
+                    m_vm = dv > m_vm ? dv : m_vm; m_bar = db > m_bar ? db : m_bar; ++n_adv;
+                }
+#endif
+            }
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { nn_gb += 128; asm volatile("" : "+s"(nn_gb)); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // ---- TN, WG_TN_SPREAD: the same idea. Fragment reads every 3 slots (0..45), DMA pieces every 4 (2..46), M0 one slot ahead of each
+    // group of four; running values: oA (A slot read: toggles after the even half-step's last A read), oAD (A slot DMA'd: toggles
+    // after the odd half-step's second M0), oR / oD (B ring, as NN), ga (+64 k after the odd half-step's last A piece), gb (+64 k after
+    // the even half-step's last B piece); lgkmcnt(0) [+ vmcnt(8) + barrier in even half-steps] after slot WG_TN_SYNC_SLOT.
+    uint32_t tn_oA = 0, tn_oAD = 0, tn_la = 0;
+    uint32_t tn_vbaseA0 = 0, tn_vbaseA1 = 0;
+    if constexpr (TRANS_A) {
+        nn_ga = (const char *)a_src(2u); nn_gb = (const char *)b_src(2u);
+        tn_vbaseA0 = lds_base + a_off[0]; tn_vbaseA1 = lds_base + a_off1[0];
+        nn_vbaseB0 = lds_base + b_off[0]; nn_vbaseB1 = lds_base + b_off[1];
+        nn_va = tn_vbaseA1; nn_vb = nn_vbaseB1;
+    }
+    auto frag_tn = [&](int op, int set) {
+        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(nn_vb + u * 2048); };
+        auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8_at(nn_va + (t & 1) * 512 + (t >> 1) * 4096)); };
+        if (op == 0) ra(0);
+        else if (op <= 8) rb(op - 1);
+        else ra(op - 8);
+    };
+    // sync_c: >= 0: lgkmcnt(0) + counted wait + barrier; -1: lgkmcnt(0) only; -2: nothing (last half-step of the tile)
+    auto half_step_tn = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto sync_c) {
+        constexpr int HS = decltype(hs_c)::value, SYNC = decltype(sync_c)::value;
+        constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
+        constexpr int nA = ADMA ? 8 : 0, nB = BDMA ? 4 : 0;
+        constexpr int DS = 4, DO = 2, RS = 3;
+        static_assert(DO + DS * 11 < WG_TN_SYNC_SLOT && RS * 15 < WG_TN_SYNC_SLOT && WG_TN_SYNC_SLOT < 64, "reads and pieces are issued before the wait");
+        static_for<64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 3, u = j & 7;
+            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
+            if constexpr (decltype(has_next)::value) {
+                if constexpr ((j % RS) == 0 && (j / RS) < 16) frag_tn(j / RS, HS ^ 1);
+            }
+            // DMA targets: computed one slot before the M0 write that uses them
+            if constexpr (ADMA && j == 0) { tn_la = lds_a_wave + tn_oAD; asm volatile("" : "+s"(tn_la)); }
+            if constexpr (ADMA && j == 4 * DS) { tn_la += 4096u; asm volatile("" : "+s"(tn_la)); }
+            if constexpr (BDMA && j == DS * nA) { nn_lb = lds_b_wave + nn_oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(nn_lb)); }
+            if constexpr (j + 1 >= DO && ((j + 1 - DO) % DS) == 0 && ((j + 1 - DO) / DS) < nA + nB && (((j + 1 - DO) / DS) & 3) == 0) {
+                constexpr int n = (j + 1 - DO) / DS;
+                if constexpr (n < nA) m16_set_m0(tn_la); else m16_set_m0(nn_lb);
+            }
+            if constexpr (j >= DO && ((j - DO) % DS) == 0 && ((j - DO) / DS) < nA + nB) {
+                constexpr int n = (j - DO) / DS;
+                if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], nn_ga);
+                else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], nn_gb);
+            }
+            // bookkeeping after each value's last use
+            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { nn_gb += 128; asm volatile("" : "+s"(nn_gb)); }          // even: 4 B pieces at slots 2..14
+            if constexpr (HS == 0 && j == 4) { nn_oD = ring3(nn_oD); asm volatile("" : "+s"(nn_oD)); }                 // even: B M0 written at slot 1
+            if constexpr (HS == 1 && j == 4 * DS + 3) { tn_oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(tn_oAD)); } // odd: second A M0 at slot 17
+            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { nn_ga += 128; asm volatile("" : "+s"(nn_ga)); }          // odd: 8 A pieces at slots 2..30
+            if constexpr (HS == 0 && j == 8 * RS + 1) { nn_oR = ring3(nn_oR); asm volatile("" : "+s"(nn_oR)); }        // last B read at slot 24
+            if constexpr (j == 8 * RS + 4) { nn_vb = (HS == 0 ? nn_vbaseB0 : nn_vbaseB1) + nn_oR; asm volatile("" : "+v"(nn_vb)); }
+            if constexpr (HS == 0 && j == 15 * RS + 2) { tn_oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(tn_oA)); } // last A read at slot 45
+            if constexpr (j == 15 * RS + 3) { nn_va = (HS == 0 ? tn_vbaseA0 : tn_vbaseA1) + tn_oA; asm volatile("" : "+v"(nn_va)); }
+            if constexpr (HS == 1 && j == 52) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (j == WG_TN_SYNC_SLOT && SYNC >= -1) {
+                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+                if constexpr (SYNC >= 0) {
+                    wait_dma_keep<(SYNC >= 0 ? SYNC : 0)>();
+                    if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
     // end of a half-step: all fragment reads done (also tells the compiler's wait-count pass that no LDS read is pending
     // across the loop back-edge -- otherwise it opens each iteration with lgkmcnt(0) AFTER new reads were issued), at most
     // KEEP DMA pieces (those issued in this and the previous half-step) still in flight, publish.
@@ -450,6 +635,20 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 next_stage();
             }
         };
+        if constexpr (WG_NN_SPREAD) {
+            using km1 = std::integral_constant<int, -1>;
+            const uint32_t s_end = S - 3u;
+            while (st < s_end) {
+                half_step_nn(c0{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{});
+                half_step_nn(c1{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{}); // ++st inside (slot 56)
+            }
+            half_step_nn(c0{}, yes{}, yes{}, yes{}, k16{}); // stage S-3: A(2S-2), second half of B(S-1)
+            half_step_nn(c1{}, yes{}, no{}, yes{}, k12{});  //            A(2S-1)
+            half_step_nn(c0{}, no{}, no{}, yes{}, k4{});    // stage S-2
+            half_step_nn(c1{}, no{}, no{}, yes{}, k0{});
+            half_step_nn(c0{}, no{}, no{}, yes{}, k0{});    // stage S-1
+            half_step_nn(c1{}, no{}, no{}, no{}, km1{});
+        } else {
         if constexpr (WG_NN_STAGGER != 0) { // one copy of the steady-state loop per wave: its DMA pieces sit in that wave's own slots
             if (wave == 0) steady(std::integral_constant<int, 0>{});
             else if (wave == 1) steady(std::integral_constant<int, 1>{});
@@ -464,6 +663,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         next_stage();
         half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k0{});    // stage S-1
         half_step(c1{}, no{}, no{}, no{}, W0{});
+        }
     } else {
         // TN: both operands live in full-stage slots, so ONE wait + barrier per stage suffices, at the end of the EVEN half-step:
         // it publishes stage st+1 (read by the odd half-step that follows and by the even one after it) and releases the slots of
@@ -471,6 +671,21 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         // still be in flight -- the full stage of A issued in the odd half-step before must have landed. Odd half-steps end
         // without any synchronisation (lgkmcnt(0) only: see advance()).
         auto soft = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); };
+        if constexpr (WG_TN_SPREAD) {
+            using km1 = std::integral_constant<int, -1>;
+            using km2 = std::integral_constant<int, -2>;
+            const uint32_t s_end = S - 3u;
+            while (st < s_end) {
+                half_step_tn(c0{}, no{}, yes{}, yes{}, k8{});
+                half_step_tn(c1{}, yes{}, yes{}, yes{}, km1{}); // ++st inside
+            }
+            half_step_tn(c0{}, no{}, yes{}, yes{}, k8{});   // stage S-3: second half of B(S-1)
+            half_step_tn(c1{}, yes{}, no{}, yes{}, km1{});  //            A(S-1)
+            half_step_tn(c0{}, no{}, no{}, yes{}, k0{});    // stage S-2: A(S-1), B(S-1) must have landed
+            half_step_tn(c1{}, no{}, no{}, yes{}, km1{});
+            half_step_tn(c0{}, no{}, no{}, yes{}, km1{});   // stage S-1
+            half_step_tn(c1{}, no{}, no{}, no{}, km2{});
+        } else {
         while (st + 3 < S) {
             half_step(c0{}, no{}, yes{}, yes{}, W0{});  advance(k8{});
             half_step(c1{}, yes{}, yes{}, yes{}, W0{}); soft();
@@ -484,6 +699,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         next_stage();
         half_step(c0{}, no{}, no{}, yes{}, W0{}); soft();           // stage S-1
         half_step(c1{}, no{}, no{}, no{}, W0{});
+        }
     }
     WG_TRACE_POINT(2);
 #if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2

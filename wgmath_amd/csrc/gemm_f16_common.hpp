@@ -74,6 +74,15 @@ static __device__ __forceinline__ half8_t lds_h8(const char *p) {
     if (WG_ABLATE & 4) { half8_t v; asm volatile("" : "=v"(v)); return v; }
     return *reinterpret_cast<const half8_t *>(p);
 }
+// the same reads from a 32-bit LDS byte address (a running value kept in a VGPR)
+static __device__ __forceinline__ short4_t lds_tr_at(uint32_t addr) {
+    if (WG_ABLATE & 4) { short4_t v; asm volatile("" : "=v"(v)); return v; }
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((WG_AS3 short4_t *)(uintptr_t)addr);
+}
+static __device__ __forceinline__ half8_t lds_h8_at(uint32_t addr) {
+    if (WG_ABLATE & 4) { half8_t v; asm volatile("" : "=v"(v)); return v; }
+    return *(WG_AS3 const half8_t *)(uintptr_t)addr;
+}
 static __device__ __forceinline__ half8_t cat(short4_t lo, short4_t hi) {
     short8_t v = { lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3] };
     return __builtin_bit_cast(half8_t, v);
