@@ -45,6 +45,7 @@ names = ["prologue (start -> first MFMA)", "main loop", "epilogue issue (cvt + s
 for i, n in enumerate(names):
     print(f"  {n:34s} mean {d[:,i].mean():8.2f} us   min {d[:,i].min():8.2f}   max {d[:,i].max():8.2f}")
 print(f"  workgroup lifetime                 mean {(ts[:,4]-ts[:,0]).mean():8.2f} us")
+print(f"  distinct (xcc, se, sh, cu) keys: {len(np.unique(key))}; xcc values {np.unique(xcc)}")
 # gap between consecutive workgroups on the same CU
 gaps = []
 for k in np.unique(key):

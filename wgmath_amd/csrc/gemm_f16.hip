@@ -19,7 +19,7 @@ namespace {
 //   * B (k-contiguous) is staged per FULL stage (64 k): a DMA piece is 8 rows x 128 bytes, i.e. whole 128-byte lines of
 //     global memory (64-byte row pieces cost the L2/TCP request slot of a full line: measured +7 %). LDS plan:
 //     A ring 4 x 16 KiB (half-stages) + B ring 3 x 32 KiB (full stages) = 160 KiB;
-//   * the LDS-DMA is `s_mov m0` two slots ahead + `global_load_lds` (nothing else in this kernel touches M0).
+//   * the LDS-DMA is `s_mov m0` one slot ahead + `global_load_lds` (nothing else in this kernel touches M0).
 // Lane (i16 = lane&15, kg = lane>>4) feeds MFMA row/column i16 with k = 8 kg .. 8 kg + 7; C/D: column i16, rows 4 kg + r.
 // MFMA tile t = 2 p + tb of the wave covers rows 32 p + 8 (i>>2) + 4 tb + (i&3), i = MFMA row: a lane's registers of a
 // tile pair are 8 consecutive rows of C (one 16-byte store), and for NN the two tiles of a pair are the two 8-byte
@@ -33,19 +33,16 @@ namespace {
 //      instruction holds two k-groups; reading the same tile they would hit the same banks. So one instruction reads
 //      k-group g for BOTH tiles of a pair (lane rows 0/1 take the low/high 8 bytes of the same units), the next one
 //      k-group g+1, and v_permlane16_swap puts the k-groups back on the lane rows the MFMA expects.
-// Pipeline (H = half-step, s = H>>1 its stage). Fragments of half-step H+1 are read during H into the other register set;
-// advance() ends every half-step with lgkmcnt(0) + counted vmcnt + barrier, so the LDS slot of A(H) / B(s) is free from the
-// start of H / of 2s+1. During H: A(H+4) -> A slot H&3; B: the first half of B(s+3) during odd H, the second half of B(s+2)
-// during even H -> B slot (stage % 3). Everything a barrier must publish was issued >= 2 half-steps before it.
+// Pipeline (H = half-step, s = H>>1 its stage). Fragments of half-step H+1 are read during H into the other register set; a
+// half-step's synchronisation (lgkmcnt(0) + counted vmcnt + barrier) sits a few MFMA slots before its end, after its last fragment
+// read and DMA piece, so the LDS slot of A(H) / B(s) is free from the start of H / of 2s+1. NN: during H, A(H+4) -> A slot H&3 (four
+// half-stage slots, a barrier every half-step); TN: A in two full-stage slots, a barrier per stage. B: the first half of B(s+3)
+// during odd H, the second half of B(s+2) during even H -> B slot (stage % 3). Everything a barrier must publish was issued >= 2
+// half-steps before it. Ring offsets, global bases and LDS read addresses are running values updated in otherwise empty MFMA gaps
+// (see "Issue model" in m16_tile).
 // ===============================================================================================================
-#ifndef WG_NN_RDENSE
-#define WG_NN_RDENSE 0
-#endif
 #ifndef WG_NN_KEEP
-#define WG_NN_KEEP 16
-#endif
-#ifndef WG_NN_STAGGER
-#define WG_NN_STAGGER 0 // NN: wave w issues its DMA pieces this many slots later than wave w-1 (0: all four waves in the same slots)
+#define WG_NN_KEEP 16   // NN: DMA pieces allowed in flight at a half-step's counted wait (8 / 12 / 20 measured: no gain, evidence 3b'')
 #endif
 #ifndef WG_NN_DSTRIDE
 #define WG_NN_DSTRIDE 8 // NN: a DMA piece every this many MFMA slots (>= 2) ...
@@ -53,29 +50,14 @@ namespace {
 #ifndef WG_NN_DOFF
 #define WG_NN_DOFF 3    // ... starting at this slot (>= 1): 4 A pieces, then 4 B pieces
 #endif
-#ifndef WG_TN_RSTRIDE
-#define WG_TN_RSTRIDE 4 // TN: a fragment read every this many MFMA slots
-#endif
-#ifndef WG_TN_DSTRIDE
-#define WG_TN_DSTRIDE 4 // TN: a DMA piece every this many slots ...
-#endif
-#ifndef WG_TN_DOFF
-#define WG_TN_DOFF 2    // ... starting at this slot (>= 1)
-#endif
-#ifndef WG_NN_SPREAD
-#define WG_NN_SPREAD 1  // NN: ring / address bookkeeping and the end-of-half-step synchronisation sit in otherwise empty MFMA gaps (see half_step_nn)
-#endif
-#ifndef WG_TN_SPREAD
-#define WG_TN_SPREAD 1
+#ifndef WG_NN_SYNC_SLOT
+#define WG_NN_SYNC_SLOT 60 // NN: lgkmcnt(0) + counted vmcnt + barrier after this MFMA slot
 #endif
 #ifndef WG_TN_SYNC_SLOT
-#define WG_TN_SYNC_SLOT 56
+#define WG_TN_SYNC_SLOT 56 // staged pipeline: likewise
 #endif
-#ifndef WG_NN_SYNC_SLOT
-#define WG_NN_SYNC_SLOT 60 // NN (WG_NN_SPREAD): lgkmcnt(0) + counted vmcnt + barrier after this MFMA slot (> the last DMA piece's and the last LDS read's slot)
-#endif
-#ifndef WG_F16_NN_SWAP
-#define WG_F16_NN_SWAP 1 // NN A reads: 1 = conflict-free transpose reads + v_permlane16_swap, 0 = direct reads (2-way bank conflicts)
+#ifndef WG_NN_STAGED
+#define WG_NN_STAGED 0  // 1: NN on the staged pipeline (A in two full-stage slots, one barrier per stage): measured slower (8192^3 -0.7 %, 32768^3 -4 %)
 #endif
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
@@ -91,7 +73,6 @@ constexpr int M16_A_RING = 4, M16_B_RING = 3;
 constexpr int M16_BS_BYTES = BN * 64 * 2;              // one full stage of B: 256 rows x 128 bytes = 32 KiB
 constexpr int M16_B_BASE = M16_A_RING * HA_BYTES;      // 64 KiB
 static_assert(M16_B_BASE + M16_B_RING * M16_BS_BYTES == 160 * 1024, "LDS plan");
-static_assert(WG_TN_DSTRIDE >= 2 && WG_TN_DOFF >= 1, "M0 of a group is set one slot before its first piece and after the previous group's last");
 
 __device__ __forceinline__ void m16_set_m0(uint32_t lds_dst) {
     if (WG_ABLATE & 2) return;
@@ -204,24 +185,19 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     };
     auto b_src = [&](uint32_t stage) -> const _Float16 * { return (const _Float16 *)((const char *)(b_base + 64u * stage) - M16_BIAS); };
 
-    // ---- per-lane LDS read offsets ----
-    uint32_t b_off[2]; // [half-step parity within the stage]
+    // ---- per-lane LDS read addresses (bytes from the start of the LDS) for half-step parity 0 / 1 of a stage ----
+    uint32_t vbaseA[2], vbaseB[2];
 #pragma unroll
-    for (int hs = 0; hs < 2; ++hs)
-        b_off[hs] = M16_B_BASE + ((uint32_t)128 * wn + i16) * 128u + (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
-    uint32_t a_off[2], a_off1[2]; // TN: [tb] for half-step parity 0 / 1 of the stage; NN: a_off[0] only
-    if constexpr (TRANS_A) {
-#pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-            const uint32_t rowb = (128u * wm + 8u * aq + 4u * tb + bb) * 128u;
-            a_off[tb] = rowb + (uint32_t)(((kg ^ gq) | ((0 ^ (bb >> 1)) << 2)) * 16);
-            a_off1[tb] = rowb + (uint32_t)(((kg ^ gq) | ((1 ^ (bb >> 1)) << 2)) * 16);
-        }
-    } else {
+    for (int hs = 0; hs < 2; ++hs) {
+        const uint32_t chunk = (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
+        vbaseB[hs] = lds_base + M16_B_BASE + ((uint32_t)128 * wn + i16) * 128u + chunk;
+        // TN: row 8 aq + bb of the even tile of a pair (odd tile: + 4 rows = + 512 bytes), chunk as B
+        if constexpr (TRANS_A) vbaseA[hs] = lds_base + (128u * wm + 8u * aq + bb) * 128u + chunk;
+    }
+    if constexpr (!TRANS_A) {
         // lane row kg reads k-group (kg&2) + ins, 8-byte half (kg&1) of unit i16 of block (kq = 2*kgroup + h, mblk = 4 wm + p)
-        if (WG_F16_NN_SWAP) a_off[0] = (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
-        else a_off[0] = (uint32_t)(kg * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u; // lane row kg reads its own k-group
-        a_off[1] = 0; a_off1[0] = a_off1[1] = 0;
+        vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        vbaseA[1] = vbaseA[0] + HA_BYTES; // the second half-stage of a full stage (staged pipeline only)
     }
 
     floatx4 acc[8][8]; // [t][u]
@@ -235,13 +211,43 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     uintx4 a_r[2][8]; // [register set][M tile]  (bit patterns of 8 halves)
     half8_t b_f[2][8];
 
-    // the fragment-producing operations of one half-stage, in the order the next half-step needs them.
-    // sa = A slot, sb = smem + B slot offset + b_off[parity]
-    constexpr int kOps = TRANS_A ? 16 : (WG_F16_NN_SWAP ? 40 : 24);
-    auto frag_op = [&](const char *sa, const char *sb, int op, int set, int hsn) { // hsn: parity of the half-step being prepared (TN)
-        auto rb = [&](int u) { b_f[set][u] = lds_h8(sb + u * 2048); };
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    using yes = std::true_type;
+    using no = std::false_type;
+    using km1 = std::integral_constant<int, -1>;
+    using km2 = std::integral_constant<int, -2>;
+    using k0 = std::integral_constant<int, 0>;
+    using k4 = std::integral_constant<int, 4>;
+    using k8 = std::integral_constant<int, 8>;
+    using k12 = std::integral_constant<int, 12>;
+    using k16 = std::integral_constant<int, 16>;
+
+    const uint32_t S = K_loc / 64u; // full stages; the launcher guarantees K_loc % 64 == 0 and S >= 3
+    uint32_t st = 0;                // current stage
+
+    // ---- Issue model (measured: profiles/r02_evidence.md 3d). With one wave per SIMD, the 16 cycles of a 16x16x32 MFMA hide up to ~3
+    // single-issue instructions of the same wave; every instruction beyond that in one MFMA-to-MFMA gap costs ~4.8 cycles. Recomputing
+    // ring slots, DMA bases and LDS read addresses at the top of a half-step, behind the waits and the barrier, put ~18 instructions in
+    // two gaps: ~80 of 1190 cycles per half-step. So every such quantity is a RUNNING value, updated in place in a gap of its own after
+    // its last use in the half-step, and the synchronisation sits in an otherwise empty gap near the end (all fragment reads and all
+    // DMA pieces of the half-step are issued by then, so the counts mean what they would at the very end; the MFMAs behind it only
+    // touch registers). `asm volatile("" : "+s"(x))` pins an update to its slot. tools/gap_hist.py lists the fillers per gap.
+    uint32_t va, vb;                                     // VGPRs: where this half-step's A / B fragment reads start
+    const char *ga, *gb, *ga2 = nullptr;                 // SGPR pairs: global bases (less M16_BIAS) of the A / B pieces issued this half-step
+    uint32_t oR = 0, oD = 2u * M16_BS_BYTES;             // B ring (3 stages): byte offset of the slot read / DMA'd this half-step
+    uint32_t rR = 1u << 14, rD = 0;                      // NN, 4 half-stage slots of A: offset of the slot read / DMA'd this half-step
+    uint32_t oA = 0, oAD = 0;                            // staged pipeline, 2 full-stage slots of A: likewise
+    uint32_t la = 0, lb = 0;                             // M0 values of the next group of four pieces
+    const uint64_t a_step = (uint64_t)BKH * g.lda * 2u;  // NN: bytes between two half-stages of A in global memory
+    auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
+
+    // the fragment-producing operations of one half-step, in the order the next half-step consumes them
+    constexpr int kOps = TRANS_A ? 16 : 40;
+    auto frag = [&](int op, int set) {
+        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(vb + u * 2048); };
         if constexpr (TRANS_A) {
-            auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8(sa + (hsn ? a_off1[t & 1] : a_off[t & 1]) + (t >> 1) * 4096)); };
+            auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8_at(va + (t & 1) * 512 + (t >> 1) * 4096)); };
             if (op == 0) ra(0);
             else if (op <= 8) rb(op - 1);
             else ra(op - 8);
@@ -250,7 +256,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             // sw(p, i): lane-row swap of dword i of the pair's two tiles
             auto tr = [&](int p, int i) {
                 const int h = i >> 1, ins = i & 1;
-                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sa + a_off[0] + (2 * ins + h) * 2048 + p * 256));
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at(va + (2 * ins + h) * 2048 + p * 256));
                 a_r[set][2 * p + ins][2 * h] = v[0];
                 a_r[set][2 * p + ins][2 * h + 1] = v[1];
             };
@@ -260,17 +266,6 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 a_r[set][2 * p][i] = r[0];
                 a_r[set][2 * p + 1][i] = r[1];
             };
-            if (!WG_F16_NN_SWAP) { // direct: op = A pair 0 (4 reads), B0..7, A pairs 1..3; read i = 2 h + tb of pair p
-                auto trd = [&](int p, int i) {
-                    const int h = i >> 1, tb = i & 1;
-                    const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sa + a_off[0] + h * 2048 + p * 256 + tb * 8));
-                    a_r[set][2 * p + tb][2 * h] = v[0];
-                    a_r[set][2 * p + tb][2 * h + 1] = v[1];
-                };
-                if (op < 4) trd(0, op);
-                else if (op < 12) rb(op - 4);
-                else trd(1 + ((op - 12) >> 2), (op - 12) & 3);
-            } else
             if (op < 4) tr(0, op);
             else if (op < 8) rb(op - 4);
             else if (op < 12) tr(1, op - 8);
@@ -283,299 +278,140 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             else sw(3, op - 36);
         }
     };
-
-    using c0 = std::integral_constant<int, 0>;
-    using c1 = std::integral_constant<int, 1>;
-    using yes = std::true_type;
-    using no = std::false_type;
-
-    const uint32_t S = K_loc / 64u; // full stages; the launcher guarantees K_loc % 64 == 0 and S >= 3
-    uint32_t st = 0;                // current stage
-    uint32_t bs0 = 0, bs1 = 1, bs2 = 2; // B ring slots of stages st, st+1, st+2 (== st+3 for bs0)
-
-    // One half-step H = 2 st + HS on register set HS: 64 MFMAs, one per slot; the fragment ops of half-step H+1 fill set HS^1.
-    // DMA, NN: the 4 pieces of A(H+4) at slots 8 i + 3 (i < 4), 4 pieces of B at i >= 4 (even H: second half of B(st+2), odd H:
-    // first half of B(st+3)). TN: even H only B; odd H the 8 pieces of the full stage A(st+2) first (its slot held A(st), read
-    // out by now; it must land by the end of the NEXT half-step, so it goes ahead of B in the in-order vmcnt queue), then B:
-    // 12 pieces at slots 4 i + 2. M0 is set once per group of four pieces, two slots ahead.
-    auto half_step = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto wsel) {
-        constexpr int HS = decltype(hs_c)::value;
-        constexpr int WSEL = decltype(wsel)::value; // wave-specific DMA slot shift (WG_NN_STAGGER slots per wave index)
-        constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
-        const uint32_t H = 2u * st + HS;
-        const char *sa;
-        if constexpr (TRANS_A) sa = smem + ((st + HS) & 1u) * M16_BS_BYTES; else sa = smem + ((H + 1u) & 3u) * HA_BYTES;
-        const char *sb = smem + (HS == 0 ? bs0 : bs1) * M16_BS_BYTES + b_off[HS ^ 1];
-        // DMA targets of this half-step
-        const _Float16 *ga = nullptr, *gb = nullptr;
-        uint32_t la = 0, lb = 0;
-        if constexpr (ADMA) {
-            if constexpr (TRANS_A) { ga = a_src(st + 2u); la = lds_a_wave + (st & 1u) * M16_BS_BYTES; }
-            else { ga = a_src(H + 4u); la = lds_a_wave + (H & 3u) * HA_BYTES; }
-        }
-        if constexpr (BDMA) {
-            gb = b_src(st + 2u + HS);
-            lb = lds_b_wave + (HS == 0 ? bs2 : bs0) * M16_BS_BYTES + (HS == 0 ? 4096u : 0u);
-        }
-        static_for<64>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            constexpr int t = j >> 3, u = j & 7;
-            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
-            if constexpr (decltype(has_next)::value) {
-                if constexpr (TRANS_A) {
-                    // one fragment read every WG_TN_RSTRIDE slots
-                    if constexpr ((j % WG_TN_RSTRIDE) == 0 && (j / WG_TN_RSTRIDE) < 16) frag_op(sa, sb, j / WG_TN_RSTRIDE, HS ^ 1, HS ^ 1);
-                } else {
-                    if constexpr (WG_NN_RDENSE) { // one fragment op in every slot from the start: all issued by slot kOps, the rest of the half-step is slack
-                        if constexpr (j < kOps) frag_op(sa, sb, j, HS ^ 1, HS ^ 1);
-                    } else if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag_op(sa, sb, 3 * (j >> 2) + (j & 3), HS ^ 1, HS ^ 1);
-                }
-            }
-            if constexpr (!TRANS_A) {
-                // piece p (0..3: A, 4..7: B) at slot WG_NN_DOFF + WG_NN_DSTRIDE p; M0 one slot before the first piece of each group of four
-                constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF + WG_NN_STAGGER * WSEL;
-                if constexpr (ADMA && j == DO - 1) m16_set_m0(la);
-                if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(lb);
-                if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
-                    constexpr int pi = (j - DO) / DS, q = pi & 3;
-                    if constexpr (pi < 4) { if constexpr (ADMA) m16_dma_imm<1024 * q>(a_voff[q], ga); }
-                    else { if constexpr (BDMA) m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb); }
-                }
-            } else {
-                // piece list of this half-step: [A0..A7 if ADMA] + [B0..B3 if BDMA]; piece n is issued at slot WG_TN_DSTRIDE n + WG_TN_DOFF,
-                // M0 (one per group of four pieces) one slot before the group's first piece
-                constexpr int nA = ADMA ? 8 : 0, nB = BDMA ? 4 : 0;
-                constexpr int DS = WG_TN_DSTRIDE, DO = WG_TN_DOFF;
-                if constexpr (j + 1 >= DO && ((j + 1 - DO) % DS) == 0 && ((j + 1 - DO) / DS) < nA + nB && (((j + 1 - DO) / DS) & 3) == 0) {
-                    constexpr int n = (j + 1 - DO) / DS;
-                    if constexpr (n < nA) m16_set_m0(la + (n >> 2) * 4096); else m16_set_m0(lb);
-                }
-                if constexpr (j >= DO && ((j - DO) % DS) == 0 && ((j - DO) / DS) < nA + nB) {
-                    constexpr int n = (j - DO) / DS;
-                    if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], ga);
-                    else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
-                }
-            }
-#if defined(WG_EXP_NOPS_SPREAD)
-            if constexpr (!TRANS_A && (j == 53 || j == 54 || j == 55 || j == 56 || j == 57 || j == 58 || j == 60 || j == 61)) asm volatile("s_nop 0"); // issue-model probe: one extra slot in each of 8 empty gaps
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#if defined(WG_EXP_NOPS_BOUNDARY)
-        asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0"); // issue-model probe: the same 8 extra slots in the boundary gap
-#endif
+    // fragment op of slot j: TN one read every 3 slots (0..45); NN 3 ops in every 4 slots (0..52: the last read in slot 41, then swaps)
+    auto frag_slot = [&](auto jc, int set) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (TRANS_A) { if constexpr ((j % 3) == 0 && (j / 3) < kOps) frag(j / 3, set); }
+        else { if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag(3 * (j >> 2) + (j & 3), set); }
     };
-    // ---- NN, WG_NN_SPREAD: the same half-step with its bookkeeping spread out ---------------------------------------------------
-    // Measured (profiles/r02_evidence.md 3d): one wave per SIMD hides up to ~3 single-issue instructions in the 16 cycles of a
-    // 16x16x32 MFMA; every instruction beyond that costs ~4.8 cycles. The form above recomputes ring slots, DMA bases and LDS read
-    // addresses at the top of each half-step, right after the waits and the barrier: ~18 instructions in two gaps, ~80 cycles of
-    // 1190 per half-step. Here every quantity is a running value updated IN PLACE, in a gap of its own after its last use:
-    //   rD  A ring offset DMA'd this half-step   (H & 3) << 14          += 16 KiB mod 64 KiB at slot 6   (M0 set at slot 2)
-    //   vb  B read address (VGPR)                 base[parity] + oR      at slot 27 (last B read: slot 25); oR moves on at slot 26 of even H
-    //   ga  global base of A(H+4)                 += 32 k rows           at slot 30 (last A piece: slot 27)
-    //   oD  B ring offset DMA'd this half-step    moves on at slot 38 of even H (M0 set at slot 34)
-    //   va  A read address (VGPR)                 baseA + rR             at slots 47/54 (last A read: slot 41)
-    //   gb  global base of the B stage            += 64 k at slot 61 of even H (last B piece: slot 59)
-    // and lgkmcnt(0) + counted vmcnt + barrier sit after slot WG_NN_SYNC_SLOT: all LDS reads were issued by slot 41, all 8 pieces by
-    // slot 59, so the counts mean what they meant at the end of the half-step; MFMAs 61..63 only touch registers.
-    uint32_t nn_rD = 0, nn_rR = 1u << 14, nn_oR = 0, nn_oD = 2u * M16_BS_BYTES;
-    const char *nn_ga = nullptr, *nn_gb = nullptr;
-    uint32_t nn_lb = 0;
-    uint32_t nn_va = 0, nn_vb = 0, nn_vbaseA = 0, nn_vbaseB0 = 0, nn_vbaseB1 = 0;
-    uint64_t nn_astep = 0;
-    if constexpr (!TRANS_A) {
-        nn_ga = (const char *)a_src(4u); nn_gb = (const char *)b_src(2u);
-        nn_astep = (uint64_t)BKH * g.lda * 2u;
-        nn_vbaseA = lds_base + a_off[0]; nn_vbaseB0 = lds_base + b_off[0]; nn_vbaseB1 = lds_base + b_off[1];
-        nn_va = nn_vbaseA + nn_rR; nn_vb = nn_vbaseB1 + nn_oR;
-    }
-    auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
-    auto frag_nn = [&](int op, int set) {
-        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(nn_vb + u * 2048); };
-        auto tr = [&](int p, int i) {
-            const int h = i >> 1, ins = i & 1;
-            const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at(nn_va + (2 * ins + h) * 2048 + p * 256));
-            a_r[set][2 * p + ins][2 * h] = v[0];
-            a_r[set][2 * p + ins][2 * h + 1] = v[1];
-        };
-        auto sw = [&](int p, int i) {
-            if (WG_ABLATE & 16) return;
-            const uintx2 r = __builtin_amdgcn_permlane16_swap(a_r[set][2 * p][i], a_r[set][2 * p + 1][i], false, false);
-            a_r[set][2 * p][i] = r[0];
-            a_r[set][2 * p + 1][i] = r[1];
-        };
-        if (op < 4) tr(0, op);
-        else if (op < 8) rb(op - 4);
-        else if (op < 12) tr(1, op - 8);
-        else if (op < 16) sw(0, op - 12);
-        else if (op < 20) rb(op - 12);
-        else if (op < 24) tr(2, op - 20);
-        else if (op < 28) sw(1, op - 24);
-        else if (op < 32) tr(3, op - 28);
-        else if (op < 36) sw(2, op - 32);
-        else sw(3, op - 36);
+    // lgkmcnt(0) [+ counted vmcnt + barrier]: all fragment reads of the half-step have returned, at most KEEP pieces still fly, publish
+    auto sync = [&](auto keep_c) {
+        constexpr int KEEP = decltype(keep_c)::value;
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0) (also tells the compiler's wait-count pass that no LDS read is pending across the back-edge)
+        if constexpr (KEEP >= 0) {
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+            q_a = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+            wait_dma_keep<(KEEP >= 0 ? KEEP : 0)>();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+            q_b = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+            if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
+#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
+            q_c = (uint32_t)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xc07f); // the three timestamps have returned: no scalar load is pending during the rest of the half-step
+            q_d = (uint32_t)__builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            {
+                const uint32_t dv = q_b - q_a, db = q_c - q_b;
+                s_vm += dv; s_bar += db; s_probe += 2u * (q_d - q_c); // two round trips of the probe itself
+                m_vm = dv > m_vm ? dv : m_vm; m_bar = db > m_bar ? db : m_bar; ++n_adv;
+            }
+#endif
+        }
     };
-    // sync_c: >= 0: counted wait keeping that many pieces + barrier at WG_NN_SYNC_SLOT; -1: none (the last half-step of the tile)
+
+    // ---- NN (default): A in four half-stage slots. Half-step H = 2 st + HS on register set HS: 64 MFMAs, one per slot; the fragment ops
+    // of half-step H+1 (A slot (H+1) & 3; B stage of H+1) fill set HS^1. DMA: the 4 pieces of A(H+4) -> slot H & 3 at slots DO + DS p
+    // (p < 4), then 4 pieces of B (even H: second half of B(st+2), odd H: first half of B(st+3)); M0 once per group of four, one slot
+    // ahead. Counted wait: a half-step issues its A pieces before its B pieces, and only the A pieces issued two half-steps ago must
+    // have landed: keep WG_NN_KEEP = 16 (20 is valid too: the 4 B pieces behind them are needed one half-step later; no gain measured).
+    //   rD  += 16 KiB mod 64 KiB at slot DO+3 (M0 written at DO-1)     oR  moves on at slot 26 of even H (last B read: slot 25)
+    //   vb  = base[parity] + oR at slot 27                             ga  += 32 k rows after the last A piece
+    //   oD  moves on after the B M0 of even H                           rR, va  at slots 47 / 54 (last A read: slot 41)
+    //   gb  += 64 k after the even half-step's last B piece             st  at slot 56 of odd H
+    // sync_c: >= 0: lgkmcnt(0) + counted wait keeping that many pieces + barrier after slot WG_NN_SYNC_SLOT; -2: nothing
     auto half_step_nn = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto sync_c) {
         constexpr int HS = decltype(hs_c)::value, SYNC = decltype(sync_c)::value;
         constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
-        static_assert(WG_F16_NN_SWAP && !WG_NN_RDENSE && WG_NN_STAGGER == 0, "the spread form implements the shipped read schedule only");
-        static_assert(WG_NN_DOFF + 7 * WG_NN_DSTRIDE < WG_NN_SYNC_SLOT && WG_NN_SYNC_SLOT < 64, "all pieces are issued before the counted wait");
+        constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
+        static_assert(DO >= 1 && DS >= 2 && DO + 7 * DS < WG_NN_SYNC_SLOT && 52 < WG_NN_SYNC_SLOT && WG_NN_SYNC_SLOT < 63, "every piece and fragment op is issued before the counted wait");
         static_for<64>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int t = j >> 3, u = j & 7;
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
-            if constexpr (decltype(has_next)::value) {
-                if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < 40) frag_nn(3 * (j >> 2) + (j & 3), HS ^ 1);
-            }
-            constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
-            if constexpr (ADMA && j == DO - 1) m16_set_m0(lds_a_wave + nn_rD);
-            if constexpr (BDMA && j == DO + 4 * DS - 4) { nn_lb = lds_b_wave + nn_oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(nn_lb)); }
-            if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(nn_lb);
+            if constexpr (decltype(has_next)::value) frag_slot(jc, HS ^ 1);
+            if constexpr (ADMA && j == DO - 1) m16_set_m0(lds_a_wave + rD);
+            if constexpr (BDMA && j == DO + 4 * DS - 4) { lb = lds_b_wave + oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(lb)); }
+            if constexpr (BDMA && j == DO + 4 * DS - 1) m16_set_m0(lb);
             if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
                 constexpr int pi = (j - DO) / DS, q = pi & 3;
-                if constexpr (pi < 4) { if constexpr (ADMA) m16_dma_imm<1024 * q>(a_voff[q], nn_ga); }
-                else { if constexpr (BDMA) m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], nn_gb); }
+                if constexpr (pi < 4) { if constexpr (ADMA) m16_dma_imm<1024 * q>(a_voff[q], ga); }
+                else { if constexpr (BDMA) m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb); }
             }
-            // bookkeeping, each in its own gap after the value's last use in this half-step
-            if constexpr (j == DO + 3) { nn_rD = (nn_rD + 0x4000u) & 0xffffu; asm volatile("" : "+s"(nn_rD)); }
-            if constexpr (j == 26 && HS == 0) { nn_oR = ring3(nn_oR); asm volatile("" : "+s"(nn_oR)); }
-            if constexpr (j == 27) { nn_vb = (HS == 0 ? nn_vbaseB0 : nn_vbaseB1) + nn_oR; asm volatile("" : "+v"(nn_vb)); }
-            if constexpr (j == DO + 3 * DS + 3) { nn_ga += nn_astep; asm volatile("" : "+s"(nn_ga)); }
-            if constexpr (j == DO + 4 * DS + 3 && HS == 0) { nn_oD = ring3(nn_oD); asm volatile("" : "+s"(nn_oD)); }
-            if constexpr (j == 47) { nn_rR = (nn_rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(nn_rR)); }
-            if constexpr (j == 54) { nn_va = nn_vbaseA + nn_rR; asm volatile("" : "+v"(nn_va)); }
+            if constexpr (j == DO + 3) { rD = (rD + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rD)); }
+            if constexpr (j == 26 && HS == 0) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
+            if constexpr (j == 27) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); } // the next half-step reads parity HS
+            if constexpr (j == DO + 3 * DS + 3) { ga += a_step; asm volatile("" : "+s"(ga)); }
+            if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
+            if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
+            if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
             if constexpr (j == 56 && HS == 1) { ++st; asm volatile("" : "+s"(st)); }
-            if constexpr (j == WG_NN_SYNC_SLOT && SYNC >= 0) {
-                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): every fragment read of this half-step has returned
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-                q_a = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-                wait_dma_keep<(SYNC >= 0 ? SYNC : 0)>();
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-                q_b = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-                if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-                q_c = (uint32_t)__builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                q_d = (uint32_t)__builtin_amdgcn_s_memtime();
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                {
-                    const uint32_t dv = q_b - q_a, db = q_c - q_b;
-                    s_vm += dv; s_bar += db; s_probe += 2u * (q_d - q_c);
-                    m_vm = dv > m_vm ? dv : m_vm; m_bar = db > m_bar ? db : m_bar; ++n_adv;
-                }
-#endif
-            }
-            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { nn_gb += 128; asm volatile("" : "+s"(nn_gb)); }
+            if constexpr (j == WG_NN_SYNC_SLOT && SYNC >= -1) sync(sync_c);
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { gb += 128; asm volatile("" : "+s"(gb)); }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // ---- TN, WG_TN_SPREAD: the same idea. Fragment reads every 3 slots (0..45), DMA pieces every 4 (2..46), M0 one slot ahead of each
-    // group of four; running values: oA (A slot read: toggles after the even half-step's last A read), oAD (A slot DMA'd: toggles
-    // after the odd half-step's second M0), oR / oD (B ring, as NN), ga (+64 k after the odd half-step's last A piece), gb (+64 k after
-    // the even half-step's last B piece); lgkmcnt(0) [+ vmcnt(8) + barrier in even half-steps] after slot WG_TN_SYNC_SLOT.
-    uint32_t tn_oA = 0, tn_oAD = 0, tn_la = 0;
-    uint32_t tn_vbaseA0 = 0, tn_vbaseA1 = 0;
-    if constexpr (TRANS_A) {
-        nn_ga = (const char *)a_src(2u); nn_gb = (const char *)b_src(2u);
-        tn_vbaseA0 = lds_base + a_off[0]; tn_vbaseA1 = lds_base + a_off1[0];
-        nn_vbaseB0 = lds_base + b_off[0]; nn_vbaseB1 = lds_base + b_off[1];
-        nn_va = tn_vbaseA1; nn_vb = nn_vbaseB1;
-    }
-    auto frag_tn = [&](int op, int set) {
-        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(nn_vb + u * 2048); };
-        auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8_at(nn_va + (t & 1) * 512 + (t >> 1) * 4096)); };
-        if (op == 0) ra(0);
-        else if (op <= 8) rb(op - 1);
-        else ra(op - 8);
-    };
+
+    // ---- The staged pipeline (TN; NN with -DWG_NN_STAGED=1: measured slower, 32768^3 -4 %, see the evidence file): A lives in two
+    // full-stage slots like B's three, so ONE counted wait + barrier per stage suffices, after slot WG_TN_SYNC_SLOT of the EVEN half-step:
+    // it publishes stage st+1 (read by the odd half-step that follows and the even one after it) and releases the slots of stage st
+    // (refilled from the odd half-step on). There, only the 4 + 4 newest pieces (the two halves of a B stage) may still be in flight --
+    // the full stage of A issued in the odd half-step before must have landed (it goes ahead of B in the in-order vmcnt queue). Even
+    // half-steps issue 4 pieces (second half of B(st+2)), odd ones 12 (A(st+2), then the first half of B(st+3)), one every 4 slots, M0
+    // one slot ahead of each group of four.
+    //   oA toggles after the even half-step's last A read, oAD after the odd half-step's second A M0; oR / oD / gb as above;
+    //   ga [ga2: NN, the stage's second half-stage] += 64 k after the odd half-step's last A piece.
     // sync_c: >= 0: lgkmcnt(0) + counted wait + barrier; -1: lgkmcnt(0) only; -2: nothing (last half-step of the tile)
-    auto half_step_tn = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto sync_c) {
+    auto half_step_s = [&](auto hs_c, auto a_dma, auto b_dma, auto has_next, auto sync_c) {
         constexpr int HS = decltype(hs_c)::value, SYNC = decltype(sync_c)::value;
         constexpr bool ADMA = decltype(a_dma)::value, BDMA = decltype(b_dma)::value;
         constexpr int nA = ADMA ? 8 : 0, nB = BDMA ? 4 : 0;
-        constexpr int DS = 4, DO = 2, RS = 3;
-        static_assert(DO + DS * 11 < WG_TN_SYNC_SLOT && RS * 15 < WG_TN_SYNC_SLOT && WG_TN_SYNC_SLOT < 64, "reads and pieces are issued before the wait");
+        constexpr int DS = 4, DO = TRANS_A ? 2 : 3;       // NN: pieces in the slots without a fragment op
+        constexpr int LASTB = TRANS_A ? 24 : 25;          // slot of the last B fragment read (of the last A read: 45 / 41)
+        constexpr uint32_t A_GROUP = TRANS_A ? 4096u : (uint32_t)HA_BYTES; // LDS distance of the second group of four A pieces
+        static_assert(DO + DS * 11 < WG_TN_SYNC_SLOT && 53 < WG_TN_SYNC_SLOT && WG_TN_SYNC_SLOT < 64, "every piece and fragment op is issued before the wait");
         static_for<64>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int t = j >> 3, u = j & 7;
             acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u], acc[t][u], 0, 0, 0);
-            if constexpr (decltype(has_next)::value) {
-                if constexpr ((j % RS) == 0 && (j / RS) < 16) frag_tn(j / RS, HS ^ 1);
-            }
-            // DMA targets: computed one slot before the M0 write that uses them
-            if constexpr (ADMA && j == 0) { tn_la = lds_a_wave + tn_oAD; asm volatile("" : "+s"(tn_la)); }
-            if constexpr (ADMA && j == 4 * DS) { tn_la += 4096u; asm volatile("" : "+s"(tn_la)); }
-            if constexpr (BDMA && j == DS * nA) { nn_lb = lds_b_wave + nn_oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(nn_lb)); }
+            if constexpr (decltype(has_next)::value) frag_slot(jc, HS ^ 1);
+            // M0 values: computed one slot before the write that uses them
+            if constexpr (ADMA && j == DO - 2) { la = lds_a_wave + oAD; asm volatile("" : "+s"(la)); }
+            if constexpr (ADMA && j == DO + 4 * DS - 2) { la += A_GROUP; asm volatile("" : "+s"(la)); }
+            if constexpr (BDMA && j == DO + DS * nA - 2) { lb = lds_b_wave + oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(lb)); }
             if constexpr (j + 1 >= DO && ((j + 1 - DO) % DS) == 0 && ((j + 1 - DO) / DS) < nA + nB && (((j + 1 - DO) / DS) & 3) == 0) {
                 constexpr int n = (j + 1 - DO) / DS;
-                if constexpr (n < nA) m16_set_m0(tn_la); else m16_set_m0(nn_lb);
+                if constexpr (n < nA) m16_set_m0(la); else m16_set_m0(lb);
             }
             if constexpr (j >= DO && ((j - DO) % DS) == 0 && ((j - DO) / DS) < nA + nB) {
                 constexpr int n = (j - DO) / DS;
-                if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], nn_ga);
-                else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], nn_gb);
+                if constexpr (n < nA) {
+                    if constexpr (TRANS_A) m16_dma_imm<1024 * (n & 3)>(a_voff[n], ga);
+                    else m16_dma_imm<1024 * (n & 3)>(a_voff[n & 3], n < 4 ? ga : ga2);
+                } else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
             }
-            // bookkeeping after each value's last use
-            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { nn_gb += 128; asm volatile("" : "+s"(nn_gb)); }          // even: 4 B pieces at slots 2..14
-            if constexpr (HS == 0 && j == 4) { nn_oD = ring3(nn_oD); asm volatile("" : "+s"(nn_oD)); }                 // even: B M0 written at slot 1
-            if constexpr (HS == 1 && j == 4 * DS + 3) { tn_oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(tn_oAD)); } // odd: second A M0 at slot 17
-            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { nn_ga += 128; asm volatile("" : "+s"(nn_ga)); }          // odd: 8 A pieces at slots 2..30
-            if constexpr (HS == 0 && j == 8 * RS + 1) { nn_oR = ring3(nn_oR); asm volatile("" : "+s"(nn_oR)); }        // last B read at slot 24
-            if constexpr (j == 8 * RS + 4) { nn_vb = (HS == 0 ? nn_vbaseB0 : nn_vbaseB1) + nn_oR; asm volatile("" : "+v"(nn_vb)); }
-            if constexpr (HS == 0 && j == 15 * RS + 2) { tn_oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(tn_oA)); } // last A read at slot 45
-            if constexpr (j == 15 * RS + 3) { nn_va = (HS == 0 ? tn_vbaseA0 : tn_vbaseA1) + tn_oA; asm volatile("" : "+v"(nn_va)); }
-            if constexpr (HS == 1 && j == 52) { ++st; asm volatile("" : "+s"(st)); }
-            if constexpr (j == WG_TN_SYNC_SLOT && SYNC >= -1) {
-                __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-                if constexpr (SYNC >= 0) {
-                    wait_dma_keep<(SYNC >= 0 ? SYNC : 0)>();
-                    if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
-                }
+            if constexpr (HS == 0 && j == DO + (TRANS_A ? 2 : 3)) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }            // even: B M0 written at slot DO - 1
+            if constexpr (HS == 0 && j == DO + DS * 3 + (TRANS_A ? 1 : 4)) { gb += 128; asm volatile("" : "+s"(gb)); }      // even: last B piece at DO + 12
+            if constexpr (HS == 1 && j == DO + 4 * DS + 1) { oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oAD)); }  // odd: second A M0 at DO + 15
+            if constexpr (HS == 1 && j == (TRANS_A ? DO + DS * 7 + 1 : 38)) {                                                // odd: last A piece at DO + 28
+                if constexpr (TRANS_A) ga += 128; else ga += 2u * a_step;
+                asm volatile("" : "+s"(ga));
             }
+            if constexpr (!TRANS_A && HS == 1 && j == 41) { ga2 += 2u * a_step; asm volatile("" : "+s"(ga2)); }
+            if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
+            if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }                             // the next half-step reads parity HS
+            if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
+            if constexpr (j == 49) { va = vbaseA[HS] + oA; asm volatile("" : "+v"(va)); }
+            if constexpr (HS == 1 && j == 53) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (j == WG_TN_SYNC_SLOT && SYNC >= -1) sync(sync_c);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    // end of a half-step: all fragment reads done (also tells the compiler's wait-count pass that no LDS read is pending
-    // across the loop back-edge -- otherwise it opens each iteration with lgkmcnt(0) AFTER new reads were issued), at most
-    // KEEP DMA pieces (those issued in this and the previous half-step) still in flight, publish.
-    auto advance = [&](auto keep_c) {
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-        q_a = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-        wait_dma_keep<decltype(keep_c)::value>();
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-        q_b = (uint32_t)__builtin_amdgcn_s_memtime();
-#endif
-        if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier();
-#if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
-        q_c = (uint32_t)__builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xc07f); // the three timestamps have returned: no scalar load is pending during the next half-step
-        q_d = (uint32_t)__builtin_amdgcn_s_memtime();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        {
-            const uint32_t dv = q_b - q_a, db = q_c - q_b;
-            s_vm += dv; s_bar += db; s_probe += 2u * (q_d - q_c); // two round trips of the probe itself sit inside the half-step that follows
-            m_vm = dv > m_vm ? dv : m_vm; m_bar = db > m_bar ? db : m_bar; ++n_adv;
-        }
-#endif
-    };
-    auto next_stage = [&]() {
-        ++st;
-        const uint32_t t0 = bs0;
-        bs0 = bs1; bs1 = bs2; bs2 = t0;
-    };
-    using k16 = std::integral_constant<int, 16>;
-    using k12 = std::integral_constant<int, 12>;
-    using k4 = std::integral_constant<int, 4>;
-    using k0 = std::integral_constant<int, 0>;
 
-    // prologue (once per tile): A(0..3), B(0), B(1) and the first half of B(2). Only what the first two half-steps read --
-    // A(0), B(0), A(1), issued first -- must have landed before the first barrier; the rest is issued in the order the steady
-    // state's counted waits expect it to retire: A(2), B(1) (needed after half-step 0), A(3), B(2) first half (after half-step 1).
+    // prologue (once per tile): A(0..3) [TN: stages 0, 1 of A], B(0), B(1) and the first half of B(2). Only what the first two
+    // half-steps read -- A(0), B(0), A(1), issued first -- must have landed before the first barrier; the rest is issued in the order
+    // the steady state's counted waits expect it to retire: A(2), B(1) (needed after half-step 0), A(3), B(2) first half (after half-step 1).
     auto pro_a = [&](int hh) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -608,10 +444,18 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     }
     wait_dma_keep<20>();
     __syncthreads();
+    va = vbaseA[0]; vb = vbaseB[0]; // half-step 0's own fragments: first half of stage 0
 #pragma unroll
-    for (int op = 0; op < kOps; ++op) frag_op(smem, smem + b_off[0], op, 0, 0);
+    for (int op = 0; op < kOps; ++op) frag(op, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing pending on entry to the loop either
     if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier(); // every wave has read A(0): half-step 0 may overwrite its slot with A(4)
+    // running values as half-step 0 expects them: it reads the second half of stage 0 and issues A(4) / stage 2 pieces
+    vb = vbaseB[1];
+    gb = (const char *)b_src(2u);
+    constexpr bool STAGED = TRANS_A || WG_NN_STAGED;
+    if constexpr (TRANS_A) { va = vbaseA[1]; ga = (const char *)a_src(2u); }
+    else if constexpr (STAGED) { va = vbaseA[1]; ga = (const char *)a_src(4u); ga2 = (const char *)a_src(5u); }
+    else { va = vbaseA[0] + rR; ga = (const char *)a_src(4u); }
     __builtin_amdgcn_sched_barrier(0);
     WG_TRACE_POINT(1);
 #if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
@@ -622,84 +466,29 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // No parity branches (two accumulator-modifying arms merging in a loop make the register allocator shuffle all 256
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
     // because they issue fewer (then no) DMA pieces.
-    using k8 = std::integral_constant<int, 8>;
-    using W0 = std::integral_constant<int, 0>;
-    if constexpr (!TRANS_A) {
-        auto steady = [&](auto wsel) {
-            while (st + 3 < S) { // st advances in next_stage()
-                // Counted wait: a half-step issues its 4 A pieces before its 4 B pieces, and B is needed one half-step later than A
-                // (A(H+4) is read during H+3, the B halves issued in H during H+4): at the end of a half-step only the A pieces issued two
-                // half-steps ago must have landed, their 4 B pieces may still fly -- keep 20, not 16 (WG_NN_KEEP; loads retire in order).
-                half_step(c0{}, yes{}, yes{}, yes{}, wsel); advance(std::integral_constant<int, WG_NN_KEEP>{});
-                half_step(c1{}, yes{}, yes{}, yes{}, wsel); advance(std::integral_constant<int, WG_NN_KEEP>{});
-                next_stage();
-            }
-        };
-        if constexpr (WG_NN_SPREAD) {
-            using km1 = std::integral_constant<int, -1>;
-            const uint32_t s_end = S - 3u;
-            while (st < s_end) {
-                half_step_nn(c0{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{});
-                half_step_nn(c1{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{}); // ++st inside (slot 56)
-            }
-            half_step_nn(c0{}, yes{}, yes{}, yes{}, k16{}); // stage S-3: A(2S-2), second half of B(S-1)
-            half_step_nn(c1{}, yes{}, no{}, yes{}, k12{});  //            A(2S-1)
-            half_step_nn(c0{}, no{}, no{}, yes{}, k4{});    // stage S-2
-            half_step_nn(c1{}, no{}, no{}, yes{}, k0{});
-            half_step_nn(c0{}, no{}, no{}, yes{}, k0{});    // stage S-1
-            half_step_nn(c1{}, no{}, no{}, no{}, km1{});
-        } else {
-        if constexpr (WG_NN_STAGGER != 0) { // one copy of the steady-state loop per wave: its DMA pieces sit in that wave's own slots
-            if (wave == 0) steady(std::integral_constant<int, 0>{});
-            else if (wave == 1) steady(std::integral_constant<int, 1>{});
-            else if (wave == 2) steady(std::integral_constant<int, 2>{});
-            else steady(std::integral_constant<int, 3>{});
-        } else steady(W0{});
-        half_step(c0{}, yes{}, yes{}, yes{}, W0{}); advance(k16{}); // stage S-3: A(2S-2), second half of B(S-1)
-        half_step(c1{}, yes{}, no{}, yes{}, W0{});  advance(k12{}); //            A(2S-1)
-        next_stage();
-        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k4{});    // stage S-2
-        half_step(c1{}, no{}, no{}, yes{}, W0{}); advance(k0{});
-        next_stage();
-        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k0{});    // stage S-1
-        half_step(c1{}, no{}, no{}, no{}, W0{});
+    const uint32_t s_end = S - 3u;
+    if constexpr (STAGED) {
+        while (st < s_end) {
+            half_step_s(c0{}, no{}, yes{}, yes{}, k8{});
+            half_step_s(c1{}, yes{}, yes{}, yes{}, km1{}); // ++st inside
         }
+        half_step_s(c0{}, no{}, yes{}, yes{}, k8{});   // stage S-3: second half of B(S-1)
+        half_step_s(c1{}, yes{}, no{}, yes{}, km1{});  //            A(S-1)
+        half_step_s(c0{}, no{}, no{}, yes{}, k0{});    // stage S-2: A(S-1), B(S-1) must have landed
+        half_step_s(c1{}, no{}, no{}, yes{}, km1{});
+        half_step_s(c0{}, no{}, no{}, yes{}, km1{});   // stage S-1
+        half_step_s(c1{}, no{}, no{}, no{}, km2{});
     } else {
-        // TN: both operands live in full-stage slots, so ONE wait + barrier per stage suffices, at the end of the EVEN half-step:
-        // it publishes stage st+1 (read by the odd half-step that follows and by the even one after it) and releases the slots of
-        // stage st (refilled from the odd half-step on). There, only the 4 + 4 newest pieces (the two halves of a B stage) may
-        // still be in flight -- the full stage of A issued in the odd half-step before must have landed. Odd half-steps end
-        // without any synchronisation (lgkmcnt(0) only: see advance()).
-        auto soft = [&]() { __builtin_amdgcn_s_waitcnt(0xc07f); };
-        if constexpr (WG_TN_SPREAD) {
-            using km1 = std::integral_constant<int, -1>;
-            using km2 = std::integral_constant<int, -2>;
-            const uint32_t s_end = S - 3u;
-            while (st < s_end) {
-                half_step_tn(c0{}, no{}, yes{}, yes{}, k8{});
-                half_step_tn(c1{}, yes{}, yes{}, yes{}, km1{}); // ++st inside
-            }
-            half_step_tn(c0{}, no{}, yes{}, yes{}, k8{});   // stage S-3: second half of B(S-1)
-            half_step_tn(c1{}, yes{}, no{}, yes{}, km1{});  //            A(S-1)
-            half_step_tn(c0{}, no{}, no{}, yes{}, k0{});    // stage S-2: A(S-1), B(S-1) must have landed
-            half_step_tn(c1{}, no{}, no{}, yes{}, km1{});
-            half_step_tn(c0{}, no{}, no{}, yes{}, km1{});   // stage S-1
-            half_step_tn(c1{}, no{}, no{}, no{}, km2{});
-        } else {
-        while (st + 3 < S) {
-            half_step(c0{}, no{}, yes{}, yes{}, W0{});  advance(k8{});
-            half_step(c1{}, yes{}, yes{}, yes{}, W0{}); soft();
-            next_stage();
+        while (st < s_end) {
+            half_step_nn(c0{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{});
+            half_step_nn(c1{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{}); // ++st inside
         }
-        half_step(c0{}, no{}, yes{}, yes{}, W0{}); advance(k8{});   // stage S-3: second half of B(S-1)
-        half_step(c1{}, yes{}, no{}, yes{}, W0{}); soft();          //            A(S-1)
-        next_stage();
-        half_step(c0{}, no{}, no{}, yes{}, W0{}); advance(k0{});    // stage S-2: A(S-1), B(S-1) must have landed
-        half_step(c1{}, no{}, no{}, yes{}, W0{}); soft();
-        next_stage();
-        half_step(c0{}, no{}, no{}, yes{}, W0{}); soft();           // stage S-1
-        half_step(c1{}, no{}, no{}, no{}, W0{});
-        }
+        half_step_nn(c0{}, yes{}, yes{}, yes{}, k16{}); // stage S-3: A(2S-2), second half of B(S-1)
+        half_step_nn(c1{}, yes{}, no{}, yes{}, k12{});  //            A(2S-1)
+        half_step_nn(c0{}, no{}, no{}, yes{}, k4{});    // stage S-2
+        half_step_nn(c1{}, no{}, no{}, yes{}, k0{});
+        half_step_nn(c0{}, no{}, no{}, yes{}, k0{});    // stage S-1
+        half_step_nn(c1{}, no{}, no{}, no{}, km2{});
     }
     WG_TRACE_POINT(2);
 #if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
@@ -778,7 +567,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     if (threadIdx.x == 0 && g.nsplit == 1 && g.part) {
         uint64_t *o = (uint64_t *)g.part + (uint64_t)bid * 8u;
         for (int i = 0; i < 5; ++i) o[i] = tr_t[i];
-        o[5] = __builtin_amdgcn_s_getreg((3 << 0) | (0 << 6) | (31 << 11)); // HW_ID
+        o[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); // HW_REG_HW_ID (4): wave [3:0] simd [5:4] pipe [7:6] cu [11:8] sh [12] se [15:13]
         o[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // XCC_ID (gfx940+)
     }
 #if WG_F16_TRACE >= 2
