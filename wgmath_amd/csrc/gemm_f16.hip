@@ -56,6 +56,10 @@ namespace {
 #ifndef WG_TN_SYNC_SLOT
 #define WG_TN_SYNC_SLOT 56 // staged pipeline: likewise
 #endif
+#ifndef WG_F16_UNPEELED
+#define WG_F16_UNPEELED 1 // 1: ONE loop over all S stages; for the last three the DMA cursors stay parked on the last stage (their pieces land in
+                          //    LDS slots nobody reads any more). 0: the last three stages peeled into six half-steps that issue fewer / no pieces
+#endif
 #ifndef WG_NN_STAGED
 #define WG_NN_STAGED 0  // 1: NN on the staged pipeline (A in two full-stage slots, one barrier per stage): measured slower (8192^3 -0.7 %, 32768^3 -4 %)
 #endif
@@ -239,7 +243,12 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     uint32_t rR = 1u << 14, rD = 0;                      // NN, 4 half-stage slots of A: offset of the slot read / DMA'd this half-step
     uint32_t oA = 0, oAD = 0;                            // staged pipeline, 2 full-stage slots of A: likewise
     uint32_t la = 0, lb = 0;                             // M0 values of the next group of four pieces
-    const uint64_t a_step = (uint64_t)BKH * g.lda * 2u;  // NN: bytes between two half-stages of A in global memory
+    const uint64_t a_step = (uint64_t)BKH * g.lda * 2u;  // NN: bytes between two half-stages of A in global memory (< 4 GiB: launcher)
+    // Unpeeled loop: how far the cursors move after this stage's pieces -- 0 once the next piece would lie past the last stage
+    // (recomputed when st advances). a_inc0 / a_inc1: ga after the even / odd half-step's A pieces; b_inc: gb after the even half-step's.
+    constexpr bool STAGED = TRANS_A || WG_NN_STAGED;
+    const uint32_t a_full = TRANS_A ? 128u : (uint32_t)a_step * (STAGED ? 2u : 1u);
+    uint32_t a_inc0 = 0, a_inc1 = 0, b_inc = 0;
     auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
 
     // the fragment-producing operations of one half-step, in the order the next half-step consumes them
@@ -342,13 +351,22 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             if constexpr (j == DO + 3) { rD = (rD + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rD)); }
             if constexpr (j == 26 && HS == 0) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
             if constexpr (j == 27) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); } // the next half-step reads parity HS
-            if constexpr (j == DO + 3 * DS + 3) { ga += a_step; asm volatile("" : "+s"(ga)); }
+            if constexpr (j == DO + 3 * DS + 3) {
+                if constexpr (WG_F16_UNPEELED) ga += (HS == 0 ? a_inc0 : a_inc1); else ga += a_step;
+                asm volatile("" : "+s"(ga));
+            }
             if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
             if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
             if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
-            if constexpr (j == 56 && HS == 1) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (j == 55 && HS == 1) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (WG_F16_UNPEELED && HS == 1 && j == 56) { a_inc0 = st + 3u <= S ? a_full : 0u; asm volatile("" : "+s"(a_inc0)); } // A(2 st + 5) exists
+            if constexpr (WG_F16_UNPEELED && HS == 1 && j == 57) { a_inc1 = st + 4u <= S ? a_full : 0u; asm volatile("" : "+s"(a_inc1)); } // A(2 st + 6) exists
+            if constexpr (WG_F16_UNPEELED && HS == 1 && j == 58) { b_inc = st + 4u <= S ? 128u : 0u; asm volatile("" : "+s"(b_inc)); }     // B(st + 3) exists
             if constexpr (j == WG_NN_SYNC_SLOT && SYNC >= -1) sync(sync_c);
-            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { gb += 128; asm volatile("" : "+s"(gb)); }
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) {
+                if constexpr (WG_F16_UNPEELED) gb += b_inc; else gb += 128;
+                asm volatile("" : "+s"(gb));
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -392,18 +410,26 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 } else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
             }
             if constexpr (HS == 0 && j == DO + (TRANS_A ? 2 : 3)) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }            // even: B M0 written at slot DO - 1
-            if constexpr (HS == 0 && j == DO + DS * 3 + (TRANS_A ? 1 : 4)) { gb += 128; asm volatile("" : "+s"(gb)); }      // even: last B piece at DO + 12
+            if constexpr (HS == 0 && j == DO + DS * 3 + (TRANS_A ? 1 : 4)) {                                                // even: last B piece at DO + 12
+                if constexpr (WG_F16_UNPEELED) gb += b_inc; else gb += 128;
+                asm volatile("" : "+s"(gb));
+            }
             if constexpr (HS == 1 && j == DO + 4 * DS + 1) { oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oAD)); }  // odd: second A M0 at DO + 15
             if constexpr (HS == 1 && j == (TRANS_A ? DO + DS * 7 + 1 : 38)) {                                                // odd: last A piece at DO + 28
-                if constexpr (TRANS_A) ga += 128; else ga += 2u * a_step;
+                if constexpr (WG_F16_UNPEELED) ga += a_inc1; else if constexpr (TRANS_A) ga += 128; else ga += 2u * a_step;
                 asm volatile("" : "+s"(ga));
             }
-            if constexpr (!TRANS_A && HS == 1 && j == 41) { ga2 += 2u * a_step; asm volatile("" : "+s"(ga2)); }
+            if constexpr (!TRANS_A && HS == 1 && j == 41) {
+                if constexpr (WG_F16_UNPEELED) ga2 += a_inc1; else ga2 += 2u * a_step;
+                asm volatile("" : "+s"(ga2));
+            }
             if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
             if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }                             // the next half-step reads parity HS
             if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
             if constexpr (j == 49) { va = vbaseA[HS] + oA; asm volatile("" : "+v"(va)); }
-            if constexpr (HS == 1 && j == 53) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (HS == 1 && j == 52) { ++st; asm volatile("" : "+s"(st)); }
+            if constexpr (WG_F16_UNPEELED && HS == 1 && j == 53) { a_inc1 = st + 4u <= S ? a_full : 0u; asm volatile("" : "+s"(a_inc1)); } // A(st + 3) exists
+            if constexpr (WG_F16_UNPEELED && HS == 1 && j == 54) { b_inc = st + 4u <= S ? 128u : 0u; asm volatile("" : "+s"(b_inc)); }    // B(st + 3) exists
             if constexpr (j == WG_TN_SYNC_SLOT && SYNC >= -1) sync(sync_c);
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -452,7 +478,6 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // running values as half-step 0 expects them: it reads the second half of stage 0 and issues A(4) / stage 2 pieces
     vb = vbaseB[1];
     gb = (const char *)b_src(2u);
-    constexpr bool STAGED = TRANS_A || WG_NN_STAGED;
     if constexpr (TRANS_A) { va = vbaseA[1]; ga = (const char *)a_src(2u); }
     else if constexpr (STAGED) { va = vbaseA[1]; ga = (const char *)a_src(4u); ga2 = (const char *)a_src(5u); }
     else { va = vbaseA[0] + rR; ga = (const char *)a_src(4u); }
@@ -467,7 +492,27 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
     // because they issue fewer (then no) DMA pieces.
     const uint32_t s_end = S - 3u;
-    if constexpr (STAGED) {
+    if constexpr (WG_F16_UNPEELED) {
+        // The steady-state body for every stage: the pieces of the last three stages re-read the last stage (3 x 64 KiB of L2 hits per
+        // tile) into LDS slots nobody reads any more -- by the same invariants that free those slots in the steady state -- so the
+        // counted waits mean the same all the way. No accumulator ever crosses from the loop into differently allocated straight-line
+        // code: the peeled form cost 450-600 v_accvgpr moves per tile there (outside a loop every MFMA result is a fresh value,
+        // nothing ties it to its accumulator's register, all 256 AGPRs are taken, and the allocator rotates accumulators through
+        // VGPRs). The last half-step's fragment reads are dead too. Keep this a `while`: as a do-while the allocator splits the
+        // accumulators inside the loop. The workgroup must not end with pieces in flight: see the vmcnt(0) at every exit.
+        a_inc0 = S >= 3u ? a_full : 0u; a_inc1 = S >= 4u ? a_full : 0u; b_inc = S >= 4u ? 128u : 0u;
+        if constexpr (STAGED) {
+            while (st < S) {
+                half_step_s(c0{}, no{}, yes{}, yes{}, k8{});
+                half_step_s(c1{}, yes{}, yes{}, yes{}, km1{}); // ++st inside
+            }
+        } else {
+            while (st < S) {
+                half_step_nn(c0{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{});
+                half_step_nn(c1{}, yes{}, yes{}, yes{}, std::integral_constant<int, WG_NN_KEEP>{}); // ++st inside
+            }
+        }
+    } else if constexpr (STAGED) {
         while (st < s_end) {
             half_step_s(c0{}, no{}, yes{}, yes{}, k8{});
             half_step_s(c1{}, yes{}, yes{}, yes{}, km1{}); // ++st inside
@@ -512,6 +557,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
     if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M)
@@ -529,6 +575,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
 #pragma unroll
@@ -560,6 +607,9 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
         }
     }
+#ifndef WG_F16_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this tile (parked DMA pieces, stores) is in flight when the workgroup ends
+#endif
 #ifdef WG_F16_TRACE
     WG_TRACE_POINT(3);                       // all stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -751,7 +801,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // the 16x16x32 kernel stages B in full stages of 64 k and peels its last three stages: every split (the last one may be
         // shorter) must be a multiple of 64 k and >= 192 k
         const uint32_t last_k = K - (nsplit - 1) * g.k_per_split;
-        if (WG_F16_M16 && g.k_per_split % 64u == 0 && last_k % 64u == 0 && last_k >= 192u && (nsplit == 1 || g.k_per_split >= 192u)) {
+        const bool a_step_fits = trans || (uint64_t)g.lda * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
+        if (WG_F16_M16 && a_step_fits && g.k_per_split % 64u == 0 && last_k % 64u == 0 && last_k >= 192u && (nsplit == 1 || g.k_per_split >= 192u)) {
 #ifdef WG_F16_TRACE
             uint64_t *trace = nullptr;
             if (nsplit == 1) {
