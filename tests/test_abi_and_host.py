@@ -2,6 +2,7 @@
 device, and the host-side mirror reproduces the reference's view arithmetic (wgcore tensor.rs / shapes.rs)."""
 import ctypes
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -187,6 +188,34 @@ def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):
         assert body.count("global_load_lds_dwordx4") >= min_dma
         loop = body[body.index("Inner Loop Header"):]
         assert "scratch_" not in loop[:loop.index("s_cbranch_scc1")], f"{name}: register spills inside the main loop"
+
+
+@pytest.mark.parametrize("which", ["ILb0", "ILb1"])  # NN, TN
+def test_f16_gemm_main_loop_issue_budget(which):
+    """The shipped f16 Gemm kernel is scheduled against a measured issue model (profiles/r02_evidence.md 3d): one wave per SIMD hides
+    about three single-issue instructions behind a 16x16x32 MFMA, each further one in the same gap costs ~4.8 cycles; and against a
+    register allocator that, outside a loop, rotates the 256 accumulators through VGPRs. Neither is visible in the source, so the
+    compiled code is checked: ONE loop that holds every MFMA of the kernel (no peeled stages), at most 3 other instructions in any
+    MFMA-to-MFMA gap, no accumulator moves and no scratch accesses inside it."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gap_hist
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "wgmath_amd", "csrc", "gemm_f16.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+                        "-ffp-contract=on", "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out],
+                       check=True, capture_output=True)
+        r = gap_hist.analyse(open(out).read(), which)
+    assert r["loops"] == 1 and r["loop_mfma"] == 128 and r["mfma_total"] == 128, (r["loops"], r["loop_mfma"], r["mfma_total"])
+    assert r["loop_acc_moves"] == 0 and r["loop_scratch"] == 0, (r["loop_acc_moves"], r["loop_scratch"])
+    over = [(i, g) for i, g in enumerate(r["gaps"]) if len(g) > 3]
+    assert not over, f"gaps with more than 3 fillers: {over[:4]}"
 
 
 def test_multi_gpu_entry_points_reject_null_handles_without_a_device():

@@ -1,29 +1,48 @@
 #!/usr/bin/env python3
-"""Filler instructions per MFMA gap in the steady-state loop of an f16 kernel (from hipcc -S output).
-usage: tools/gap_hist.py file.s [ILb0|ILb1]   (NN | TN)
-One wave per SIMD hides ~3 single-issue instructions behind a 16x16x32 MFMA; gaps with more pay ~4.8 cycles each (r02_evidence 3d)."""
+"""Filler instructions per MFMA-to-MFMA gap in the main loop of an f16 kernel (from `hipcc -S --cuda-device-only` output).
+usage: tools/gap_hist.py file.s [ILb0|ILb1]   (NN | TN instance of gemm_f16_m16_kernel)
+One wave per SIMD hides ~3 single-issue instructions behind a 16x16x32 MFMA; every further one in the same gap costs ~4.8 cycles
+(profiles/r02_evidence.md 3d). tests/test_abi_and_host.py::test_f16_gemm_main_loop_issue_budget pins the shipped kernel to that budget."""
+import re
 import sys
 from collections import Counter
-L = open(sys.argv[1]).read().split('\n')
-which = sys.argv[2] if len(sys.argv) > 2 else 'ILb0'
-start = [i for i, l in enumerate(L) if l.startswith('_ZN') and 'gemm_f16_m16_kernel' + which in l][0]
-end = [i for i, l in enumerate(L) if i > start and 's_endpgm' in l][0]
-K = L[start:end]
-print('spills:', sum('Folded' in l for l in K), ' scratch:', sum('scratch_' in l for l in K))
-hs = [i for i, l in enumerate(K) if 'Loop Header' in l][0]
-lbl = K[hs].split(':')[0]
-be = [i for i, l in enumerate(K) if i > hs and 's_cbranch' in l and lbl in l][0]
-body = [l.strip() for l in K[hs + 1:be + 1] if l.strip() and not l.strip().startswith(';') and not l.strip().startswith('.')]
-print(len(body), 'instructions in the steady loop;', sum(1 for l in body if l.startswith('v_mfma')), 'MFMAs')
-gaps, cur = [], []
-for l in body:
-    if l.startswith('v_mfma'):
-        gaps.append(cur); cur = []
-    else:
-        cur.append(l.split()[0])
-gaps.append(cur)
-gaps[0] = gaps[-1] + gaps[0]  # the gap across the back-edge
-gaps.pop()
-print('fillers per gap histogram:', sorted(Counter(len(g) for g in gaps).items()), ' excess over 3:', sum(max(0, len(g) - 3) for g in gaps))
-for i, g in enumerate(gaps):
-    print(i, len(g), ' '.join(g))
+
+
+def kernel_text(asm: str, which: str, kernel: str = "gemm_f16_m16_kernel") -> str:
+    """The lines of one kernel instance: from its label to .Lfunc_end (a kernel has several s_endpgm)."""
+    m = re.search(r"^(_ZN\S*" + kernel + which + r"\S*):.*?^\.Lfunc_end", asm, flags=re.S | re.M)
+    if not m:
+        raise ValueError(f"{kernel}{which} not found")
+    return m.group(0)
+
+
+def analyse(asm: str, which: str = "ILb0", kernel: str = "gemm_f16_m16_kernel") -> dict:
+    K = kernel_text(asm, which, kernel).split("\n")
+    headers = [i for i, l in enumerate(K) if "Loop Header" in l]
+    out = {"loops": len(headers), "mfma_total": sum("v_mfma" in l for l in K), "spills": sum("Folded" in l for l in K),
+           "acc_moves_total": sum(("v_accvgpr_mov" in l) or ("v_accvgpr_write" in l and not l.rstrip().endswith(", 0")) for l in K)}
+    hs = headers[0]
+    lbl = K[hs].split(":")[0]
+    be = [i for i, l in enumerate(K) if i > hs and "s_cbranch" in l and lbl in l][0]
+    body = [l.strip() for l in K[hs + 1:be + 1] if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
+    gaps, cur = [], []
+    for l in body:
+        if l.startswith("v_mfma"):
+            gaps.append(cur)
+            cur = []
+        else:
+            cur.append(l.split()[0])
+    gaps[0] = cur + gaps[0]  # the gap across the back-edge
+    out.update(loop_instructions=len(body), loop_mfma=len(gaps), gaps=gaps,
+               loop_acc_moves=sum(x.startswith("v_accvgpr") for g in gaps for x in g), loop_scratch=sum(x.startswith("scratch_") for g in gaps for x in g),
+               excess=sum(max(0, len(g) - 3) for g in gaps))
+    return out
+
+
+if __name__ == "__main__":
+    r = analyse(open(sys.argv[1]).read(), sys.argv[2] if len(sys.argv) > 2 else "ILb0")
+    print(f"kernel: {r['loops']} loop(s), {r['mfma_total']} MFMAs in all, {r['spills']} spill instructions, {r['acc_moves_total']} accumulator moves (v_accvgpr_mov / non-zero write)")
+    print(f"main loop: {r['loop_instructions']} instructions, {r['loop_mfma']} MFMAs, {r['loop_acc_moves']} accumulator moves, {r['loop_scratch']} scratch accesses")
+    print("fillers per gap histogram:", sorted(Counter(len(g) for g in r["gaps"]).items()), " excess over 3:", r["excess"])
+    for i, g in enumerate(r["gaps"]):
+        print(i, len(g), " ".join(g))
