@@ -56,10 +56,17 @@ for k in np.unique(key):
 if gaps:
     gaps = np.array(gaps)
     print(f"  gap: end of a workgroup -> start of the next on the same CU: mean {gaps.mean():.2f} us  min {gaps.min():.2f}  max {gaps.max():.2f}  (n={len(gaps)}, {len(np.unique(key))} CUs)")
+loop_us = ts[:, 2] - ts[:, 1]
+print("  per XCD: tiles, mean / min / max loop us, last tile end us:")
+for x in np.unique(xcc):
+    m = xcc == x
+    print(f"    xcd {x}: {m.sum():5d} tiles  {loop_us[m].mean():8.2f} {loop_us[m].min():8.2f} {loop_us[m].max():8.2f}   end {ts[m, 4].max():10.1f}")
+ends = np.array([ts[key == k, 4].max() for k in np.unique(key)])
+print(f"  last tile end per CU: min {ends.min():.1f}  mean {ends.mean():.1f}  max {ends.max():.1f} us  -> idle at the end, mean over CUs: {ends.max() - ends.mean():.1f} us ({100 * (ends.max() - ends.mean()) / ends.max():.2f} %)")
 starts = np.sort(ts[:, 0])
 print("  start times of the first 8 and of workgroups 256..263:", np.round(starts[:8], 2), np.round(starts[256:264], 2) if len(starts) > 264 else "")
 
-if fine is not None:
+if fine is not None and fine[:, :, 0].sum() > 0:
     loop, vm, bar, probe, mvm, mbar, nadv = (fine[:, :, i] for i in range(7))
     n = nadv.mean()
     hs = K // 32                      # half-steps per tile; each 64 MFMAs per wave = 1024 cycles at 16 cycles / MFMA

@@ -21,9 +21,15 @@ def analyse(asm: str, which: str = "ILb0", kernel: str = "gemm_f16_m16_kernel") 
     headers = [i for i, l in enumerate(K) if "Loop Header" in l]
     out = {"loops": len(headers), "mfma_total": sum("v_mfma" in l for l in K), "spills": sum("Folded" in l for l in K),
            "acc_moves_total": sum(("v_accvgpr_mov" in l) or ("v_accvgpr_write" in l and not l.rstrip().endswith(", 0")) for l in K)}
-    hs = headers[0]
-    lbl = K[hs].split(":")[0]
-    be = [i for i, l in enumerate(K) if i > hs and "s_cbranch" in l and lbl in l][0]
+    best = None  # the loop that holds the most MFMAs
+    for h in headers:
+        lbl = K[h].split(":")[0]
+        ends = [i for i, l in enumerate(K) if i > h and "s_cbranch" in l and l.split()[-1] == lbl]
+        if ends:
+            n = sum("v_mfma" in l for l in K[h:ends[-1]])
+            if best is None or n > best[2]:
+                best = (h, ends[-1], n)
+    hs, be = best[0], best[1]
     body = [l.strip() for l in K[hs + 1:be + 1] if l.strip() and not l.strip().startswith(";") and not l.strip().startswith(".")]
     gaps, cur = [], []
     for l in body:

@@ -629,10 +629,50 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #endif
 }
 
+// Dynamic tile scheduler. Hardware deals workgroup ids round-robin to the 8 XCDs, i.e. every XCD gets the same NUMBER of tiles -- and
+// the XCDs of one chip do not run at the same speed under the power cap (measured per-tile times differ by up to 10 % between XCDs,
+// which XCD is slow differs from box to box): at 32768^3 the fast XCDs idle for the last 3.5 % of the kernel. So the launch carries
+// 25 % more workgroups than tiles and a workgroup TAKES its tile: from the bottom of its own XCD's queue (the same tile, in the same
+// order, the static id -> tile map would have given that XCD: XCD x's t-th tile is id 8 t + x), and once that queue is empty from the TOP
+// of the queue with the most tiles left (the tiles the victim would have reached last; consecutive steals are neighbours, so the
+// thieves share panels through their own L2). One 64-bit word per XCD holds both ends -- low half: taken from the bottom, high half:
+// taken from the top -- so one atomic add claims a tile exactly when low + high < the queue's length. Workgroups that find every queue
+// empty exit. Returns the id to run as, or ~0u.
+static __device__ uint32_t m16_acquire_tile(const GemmArgs &g) {
+    const uint32_t x = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u; // HW_REG_XCC_ID[3:0]: the XCD this workgroup runs on
+    const uint32_t q = g.sched_tiles / 8u, r = g.sched_tiles % 8u;
+    auto len = [&](uint32_t v) { return q + (v < r ? 1u : 0u); };
+    unsigned long long old = atomicAdd(&g.sched[16u * x], 1ull);
+    uint32_t lo = (uint32_t)old, hi = (uint32_t)(old >> 32);
+    if (lo + hi < len(x)) return 8u * lo + x;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        uint32_t best = 0, victim = 8;
+        for (uint32_t v = 0; v < 8u; ++v) {
+            if (v == x) continue;
+            const unsigned long long w = __hip_atomic_load(&g.sched[16u * v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t taken = (uint32_t)w + (uint32_t)(w >> 32), n = len(v);
+            if (taken < n && n - taken > best) { best = n - taken; victim = v; }
+        }
+        if (victim == 8u) return ~0u;
+        old = atomicAdd(&g.sched[16u * victim], 1ull << 32);
+        lo = (uint32_t)old; hi = (uint32_t)(old >> 32);
+        if (lo + hi < len(victim)) return 8u * (len(victim) - 1u - hi) + victim;
+    }
+    return ~0u;
+}
+
 template <bool TRANS_A>
 __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
-    m16_tile<TRANS_A>(g, blockIdx.x, smem);
+    uint32_t bid = blockIdx.x;
+    if (g.sched) { // workgroup-uniform
+        if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t *>(smem) = m16_acquire_tile(g);
+        __syncthreads();
+        bid = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(smem));
+        __syncthreads(); // everyone has read the word before the tile's first DMA piece may land on it
+        if (bid == ~0u) return;
+    }
+    m16_tile<TRANS_A>(g, bid, smem);
 }
 
 #ifndef WG_F16_PERSIST
@@ -721,6 +761,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
     g.tile_base = 0; g.tail_tiles = 0;
+    g.sched = nullptr; g.sched_tiles = 0;
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
@@ -812,6 +853,25 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 g.trace_tiles = (uint32_t)(tiles * nmats);
             }
 #endif
+            // the launch of `ntiles` whole tiles (ids 0 .. ntiles - 1). From WG_F16_SCHED_ROUNDS rounds of the chip on, the workgroups
+            // take their tiles from the per-XCD queues (m16_acquire_tile) and the launch carries a quarter more of them than tiles.
+#ifndef WG_F16_SCHED_ROUNDS
+#define WG_F16_SCHED_ROUNDS 8
+#endif
+            auto launch_tiles = [&](GemmArgs gm, uint32_t ntiles) -> int {
+                uint32_t nwg = ntiles;
+                static const int sched_env = [] { const char *e = getenv("WG_F16_SCHED"); return e ? atoi(e) : -1; }(); // 0 / 1 force, default: by size
+                const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)(WG_F16_SCHED_ROUNDS * cus));
+                if (dyn) {
+                    if (!ctx->tile_queues) WG_HIP_TRY(hipMalloc((void **)&ctx->tile_queues, 8 * 128));
+                    WG_HIP_TRY(hipMemsetAsync(ctx->tile_queues, 0, 8 * 128, ctx->stream));
+                    gm.sched = ctx->tile_queues; gm.sched_tiles = ntiles;
+                    nwg = (ntiles + ntiles / 4u + 7u) & ~7u;
+                }
+                if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
+                else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
+                return WG_OK;
+            };
             // tail split: full rounds as they are, the few tiles of a nearly empty last round cut along K over the idle CUs
             uint32_t tail = 0, tail_split = 1, tail_kps = K;
 #ifndef WG_F16_TAIL_SPLIT
@@ -835,9 +895,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 void *ws = nullptr;
                 if (int rc = wg_ctx_workspace(ctx, (size_t)tail_split * tail * 65536u * sizeof(float), &ws)) return rc;
                 const uint32_t full = (uint32_t)tiles - tail;
-                GemmArgs gm = g; // the full rounds
-                if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(full, 1), dim3(256), 0, ctx->stream, gm);
-                else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(full, 1), dim3(256), 0, ctx->stream, gm);
+                if (int rc = launch_tiles(g, full)) return rc; // the full rounds
                 GemmArgs gt = g; // the tail tiles, cut along K
                 gt.tile_base = full; gt.tail_tiles = tail; gt.nsplit = tail_split; gt.k_per_split = tail_kps; gt.part = (float *)ws;
                 if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(tail, tail_split), dim3(256), 0, ctx->stream, gt);
@@ -853,8 +911,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 else hipLaunchKernelGGL((gemm_f16_m16p_kernel<false>), pg, dim3(256), 0, ctx->stream, g, (uint32_t)tiles);
             } else
 #endif
-            if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), grid, dim3(256), 0, ctx->stream, g);
-            else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), grid, dim3(256), 0, ctx->stream, g);
+            if (int rc = launch_tiles(g, (uint32_t)tiles)) return rc;
 #ifdef WG_F16_TRACE
             if (trace) {
                 WG_HIP_TRY(hipStreamSynchronize(ctx->stream));

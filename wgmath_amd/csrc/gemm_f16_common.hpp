@@ -42,6 +42,9 @@ struct GemmArgs {
     // "tail split" launches of the 16x16x32 kernel: tile id = tile_base + blockIdx.x; with tail_tiles > 0 the workgroup (tile, split)
     // writes its f32 partial tile to part[(split * tail_tiles + blockIdx.x) * 65536 + col_local * 256 + row_local]
     uint32_t tile_base, tail_tiles;
+    // dynamic tile scheduler of the 16x16x32 kernel (nullptr: tile = blockIdx.x): 8 queue words, one per XCD, 128 bytes apart;
+    // sched_tiles tiles are dealt out (gemm_f16.hip: m16_acquire_tile)
+    unsigned long long *sched; uint32_t sched_tiles;
 #ifdef WG_F16_TRACE
     uint32_t trace_tiles; // timing experiment: records in `part` (gemm_f16.hip)
 #endif

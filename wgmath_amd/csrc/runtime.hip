@@ -141,6 +141,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     if (ctx->pad_workspace) (void)hipFree(ctx->pad_workspace);
     for (void *p : ctx->retired_scratch) (void)hipFree(p);
     if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->tile_queues) (void)hipFree(ctx->tile_queues);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;

@@ -25,6 +25,7 @@ struct wg_ctx {
     size_t pad_workspace_bytes = 0;
     int compute_units = 0;
     unsigned *flags = nullptr;           // a few zeroed device words (arrival counters of fused epilogues), created on first use
+    unsigned long long *tile_queues = nullptr; // f16 Gemm tile scheduler: 8 per-XCD queue words, 128 bytes apart (gemm_f16.hip), created on first use
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
 };
