@@ -528,6 +528,9 @@ WORKLOADS = {
     # short K on many tiles: the per-tile prologue / pipeline drain / epilogue weigh most here (A/B shapes of tools/ab2.sh)
     "gemm_f16_8192x8192x512": lambda: GemmWorkload("gemm_f16_8192x8192x512", 8192, 8192, 512, "f16"),
     "gemm_f16_8192x8192x2048": lambda: GemmWorkload("gemm_f16_8192x8192x2048", 8192, 8192, 2048, "f16"),
+    # 16 and 12 rounds of 256 tiles: where the dynamic tile scheduler starts to pay (WG_F16_SCHED=0|1 forces)
+    "gemm_f16_16384x16384x8192": lambda: GemmWorkload("gemm_f16_16384x16384x8192", 16384, 16384, 8192, "f16"),
+    "gemm_f16_16384x12288x8192": lambda: GemmWorkload("gemm_f16_16384x12288x8192", 16384, 12288, 8192, "f16"),
     "gemmtr_f32_4096": lambda: GemmWorkload("gemmtr_f32_4096", 4096, 4096, 4096, "f32", trans=True),
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
