@@ -632,7 +632,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 // Dynamic tile scheduler. Hardware deals workgroup ids round-robin to the 8 XCDs, i.e. every XCD gets the same NUMBER of tiles -- and
 // the XCDs of one chip do not run at the same speed under the power cap (measured per-tile times differ by up to 10 % between XCDs,
 // which XCD is slow differs from box to box): at 32768^3 the fast XCDs idle for the last 3.5 % of the kernel. So the launch carries
-// 25 % more workgroups than tiles and a workgroup TAKES its tile: from the bottom of its own XCD's queue (the same tile, in the same
+// 12.5 % more workgroups than tiles and a workgroup TAKES its tile: from the bottom of its own XCD's queue (the same tile, in the same
 // order, the static id -> tile map would have given that XCD: XCD x's t-th tile is id 8 t + x), and once that queue is empty from the TOP
 // of the queue with the most tiles left (the tiles the victim would have reached last; consecutive steals are neighbours, so the
 // thieves share panels through their own L2). One 64-bit word per XCD holds both ends -- low half: taken from the bottom, high half:
@@ -854,7 +854,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             }
 #endif
             // the launch of `ntiles` whole tiles (ids 0 .. ntiles - 1). From WG_F16_SCHED_ROUNDS rounds of the chip on, the workgroups
-            // take their tiles from the per-XCD queues (m16_acquire_tile) and the launch carries a quarter more of them than tiles.
+            // take their tiles from the per-XCD queues (m16_acquire_tile) and the launch carries an eighth more of them than tiles.
             // Stealing whole tiles evens the XCDs out to about half a tile per CU, and taking a tile costs ~1.5 us (an atomic and two
             // barriers ahead of the prologue): measured neutral at 8-16 rounds, -0.9 % at 4, +3.4 % at 64 (32768^3).
 #ifndef WG_F16_SCHED_ROUNDS
@@ -868,7 +868,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                     if (!ctx->tile_queues) WG_HIP_TRY(hipMalloc((void **)&ctx->tile_queues, 8 * 128));
                     WG_HIP_TRY(hipMemsetAsync(ctx->tile_queues, 0, 8 * 128, ctx->stream));
                     gm.sched = ctx->tile_queues; gm.sched_tiles = ntiles;
-                    nwg = (ntiles + ntiles / 4u + 7u) & ~7u;
+                    nwg = (ntiles + ntiles / 8u + 7u) & ~7u; // a fast XCD takes ~5 % more than its share; the surplus workgroups exit in ~2 us each
                 }
                 if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
                 else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
