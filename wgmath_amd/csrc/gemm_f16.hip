@@ -489,8 +489,9 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #endif
 
     // No parity branches (two accumulator-modifying arms merging in a loop make the register allocator shuffle all 256
-    // accumulators): stages are processed as pairs of half-steps in straight-line code; the last three stages are peeled
-    // because they issue fewer (then no) DMA pieces.
+    // accumulators): stages are processed as pairs of half-steps in straight-line code. The last three stages would issue fewer
+    // (then no) DMA pieces and wait with smaller counts; -DWG_F16_UNPEELED=0 peels them into six half-steps (the form measured
+    // against in profiles/r02_evidence.md 3e).
     const uint32_t s_end = S - 3u;
     if constexpr (WG_F16_UNPEELED) {
         // The steady-state body for every stage: the pieces of the last three stages re-read the last stage (3 x 64 KiB of L2 hits per
@@ -839,7 +840,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifndef WG_F16_M16
 #define WG_F16_M16 1 // 1 = 16x16x32 MFMA kernel, 0 = 32x32x16 MFMA kernel
 #endif
-        // the 16x16x32 kernel stages B in full stages of 64 k and peels its last three stages: every split (the last one may be
+        // the 16x16x32 kernel stages B in full stages of 64 k and its DMA stream runs three stages ahead: every split (the last one may be
         // shorter) must be a multiple of 64 k and >= 192 k
         const uint32_t last_k = K - (nsplit - 1) * g.k_per_split;
         const bool a_step_fits = trans || (uint64_t)g.lda * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
