@@ -403,6 +403,42 @@ def test_gemm_f16_shapes(gpu, f16_tile, M, K, N, mats, tr):
 
 
 @pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N", [(1280, 1024, 768), (2056, 448, 1000), (256, 192, 4096)])
+def test_gemm_f16_tile_scheduler_is_bit_identical(gpu, M, K, N, tr):
+    """The cross-XCD tile scheduler (workgroups take their tile from per-XCD queues; on by default from 16 rounds of tiles) changes
+    WHERE a tile runs, never what it computes: forced on a few-tile shape (ragged edges included) it must reproduce the static
+    launch bit for bit -- and every tile must have been written exactly once (NaN pre-fill)."""
+    import os
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + K + N + int(tr))
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    m1 = upload(gpu, (K, M, 1) if tr else (M, K, 1), a, np.float16)
+    m2 = upload(gpu, (K, N, 1), b, np.float16)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    res = {}
+    old = {k: os.environ.pop(k, None) for k in ("WG_F16_SCHED", "WG_F16_TILE")}
+    try:
+        os.environ["WG_F16_TILE"] = "256"
+        for sched in ("0", "1", "1"):
+            os.environ["WG_F16_SCHED"] = sched
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            res.setdefault(sched, []).append(out.read(gpu.device()).view(np.uint16).copy())
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+    assert not np.isnan(res["0"][0].view(np.float16)).any()
+    for r in res["1"]:
+        assert np.array_equal(r, res["0"][0])
+    A = wo.view(a, wo.Shape(K, M, 1) if tr else wo.Shape(M, K, 1))[:, :, 0]
+    f16_check(res["1"][0].view(np.float16).reshape(N, M).T, (A.T if tr else A).astype(np.float64), wo.view(b, wo.Shape(K, N, 1))[:, :, 0].astype(np.float64), K, "scheduler")
+
+
+@pytest.mark.parametrize("tr", [False, True])
 def test_gemm_f16_identity_asymmetric(gpu, f16_tile, tr):
     """A = I, asymmetric small-integer B (exact in f16): any row/column permutation or transposition in the tr-read,
     the interleaved tile map or the epilogue shows up as a bit mismatch."""

@@ -863,7 +863,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #endif
             auto launch_tiles = [&](GemmArgs gm, uint32_t ntiles) -> int {
                 uint32_t nwg = ntiles;
-                static const int sched_env = [] { const char *e = getenv("WG_F16_SCHED"); return e ? atoi(e) : -1; }(); // 0 / 1 force, default: by size
+                const char *sched_s = getenv("WG_F16_SCHED"); // 0 / 1 force (read per call: tests), default: by size
+                const int sched_env = sched_s ? atoi(sched_s) : -1;
                 const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)(WG_F16_SCHED_ROUNDS * cus));
                 if (dyn) {
                     if (!ctx->tile_queues) WG_HIP_TRY(hipMalloc((void **)&ctx->tile_queues, 8 * 128));
