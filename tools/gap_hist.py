@@ -23,7 +23,10 @@ def analyse(asm: str, which: str = "ILb0", kernel: str = "gemm_f16_m16_kernel") 
            "acc_moves_total": sum(("v_accvgpr_mov" in l) or ("v_accvgpr_write" in l and not l.rstrip().endswith(", 0")) for l in K)}
     best = None  # the loop that holds the most MFMAs
     for h in headers:
-        lbl = K[h].split(":")[0]
+        hl = h
+        while not K[hl].startswith(".LBB"):  # nested loops: the label sits on the first line of a multi-line loop comment
+            hl -= 1
+        lbl = K[hl].split(":")[0]
         ends = [i for i, l in enumerate(K) if i > h and "s_cbranch" in l and l.split()[-1] == lbl]
         if ends:
             n = sum("v_mfma" in l for l in K[h:ends[-1]])
