@@ -525,6 +525,7 @@ WORKLOADS = {
     "gemm_f16_ts_131072x1024x8192": lambda: GemmWorkload("gemm_f16_ts_131072x1024x8192", 131072, 1024, 8192, "f16"),
     "gemm_f32_ts_65536x512x4096": lambda: GemmWorkload("gemm_f32_ts_65536x512x4096", 65536, 512, 4096, "f32"),
     "gemmtr_f16_8192": lambda: GemmWorkload("gemmtr_f16_8192", 8192, 8192, 8192, "f16", trans=True),
+    "gemmtr_f16_32768": lambda: GemmWorkload("gemmtr_f16_32768", 32768, 32768, 32768, "f16", trans=True),
     # short K on many tiles: the per-tile prologue / pipeline drain / epilogue weigh most here (A/B shapes of tools/ab2.sh)
     "gemm_f16_8192x8192x512": lambda: GemmWorkload("gemm_f16_8192x8192x512", 8192, 8192, 512, "f16"),
     "gemm_f16_8192x8192x2048": lambda: GemmWorkload("gemm_f16_8192x8192x2048", 8192, 8192, 2048, "f16"),
