@@ -867,7 +867,10 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 const int sched_env = sched_s ? atoi(sched_s) : -1;
                 const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)(WG_F16_SCHED_ROUNDS * cus));
                 if (dyn) {
-                    if (!ctx->tile_queues) WG_HIP_TRY(hipMalloc((void **)&ctx->tile_queues, 8 * 128));
+                    if (!ctx->tile_queues) {
+                        if (ctx->recording) return wg_set_error(WG_ERR_WORKSPACE, "Gemm: the tile queues are needed while recording: run the call once outside the recording first");
+                        WG_HIP_TRY(hipMalloc((void **)&ctx->tile_queues, 8 * 128));
+                    }
                     WG_HIP_TRY(hipMemsetAsync(ctx->tile_queues, 0, 8 * 128, ctx->stream));
                     gm.sched = ctx->tile_queues; gm.sched_tiles = ntiles;
                     nwg = (ntiles + ntiles / 8u + 7u) & ~7u; // a fast XCD takes ~5 % more than its share; the surplus workgroups exit in ~2 us each
