@@ -219,6 +219,53 @@ def test_f16_gemm_main_loop_issue_budget(which):
     assert not over, f"gaps with more than 3 fillers: {over[:4]}"
 
 
+@pytest.mark.parametrize("ntiles,surplus_eighths", [(4096, 1), (4099, 1), (17, 8), (8, 1), (16384, 1)])
+def test_tile_scheduler_protocol_claims_every_tile_once(ntiles, surplus_eighths):
+    """Model of gemm_f16.hip's m16_acquire_tile (the f16 Gemm's cross-XCD tile scheduler): one 64-bit word per XCD, low half = tiles
+    taken from the bottom by the XCD's own workgroups, high half = tiles stolen from the top; a claim is valid iff low + high (before
+    the add) < the queue's length. Whatever the interleaving of workgroups and however unevenly the XCDs progress, every tile id must
+    be handed out exactly once and surplus workgroups must come back empty-handed."""
+    rng = np.random.default_rng(ntiles * 31 + surplus_eighths)
+    q, r = divmod(ntiles, 8)
+    length = [q + (1 if v < r else 0) for v in range(8)]
+    words = [[0, 0] for _ in range(8)]  # [low, high]
+    nwg = (ntiles + ntiles * surplus_eighths // 8 + 7) & ~7
+
+    def acquire(x):
+        lo, hi = words[x]
+        words[x][0] += 1  # atomicAdd(word[x], 1) returns the old value
+        if lo + hi < length[x]:
+            return 8 * lo + x
+        for _ in range(64):
+            best, victim = 0, None
+            for v in range(8):
+                if v == x:
+                    continue
+                taken = words[v][0] + words[v][1]
+                if taken < length[v] and length[v] - taken > best:
+                    best, victim = length[v] - taken, v
+            if victim is None:
+                return None
+            lo, hi = words[victim]
+            words[victim][1] += 1  # atomicAdd(word[victim], 1 << 32)
+            if lo + hi < length[victim]:
+                return 8 * (length[victim] - 1 - hi) + victim
+        return None
+
+    # hardware deals workgroup ids round-robin to the XCDs; each XCD works through its list at its own (random, skewed) pace
+    speed = rng.random(8) + 0.2
+    pending = [list(range(x, nwg, 8)) for x in range(8)]
+    got = []
+    while any(pending):
+        live = [x for x in range(8) if pending[x]]
+        x = live[int(rng.choice(len(live), p=speed[live] / speed[live].sum()))]
+        pending[x].pop(0)
+        t = acquire(x)
+        if t is not None:
+            got.append(t)
+    assert sorted(got) == list(range(ntiles)), (len(got), len(set(got)))
+
+
 def test_multi_gpu_entry_points_reject_null_handles_without_a_device():
     """The multi-GPU section of the ABI (wg_comm_*, wg_gemm_sharded, ...) validates its handles before touching HIP / RCCL: callable on a
     machine without a GPU, status + message instead of a crash. (Compute paths need a GPU: tests/cpp/comm_tests.cpp, test_gpu_dist2.py.)"""
