@@ -117,7 +117,8 @@ int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out);
  * heuristics then plan for `cu_count` CUs. */
 int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out);
 int wg_ctx_destroy(wg_ctx *ctx);
-/* queue.submit(..) + device.poll(PollType::wait()) (tensor.rs:304-312): block until all enqueued work is done. */
+/* queue.submit(..) + device.poll(PollType::wait()) (tensor.rs:304-312): block until all enqueued work is done. Also reports (once) an
+ * error a kernel of this context raised asynchronously -- a sharded Gemm whose peer never delivered (WG_ERR_HIP); so does wg_buf_read. */
 int wg_ctx_sync(wg_ctx *ctx);
 int wg_ctx_device(const wg_ctx *ctx);
 void *wg_ctx_stream(const wg_ctx *ctx); /* the hipStream_t, for interop */
@@ -141,6 +142,23 @@ int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in
  * 1-thread kernel enqueued just before). Stand-in for a collective library's copy kernel when studying queue interleaving.
  */
 int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_ticks);
+
+/*
+ * Kernel-selection knobs of a context (tests and experiments; production code never needs them). The launchers choose between
+ * kernel families by shape; a knob forces one choice for every later call on this context. Defaults come from the environment
+ * ONCE, when the context is created (WG_F16_TILE, WG_F16_SCHED, WG_F32_SKINNY, WG_F32_PANELS, WG_F16_BALANCE): the dispatch path itself never
+ * reads the environment.
+ */
+typedef enum wg_tuning {
+    WG_TUNE_F16_TILE = 0,    /* 0 = by shape (default), 128 / 256 = force the 128 x 128 / 256 x 256 f16 kernel family */
+    WG_TUNE_F16_SCHED = 1,   /* -1 = by size (default), 0 / 1 = static tile map / tile queues with stealing across XCDs */
+    WG_TUNE_F32_SKINNY = 2,  /* -1 = by shape, 0 / 1 = never / whenever applicable: the few-column f32 kernel */
+    WG_TUNE_F32_PANELS = 3,  /* -1 = by estimate, 0 / 1: 64-column panels of the few-column kernel for small square f32 products */
+    WG_TUNE_F16_BALANCE = 4, /* -1 = by size (default), 0 / 1: calibrated per-XCD shares (K-prefix units) for f16 products of few rounds */
+    WG_TUNE_COUNT_ = 5
+} wg_tuning;
+int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);
+int wg_ctx_get_tuning(const wg_ctx *ctx, wg_tuning key, int *value);
 
 /* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. An operator that would
  * have to grow a scratch region inside a recording returns WG_ERR_WORKSPACE. Scratch regions that a live command buffer may
@@ -324,7 +342,7 @@ int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collec
 /* Pipelined steps (WG_GATHER_PEER_STAGED): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
  * exchange nothing of its own call can hide -- to the next call on the communicator, which runs it right after enqueueing its first Gemm
  * (wg_comm_join / _flush / _barrier / a call in another mode complete it too). `out` is then complete in stream order only after that. */
-int wg_comm_set_pipelined(wg_comm *comm, int on);
+int wg_comm_set_pipelined(wg_comm *comm, int on); /* (a step with ONE panel always completes in its call: deferring it would let a rank run two steps ahead of a peer) */
 int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */
 int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined into the context: all ranks' earlier exchanges are complete */
 /* One process per GPU: export a device buffer / map a peer's (hipIpcGetMemHandle / hipIpcOpenMemHandle; needs the dmabuf IPC mode,
@@ -334,7 +352,11 @@ int wg_buf_ipc_open(wg_ctx *ctx, const void *handle, wg_buf **out);
 /* WG_GATHER_PEER_STAGED: make the communicator's staging cubes (>= 2 * sizeof(T) * M * N bytes: two steps in flight) and its flag array
  * exist and return them (owned by the communicator) so that the caller can export them (wg_buf_ipc_export) to the peers; then register
  * every peer's pair as addressable from here (wg_buf_ipc_open, or the buffers themselves when the ranks share a process). Growing the
- * cubes invalidates the registration on every rank. */
+ * cubes invalidates the registration on every rank. EVERY RANK MUST RESERVE THE SAME SIZE: the two step-parity halves sit at offsets 0
+ * and bytes / 2 whatever the shape of a step (wg_comm_set_peer_stages checks it), which is what lets M / N / panel_cols change between
+ * steps without a barrier. A receiver waits WG_COMM_TIMEOUT_MS (environment, read when the communicator is created; default 30000) for
+ * a peer's slot; after that the panel's columns of `out` are filled with NaN bit patterns and the error is returned by the next
+ * wg_ctx_sync / wg_buf_read on the context, wg_comm_flush / _join / _barrier, or wg_gemm_sharded call -- never a hung queue, never stale data. */
 int wg_comm_stage_reserve(wg_comm *comm, size_t bytes, wg_buf **stage, wg_buf **flags);
 int wg_comm_set_peer_stages(wg_comm *comm, wg_buf *const *peer_stage, wg_buf *const *peer_flags);
 /* Relayout of a gathered GpuCube [M/P, np, P] (dense) into the (M x np) column-major view `out`: out[g*M/P + i, j] = cube[i, j, g].

@@ -237,3 +237,76 @@ def test_two_ranks_one_gpu_staged_peer_copies():
         p.join(60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+# --------------------------------------------------------------------------------------------------------
+# Staged engine, operands that CHANGE every step and shapes that change between steps, pipelined, no host synchronisation anywhere:
+# a slot overwritten while the peer still reads it (single-panel steps used to run two steps ahead), or a parity half that moved with
+# the shape, shows up as wrong rows in one of the per-step outputs. Every step has its own B and its own output tensor.
+# --------------------------------------------------------------------------------------------------------
+def _staged_steps_worker(rank, world, port, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+        import torch  # noqa: F401  first: one HIP runtime per process
+        import torch.distributed as dist
+        import wgmath_amd as wg
+        from wgmath_amd.sharded import Comm, GatherMode
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        M, K = 1024, 512
+        Mg = M // world
+        # (N, panel_cols): one-panel steps back to back (the case that ran ahead), several panels, and a change of shape in between
+        plan = [(1536, 1536), (1536, 1536), (1536, 1536), (1536, 1536), (1024, 512), (1024, 512), (1536, 1536), (1536, 512), (512, 512), (512, 512)]
+        gpu = wg.GpuInstance.new(0)
+        dev, S = gpu.device(), wg.BufferUsages
+        U = S.STORAGE | S.COPY_SRC | S.COPY_DST
+        rng = np.random.default_rng(123)
+        A = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        ta = wg.TensorBuilder.matrix(Mg, K, U).build_init(dev, np.ascontiguousarray(A[rank * Mg:(rank + 1) * Mg].reshape(-1, order="F")))
+        Bs, tbs, tcs = [], [], []
+        for (N, _) in plan:
+            B = (rng.random((K, N), dtype=np.float32) * 2 - 1).astype(np.float16)
+            Bs.append(B)
+            tbs.append(wg.TensorBuilder.matrix(K, N, U).build_init(dev, np.ascontiguousarray(B.reshape(-1, order="F"))))
+            tcs.append(wg.TensorBuilder.matrix(M, N, U).build_init(dev, np.full(M * N, np.nan, np.float16)))
+        comm = Comm(gpu, world, rank, None)
+        pairs = [None] * world
+        dist.all_gather_object(pairs, comm.stage_export(2 * M * 1536 * 2))
+        comm.set_peer_stages(pairs)
+        dist.barrier()
+        comm.set_pipelined(True)
+        for (N, pc), tb, tc in zip(plan, tbs, tcs):
+            comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, pc)
+        comm.join()
+        bad = []
+        A64 = A.astype(np.float64)
+        for s, ((N, pc), B, tc) in enumerate(zip(plan, Bs, tcs)):
+            got = tc.read(dev).reshape(M, N, order="F").astype(np.float64)
+            B64 = B.astype(np.float64)
+            truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
+            tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+            if not bool((np.abs(got - truth) <= tol).all()):
+                bad.append(s)
+        comm.flush()
+        dist.barrier()
+        q.put((rank, not bad, f"steps with wrong rows: {bad}"))
+        comm.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(e)))
+
+
+def test_two_ranks_one_gpu_staged_steps_with_changing_operands_and_shapes():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_staged_steps_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

@@ -358,17 +358,12 @@ F16_SHAPES = [
 
 
 @pytest.fixture(params=["auto", "128", "256"])
-def f16_tile(request):
-    """The f16 launcher picks between the 256 x 256 kernels and the 128 x 128 kernel (mid-size outputs) by shape; WG_F16_TILE forces
-    one family (read per call), so that every shape below exercises both."""
-    import os
-    old = os.environ.pop("WG_F16_TILE", None)
-    if request.param != "auto":
-        os.environ["WG_F16_TILE"] = request.param
+def f16_tile(request, gpu):
+    """The f16 launcher picks between the 256 x 256 kernels and the 128 x 128 kernel (mid-size outputs) by shape; the context's
+    WG_TUNE_F16_TILE knob (wg_ctx_set_tuning) forces one family, so that every shape below exercises both."""
+    old = gpu.set_tuning("f16_tile", 0 if request.param == "auto" else int(request.param))
     yield request.param
-    os.environ.pop("WG_F16_TILE", None)
-    if old is not None:
-        os.environ["WG_F16_TILE"] = old
+    gpu.set_tuning("f16_tile", old)
 
 
 def f16_check(got, a64, b64, K, what):
@@ -408,7 +403,6 @@ def test_gemm_f16_tile_scheduler_is_bit_identical(gpu, M, K, N, tr):
     """The cross-XCD tile scheduler (workgroups take their tile from per-XCD queues; on by default from 16 rounds of tiles) changes
     WHERE a tile runs, never what it computes: forced on a few-tile shape (ragged edges included) it must reproduce the static
     launch bit for bit -- and every tile must have been written exactly once (NaN pre-fill)."""
-    import os
     wg, wo = _wg(), _wo()
     rng = np.random.default_rng(M + K + N + int(tr))
     a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
@@ -418,19 +412,17 @@ def test_gemm_f16_tile_scheduler_is_bit_identical(gpu, M, K, N, tr):
     m2 = upload(gpu, (K, N, 1), b, np.float16)
     gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
     res = {}
-    old = {k: os.environ.pop(k, None) for k in ("WG_F16_SCHED", "WG_F16_TILE")}
+    old = {k: gpu.get_tuning(k) for k in ("f16_sched", "f16_tile")}
     try:
-        os.environ["WG_F16_TILE"] = "256"
+        gpu.set_tuning("f16_tile", 256)
         for sched in ("0", "1", "1"):
-            os.environ["WG_F16_SCHED"] = sched
+            gpu.set_tuning("f16_sched", int(sched))
             out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
             run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
             res.setdefault(sched, []).append(out.read(gpu.device()).view(np.uint16).copy())
     finally:
         for k, v in old.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
+            gpu.set_tuning(k, v)
     assert not np.isnan(res["0"][0].view(np.float16)).any()
     for r in res["1"]:
         assert np.array_equal(r, res["0"][0])
@@ -811,15 +803,14 @@ def test_gemm_f32_fuzz_few_columns(gpu, seed):
 @pytest.mark.parametrize("seed", range(8))
 def test_gemm_f32_fuzz_column_panels(gpu, seed):
     """64-column panels of the few-column kernel (what small squares run on), forced for ragged sizes, batches, both variants, alpha / beta."""
-    import os
     rng = np.random.default_rng(6000 + seed)
     M, N = 4 * int(rng.integers(32, 300)), 4 * int(rng.integers(17, 200))
     K = int(rng.choice([128, 132, 516, 1024]))
-    os.environ["WG_F32_PANELS"] = "1"
+    old = gpu.set_tuning("f32_panels", 1)
     try:
         _gemm_f32_fuzz_case(gpu, rng, seed, M, N, K, int(rng.choice([1, 1, 2])), bool(rng.integers(0, 2)))
     finally:
-        os.environ.pop("WG_F32_PANELS", None)
+        gpu.set_tuning("f32_panels", old)
 
 
 @pytest.mark.parametrize("seed", range(10))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""f16 Gemm on outputs of one to a few rounds of 256 x 256 tiles: the launcher's choice, both tile families forced (WG_F16_TILE), and hipBLASLt
+"""f16 Gemm on outputs of one to a few rounds of 256 x 256 tiles: the launcher's choice, both tile families forced (wg_ctx_set_tuning), and hipBLASLt
 through torch.matmul when torch is importable. usage: python tools/midsize_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,8 +13,7 @@ from bench import device_random
 gpu = wg.GpuInstance.new(0); dev, shapes = gpu.device(), wg.ViewShapeBuffers(); S = wg.BufferUsages
 gemm = wg.Gemm.from_device(dev)
 def ours(M, N, K, tile):
-    os.environ.pop("WG_F16_TILE", None)
-    if tile: os.environ["WG_F16_TILE"] = tile
+    gpu.set_tuning("f16_tile", int(tile) if tile else 0)
     a = device_random(wg, gpu, (M, K), np.float16, 1); b = device_random(wg, gpu, (K, N), np.float16, 2)
     c = wg.TensorBuilder.matrix(M, N, S.STORAGE).build(dev, np.float16)
     enc = dev.create_command_encoder(); p = enc.compute_pass("t", None)
@@ -22,7 +21,7 @@ def ours(M, N, K, tile):
     gpu.sync(); n = max(20, int(0.3 / (2.0 * M * N * K / 1.2e15))); t0 = time.perf_counter()
     for _ in range(n): gemm.dispatch(dev, shapes, p, c, a, b)
     gpu.sync(); dt = (time.perf_counter() - t0) / n
-    os.environ.pop("WG_F16_TILE", None)
+    gpu.set_tuning("f16_tile", 0)
     return dt
 def vendor(M, N, K):
     if torch is None: return float("nan")

@@ -17,6 +17,7 @@ WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_
 WG_GATHER_RCCL, WG_GATHER_PEER_COPY, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 1, 2, 3
 WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
 WG_F32, WG_F16 = 0, 1
+WG_TUNE_F16_TILE, WG_TUNE_F16_SCHED, WG_TUNE_F32_SKINNY, WG_TUNE_F32_PANELS, WG_TUNE_F16_BALANCE = range(5)
 
 
 class ViewShapeC(ctypes.Structure):
@@ -81,6 +82,8 @@ def _load() -> ctypes.CDLL:
         "wg_ctx_stream": (vp, [vp]),
         "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
         "wg_ctx_reserve_workspace": (ci, [vp, sz]),
+        "wg_ctx_set_tuning": (ci, [vp, ci, ci]),
+        "wg_ctx_get_tuning": (ci, [vp, ci, ctypes.POINTER(ci)]),
         "wg_debug_spin": (ci, [vp, ctypes.c_uint32, ctypes.c_uint32, vp]),
         "wg_geometry_apply": (ci, [vp, ci, ctypes.c_uint32, vp, vp, ctypes.c_uint32]),
         "wg_buf_create": (ci, [vp, sz, u32, pvp]),

@@ -170,11 +170,12 @@ struct wg_comm {
     std::vector<wg_buf *> peer_stage, peer_flags; // the peers' staging cubes / flag arrays as addressable from here
     std::vector<hipStream_t> peer_stream;         // one copy stream per peer
     std::vector<hipEvent_t> sent_ev;              // [parity][panel][peer]: my slot of that panel has left for that peer
-    uint32_t *seq_src = nullptr;     // device word holding the current step's sequence number (source of the flag copies)
-    uint32_t *seq_host = nullptr;    // pinned ring of sequence numbers (source of seq_src's update)
-    uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout
+    uint32_t *seq_src = nullptr;     // 64 device words: word (seq % 64) holds step seq's sequence number (source of that step's flag copies; set_word_kernel)
+    uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout (registered with the context)
+    uint64_t timeout_ticks = 3000000000ull; // wait kernel's patience in 100 MHz ticks (WG_COMM_TIMEOUT_MS at creation, default 30 s)
     uint32_t step = 0;
     uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
+    uint32_t staged_npanels = 0;              // panels of that call (its sent_ev layout)
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
@@ -268,12 +269,18 @@ int nccl_fail(const char *what, ncclResult_t r) {
 }
 
 // cube [mg, np, P] (contiguous slots) -> columns of a column-major matrix: c[(j)*ldc + g*mg + i] = stage[(g*np + j)*mg + i], in units of V
+// `err` (may be null): the wait kernel's time-out word. Set => a slot of this cube never arrived: write NaN bit patterns (all ones: a NaN in
+// f16 and in f32) instead of whatever the slots hold, so that a result read before the error is reported cannot pass for data.
 template <typename V>
-__global__ __launch_bounds__(256) void cube_to_matrix_kernel(const V *__restrict__ stage, V *__restrict__ c, uint32_t mg_v, uint32_t np, uint64_t ldc_v) {
+__global__ __launch_bounds__(256) void cube_to_matrix_kernel(const V *__restrict__ stage, V *__restrict__ c, uint32_t mg_v, uint32_t np, uint64_t ldc_v,
+                                                             const uint32_t *err) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x, g = blockIdx.z;
     if (i >= mg_v) return;
+    const bool poison = err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
     for (uint32_t j = blockIdx.y; j < np; j += gridDim.y) {
-        const V v = __builtin_nontemporal_load(stage + ((uint64_t)g * np + j) * mg_v + i);
+        V v;
+        if (poison) __builtin_memset(&v, 0xff, sizeof v);
+        else v = __builtin_nontemporal_load(stage + ((uint64_t)g * np + j) * mg_v + i);
         __builtin_nontemporal_store(v, c + (uint64_t)j * ldc_v + (uint64_t)g * mg_v + i);
     }
 }
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void cube_to_matrix_kernel(const V *__restrict
 typedef uint32_t wg_u4 __attribute__((ext_vector_type(4)));
 typedef uint32_t wg_u2 __attribute__((ext_vector_type(2)));
 
-int launch_cube_to_matrix(wg_ctx *ctx, const void *stage, void *c_col0, uint32_t mg, uint32_t np, uint32_t nranks, uint64_t ldc, size_t es) {
+int launch_cube_to_matrix(wg_ctx *ctx, const void *stage, void *c_col0, uint32_t mg, uint32_t np, uint32_t nranks, uint64_t ldc, size_t es, const uint32_t *err = nullptr) {
     if (mg == 0 || np == 0) return WG_OK;
     const size_t row_bytes = (size_t)mg * es, ld_bytes = (size_t)ldc * es;
     const uintptr_t align = (uintptr_t)stage | (uintptr_t)c_col0 | row_bytes | ld_bytes;
@@ -289,15 +296,15 @@ int launch_cube_to_matrix(wg_ctx *ctx, const void *stage, void *c_col0, uint32_t
     if (align % 16 == 0) {
         const uint32_t mv = (uint32_t)(row_bytes / 16);
         hipLaunchKernelGGL(cube_to_matrix_kernel<wg_u4>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const wg_u4 *)stage, (wg_u4 *)c_col0, mv,
-                           np, (uint64_t)(ld_bytes / 16));
+                           np, (uint64_t)(ld_bytes / 16), err);
     } else if (align % 8 == 0) {
         const uint32_t mv = (uint32_t)(row_bytes / 8);
         hipLaunchKernelGGL(cube_to_matrix_kernel<wg_u2>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const wg_u2 *)stage, (wg_u2 *)c_col0, mv,
-                           np, (uint64_t)(ld_bytes / 8));
+                           np, (uint64_t)(ld_bytes / 8), err);
     } else if (align % 4 == 0) {
         const uint32_t mv = (uint32_t)(row_bytes / 4);
         hipLaunchKernelGGL(cube_to_matrix_kernel<uint32_t>, dim3((mv + 255u) / 256u, gy, nranks), dim3(256), 0, ctx->stream, (const uint32_t *)stage,
-                           (uint32_t *)c_col0, mv, np, (uint64_t)(ld_bytes / 4));
+                           (uint32_t *)c_col0, mv, np, (uint64_t)(ld_bytes / 4), err);
     } else {
         return wg_set_error(WG_ERR_PRECONDITION, "cube_to_matrix: row blocks are not 4-byte aligned");
     }
@@ -309,22 +316,28 @@ constexpr uint32_t kMaxPanels = 1024, kMaxRanks = 16;
 constexpr size_t kFlagBytes = (size_t)kMaxRanks * kMaxPanels * sizeof(uint32_t);
 
 // One wave: lane r waits until rank r's slot of `panel` carries sequence number >= seq (wrap-safe). The flags live in uncached device
-// memory written by the peers' copy engines; system-scope loads. Gives up after ~4 s (100 MHz ticks) and raises *err instead of hanging
-// the queue: a missing peer is then reported by the next call instead of wedging the GPU.
-__global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32_t self, uint32_t panel, uint32_t seq, uint32_t *err) {
+// memory written by the peers' copy engines; system-scope loads. Gives up after `timeout_ticks` (100 MHz; wg_comm's timeout_ms, default
+// 30 s, WG_COMM_TIMEOUT_MS) and raises *err instead of hanging the queue. *err is sticky until the host has reported it: the relayout
+// behind a failed wait poisons its output (NaN bit patterns), every later wait fails fast, and wg_ctx_sync / wg_buf_read on the
+// context, wg_comm_flush / _join / _barrier and the next sharded call all return the error.
+__global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32_t self, uint32_t panel, uint32_t seq, uint32_t *err, uint64_t timeout_ticks) {
     const uint32_t r = threadIdx.x;
     if (r >= nranks || r == self) return;
     const uint32_t *f = flags + (size_t)r * kMaxPanels + panel;
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // an earlier wait of this step already gave up: fail fast
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // an earlier wait already gave up: fail fast
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
         __builtin_amdgcn_s_sleep(64);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
             __hip_atomic_store(err, 1u + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
     }
 }
+
+// sequence number of a step -> the device word the flag copies of that step read (runs on the context's stream ahead of the step's Gemms;
+// a kernel argument, so nothing the host may overwrite later is read at execution time)
+__global__ void set_word_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
 
 hipEvent_t take_event(wg_comm *c) {
     std::lock_guard<std::mutex> lk(c->mu);
@@ -341,11 +354,7 @@ hipEvent_t take_event(wg_comm *c) {
 int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far has landed
     for (hipStream_t st : c->peer_stream)
         if (st) WG_HIP_TRY(hipStreamSynchronize(st));
-    if (c->wait_err && *c->wait_err) {
-        const uint32_t r = *c->wait_err - 1u;
-        *c->wait_err = 0;
-        return wg_set_error(WG_ERR_HIP, "Gemm (sharded): rank %u's slot did not arrive within 4 s (peer gone, or peer buffers not registered on it)", r);
-    }
+    if (int rc = wg_ctx_check_async(c->ctx)) return rc; // a wait kernel gave up (reported once, then cleared)
     if (c->nranks > 1 && c->use_sdma && c->worker.joinable()) {
         std::unique_lock<std::mutex> lk(c->mu);
         c->jobs.push_back(CopyJob());
@@ -376,10 +385,11 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
     c->pending.on = false;
     const wg_comm::Pending &q = c->pending;
     if (c->nranks > 1) {
-        hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, c->ctx->stream, c->pflags, (uint32_t)c->nranks, (uint32_t)c->rank, q.panel, q.seq, c->wait_err);
+        hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, c->ctx->stream, c->pflags, (uint32_t)c->nranks, (uint32_t)c->rank, q.panel, q.seq, c->wait_err,
+                           c->timeout_ticks);
         WG_HIP_TRY(hipGetLastError());
     }
-    return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es);
+    return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es, c->nranks > 1 ? c->wait_err : nullptr);
 }
 
 struct IpcHandle { // WG_IPC_HANDLE_BYTES
@@ -429,6 +439,10 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
         memcpy(&u, id, sizeof u);
         ncclResult_t r = R.CommInitRank(&c->nccl, nranks, u, rank);
         if (r != ncclSuccess) return fail(nccl_fail("ncclCommInitRank", r));
+    }
+    if (const char *t = getenv("WG_COMM_TIMEOUT_MS")) { // read once, here: how long a receiver waits for a peer's slot before it reports the peer missing
+        const long long ms = atoll(t);
+        if (ms > 0) c->timeout_ticks = (uint64_t)ms * 100000ull;
     }
     // peer-copy engine: SDMA rect copies through the HSA runtime unless WG_PEER_COPY_ENGINE=hip2d (or HSA cannot be bound)
     const char *eng = getenv("WG_PEER_COPY_ENGINE");
@@ -484,8 +498,10 @@ int wg_comm_destroy(wg_comm *c) {
     if (c->pstage) (void)hipFree(c->pstage);
     if (c->pflags) (void)hipFree(c->pflags);
     if (c->seq_src) (void)hipFree(c->seq_src);
-    if (c->seq_host) (void)hipHostFree(c->seq_host);
-    if (c->wait_err) (void)hipHostFree(c->wait_err);
+    if (c->wait_err) {
+        wg_ctx_unregister_async_error(c->ctx, c->wait_err);
+        (void)hipHostFree(c->wait_err);
+    }
     if (c->stage) (void)hipFree(c->stage);
     if (c->token) (void)hipFree(c->token);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -631,13 +647,20 @@ int wg_comm_stage_reserve(wg_comm *c, size_t bytes, wg_buf **stage, wg_buf **fla
         hipError_t e = hipExtMallocWithFlags((void **)&c->pflags, kFlagBytes, hipDeviceMallocUncached);
         if (e != hipSuccess) {
             (void)hipGetLastError();
+            c->pflags = nullptr;
             WG_HIP_TRY(hipExtMallocWithFlags((void **)&c->pflags, kFlagBytes, hipDeviceMallocFinegrained));
         }
         WG_HIP_TRY(hipMemset(c->pflags, 0, kFlagBytes));
-        WG_HIP_TRY(hipMalloc((void **)&c->seq_src, 256));
-        WG_HIP_TRY(hipHostMalloc((void **)&c->seq_host, 64 * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    // each of these is tested on its own: a failed allocation leaves the others for the next attempt, never a half-built set in use
+    if (!c->seq_src) {
+        WG_HIP_TRY(hipMalloc((void **)&c->seq_src, 64 * sizeof(uint32_t)));
+        WG_HIP_TRY(hipMemset(c->seq_src, 0, 64 * sizeof(uint32_t)));
+    }
+    if (!c->wait_err) {
         WG_HIP_TRY(hipHostMalloc((void **)&c->wait_err, 64, hipHostMallocDefault));
         *c->wait_err = 0;
+        wg_ctx_register_async_error(c->ctx, c->wait_err, "Gemm (sharded): a peer's slot did not arrive within the communicator's time-out (peer gone, or its buffers not registered): rank");
     }
     c->stage_buf.ctx = c->ctx; c->stage_buf.ptr = c->pstage; c->stage_buf.bytes = c->pstage_bytes; c->stage_buf.usage = WG_USAGE_STORAGE; c->stage_buf.owned = false;
     c->flags_buf.ctx = c->ctx; c->flags_buf.ptr = c->pflags; c->flags_buf.bytes = kFlagBytes; c->flags_buf.usage = WG_USAGE_STORAGE; c->flags_buf.owned = false;
@@ -652,8 +675,9 @@ int wg_comm_set_peer_stages(wg_comm *c, wg_buf *const *peer_stage, wg_buf *const
     if (!c->pstage) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: call wg_comm_stage_reserve first");
     for (int r = 0; r < c->nranks; ++r) {
         if (r == c->rank) continue;
-        if (!peer_stage[r] || !peer_flags[r] || peer_stage[r]->bytes < c->pstage_bytes || peer_flags[r]->bytes < kFlagBytes)
-            return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: rank %d's staging cube / flag array is missing or smaller than this rank's", r);
+        // the two step-parity halves of a cube sit at offsets 0 and bytes / 2: every rank must have reserved the SAME size
+        if (!peer_stage[r] || !peer_flags[r] || peer_stage[r]->bytes != c->pstage_bytes || peer_flags[r]->bytes < kFlagBytes)
+            return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_peer_stages: rank %d's staging cube / flag array is missing, or its cube is not the size of this rank's (%zu bytes)", r, c->pstage_bytes);
     }
     WG_HIP_TRY(hipSetDevice(c->ctx->device));
     c->peer_stage.assign(peer_stage, peer_stage + c->nranks);
@@ -731,20 +755,23 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // ---- contiguous per-link copies into the peers' staging cubes + flag, wait kernel + relayout on the receiving side ----
         if (npanels > kMaxPanels) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): more than %u panels", kMaxPanels);
         const size_t cube_bytes = (size_t)M * N * es;
-        if (!c->pstage || c->pstage_bytes < 2 * cube_bytes)
+        if (!c->pstage || ((c->pstage_bytes / 2) & ~(size_t)15) < cube_bytes)
             return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_STAGED needs wg_comm_stage_reserve(>= %zu bytes) and, with > 1 rank, wg_comm_set_peer_stages", 2 * cube_bytes);
         if (P > 1 && (int)c->peer_stage.size() != c->nranks)
             return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_STAGED: peers' staging cubes are not registered (wg_comm_set_peer_stages)");
-        if (2ull * M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
-        if (c->wait_err && *c->wait_err) {
-            const uint32_t r = *c->wait_err - 1u;
-            *c->wait_err = 0;
-            return wg_set_error(WG_ERR_HIP, "Gemm (sharded): rank %u's slot did not arrive within 4 s in an earlier step", r);
-        }
+        // The two step-parity halves of the cube sit at FIXED offsets (0 and half of the reserved size, the same on every rank:
+        // wg_comm_set_peer_stages), whatever the shape of a step. A step's copies into a peer's half are issued after this rank has
+        // seen the peer's flags of the previous step -- which the peer raises after its Gemms of that step, i.e. after it has
+        // finished every relayout out of that half (two steps ago) -- so a change of M / N / panel_cols between steps needs no
+        // cross-rank agreement beyond the one every step makes.
+        const uint64_t half_elems = ((c->pstage_bytes / 2) & ~(size_t)15) / es;
+        if (half_elems + (uint64_t)M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
+        if (int rc = wg_ctx_check_async(ctx)) return rc; // a wait of an earlier step gave up
         const uint64_t geom[4] = { M, N, panel_cols, es };
         if (memcmp(geom, c->staged_geom, sizeof geom) != 0) {
-            // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything that is
-            // still leaving the old layout finish before any Gemm writes the cubes (host-blocking, first call of a new shape only)
+            // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything of
+            // THIS rank that is still leaving the old layout finish before any Gemm writes the cubes (host-blocking on this rank's own
+            // copy streams only, first call of a new shape only)
             if (int rc = run_pending(c)) return rc;
             for (hipStream_t st : c->peer_stream)
                 if (st) WG_HIP_TRY(hipStreamSynchronize(st));
@@ -753,30 +780,32 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             memcpy(c->staged_geom, geom, sizeof geom);
         }
         const uint32_t seq = ++c->step, parity = seq & 1u;
-        // the sequence number the flag copies carry: pinned ring entry -> device word, on the context's stream ahead of this step's Gemms
-        c->seq_host[seq % 64u] = seq;
-        WG_HIP_TRY(hipMemcpyAsync(c->seq_src + (seq % 64u), c->seq_host + (seq % 64u), sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        const size_t nev = 2 * (size_t)kMaxPanels; // sent_ev[parity][panel]: recorded on every peer stream -> one event per (parity, panel, peer)
-        (void)nev;
+        // the sequence number the flag copies carry: written into word (seq % 64) on the context's stream ahead of this step's Gemms, by
+        // a kernel that takes it as an argument. (Word seq % 64 is next written for step seq + 64, on the context's stream behind Gemms
+        // that waited for the copies of step seq + 62, which follow step seq's on every peer stream.)
+        hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, ctx->stream, c->seq_src + (seq % 64u), seq);
+        WG_HIP_TRY(hipGetLastError());
         while (c->sent_ev.size() < (size_t)2 * npanels * P) c->sent_ev.push_back(nullptr);
         wg_buf sbuf;
         sbuf.ctx = ctx; sbuf.ptr = c->pstage; sbuf.bytes = c->pstage_bytes; sbuf.usage = 0; sbuf.owned = false; sbuf.host_pinned = false;
-        auto slot_elem = [&](uint32_t c0, uint32_t np, uint32_t r) { return (uint64_t)parity * M * N + (uint64_t)c0 * M + (uint64_t)r * mg * np; };
+        auto slot_elem = [&](uint32_t c0, uint32_t np, uint32_t r) { return (uint64_t)parity * half_elems + (uint64_t)c0 * M + (uint64_t)r * mg * np; };
         auto finish_panel = [&](uint32_t p) -> int { // wait for the peers' slots of panel p, then relayout it into columns of `out`
             const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
             if (P > 1) {
-                hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err);
+                hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err, c->timeout_ticks);
                 WG_HIP_TRY(hipGetLastError());
             }
             const char *src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
             char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
-            return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es);
+            return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->wait_err : nullptr);
         };
         for (uint32_t p = 0; p < npanels; ++p) {
             const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
             wg_view_shape bs = b_shape;
             bs.size[1] = np;
-            bs.offset = b_shape.offset + c0 * b_shape.stride;
+            const uint64_t b_off = (uint64_t)b_shape.offset + (uint64_t)c0 * b_shape.stride; // 64-bit: K * N may reach 2^32 elements
+            if (b_off >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): panel %u of m2 starts beyond u32 element indexing", p);
+            bs.offset = (uint32_t)b_off;
             wg_view_shape os;
             os.size[0] = mg; os.size[1] = np; os.size[2] = 1; os.stride = mg; os.stride_mat = mg * np;
             os.offset = (uint32_t)slot_elem(c0, np, g);
@@ -807,7 +836,11 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 if (int rc = finish_panel(p - 1)) return rc; // after this panel's Gemm: the previous panel's slots travelled beside it
             } else if (int rc = run_pending(c)) return rc;   // ... and the previous CALL's last panel beside this call's first Gemm (pipelined steps)
         }
-        if (c->pipelined) { // leave the last panel to the next call (or wg_comm_join): nothing in this call can hide its exchange
+        // Pipelined steps leave the last panel to the next call (or wg_comm_join): nothing in this call can hide its exchange. NOT with a
+        // single panel: the next call would then enqueue its Gemm and its copy into the peers' other half before having waited for
+        // anything of this step -- the "at most one step ahead of a peer" rule the parity halves rely on would not hold (the peer could
+        // still be reading that half) -- so a one-panel step completes in the call.
+        if (c->pipelined && npanels > 1) {
             const uint32_t p = npanels - 1, c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
             c->pending.on = true;
             c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
@@ -852,7 +885,9 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
         wg_view_shape bs = b_shape;
         bs.size[1] = np;
-        bs.offset = b_shape.offset + c0 * b_shape.stride;
+        const uint64_t b_off = (uint64_t)b_shape.offset + (uint64_t)c0 * b_shape.stride; // 64-bit: K * N may reach 2^32 elements
+        if (b_off >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): panel %u of m2 starts beyond u32 element indexing", p);
+        bs.offset = (uint32_t)b_off;
         wg_view_shape os;
         os.size[0] = mg; os.size[1] = np; os.size[2] = 1;
         if (staged) { // slot g of the staging cube of this panel

@@ -809,7 +809,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 if (ns < 2) ns = 1;
             }
             bool want128 = false;
-            if (const char *force = getenv("WG_F16_TILE")) want128 = atoi(force) == 128;
+            if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
             else if (tiles * nmats < (uint64_t)cus) {
                 const double w128 = (double)(tiles128 * nmats * ns) / cus, k128 = (double)(((K / 64u + ns - 1) / ns) * 64u);
                 const double est128 = (w128 <= 1.0 ? k128 * 0.00875 : w128 * k128 * 0.0108) + 6.0 + slabs(ns);
@@ -837,6 +837,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         }
         // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split
         uint32_t nsplit = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
+#ifdef WG_F16_TRACE
+        if (getenv("WG_F16_NOSPLIT")) nsplit = 1; // timing experiments: fewer tiles than CUs on the big kernel, unsplit
+#endif
         g.nsplit = nsplit;
         g.k_per_split = nsplit > 1 ? ((K / BKH + nsplit - 1) / nsplit) * BKH : K;
         g.part = nullptr;
@@ -874,8 +877,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #endif
             auto launch_tiles = [&](GemmArgs gm, uint32_t ntiles) -> int {
                 uint32_t nwg = ntiles;
-                const char *sched_s = getenv("WG_F16_SCHED"); // 0 / 1 force (read per call: tests), default: by size
-                const int sched_env = sched_s ? atoi(sched_s) : -1;
+                const int sched_env = ctx->tuning[WG_TUNE_F16_SCHED]; // 0 / 1 force (tests), default: by size
                 const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)(WG_F16_SCHED_ROUNDS * cus));
                 if (dyn) {
                     if (!ctx->tile_queues) {

@@ -534,12 +534,11 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = wgk_gemm_f32(ctx, true, N, M, K, nmats, ct, N, ct_elems, m2, a2, alpha, 0.f)) return rc;
         return wgk_transpose(ctx, WG_F32, N, M, nmats, ct, N, ct_elems, out, out_ld, out_batch);
     }
-    // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. WG_F32_SKINNY=0 disables
+    // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. wg_ctx_set_tuning(WG_TUNE_F32_SKINNY, 0) disables
     // it (experiments / tests of the tiled kernel on these shapes).
     // (32-bit DMA offsets within a 32-row / 32-k block of m1 and within the 64 columns of m2: both variants build them)
     if (N <= 64 && M >= 512 && K >= 128 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
-        const char *e = getenv("WG_F32_SKINNY");
-        if (!(e && atoi(e) == 0)) return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
+        if (ctx->tuning[WG_TUNE_F32_SKINNY] != 0) return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }
     GemmArgs g;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
@@ -600,8 +599,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             const double t = rounds(wgs * ns) * (stages * 1.4 + 2.5) + (ns > 1 ? 4.0 + ns * out_bytes / 7.0e6 : 0.0); // (slab writes are in the per-stage figure)
             if (t < best_p) { best_p = t; ns_p = ns; }
         }
-        const char *e = getenv("WG_F32_PANELS"); // experiments: 0 = never, 1 = whenever applicable
-        if ((e ? atoi(e) == 1 : best_p < 0.9 * best))
+        const int force = ctx->tuning[WG_TUNE_F32_PANELS]; // experiments: 0 = never, 1 = whenever applicable
+        if ((force >= 0 ? force == 1 : best_p < 0.9 * best))
             return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, 1u, false, ns_p);
     }
     float *part = nullptr;

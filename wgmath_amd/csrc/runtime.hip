@@ -5,6 +5,7 @@
 
 #include <vector>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -55,6 +56,22 @@ int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out) {
 int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out) {
     return grow_scratch(ctx, &ctx->pad_workspace, &ctx->pad_workspace_bytes, bytes, "padding workspace", out);
 }
+void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what) { ctx->async_errors.push_back({ word, what }); }
+void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word) {
+    for (size_t i = 0; i < ctx->async_errors.size(); ++i)
+        if (ctx->async_errors[i].word == word) { ctx->async_errors.erase(ctx->async_errors.begin() + (long)i); return; }
+}
+int wg_ctx_check_async(wg_ctx *ctx) {
+    for (const wg_ctx::AsyncError &e : ctx->async_errors) {
+        const uint32_t v = *(volatile uint32_t *)e.word;
+        if (v) {
+            *(volatile uint32_t *)e.word = 0;
+            return wg_set_error(WG_ERR_HIP, "%s %u", e.what, v - 1u);
+        }
+    }
+    return WG_OK;
+}
+
 extern "C" {
 
 int wg_abi_version(void) { return WGEBRA_HIP_ABI_VERSION; }
@@ -95,6 +112,12 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
         ctx->stream = stream;
     }
     ctx->owns_stream = owns;
+    // kernel-selection knobs: the environment is consulted here and nowhere on the dispatch path
+    static const struct { const char *env; wg_tuning key; } knobs[] = {
+        { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
+        { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE } };
+    for (const auto &k : knobs)
+        if (const char *v = getenv(k.env)) ctx->tuning[k.key] = atoi(v);
     *out = ctx;
     return WG_OK;
 }
@@ -151,7 +174,7 @@ int wg_ctx_sync(wg_ctx *ctx) {
     if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_sync: ctx is NULL");
     if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_sync: cannot synchronise while recording");
     WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return WG_OK;
+    return wg_ctx_check_async(ctx);
 }
 int wg_ctx_device(const wg_ctx *ctx) { return ctx ? ctx->device : -1; }
 void *wg_ctx_stream(const wg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -185,6 +208,21 @@ int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_tic
     if (p) hipLaunchKernelGGL(wg_debug_now_kernel, dim3(1), dim3(1), 0, ctx->stream, p + blocks); // tick at enqueue position
     hipLaunchKernelGGL(wg_debug_spin_kernel, dim3(blocks), dim3(256), 0, ctx->stream, p, usec);
     WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value) {
+    if (!ctx || (int)key < 0 || (int)key >= (int)WG_TUNE_COUNT_) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: bad context or key %d", (int)key);
+    if (key == WG_TUNE_F16_TILE && value != 0 && value != 128 && value != 256)
+        return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F16_TILE takes 0, 128 or 256, not %d", value);
+    if (key != WG_TUNE_F16_TILE && (value < -1 || value > 1))
+        return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: knob %d takes -1, 0 or 1, not %d", (int)key, value);
+    ctx->tuning[key] = value;
+    return WG_OK;
+}
+int wg_ctx_get_tuning(const wg_ctx *ctx, wg_tuning key, int *value) {
+    if (!ctx || !value || (int)key < 0 || (int)key >= (int)WG_TUNE_COUNT_) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_get_tuning: bad argument");
+    *value = ctx->tuning[key];
     return WG_OK;
 }
 
@@ -299,7 +337,7 @@ int wg_buf_read(wg_ctx *ctx, const wg_buf *src, size_t offset, void *dst, size_t
     WG_HIP_TRY(hipSetDevice(ctx->device));
     if (bytes) WG_HIP_TRY(hipMemcpyAsync(dst, (const char *)src->ptr + offset, bytes, hipMemcpyDefault, ctx->stream));
     WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return WG_OK;
+    return wg_ctx_check_async(ctx); // e.g. a sharded Gemm whose peer never delivered: the bytes just read are poison, say so
 }
 
 int wg_buf_copy(wg_ctx *ctx, const wg_buf *src, size_t src_offset, wg_buf *dst, size_t dst_offset, size_t bytes) {

@@ -26,9 +26,17 @@ struct wg_ctx {
     int compute_units = 0;
     unsigned *flags = nullptr;           // a few zeroed device words (arrival counters of fused epilogues), created on first use
     unsigned long long *tile_queues = nullptr; // f16 Gemm tile scheduler: 8 per-XCD queue words, 128 bytes apart (gemm_f16.hip), created on first use
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
+    // pinned host words that kernels of this context's stream raise when something went wrong asynchronously (a communicator's wait
+    // kernel timing out on a peer): checked -- reported once, then cleared -- by wg_ctx_sync, wg_buf_read and the communicator's calls
+    struct AsyncError { uint32_t *word; const char *what; };
+    std::vector<AsyncError> async_errors;
 };
+void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what);
+void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word);
+int wg_ctx_check_async(wg_ctx *ctx); // WG_ERR_HIP + message "<what> <word - 1>" if a registered word is set (and clears it)
 
 struct wg_buf {
     wg_ctx *ctx = nullptr;

@@ -296,6 +296,20 @@ class GpuInstance:
     def close(self) -> None:
         self._ctx.close()
 
+    _TUNING = {"f16_tile": _lib.WG_TUNE_F16_TILE, "f16_sched": _lib.WG_TUNE_F16_SCHED, "f32_skinny": _lib.WG_TUNE_F32_SKINNY,
+               "f32_panels": _lib.WG_TUNE_F32_PANELS, "f16_balance": _lib.WG_TUNE_F16_BALANCE}
+
+    def set_tuning(self, knob: str, value: int) -> int:
+        """wg_ctx_set_tuning: force a kernel-family choice for later calls on this context (tests / experiments); returns the old value."""
+        old = self.get_tuning(knob)
+        check(lib.wg_ctx_set_tuning(self._ctx.handle, self._TUNING[knob], int(value)))
+        return old
+
+    def get_tuning(self, knob: str) -> int:
+        v = ctypes.c_int()
+        check(lib.wg_ctx_get_tuning(self._ctx.handle, self._TUNING[knob], ctypes.byref(v)))
+        return v.value
+
 
 # ---------------------------------------------------------------------------------------------------
 # tensor.rs
