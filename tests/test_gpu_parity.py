@@ -430,6 +430,86 @@ def test_gemm_f16_tile_scheduler_is_bit_identical(gpu, M, K, N, tr):
     f16_check(res["1"][0].view(np.float16).reshape(N, M).T, (A.T if tr else A).astype(np.float64), wo.view(b, wo.Shape(K, N, 1))[:, :, 0].astype(np.float64), K, "scheduler")
 
 
+def test_gemm_f16_balance_units_see_fresh_accumulators_every_launch(gpu):
+    """The prefix -> suffix hand-off reuses the same scratch tiles and flags launch after launch, written on one XCD and read on another
+    whose L2 may still hold last launch's lines: back-to-back launches on DIFFERENT operands (small enough for everything to stay
+    cached) must each reproduce their own static result bit for bit -- stale accumulators or a stale flag would show here."""
+    wg = _wg()
+    M = N = 4096  # 256 tiles: one workgroup per CU, no split-K; everything stays in the caches between launches
+    K = 512
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    rng = np.random.default_rng(99)
+    sets = []
+    for i in range(4):
+        a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
+        b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
+        sets.append((upload(gpu, (M, K, 1), a, np.float16), upload(gpu, (K, N, 1), b, np.float16)))
+    old = {k: gpu.get_tuning(k) for k in ("f16_sched", "f16_tile", "f16_balance")}
+    try:
+        gpu.set_tuning("f16_tile", 256)
+        gpu.set_tuning("f16_sched", 0)
+        ref, got = [], []
+        gpu.set_tuning("f16_balance", 0)
+        for m1, m2 in sets:
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, out, m1, m2))
+            ref.append(out.read(gpu.device()).view(np.uint16).copy())
+        gpu.set_tuning("f16_balance", 1)
+        n_before = gpu.f16_balance_info()["balanced_launches"]
+        outs = [upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16) for _ in range(3 * len(sets))]
+
+        def burst(p):  # one pass, no synchronisation between the launches: operands change from launch to launch
+            for j, out in enumerate(outs):
+                m1, m2 = sets[j % len(sets)]
+                gemm.dispatch(gpu.device(), shapes, p, out, m1, m2)
+        run_pass(gpu, burst)
+        got = [o.read(gpu.device()).view(np.uint16).copy() for o in outs]
+        assert gpu.f16_balance_info()["balanced_launches"] == n_before + len(outs)  # the launches really ran as prefix / suffix units
+    finally:
+        for k, v in old.items():
+            gpu.set_tuning(k, v)
+    for j, g_ in enumerate(got):
+        assert np.array_equal(g_, ref[j % len(sets)]), f"launch {j}: {(g_ != ref[j % len(sets)]).sum()} elements differ from the static launch"
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N", [(4096, 1024, 4096), (4104, 768, 4352), (8192, 512, 2048), (2048, 2048, 8448)])  # >= 256 tiles: no split-K
+def test_gemm_f16_balance_units_are_bit_identical(gpu, M, K, N, tr):
+    """Calibrated shares across XCDs: a fast XCD's workgroups run the first stages of K of a slow XCD's tiles (raw f32 accumulators to
+    scratch + a flag) and the owner continues from those accumulators -- the same k-ordered chain in the same registers, so the result
+    must equal the unsplit launch bit for bit. WG_TUNE_F16_BALANCE = 1 forces a fixed pattern of takers and givers (two giving rounds
+    included) on shapes of a few tiles per XCD, ragged edges included; every element must have been written (NaN pre-fill), and repeated
+    launches (flag epochs) must agree."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + K + N + int(tr) + 5)
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    m1 = upload(gpu, (K, M, 1) if tr else (M, K, 1), a, np.float16)
+    m2 = upload(gpu, (K, N, 1), b, np.float16)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    res = {}
+    old = {k: gpu.get_tuning(k) for k in ("f16_sched", "f16_tile", "f16_balance")}
+    try:
+        gpu.set_tuning("f16_tile", 256)
+        gpu.set_tuning("f16_sched", 0)
+        n_before = gpu.f16_balance_info()["balanced_launches"]
+        for bal in (0, 1, 1, 1):
+            gpu.set_tuning("f16_balance", bal)
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            res.setdefault(bal, []).append(out.read(gpu.device()).view(np.uint16).copy())
+        assert gpu.f16_balance_info()["balanced_launches"] == n_before + 3  # the forced launches really ran as prefix / suffix units
+    finally:
+        for k, v in old.items():
+            gpu.set_tuning(k, v)
+    assert not np.isnan(res[0][0].view(np.float16)).any()
+    for r in res[1]:
+        assert np.array_equal(r, res[0][0])
+    A = wo.view(a, wo.Shape(K, M, 1) if tr else wo.Shape(M, K, 1))[:, :, 0]
+    f16_check(res[1][0].view(np.float16).reshape(N, M).T, (A.T if tr else A).astype(np.float64), wo.view(b, wo.Shape(K, N, 1))[:, :, 0].astype(np.float64), K, "balance")
+
+
 @pytest.mark.parametrize("tr", [False, True])
 def test_gemm_f16_identity_asymmetric(gpu, f16_tile, tr):
     """A = I, asymmetric small-integer B (exact in f16): any row/column permutation or transposition in the tr-read,

@@ -23,7 +23,7 @@ c = wg.TensorBuilder.matrix(M, N, S.STORAGE).build(dev, np.float16)
 gemm = wg.Gemm.from_device(dev)
 variant = wg.GemmVariant.GemmTr if TN else wg.GemmVariant.Gemm
 enc = dev.create_command_encoder(); p = enc.compute_pass("t", None)
-for _ in range(6): gemm.dispatch_generic(dev, shapes, p, c, a, b, variant)
+for _ in range(int(os.environ.get("WG_TRACE_REPS", "6"))): gemm.dispatch_generic(dev, shapes, p, c, a, b, variant)
 gpu.sync()
 raw = np.fromfile("/tmp/wg_f16_trace.bin", dtype=np.uint64)
 ntile = (M // 256) * (N // 256)

@@ -82,6 +82,8 @@ def _load() -> ctypes.CDLL:
         "wg_ctx_stream": (vp, [vp]),
         "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
         "wg_ctx_reserve_workspace": (ci, [vp, sz]),
+        "wg_debug_f16_balance_plan": (ci, [ctypes.POINTER(ctypes.c_double), u32, u32, ci, ctypes.POINTER(u32), u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]),
+        "wg_ctx_f16_balance_info": (ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci), ctypes.POINTER(u32), ctypes.POINTER(u32)]),
         "wg_ctx_set_tuning": (ci, [vp, ci, ci]),
         "wg_ctx_get_tuning": (ci, [vp, ci, ctypes.POINTER(ci)]),
         "wg_debug_spin": (ci, [vp, ctypes.c_uint32, ctypes.c_uint32, vp]),

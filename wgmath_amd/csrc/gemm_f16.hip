@@ -107,8 +107,12 @@ __device__ __forceinline__ void m16_dma(int q, uint32_t voff, const void *sbase)
 constexpr uint32_t M16_BIAS = 3072; // scalar bases are lowered by this many bytes, voff of piece q raised by BIAS - 1024 q
 
 // One 256 x 256 tile (tile id `bid`), K range of this workgroup's split. `smem` is the kernel's 160 KiB LDS array.
+// Balance units (BalancePlan; workgroup-uniform arguments): unit_mode 1 = PREFIX, stages [0, unit_ns) of the tile, raw f32 accumulators to
+// scratch tile `unit_pair`, then its flag; 2 = SUFFIX, stages [unit_kb, unit_kb + unit_ns) on top of the accumulators of prefix `unit_pair`
+// (waits for its flag; should that never come -- its workgroup was never scheduled -- the whole tile is computed here from zeros).
 template <bool TRANS_A>
-__device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, char *const smem) {
+__device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, char *const smem, const uint32_t unit_mode = 0, uint32_t unit_kb = 0,
+                                         uint32_t unit_ns = 0, const uint32_t unit_pair = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -133,18 +137,42 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
-    const uint32_t k_begin = split * g.k_per_split;
-    const uint32_t K_loc = min(g.K - k_begin, g.k_per_split);
+    uint32_t k_begin = split * g.k_per_split;
+    uint32_t K_loc = min(g.K - k_begin, g.k_per_split);
+    bool from_partial = false; // workgroup-uniform
+    if (unit_mode == 2) {
+        // consumer side of the hand-off (guide, G16): ONE lane polls relaxed, ONE agent-scope acquire, barrier, then plain loads by everyone
+        if (threadIdx.x == 0) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            uint32_t ok = 1;
+            // (system scope: an agent-scope load is served by THIS XCD's L2, which may still hold the flag's line with last launch's epoch --
+            // measured: 32 suffix units polling ~45 us each until the line happened to be replaced)
+            while (__hip_atomic_load(g.bal.flags + unit_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != g.bal.epoch) {
+                __builtin_amdgcn_s_sleep(16);
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000ull) { ok = 0; break; } // 1 ms: the prefix ran at the start of the launch or never will
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *reinterpret_cast<volatile uint32_t *>(smem) = ok;
+        }
+        __syncthreads();
+        from_partial = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(smem)) != 0;
+        __syncthreads(); // everyone has read the word before the first DMA piece may land on it
+        if (!from_partial) { unit_ns += unit_kb; unit_kb = 0; }
+    }
+    if (unit_mode) { k_begin = unit_kb * 64u; K_loc = unit_ns * 64u; }
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
     _Float16 *C = g.c + z * g.c_batch;
     // Pin the epilogue's kernel arguments in SGPRs NOW: left alone, the compiler loads them (s_load, also an lgkmcnt event,
     // returning out of order with LDS reads) right in front of the main loop, and every counted LDS wait of the first
     // half-step then degrades to lgkmcnt(0).
-    float *part = g.part;
+    float *part = unit_mode ? g.bal.part + (uint64_t)unit_pair * 65536u : g.part;
     float alpha = g.alpha, beta = g.beta;
     uint32_t ldc = g.ldc;
-    asm volatile("" : "+s"(C), "+s"(part), "+s"(alpha), "+s"(beta), "+s"(ldc));
+    uint32_t *bal_flag = g.bal.flags + unit_pair;
+    uint32_t bal_epoch = g.bal.epoch;
+    unsigned long long *calib = g.calib;
+    asm volatile("" : "+s"(C), "+s"(part), "+s"(alpha), "+s"(beta), "+s"(ldc), "+s"(bal_flag), "+s"(bal_epoch), "+s"(calib));
 
     // ---- DMA addressing; ragged tiles: rows past the end are clamped to the last valid one (results discarded by the epilogue) ----
     // A half-stage = 16 pieces of 1 KiB, wave stages P = 4 wave + q; B full stage = 32 pieces, wave stages P = 8 wave + q.
@@ -211,6 +239,24 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][u][e] = 0.f;
+    if (from_partial) {
+        // the prefix unit's accumulators (written in the tail split's tile-local format by the same lane -> element map): this unit
+        // continues their k-ordered chain. Loaded by inline asm straight into the accumulator registers and waited for here: a load the
+        // compiler can see makes its wait-count pass put an `s_waitcnt vmcnt(n)` in front of the first MFMA of the LOOP (where it would
+        // drain this kernel's DMA pipeline in every iteration), and 64 loads through VGPRs spill.
+        const uint32_t pvoff = ((128u * wn + i16) * 256u + 128u * wm + 8u * kg) * 4u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t vo = pvoff + (uint32_t)u * 16384u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                // sc0 sc1: the scratch tile is rewritten by another XCD every launch; read it past this XCD's L2 as well
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p][u]) : "v"(vo), "s"(part), "i"(p * 128));
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p + 1][u]) : "v"(vo), "s"(part), "i"(p * 128 + 16));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     uintx4 a_r[2][8]; // [register set][M tile]  (bit patterns of 8 halves)
     half8_t b_f[2][8];
@@ -473,6 +519,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     va = vbaseA[0]; vb = vbaseB[0]; // half-step 0's own fragments: first half of stage 0
 #pragma unroll
     for (int op = 0; op < kOps; ++op) frag(op, 0);
+    const uint64_t calib_t0 = __builtin_amdgcn_s_memrealtime(); // per-XCD rate measurement (returns before the wait below)
     __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): nothing pending on entry to the loop either
     if (!(WG_ABLATE & 1)) __builtin_amdgcn_s_barrier(); // every wave has read A(0): half-step 0 may overwrite its slot with A(4)
     // running values as half-step 0 expects them: it reads the second half of stage 0 and issues A(4) / stage 2 pieces
@@ -541,12 +588,21 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     loop_t1 = (uint32_t)__builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_waitcnt(0xc07f);
 #endif
+    if (calib) { // this tile's main-loop time and stage count to the XCD it really ran on (fire-and-forget atomics, one lane)
+        const uint64_t calib_t1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (threadIdx.x == 0) {
+            const uint32_t x = blockIdx.x & 7u; // the workgroup SLOT (hardware deals ids round-robin to the XCDs): what the plan hands work to
+            atomicAdd(calib + 2u * x, (unsigned long long)(calib_t1 - calib_t0));
+            atomicAdd(calib + 2u * x + 1u, (unsigned long long)S);
+        }
+    }
 
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
     const uint32_t row0 = m0 + 128u * wm + 8u * kg;
-    if (g.tail_tiles > 0) { // tail split: raw f32 partial TILE (256 x 256, dense) of this split; gemm_f16_tail_reduce finishes the job
-        float *P = part + ((uint64_t)split * g.tail_tiles + bid) * 65536u;
+    if (g.tail_tiles > 0 || unit_mode == 1) { // tail split: raw f32 partial TILE (256 x 256, dense) of this split; gemm_f16_tail_reduce finishes the job
+        float *P = unit_mode == 1 ? part : part + ((uint64_t)split * g.tail_tiles + bid) * 65536u; // (prefix unit: its pair's scratch tile)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const uint32_t cl = 128u * wn + 16u * u + i16; // column within the tile
@@ -559,6 +615,14 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (unit_mode == 1) { // producer side of the hand-off (guide, G16): every wave's stores done, ONE agent-scope release, then the flag
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the compiler may drop the wait behind buffer_wbl2: restated where it cannot)
+                __hip_atomic_store(bal_flag, bal_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
         return;
     }
     if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M)
@@ -666,14 +730,17 @@ template <bool TRANS_A>
 __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
     uint32_t bid = blockIdx.x;
+    uint32_t mode = 0, kb = 0, ns = 0, pair = 0; // balance unit (BalancePlan); 0: a whole tile
     if (g.sched) { // workgroup-uniform
         if (threadIdx.x == 0) *reinterpret_cast<volatile uint32_t *>(smem) = m16_acquire_tile(g);
         __syncthreads();
         bid = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(smem));
         __syncthreads(); // everyone has read the word before the tile's first DMA piece may land on it
         if (bid == ~0u) return;
+    } else if (g.bal.on) { // calibrated shares: workgroup b is unit b / 8 of XCD b % 8's list (the hardware's deal; any unit may run anywhere)
+        if (!bal_decode(g.bal, blockIdx.x, g.K / 64u, bid, mode, kb, ns, pair)) return;
     }
-    m16_tile<TRANS_A>(g, bid, smem);
+    m16_tile<TRANS_A>(g, bid, smem, mode, kb, ns, pair); // (ONE call site: the tile body must exist once in the kernel)
 }
 
 #ifndef WG_F16_PERSIST
@@ -751,6 +818,133 @@ __global__ __launch_bounds__(256) void pad_copy_f16(_Float16 *dst, uint32_t ld_d
 using namespace wgf16;
 
 namespace {
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Calibrated shares across XCDs ("balance", BalancePlan in gemm_f16_common.hpp). Measured (profiles/r03_evidence.md): under the power
+// cap the eight XCDs of a chip run the same tile 2-4 % apart (the same XCDs every run), hardware deals every XCD the same number of
+// workgroups, and at 8192^3 (4 tiles per CU) 3.7 % of the CU time is idle at the end. Every launch of the kernel over full rounds adds
+// each tile's main-loop time to the accumulator of its workgroup slot (b % 8); a 128-byte snapshot of the accumulators travels to the
+// host on a side stream now and then; the launcher turns the measured rates into prefix / suffix units of a few stages per CU.
+// ---------------------------------------------------------------------------------------------------------------------------------
+// MEASURED OUTCOME (profiles/r03_evidence.md section 1): the hand-off costs what it saves. A prefix unit costs its taker ~12 us (prologue,
+// 256 KiB of raw accumulators written at the CU's store rate, flag), a suffix unit costs its giver ~10 us (flag, acquire, 256 KiB read past
+// its L2) -- together more than the 15-30 us a CU of the slowest XCD is behind at 8192^3. A/B on two boxes: -0.7 ... -1.2 %. So the
+// default is OFF (WG_TUNE_F16_BALANCE = 0: no calibration traffic, no plan); -1 lets the planner act where its cost model -- these
+// measured overheads -- still predicts a gain (speed spreads above ~5 %), 1 is the tests' fixed pattern. The units themselves are
+// bit-identical to the unsplit launch and stay tested.
+constexpr double kBalTileOverhead = 5.0; // per tile outside the main loop (prologue, epilogue, re-dispatch), in stages of ~1.4 us
+constexpr double kBalTakeOverhead = 8.5; // a prefix unit's extra cost to its taker
+constexpr double kBalGiveOverhead = 7.0; // a suffix unit's extra cost to its giver
+constexpr uint32_t kBalFlagsOffset = 2048, kBalMaxPairs = 1024, kBalDevBytes = kBalFlagsOffset + kBalMaxPairs * 4;
+
+int bal_prepare(wg_ctx *ctx) { // device block + side stream on first use; harvest a finished snapshot, start the next one
+    wg_ctx::F16Balance &b = ctx->bal;
+    if (ctx->recording) return WG_OK; // (no allocation, no other-stream work inside a capture)
+    if (!b.dev) {
+        WG_HIP_TRY(hipMalloc((void **)&b.dev, kBalDevBytes));
+        WG_HIP_TRY(hipMemset(b.dev, 0, kBalDevBytes));
+        WG_HIP_TRY(hipHostMalloc((void **)&b.host, 16 * sizeof(unsigned long long), hipHostMallocDefault));
+        WG_HIP_TRY(hipStreamCreateWithFlags(&b.side, hipStreamNonBlocking));
+        WG_HIP_TRY(hipEventCreateWithFlags(&b.ev, hipEventDisableTiming));
+    }
+    if (b.inflight) {
+        const hipError_t q = hipEventQuery(b.ev);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return WG_OK; }
+        WG_HIP_TRY(q);
+        b.inflight = false;
+        double r[8], mean = 0;
+        bool ok = true;
+        for (int x = 0; x < 8; ++x) {
+            const unsigned long long dt = b.host[2 * x] - b.prev[2 * x], ds = b.host[2 * x + 1] - b.prev[2 * x + 1];
+            if (ds < 512) ok = false; // a few tiles per slot at least
+            r[x] = ds ? (double)dt / (double)ds : 0.0;
+            mean += r[x] / 8.0;
+        }
+        if (ok) { // (else: keep accumulating into the same interval)
+            for (int x = 0; x < 8; ++x) b.prev[2 * x] = b.host[2 * x], b.prev[2 * x + 1] = b.host[2 * x + 1];
+            for (int x = 0; x < 8; ++x) ok = ok && r[x] > 0.8 * mean && r[x] < 1.25 * mean;
+            if (ok) {
+                double m2 = 0;
+                for (int x = 0; x < 8; ++x) {
+                    const double rn = r[x] / mean;
+                    b.rel[x] = b.valid ? 0.5 * b.rel[x] + 0.5 * rn : rn;
+                    m2 += b.rel[x] / 8.0;
+                }
+                for (int x = 0; x < 8; ++x) b.rel[x] /= m2;
+                b.valid = true;
+                b.updates++;
+            }
+        }
+    }
+    // a snapshot per eligible launch until the rates have settled, then one in sixteen
+    static thread_local uint32_t tick = 0;
+    if (!b.inflight && (b.updates < 8 || (++tick & 15u) == 0)) {
+        WG_HIP_TRY(hipMemcpyAsync(b.host, b.dev, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b.side));
+        WG_HIP_TRY(hipEventRecord(b.ev, b.side));
+        b.inflight = true;
+    }
+    return WG_OK;
+}
+
+// rel[x]: time per stage of slot x relative to the mean. Returns the number of pairs (0: nothing worth moving).
+// `forced` (WG_TUNE_F16_BALANCE = 1, tests): a fixed pattern of takers and givers, two giving rounds included, whatever the size.
+uint32_t bal_plan(const double rel[8], uint32_t tiles, uint32_t S, bool forced, BalancePlan &bp) {
+    uint32_t n[8];
+    double w[8], delta[8], sum_w = 0, sum_inv = 0;
+    for (int x = 0; x < 8; ++x) {
+        n[x] = tiles / 8u + ((uint32_t)x < tiles % 8u ? 1u : 0u);
+        w[x] = ((double)S + kBalTileOverhead) * n[x] / 32.0; // stage-equivalents per CU
+        sum_w += w[x];
+        sum_inv += 1.0 / rel[x];
+    }
+    const double T = sum_w / sum_inv; // common finishing time if work could move freely
+    for (int x = 0; x < 8; ++x) delta[x] = T / rel[x] - w[x];
+    if (forced) {
+        const double s = (double)S, take[8] = { s / 3, 0, s / 2, s / 4, 0, 0, s / 4, 0 }, give[8] = { 0, s / 4, 0, 0, 0, s / 2, 0, s / 2 + s / 4 };
+        for (int x = 0; x < 8; ++x) delta[x] = take[x] > 0 ? take[x] + kBalTakeOverhead : (give[x] > 0 ? -give[x] + kBalGiveOverhead : 0.0);
+    }
+    double rem[8];
+    uint32_t rounds_used[8] = { 0 }, max_rounds[8], pairs = 0;
+    for (int x = 0; x < 8; ++x) {
+        rem[x] = delta[x] < 0 ? -delta[x] + kBalGiveOverhead : 0.0;
+        // a giving round = up to 32 tiles at the end of the slot's list; at least as many plain tiles stay in front of every giving round
+        const uint32_t r = n[x] / 64u;
+        max_rounds[x] = r > 2u ? 2u : r;
+        if (n[x] < 64u) max_rounds[x] = n[x] >= 4u ? 2u : (n[x] >= 2u ? 1u : 0u); // few tiles (tests, small products): rounds of n / 4
+        bp.len[x] = n[x];
+        bp.pre_cnt[x] = 0; bp.pre_src[x] = 0; bp.pre_p[x] = bp.pre_slot[x] = bp.pre_pair0[x] = 0;
+        for (int r2 = 0; r2 < 2; ++r2) bp.suf_lo[x][r2] = bp.suf_p[x][r2] = bp.suf_pair0[x][r2] = 0, bp.suf_cnt[x][r2] = 0;
+    }
+    bool taken[8] = { false };
+    for (;;) {
+        int f = -1;
+        for (int x = 0; x < 8; ++x)
+            if (!taken[x] && delta[x] - kBalTakeOverhead >= 3.0 && (f < 0 || delta[x] > delta[f])) f = x;
+        if (f < 0) break;
+        taken[f] = true;
+        int g = -1;
+        for (int x = 0; x < 8; ++x)
+            if (rem[x] >= 3.0 && rounds_used[x] < max_rounds[x] && (g < 0 || rem[x] > rem[g])) g = x;
+        if (g < 0) break;
+        double pd = delta[f] - kBalTakeOverhead;
+        if (pd > rem[g]) pd = rem[g];
+        uint32_t p = (uint32_t)(pd + 0.5);
+        if (p + 3u > S) p = S - 3u;
+        if (p < 3u) continue;
+        if (!forced && (double)p < kBalGiveOverhead + 1.0) continue; // the giver must come out ahead too
+        const uint32_t round = n[g] >= 64u ? 32u : (n[g] >= 4u ? n[g] / 4u : 1u);     // tiles per giving round of this giver
+        const uint32_t cnt = round < 32u ? round : 32u;                                // (a taker has 32 CUs)
+        const uint32_t lo = n[g] - round * (rounds_used[g] + 1u);
+        if (pairs + cnt > kBalMaxPairs) break;
+        bp.pre_cnt[f] = cnt; bp.pre_src[f] = (uint32_t)g; bp.pre_p[f] = p; bp.pre_slot[f] = lo; bp.pre_pair0[f] = pairs;
+        bp.len[f] = n[f] + cnt;
+        const uint32_t r2 = rounds_used[g]++;
+        bp.suf_lo[g][r2] = lo; bp.suf_cnt[g][r2] = cnt; bp.suf_p[g][r2] = p; bp.suf_pair0[g][r2] = pairs;
+        pairs += cnt;
+        rem[g] -= (double)p;
+    }
+    return pairs;
+}
+
 thread_local bool g_padding = false; // set while wgk_gemm_f16 runs on padded copies (see the staging branch)
 int pad_copy(wg_ctx *ctx, _Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd, const _Float16 *src, uint32_t ld_src,
              uint64_t src_batch, uint32_t rs, uint32_t cs, uint32_t nmats) {
@@ -774,6 +968,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.alpha = alpha; g.beta = beta;
     g.tile_base = 0; g.tail_tiles = 0;
     g.sched = nullptr; g.sched_tiles = 0;
+    g.calib = nullptr; g.bal = BalancePlan{};
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
@@ -888,6 +1083,30 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                     gm.sched = ctx->tile_queues; gm.sched_tiles = ntiles;
                     nwg = (ntiles + ntiles / 8u + 7u) & ~7u; // a fast XCD takes ~5 % more than its share; the surplus workgroups exit in ~2 us each
                 }
+                // Calibrated shares (bal_plan): few rounds of tiles on the whole chip. Below the scheduler's threshold whole tiles are too
+                // coarse to steal; prefix / suffix units of a few stages per CU even the XCDs out from measured rates, bit-identically.
+                // WG_TUNE_F16_BALANCE: 0 never, 1 whenever the shape allows (tests: made-up rates until real ones exist), -1 by size.
+                const int bal_knob = ctx->tuning[WG_TUNE_F16_BALANCE];
+                const uint32_t S = gm.K / 64u;
+                if (bal_knob != 0 && !dyn && gm.nsplit == 1 && nmats == 1 && gm.tail_tiles == 0 && gm.tile_base == 0 && cus == 256 && ntiles >= 16u && ntiles < 8u * 65535u && S >= 8u) {
+                    if (int rc = bal_prepare(ctx)) return rc;
+                    wg_ctx::F16Balance &b = ctx->bal;
+                    if (b.dev && ntiles >= (uint32_t)cus) gm.calib = b.dev; // full rounds only: a slot's rate with the whole chip busy
+                    const bool want = bal_knob == 1 || (bal_knob < 0 && b.valid && ntiles >= 2u * (uint32_t)cus);
+                    if (want && b.dev && !ctx->recording) { // (a recorded launch would replay with this launch's flag epoch)
+                        const uint32_t pairs = bal_plan(b.rel, ntiles, S, bal_knob == 1, gm.bal);
+                        if (pairs) {
+                            void *ws = nullptr;
+                            if (int rc = wg_ctx_bal_workspace(ctx, (size_t)pairs * 65536u * sizeof(float), &ws)) return rc;
+                            gm.bal.on = 1; gm.bal.epoch = ++b.epoch;
+                            gm.bal.flags = (uint32_t *)((char *)b.dev + kBalFlagsOffset);
+                            gm.bal.part = (float *)ws;
+                            uint32_t mx = 0;
+                            for (int x = 0; x < 8; ++x) mx = gm.bal.len[x] > mx ? gm.bal.len[x] : mx;
+                            nwg = 8u * mx;
+                        } else gm.bal = BalancePlan{};
+                    }
+                }
                 if (trans) hipLaunchKernelGGL((gemm_f16_m16_kernel<true>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
                 else hipLaunchKernelGGL((gemm_f16_m16_kernel<false>), dim3(nwg, gm.nsplit * nmats), dim3(256), 0, ctx->stream, gm);
                 return WG_OK;
@@ -990,5 +1209,38 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = generic_launch(ctx, trans, dim3(g.tiles_m, g.tiles_n, nmats), g)) return rc;
     }
     WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+
+// Host-side check of the planner (tests/test_abi_and_host.py; no device needed): the plan for `tiles` whole tiles of `stages` stages from the
+// relative slot rates rel8 (or the fixed test pattern), decoded for every workgroup id exactly as the kernel decodes it.
+// units[5 i .. 5 i + 4] = (tile, mode, first stage, stages, pair) of the i-th workgroup that has a unit.
+extern "C" int wg_debug_f16_balance_plan(const double *rel8, uint32_t tiles, uint32_t stages, int forced, uint32_t *units, uint32_t capacity, uint32_t *nunits,
+                                          uint32_t *nworkgroups) {
+    if (!rel8 || !nunits || (capacity && !units)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_debug_f16_balance_plan: NULL argument");
+    BalancePlan bp = BalancePlan{};
+    const uint32_t pairs = bal_plan(rel8, tiles, stages, forced != 0, bp);
+    (void)pairs;
+    uint32_t mx = 0, n = 0;
+    for (int x = 0; x < 8; ++x) mx = bp.len[x] > mx ? bp.len[x] : mx;
+    for (uint32_t b = 0; b < 8u * mx; ++b) {
+        uint32_t tile, mode, kb, ns, pair;
+        if (!bal_decode(bp, b, stages, tile, mode, kb, ns, pair)) continue;
+        if (n < capacity) { units[5 * n] = tile; units[5 * n + 1] = mode; units[5 * n + 2] = kb; units[5 * n + 3] = mode ? ns : stages; units[5 * n + 4] = pair; }
+        ++n;
+    }
+    *nunits = n;
+    if (nworkgroups) *nworkgroups = 8u * mx;
+    return WG_OK;
+}
+
+// What the calibration has measured so far on this context and how many launches ran with calibrated shares (bench.py reports it; tests
+// check that a forced launch really took the balanced path).
+extern "C" int wg_ctx_f16_balance_info(const wg_ctx *ctx, double *rel8, int *valid, uint32_t *updates, uint32_t *balanced_launches) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_f16_balance_info: ctx is NULL");
+    if (rel8) for (int x = 0; x < 8; ++x) rel8[x] = ctx->bal.rel[x];
+    if (valid) *valid = ctx->bal.valid ? 1 : 0;
+    if (updates) *updates = ctx->bal.updates;
+    if (balanced_launches) *balanced_launches = ctx->bal.epoch;
     return WG_OK;
 }

@@ -29,6 +29,47 @@ constexpr int HB_BYTES = BN * BKH * 2;
 constexpr int HSTAGE_BYTES = HA_BYTES + HB_BYTES; // 32 KiB
 constexpr int NSLOT = 5;                    // 5 x 32 KiB = all 160 KiB of LDS
 
+// Calibrated shares across XCDs (gemm_f16.hip, "balance"). The XCDs of one chip differ by a few per cent in speed under the power cap,
+// hardware deals every XCD the same number of workgroups, and with a handful of tiles per CU whole tiles are too coarse to even that
+// out. So a FAST XCD ("taker") starts with one extra unit per CU -- the first `p` stages of K of a tile that belongs to a SLOW XCD
+// ("giver"), raw f32 accumulators written to a scratch tile -- and the giver's workgroup for that tile, in its last round, starts from
+// those accumulators instead of zeros and runs the remaining stages: the same k-ordered accumulation chain in the same registers, bit
+// for bit the unsplit result. Workgroup id b is unit b / 8 of XCD b % 8's list: `pre_cnt` prefix units, then the XCD's own tiles
+// (ids = x mod 8, in order) of which up to two ranges are suffix units. Everything is decided on the host from measured per-XCD rates.
+struct BalancePlan {
+    uint32_t on, epoch;          // flag value of this launch's finished prefix units
+    uint32_t *flags;             // [pair]
+    float *part;                 // [pair][256 x 256] raw accumulators, tile-local column-major (the tail split's format)
+    // Every field is a 32-bit word ON PURPOSE: the kernel indexes these arrays with a run-time slot number straight out of its argument
+    // block, and with 1- and 2-byte elements hipcc (ROCm 7.2) builds scalar loads on a byte-granular base (kernarg + x) -- whose two
+    // low address bits the scalar memory unit ignores: slot 7 then read slot 6's entry (found on the GPU, not in the source).
+    uint32_t len[8];             // units of slot x (workgroups with b / 8 >= len[b % 8] exit)
+    uint32_t pre_cnt[8], pre_src[8], pre_p[8], pre_slot[8], pre_pair0[8]; // taker: p stages of the tiles 8 (pre_slot + j) + pre_src, j < pre_cnt; pair pre_pair0 + j
+    uint32_t suf_lo[8][2], suf_cnt[8][2], suf_p[8][2], suf_pair0[8][2];   // giver: own tiles [suf_lo, suf_lo + suf_cnt) start at stage suf_p from pair suf_pair0 + ...
+};
+
+// workgroup id b -> its unit (false: none, the workgroup exits). mode 0: whole tile; 1: prefix, stages [0, ns); 2: suffix, stages [kb, kb + ns).
+// `stages` = K / 64. Shared by the kernel and by the host-side check of the planner (wg_debug_f16_balance_plan).
+__host__ __device__ inline bool bal_decode(const BalancePlan &bp, uint32_t b, uint32_t stages, uint32_t &tile, uint32_t &mode, uint32_t &kb, uint32_t &ns,
+                                           uint32_t &pair) {
+    const uint32_t x = b & 7u, c = b >> 3;
+    mode = 0; kb = 0; ns = 0; pair = 0; tile = b;
+    if (c >= bp.len[x]) return false;
+    const uint32_t npre = bp.pre_cnt[x];
+    if (c < npre) {
+        mode = 1; ns = bp.pre_p[x]; pair = bp.pre_pair0[x] + c;
+        tile = 8u * (bp.pre_slot[x] + c) + bp.pre_src[x];
+        return true;
+    }
+    const uint32_t t = c - npre;
+    tile = 8u * t + x;
+    for (int r = 0; r < 2; ++r)
+        if (t - bp.suf_lo[x][r] < (uint32_t)bp.suf_cnt[x][r]) {
+            mode = 2; kb = bp.suf_p[x][r]; ns = stages - kb; pair = bp.suf_pair0[x][r] + (t - bp.suf_lo[x][r]);
+        }
+    return true;
+}
+
 struct GemmArgs {
     const _Float16 *a; uint32_t lda; uint64_t a_batch;
     const _Float16 *b; uint32_t ldb; uint64_t b_batch;
@@ -45,6 +86,9 @@ struct GemmArgs {
     // dynamic tile scheduler of the 16x16x32 kernel (nullptr: tile = blockIdx.x): 8 queue words, one per XCD, 128 bytes apart;
     // sched_tiles tiles are dealt out (gemm_f16.hip: m16_acquire_tile)
     unsigned long long *sched; uint32_t sched_tiles;
+    // per-XCD rate measurement (nullptr: off): calib[2 x] += main-loop time of a tile that ran on XCD x (100 MHz ticks), calib[2 x + 1] += its stages
+    unsigned long long *calib;
+    BalancePlan bal;
 #ifdef WG_F16_TRACE
     uint32_t trace_tiles; // timing experiment: records in `part` (gemm_f16.hip)
 #endif

@@ -72,6 +72,10 @@ int wg_ctx_check_async(wg_ctx *ctx) {
     return WG_OK;
 }
 
+int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out) {
+    return grow_scratch(ctx, &ctx->bal.scratch, &ctx->bal.scratch_bytes, bytes, "balance workspace", out);
+}
+
 extern "C" {
 
 int wg_abi_version(void) { return WGEBRA_HIP_ABI_VERSION; }
@@ -165,6 +169,11 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     for (void *p : ctx->retired_scratch) (void)hipFree(p);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->tile_queues) (void)hipFree(ctx->tile_queues);
+    if (ctx->bal.side) { (void)hipStreamSynchronize(ctx->bal.side); (void)hipStreamDestroy(ctx->bal.side); }
+    if (ctx->bal.ev) (void)hipEventDestroy(ctx->bal.ev);
+    if (ctx->bal.dev) (void)hipFree(ctx->bal.dev);
+    if (ctx->bal.host) (void)hipHostFree(ctx->bal.host);
+    if (ctx->bal.scratch) (void)hipFree(ctx->bal.scratch);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;

@@ -26,7 +26,21 @@ struct wg_ctx {
     int compute_units = 0;
     unsigned *flags = nullptr;           // a few zeroed device words (arrival counters of fused epilogues), created on first use
     unsigned long long *tile_queues = nullptr; // f16 Gemm tile scheduler: 8 per-XCD queue words, 128 bytes apart (gemm_f16.hip), created on first use
-    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    // f16 Gemm, calibrated shares across XCDs (gemm_f16.hip "balance"): measured relative time per stage of the workgroup slots b % 8,
+    // the device block that holds the accumulators (and the prefix -> suffix flags), and the snapshot in flight on the side stream
+    struct F16Balance {
+        unsigned long long *dev = nullptr;  // [0, 16): calib accumulators (ticks, stages per slot); flags (u32) from byte 2048 on: 1024 of them
+        unsigned long long *host = nullptr; // pinned: 16 words, the snapshot
+        unsigned long long prev[16] = { 0 };
+        hipStream_t side = nullptr;
+        hipEvent_t ev = nullptr;
+        bool inflight = false, valid = false, have_prev = false;
+        double rel[8] = { 1, 1, 1, 1, 1, 1, 1, 1 };
+        uint32_t epoch = 0, updates = 0;
+        void *scratch = nullptr;            // raw f32 accumulator tiles of the prefix units (grow-only)
+        size_t scratch_bytes = 0;
+    } bal;
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
     // pinned host words that kernels of this context's stream raise when something went wrong asynchronously (a communicator's wait
@@ -77,6 +91,7 @@ void wg_clear_error();
 int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out);
+int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wgk_transpose(wg_ctx *ctx, wg_dtype dtype, uint32_t rows, uint32_t cols, uint32_t nmats, const void *src, uint32_t ld_src,
                   uint64_t src_batch, void *dst, uint32_t ld_dst, uint64_t dst_batch);
 

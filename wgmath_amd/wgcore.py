@@ -305,6 +305,12 @@ class GpuInstance:
         check(lib.wg_ctx_set_tuning(self._ctx.handle, self._TUNING[knob], int(value)))
         return old
 
+    def f16_balance_info(self) -> dict:
+        """wg_ctx_f16_balance_info: measured per-slot rates, snapshots used, launches that ran with calibrated shares."""
+        rel, valid, upd, n = (ctypes.c_double * 8)(), ctypes.c_int(), ctypes.c_uint32(), ctypes.c_uint32()
+        check(lib.wg_ctx_f16_balance_info(self._ctx.handle, rel, ctypes.byref(valid), ctypes.byref(upd), ctypes.byref(n)))
+        return {"rel": [round(float(v), 4) for v in rel], "valid": bool(valid.value), "updates": upd.value, "balanced_launches": n.value}
+
     def get_tuning(self, knob: str) -> int:
         v = ctypes.c_int()
         check(lib.wg_ctx_get_tuning(self._ctx.handle, self._TUNING[knob], ctypes.byref(v)))
