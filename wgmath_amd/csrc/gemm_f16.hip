@@ -898,14 +898,17 @@ uint32_t bal_plan(const double rel[8], uint32_t tiles, uint32_t S, bool forced, 
     }
     const double T = sum_w / sum_inv; // common finishing time if work could move freely
     for (int x = 0; x < 8; ++x) delta[x] = T / rel[x] - w[x];
+    double want[8], rem[8]; // stages per CU a taker wants to add / a giver wants to shed (hand-off costs included)
+    for (int x = 0; x < 8; ++x) {
+        want[x] = delta[x] > 0 ? delta[x] - kBalTakeOverhead : 0.0;
+        rem[x] = delta[x] < 0 ? -delta[x] + kBalGiveOverhead : 0.0;
+    }
     if (forced) {
         const double s = (double)S, take[8] = { s / 3, 0, s / 2, s / 4, 0, 0, s / 4, 0 }, give[8] = { 0, s / 4, 0, 0, 0, s / 2, 0, s / 2 + s / 4 };
-        for (int x = 0; x < 8; ++x) delta[x] = take[x] > 0 ? take[x] + kBalTakeOverhead : (give[x] > 0 ? -give[x] + kBalGiveOverhead : 0.0);
+        for (int x = 0; x < 8; ++x) want[x] = take[x], rem[x] = give[x];
     }
-    double rem[8];
     uint32_t rounds_used[8] = { 0 }, max_rounds[8], pairs = 0;
     for (int x = 0; x < 8; ++x) {
-        rem[x] = delta[x] < 0 ? -delta[x] + kBalGiveOverhead : 0.0;
         // a giving round = up to 32 tiles at the end of the slot's list; at least as many plain tiles stay in front of every giving round
         const uint32_t r = n[x] / 64u;
         max_rounds[x] = r > 2u ? 2u : r;
@@ -918,14 +921,14 @@ uint32_t bal_plan(const double rel[8], uint32_t tiles, uint32_t S, bool forced, 
     for (;;) {
         int f = -1;
         for (int x = 0; x < 8; ++x)
-            if (!taken[x] && delta[x] - kBalTakeOverhead >= 3.0 && (f < 0 || delta[x] > delta[f])) f = x;
+            if (!taken[x] && want[x] >= 3.0 && (f < 0 || want[x] > want[f])) f = x;
         if (f < 0) break;
         taken[f] = true;
         int g = -1;
         for (int x = 0; x < 8; ++x)
             if (rem[x] >= 3.0 && rounds_used[x] < max_rounds[x] && (g < 0 || rem[x] > rem[g])) g = x;
         if (g < 0) break;
-        double pd = delta[f] - kBalTakeOverhead;
+        double pd = want[f];
         if (pd > rem[g]) pd = rem[g];
         uint32_t p = (uint32_t)(pd + 0.5);
         if (p + 3u > S) p = S - 3u;
