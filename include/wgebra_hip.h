@@ -43,7 +43,7 @@ extern "C" {
 typedef enum wg_status {
     WG_OK = 0,
     WG_ERR_DIM_MISMATCH = 1,  /* reference: assert_eq!(.., "Gemm: dimension mismatch.") & friends -> panic   */
-    WG_ERR_PRECONDITION = 2,  /* vec4 alignment (rows/stride/stride_mat/offset % 4), GemvFast rows%4 (gemv.rs:122) */
+    WG_ERR_PRECONDITION = 2,  /* an assertion of the reference that is not a dimension check: GemvFast rows % 4 (gemv.rs:122), ... */
     WG_ERR_INVALID_ARG = 3,   /* null handle, unknown enum value, foreign-context buffer                      */
     WG_ERR_OUT_OF_BOUNDS = 4, /* the view addresses elements past the end of its buffer                       */
     WG_ERR_HIP = 5,           /* a HIP runtime call failed; message carries hipGetErrorString                 */
@@ -202,8 +202,11 @@ int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
  * Gemm::dispatch_generic (wgebra gemm.rs:65-127): out = m1 * m2 (WG_GEMM, WG_GEMM_FAST) or m1^T * m2
  * (WG_GEMM_TR, WG_GEMM_TR_FAST), batched over size[2]; `out` is overwritten.
  *   DIM_MISMATCH  : the five assert_eq! of gemm.rs:91-95.
- *   PRECONDITION  : rows/stride/stride_mat/offset of any view, or K or N, not a multiple of 4 (the vec4 view of
- *                   shape.wgsl:64-66 makes the reference's result undefined there).
+ *   Views that are not vec4-aligned (rows / stride / stride_mat / offset of a view, or M, N, K, not a multiple of 4 -- what
+ *                   GpuMatrix::slice / rows / column hand out for odd offsets and lengths, tensor.rs:574-626): the reference's
+ *                   kernels bind array<vec4<f32>> and address the wrong elements there (shape.wgsl:64-66). Here they compute
+ *                   op(m1) m2 like any other view, on dense zero-padded staged copies (three HBM-bound passes in a context scratch
+ *                   that cannot grow inside a recording: WG_ERR_WORKSPACE). Only a view that exceeds its buffer is an error.
  *   *_FAST        : the reference requires K % 256 == 0 and reads out of bounds otherwise (gemm.wgsl:40,162);
  *                   here every K % 4 == 0 is accepted and all four variants run the same tuned kernel.
  * dtype WG_F16 (extension): f16 operands, f32 accumulation, result rounded once (RNE) to f16.
@@ -227,7 +230,8 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
  * Gemv::dispatch_generic (wgebra gemv.rs:64-137): out[:,y,z] = m[:,:,z] * v[:,y,z] (or m^T), for every RHS
  * column y < out.size[1] and matrix z < out.size[2]; `out` is overwritten.
  *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).
- *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122), vec4 alignment.
+ *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122). Views that are not
+ *                   vec4-aligned run on staged copies, as for wg_gemm.
  *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
  * dtype WG_F16 (extension): f16 elements, f32 accumulation, one rounding at the store -- the same HBM-bound kernels (> 8 right-hand
  * sides: the f16 Gemm kernels).

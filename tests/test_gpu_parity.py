@@ -208,6 +208,85 @@ def test_gemm_strided_views(gpu, oracle_c):
     U.assert_close_oracle(wo.view(got, sh(o_view))[:, :, 0], wo.view(orc, sh(o_view))[:, :, 0], 32, sabs, "strided gemm vs oracle")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_unaligned_views(gpu, dtype, tr):
+    """Views that are not vec4-aligned -- what GpuMatrix::slice((1, 0), ..), rows(1, n), columns of a parent with an odd row count and
+    lengths that are not multiples of 4 produce (tensor.rs:574-626) -- which the reference's vec4 kernels cannot address
+    (shape.wgsl:64-66). They compute op(A) B on dense staged copies here: against f64 with the usual bound, nothing outside the output
+    view touched, alpha / beta honoured."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(321 + int(tr))
+    PR, PC = 101, 90  # parents with an odd leading dimension
+    pa = (rng.random(PR * PC, dtype=np.float32) - 0.5).astype(dtype)
+    pb = (rng.random(PR * PC, dtype=np.float32) - 0.5).astype(dtype)
+    po0 = rng.random(PR * PC, dtype=np.float32).astype(dtype)
+    ta, tb, to = upload(gpu, (PR, PC), pa, dtype), upload(gpu, (PR, PC), pb, dtype), upload(gpu, (PR, PC), po0, dtype)
+    M, K, N = 37, 26, 19
+    # rows(1, ..) then columns: offset 1 + 3 * 101, stride 101, odd lengths
+    a_view = wg.GpuTensorView(wg.ViewShape(((K, M) if tr else (M, K)) + (1,), PR, PR * PC, 1 + 3 * PR), ta, 2)
+    b_view = tb.slice((1, 0), (K, N))                      # the reference's slice: offset i + j * nrows = 1, stride = parent rows
+    o_view = wg.GpuTensorView(wg.ViewShape((M, N, 1), PR, PR * PC, 2 + 5 * PR), to, 2)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, o_view, a_view, b_view, variant))
+    got = to.read(gpu.device())
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    A, B = wo.view(pa, sh(a_view))[:, :, 0].astype(np.float64), wo.view(pb, sh(b_view))[:, :, 0].astype(np.float64)
+    A = A.T if tr else A
+    truth, sabs = A @ B, np.abs(A) @ np.abs(B)
+    G = wo.view(got, sh(o_view))[:, :, 0].astype(np.float64)
+    tol = U.f32_gate(K, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0.0)
+    assert (np.abs(G - truth) <= tol).all(), f"unaligned gemm: worst err/tol {(np.abs(G - truth) / tol).max():.3g}"
+    mask = np.ones(po0.size, bool)
+    s_ = sh(o_view).resolved()
+    mask[(s_.offset + np.arange(M)[:, None] + np.arange(N)[None, :] * s_.stride).ravel()] = False
+    assert np.array_equal(got[mask], po0[mask]), "unaligned gemm wrote outside its output view"
+    # alpha / beta through the same path (wg_gemm_ex): out = 0.5 * A B - 2 * out
+    from wgmath_amd import _lib
+    to2 = upload(gpu, (PR, PC), po0, dtype)
+    o2 = wg.GpuTensorView(o_view.shape(), to2, 2)
+    _lib.check(_lib.lib.wg_gemm_ex(gpu._ctx.handle, int(variant), wg.wgcore.wg_dtype(dtype), 0.5, -2.0, to2._h, o2.shape().to_c(), ta._h, a_view.shape().to_c(),
+                                   tb._h, b_view.shape().to_c()))
+    got2 = wo.view(to2.read(gpu.device()), sh(o_view))[:, :, 0].astype(np.float64)
+    C0 = wo.view(po0, sh(o_view))[:, :, 0].astype(np.float64)
+    want = 0.5 * truth - 2.0 * C0
+    tol2 = 0.5 * tol + 4 * 2.0 ** (-11 if dtype == np.float16 else -24) * (np.abs(want) + 2 * np.abs(C0)) + 1e-6
+    assert (np.abs(got2 - want) <= tol2).all()
+
+
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemv_unaligned_views(gpu, tr):
+    """Gemv on a matrix view at an odd row / with odd lengths and vectors at odd offsets (GpuVector::rows(1, n), tensor.rs:669-680), 3
+    right-hand sides: staged copies, checked against f64; nothing outside the output view touched."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(654 + int(tr))
+    PR, PC = 203, 150
+    pm = (rng.random(PR * PC, dtype=np.float32) - 0.5).astype(np.float32)
+    tm = upload(gpu, (PR, PC), pm)
+    R, C = 131, 94
+    m_view = wg.GpuTensorView(wg.ViewShape((R, C, 1), PR, PR * PC, 3 + 7 * PR), tm, 2)
+    vlen, olen = (R, C) if tr else (C, R)
+    pv = (rng.random(5 + 3 * (vlen + 3), dtype=np.float32) - 0.5).astype(np.float32)
+    po = rng.random(7 + 3 * (olen + 1), dtype=np.float32)
+    tv, to = upload(gpu, (pv.size,), pv), upload(gpu, (po.size,), po)
+    v_view = wg.GpuTensorView(wg.ViewShape((vlen, 3, 1), vlen + 3, 1, 5), tv, 2)
+    o_view = wg.GpuTensorView(wg.ViewShape((olen, 3, 1), olen + 1, 1, 7), to, 2)
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, o_view, m_view, v_view, variant))
+    got = to.read(gpu.device())
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    A, X = wo.view(pm, sh(m_view))[:, :, 0], wo.view(pv, sh(v_view))[:, :, 0]
+    A = A.T if tr else A
+    truth, sabs = wo.gemm_f64(A, X)
+    U.assert_close_f64(wo.view(got, sh(o_view))[:, :, 0], truth, vlen, sabs, "unaligned gemv vs f64")
+    mask = np.ones(po.size, bool)
+    s_ = sh(o_view).resolved()
+    mask[(s_.offset + np.arange(olen)[:, None] + np.arange(3)[None, :] * s_.stride).ravel()] = False
+    assert np.array_equal(got[mask], po[mask]), "unaligned gemv wrote outside its output view"
+
+
 GEMV_SHAPES = [
     # R,    C, nrhs, mats
     (4, 4, 1, 1), (8, 260, 1, 1), (260, 8, 1, 1), (1024, 1024, 1, 1), (512, 4096, 2, 1), (4096, 512, 3, 2),
@@ -286,8 +365,7 @@ def test_errors_and_skips(gpu):
         wg.OpAssign.new(dev, wg.OpAssignVariant.Add).dispatch(dev, shapes, p, z(8), z(12))
     with pytest.raises(wg.PreconditionFailed):  # gemv.rs:122
         gemv.dispatch_generic(dev, shapes, p, z(6), z(6, 8), z(8), wg.GemvVariant.GemvFast)
-    with pytest.raises(wg.PreconditionFailed):  # not vec4-aligned
-        gemm.dispatch(dev, shapes, p, z(6, 8), z(6, 8), z(8, 8))
+    gemm.dispatch(dev, shapes, p, z(6, 8), z(6, 8), z(8, 8))  # not vec4-aligned: computed on staged copies (test_gemm_unaligned_views), no error
     with pytest.raises(wg.WgError, match="addresses"):  # view larger than its buffer
         big = z(8, 8)
         gemm.dispatch(dev, shapes, p, wg.GpuTensorView(wg.ViewShape((16, 16, 1), 16, 256, 0), big, 2), z(16, 16), z(16, 16))
@@ -395,6 +473,22 @@ def test_gemm_f16_shapes(gpu, f16_tile, M, K, N, mats, tr):
     for t in range(mats):
         amk = (A[:, :, t].T if tr else A[:, :, t]).astype(np.float64)
         f16_check(wo.view(got, so)[:, :, t], amk, B[:, :, t].astype(np.float64), K, f"f16 gemm {M}x{K}x{N} mat {t} tr={tr}")
+    # SURVEY 8(c)'s f16 oracle: the f32 WGSL restatement (oracle/wgsl_oracle.c) on the exactly representable f16 operands. The MFMA
+    # kernels accumulate the same exact products in f32 in another order and round once to f16: both sit within the f32 gate of the
+    # truth, so |gpu - oracle| <= 2 x gate + half an f16 ulp of the result (+ the subnormal floor). Shapes the C oracle finishes in
+    # seconds (and whose dimensions the WGSL kernels take: multiples of 4).
+    if (tr or f16_tile == "auto") and M * K * N * mats <= (1 << 31):
+        C = wo.CLib()
+        orc = np.zeros(M * N * mats, np.float32)
+        C.gemm(wo.GEMM_TR if tr else wo.GEMM, orc, so, a.astype(np.float32), s1, b.astype(np.float32), s2)
+        O = wo.view(orc, so)
+        for t in range(mats):
+            amk = (A[:, :, t].T if tr else A[:, :, t]).astype(np.float64)
+            sabs = np.abs(amk) @ np.abs(B[:, :, t].astype(np.float64))
+            o64 = O[:, :, t].astype(np.float64)
+            tol = 2.0 * U.f32_gate(K, sabs) + 2.0 ** -11 * np.abs(o64) + 2.0 ** -25
+            err = np.abs(wo.view(got, so)[:, :, t].astype(np.float64) - o64)
+            assert (err <= tol).all(), f"f16 gemm {M}x{K}x{N} mat {t} tr={tr} vs the f32 restatement on f16 operands: worst err/tol {(err / tol).max():.3g}"
 
 
 @pytest.mark.parametrize("tr", [False, True])
@@ -755,6 +849,49 @@ def test_gemv_row_major_multi_rhs(gpu, tr, R, Cn, nrhs, mats):
         assert (np.abs(got[z] - truth) <= U.f32_gate(vlen, sabs)).all(), f"row-major Gemv x{nrhs}: matrix {z}"
 
 
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N", [(512, 192 + 8, 512), (512, 192 + 32, 264), (776, 256 + 40, 520), (512, 448 + 56, 512), (4352, 1024 + 24, 4352), (256, 8192 + 16, 256),
+                                   (4096, 512 + 48, 4096)])
+def test_gemm_f16_k_remainder(gpu, M, K, N, tr):
+    """K % 64 != 0 (any multiple of 8) on the 16x16x32 kernel: the remainder is the loop's stage 0 -- zero-padded through the LDS by
+    ordinary loads + stores in the DMA's image -- on plain launches, ragged tiles, the tail split (17 x 17 tiles), split-K (the last
+    split takes it) and, forced, the balance units (the prefix unit multiplies it). Poisoned neighbours: the k-values just past K in
+    memory (the next column / row block) are NaN, so a remainder stage that reads one element too many cannot pass."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + K + N + int(tr))
+    KP = K + 8  # parents with 8 extra k, filled with NaN
+    if tr:   # m1 stored K x M: k runs down the columns -> pad rows
+        pa = np.full((M, KP), np.nan, np.float16); pa[:, :K] = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        a_flat, a_view_shape = pa.reshape(-1), wg.ViewShape((K, M, 1), KP, KP * M, 0)
+        A64 = pa[:, :K].astype(np.float64)
+    else:    # m1 stored M x K column-major: k indexes columns -> extra NaN columns behind
+        pa = np.full((KP, M), np.nan, np.float16); pa[:K] = (rng.random((K, M), dtype=np.float32) * 2 - 1).astype(np.float16)
+        a_flat, a_view_shape = pa.reshape(-1), wg.ViewShape((M, K, 1), M, M * KP, 0)
+        A64 = pa[:K].T.astype(np.float64)
+    pb = np.full((N, KP), np.nan, np.float16); pb[:, :K] = (rng.random((N, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+    B64 = pb[:, :K].T.astype(np.float64)
+    ta, tb = upload(gpu, (a_flat.size,), a_flat, np.float16), upload(gpu, (pb.size,), pb.reshape(-1), np.float16)
+    va = wg.GpuTensorView(a_view_shape, ta, 2)
+    vb = wg.GpuTensorView(wg.ViewShape((K, N, 1), KP, KP * N, 0), tb, 2)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    res = []
+    old = {k: gpu.get_tuning(k) for k in ("f16_tile", "f16_balance", "f16_sched")}
+    try:
+        for tile, bal, sched in ((0, 0, -1), (256, 0, 0), (256, 1, 0), (256, 0, 1)):
+            gpu.set_tuning("f16_tile", tile); gpu.set_tuning("f16_balance", bal); gpu.set_tuning("f16_sched", sched)
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, va, vb, variant))
+            res.append(out.read(gpu.device()).reshape(N, M).T.copy())
+    finally:
+        for k, v in old.items():
+            gpu.set_tuning(k, v)
+    for r in res:
+        f16_check(r, A64, B64, K, f"K remainder {M}x{K}x{N} tr={tr}")
+    # static map, balance units and the tile scheduler run the same accumulation chains: bit-identical
+    assert np.array_equal(res[1].view(np.uint16), res[2].view(np.uint16)) and np.array_equal(res[1].view(np.uint16), res[3].view(np.uint16))
+
+
 # --------------------------------------------------------------------------------------------------------
 # seeded fuzz over the f16 MFMA paths: random ragged sizes, strides, offsets, batches, both variants, alpha/beta
 # --------------------------------------------------------------------------------------------------------
@@ -763,7 +900,7 @@ def test_gemm_f16_fuzz(gpu, f16_tile, seed):
     wg = _wg()
     rng = np.random.default_rng(1000 + seed)
     M, N = int(rng.integers(1, 80)) * 8, int(rng.integers(1, 80)) * 8
-    K = int(rng.choice([192, 256, 320, 448, 576, 1024, 96, 160, 2048 + 64]))  # mostly the 16x16x32 kernel, some 32x32x16
+    K = int(rng.choice([192, 256, 320, 448, 576, 1024, 96, 160, 2048 + 64, 200, 232, 248, 440, 1000, 64, 128, 72]))  # whole stages, K % 64 remainders of every size, short K
     mats = int(rng.choice([1, 1, 2, 3]))
     tr = bool(rng.integers(0, 2))
     ex = bool(rng.integers(0, 2))

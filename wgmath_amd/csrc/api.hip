@@ -24,19 +24,12 @@ int check_bounds(const char *op, const char *name, const View &v, const wg_buf *
     return WG_OK;
 }
 
-// The kernels bind every buffer as array<vec4<f32>> (gemm.wgsl:9-14, gemv.wgsl:9-14) and convert shapes with
+// The reference's kernels bind every buffer as array<vec4<f32>> (gemm.wgsl:9-14, gemv.wgsl:9-14) and convert shapes with
 // with_vec4_elts (shape.wgsl:64-66): rows, stride, stride_mat and offset must be multiples of 4 for that to address
 // the same elements. (stride only matters with > 1 column, stride_mat with > 1 matrix: GpuMatrix::column sets
-// stride = 1 and GpuCubeView::matrix sets stride_mat = 1, tensor.rs:474,574-584.)
-int check_vec4(const char *op, const char *name, const View &v) {
-    if (v.rows % 4 || v.offset % 4 || (v.cols > 1 && v.stride % 4) || (v.mats > 1 && v.stride_mat % 4))
-        return wg_set_error(WG_ERR_PRECONDITION,
-                            "%s: view `%s` {size:[%u,%u,%u], stride:%u, stride_mat:%u, offset:%u} is not vec4-aligned "
-                            "(rows, stride, stride_mat, offset must be multiples of 4: shape.wgsl:64-66)",
-                            op, name, v.rows, v.cols, v.mats, v.stride, v.stride_mat, v.offset);
-    return WG_OK;
-}
-
+// stride = 1 and GpuCubeView::matrix sets stride_mat = 1, tensor.rs:474,574-584.) Views like that go to the kernels as they
+// are (16-byte accesses); all others are staged (gemm_staged / gemv_staged below).
+inline bool vec4_ok(const View &v) { return !(v.rows % 4 || v.offset % 4 || (v.cols > 1 && v.stride % 4) || (v.mats > 1 && v.stride_mat % 4)); }
 int check_common(const char *op, const wg_ctx *ctx, wg_dtype dtype, const wg_buf *const *bufs, int n) {
     if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "%s: ctx is NULL", op);
     if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "%s: unknown dtype %d", op, (int)dtype);
@@ -50,6 +43,53 @@ int check_common(const char *op, const wg_ctx *ctx, wg_dtype dtype, const wg_buf
 }
 
 inline const void *elem_ptr(const wg_buf *b, uint64_t elem, wg_dtype dt) { return (const char *)b->ptr + elem * wg_dtype_size(dt); }
+
+inline uint32_t up8(uint32_t x) { return (x + 7u) & ~7u; }
+
+// Views that are not vec4-aligned. The reference's kernels cannot address them (they bind array<vec4<f32>> and divide rows, strides
+// and offsets by 4, shape.wgsl:64-66: a slice at an odd row, a column block with an odd stride or a length that is not a multiple of
+// 4 reads the wrong elements there), yet its own constructors hand them out (GpuMatrix::slice / rows / column, tensor.rs:574-626).
+// Here they compute op(A) B exactly as the aligned call would: every operand is staged into a dense, 16-byte aligned, zero-padded
+// copy (dimensions rounded up to 8; zeros add nothing to a dot product), the usual kernels run on the copies, and the M x N result
+// is copied back into the output view -- three HBM-bound passes in a fourth context scratch (it cannot grow inside a recording).
+int gemm_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, float alpha, float beta, wg_buf *out, const View &o, const wg_buf *m1, const View &a, const wg_buf *m2,
+                const View &b, uint32_t M, uint32_t N, uint32_t K) {
+    const size_t es = wg_dtype_size(dtype);
+    const uint32_t Mp = up8(M), Np = up8(N), Kp = up8(K), mats = o.mats;
+    const uint64_t ae = (uint64_t)Mp * Kp, be = (uint64_t)Kp * Np, ce = (uint64_t)Mp * Np;
+    if (ae * mats >= (1ull << 32) || be * mats >= (1ull << 32) || ce * mats >= (1ull << 32))
+        return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: operands too large for the staging path of views that are not vec4-aligned");
+    void *ws = nullptr;
+    if (int rc = wg_ctx_stage_workspace(ctx, (size_t)((ae + be + ce) * mats * es), &ws)) return rc;
+    char *ap = (char *)ws, *bp = ap + ae * mats * es, *cp = bp + be * mats * es;
+    const uint32_t a_ld = tr ? Kp : Mp;
+    if (int rc = wgk_stage_copy(ctx, dtype, ap, a_ld, ae, tr ? Kp : Mp, tr ? Mp : Kp, elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat, a.rows, a.cols, mats)) return rc;
+    if (int rc = wgk_stage_copy(ctx, dtype, bp, Kp, be, Kp, Np, elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat, b.rows, b.cols, mats)) return rc;
+    if (beta != 0.f)
+        if (int rc = wgk_stage_copy(ctx, dtype, cp, Mp, ce, Mp, Np, elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, N, mats)) return rc;
+    const wgk_mat A = { ap, a_ld, ae }, B = { bp, Kp, be };
+    if (int rc = dtype == WG_F32 ? wgk_gemm_f32(ctx, tr, Mp, Np, Kp, mats, (float *)cp, Mp, ce, A, B, alpha, beta)
+                                 : wgk_gemm_f16(ctx, tr, Mp, Np, Kp, mats, (__half *)cp, Mp, ce, A, B, alpha, beta))
+        return rc;
+    return wgk_stage_copy(ctx, dtype, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, N, cp, Mp, ce, Mp, Np, mats);
+}
+
+int gemv_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, wg_buf *out, const View &o, const wg_buf *m, const View &mm, const wg_buf *v, const View &vv,
+                uint32_t rows_out, uint32_t k) {
+    const size_t es = wg_dtype_size(dtype);
+    const uint32_t Rp = up8(mm.rows), Cp = up8(mm.cols), Op = up8(rows_out), Kp = up8(k), nrhs = o.cols, mats = o.mats;
+    const uint64_t me = (uint64_t)Rp * Cp, ve = (uint64_t)Kp * nrhs, oe = (uint64_t)Op * nrhs;
+    if (me * mats >= (1ull << 32) || ve * mats >= (1ull << 32) || oe * mats >= (1ull << 32))
+        return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: operands too large for the staging path of views that are not vec4-aligned");
+    void *ws = nullptr;
+    if (int rc = wg_ctx_stage_workspace(ctx, (size_t)((me + ve + oe) * mats * es), &ws)) return rc;
+    char *mp = (char *)ws, *vp = mp + me * mats * es, *op = vp + ve * mats * es;
+    if (int rc = wgk_stage_copy(ctx, dtype, mp, Rp, me, Rp, Cp, elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat, mm.rows, mm.cols, mats)) return rc;
+    if (int rc = wgk_stage_copy(ctx, dtype, vp, Kp, ve, Kp, nrhs, elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat, k, nrhs, mats)) return rc;
+    const wgk_mat Mx = { mp, Rp, me }, Vx = { vp, Kp, ve };
+    if (int rc = wgk_gemv(ctx, tr, dtype, Op, Kp, nrhs, mats, op, Op, oe, Mx, Vx)) return rc;
+    return wgk_stage_copy(ctx, dtype, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, rows_out, nrhs, op, Op, oe, Op, nrhs, mats);
+}
 
 } // namespace
 
@@ -79,17 +119,14 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
     if (o.rows == 0 || o.mats == 0) return WG_OK;
     if (o.cols == 0) return WG_OK; // the kernels' k-loop over m2 columns runs zero times
 
-    if (int rc = check_vec4("Gemm", "out", o)) return rc;
-    if (int rc = check_vec4("Gemm", "m1", a)) return rc;
-    if (int rc = check_vec4("Gemm", "m2", b)) return rc;
-    if (o.cols % 4 || m_cols % 4 || m_rows % 4)
-        return wg_set_error(WG_ERR_PRECONDITION, "Gemm: M=%u, N=%u, K=%u must be multiples of 4 (4x4 blocks, gemm.wgsl:87,94)",
-                            m_rows, o.cols, m_cols);
     if (int rc = check_bounds("Gemm", "out", o, out, dtype)) return rc;
     if (int rc = check_bounds("Gemm", "m1", a, m1, dtype)) return rc;
     if (int rc = check_bounds("Gemm", "m2", b, m2, dtype)) return rc;
 
     WG_HIP_TRY(hipSetDevice(ctx->device));
+    // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemm.wgsl:87,94: 4 x 4 blocks): dense staged copies
+    if (!vec4_ok(o) || !vec4_ok(a) || !vec4_ok(b) || o.cols % 4 || m_cols % 4 || m_rows % 4)
+        return gemm_staged(ctx, tr, dtype, alpha, beta, out, o, m1, a, m2, b, m_rows, o.cols, m_cols);
     wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
     wgk_mat B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };
     void *C = (void *)elem_ptr(out, o.offset, dtype);
@@ -123,16 +160,14 @@ int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out, w
     // that are actually addressed take their column / matrix counts from `out`.
     const View m_eff = { mm.rows, mm.cols, o.mats, mm.stride, mm.stride_mat, mm.offset };
     const View v_eff = { vv.rows, o.cols, o.mats, vv.stride, vv.stride_mat, vv.offset };
-    if (int rc = check_vec4("Gemv", "out", o)) return rc;
-    if (int rc = check_vec4("Gemv", "m", m_eff)) return rc;
-    if (int rc = check_vec4("Gemv", "v", v_eff)) return rc;
-    if (m_cols % 4 || m_rows % 4)
-        return wg_set_error(WG_ERR_PRECONDITION, "Gemv: matrix dimensions %u x %u must be multiples of 4 (gemv.wgsl:73,76)", mm.rows, mm.cols);
     if (int rc = check_bounds("Gemv", "out", o, out, dtype)) return rc;
     if (int rc = check_bounds("Gemv", "m", m_eff, m, dtype)) return rc;
     if (int rc = check_bounds("Gemv", "v", v_eff, v, dtype)) return rc;
 
     WG_HIP_TRY(hipSetDevice(ctx->device));
+    // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemv.wgsl:73,76): dense staged copies
+    if (!vec4_ok(o) || !vec4_ok(m_eff) || !vec4_ok(v_eff) || m_cols % 4 || m_rows % 4)
+        return gemv_staged(ctx, tr, dtype, out, o, m, m_eff, v, v_eff, m_rows, m_cols);
     wgk_mat M = { elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat };
     wgk_mat V = { elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat };
     return wgk_gemv(ctx, tr, dtype, o.rows, m_cols, o.cols, o.mats, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, V);
@@ -291,7 +326,6 @@ int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out
     // m1 is K x M row-major == column-major M x K (ld = stride); the column-major Gemm needs it as K x M column-major
     if (out->bytes == 0 || m1->bytes == 0 || m2->bytes == 0 || o.rows == 0 || o.cols == 0 || o.mats == 0) return WG_OK;
     const View a_cm = mk(relabel(m1_shape)); // M x K column-major
-    if (int rc = check_vec4("Gemm", "m1", a_cm)) return rc;
     if (int rc = check_bounds("Gemm", "m1", a_cm, m1, dtype)) return rc;
     const size_t es = dtype == WG_F32 ? 4 : 2;
     const uint32_t K = a.rows, M = a.cols;

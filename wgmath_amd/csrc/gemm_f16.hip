@@ -138,7 +138,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     uint32_t k_begin = split * g.k_per_split;
-    uint32_t K_loc = min(g.K - k_begin, g.k_per_split);
+    uint32_t K_loc = split + 1u == g.nsplit ? g.K - k_begin : g.k_per_split; // (the last split takes whatever is left, K remainder included)
     bool from_partial = false; // workgroup-uniform
     if (unit_mode == 2) {
         // consumer side of the hand-off (guide, G16): ONE lane polls relaxed, ONE agent-scope acquire, barrier, then plain loads by everyone
@@ -157,9 +157,17 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         __syncthreads();
         from_partial = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t *>(smem)) != 0;
         __syncthreads(); // everyone has read the word before the first DMA piece may land on it
-        if (!from_partial) { unit_ns += unit_kb; unit_kb = 0; }
     }
-    if (unit_mode) { k_begin = unit_kb * 64u; K_loc = unit_ns * 64u; }
+    // K remainder (K % 64, a multiple of 8): the k-values past the last whole stage of this workgroup's range are multiplied FIRST -- they
+    // are the accumulators' initial value (rem_block below) -- by the unit that starts the tile's accumulation chain: a prefix unit,
+    // a whole tile, the last split. A suffix unit continues a chain that already holds them.
+    uint32_t rem = 0, rem_k0 = 0;
+    if (unit_mode == 1) { k_begin = 0; K_loc = unit_ns * 64u; rem = g.K & 63u; rem_k0 = g.K - rem; }
+    else if (unit_mode == 2 && from_partial) { k_begin = unit_kb * 64u; K_loc = (g.K & ~63u) - k_begin; }
+    else {
+        if (unit_mode == 2) { k_begin = 0; K_loc = g.K; } // a suffix unit without its prefix: the whole tile
+        rem = K_loc & 63u; K_loc -= rem; rem_k0 = k_begin + K_loc;
+    }
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
     _Float16 *C = g.c + z * g.c_batch;
@@ -179,6 +187,14 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     uint32_t a_voff[TRANS_A ? 8 : 4], b_voff[8];
     const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
+    // K remainder (see the prologue): where its k-values start, and the loop's stage 0 becomes the remainder -- every base one stage back
+    const uint32_t rem_dk = rem_k0 - k_begin;
+    const char *rem_a = TRANS_A ? (const char *)(a_base + rem_dk) : (const char *)(a_base + (uint64_t)rem_dk * g.lda);
+    const char *rem_b = (const char *)(b_base + rem_dk);
+    if (rem) {
+        if constexpr (TRANS_A) a_base -= 64; else a_base -= (uint64_t)64u * g.lda;
+        b_base -= 64;
+    }
     if constexpr (TRANS_A) { // op(A) rows are k-contiguous: full stages like B -- rows 8P..8P+7, 128 bytes each, P = 8 wave + q
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -273,7 +289,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     using k12 = std::integral_constant<int, 12>;
     using k16 = std::integral_constant<int, 16>;
 
-    const uint32_t S = K_loc / 64u; // full stages; the launcher guarantees K_loc % 64 == 0 and S >= 3
+    const uint32_t S = K_loc / 64u + (rem ? 1u : 0u); // stages of the loop (the K remainder, if any, is its stage 0); the launcher guarantees >= 3 whole ones
     uint32_t st = 0;                // current stage
 
     // ---- Issue model (measured: profiles/r02_evidence.md 3d). With one wave per SIMD, the 16 cycles of a 16x16x32 MFMA hide up to ~3
@@ -505,7 +521,45 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             }
         }
     };
-    if (!(WG_ABLATE & 2)) {
+    if (rem) {
+        // K remainder = stage 0 of the loop. Its k-values, zero-padded to a whole stage, go through the LDS by ordinary loads + stores in
+        // exactly the image the DMA pieces of stage 0 would have written (same per-lane source addresses, same lane-linear destinations);
+        // the DMA stream starts with stage 1 = the range's first 64 k (the bases were moved back by one stage above). No MFMA outside the
+        // one loop, no second accumulation chain: the remainder is simply multiplied first.
+        auto put = [&](uint32_t lds_dst, const char *src, bool valid) {
+            uintx4 v = { 0u, 0u, 0u, 0u };
+            if (valid) v = *reinterpret_cast<const uintx4 *>(src);
+            *(WG_AS3 uintx4 *)(uintptr_t)(lds_dst + 16u * (uint32_t)lane) = v;
+        };
+        if constexpr (TRANS_A) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+                const uint32_t chunk = (lane & 7u) ^ (((4u - ((row >> 3) & 3u)) & 3u) | (((row >> 1) & 1u) << 2));
+                put(lds_a_wave + (uint32_t)(q >> 2) * 4096u + (uint32_t)(q & 3) * 1024u, rem_a + (a_voff[q] - (M16_BIAS - 1024u * (q & 3))), 8u * chunk < rem);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t k_local = 32u * h + 4u * ((4u * wave + q) >> 1) + ((lane >> 2) & 3u);
+                    put(lds_a_wave + (uint32_t)h * HA_BYTES + (uint32_t)q * 1024u, rem_a + (uint64_t)(32u * h) * g.lda * 2u + (a_voff[q] - (M16_BIAS - 1024u * q)), k_local < rem);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+            const uint32_t chunk = (lane & 7u) ^ (((4u - ((row >> 2) & 3u)) & 3u) | (((row >> 1) & 1u) << 2));
+            put(lds_b_wave + (uint32_t)(q >> 2) * 4096u + (uint32_t)(q & 3) * 1024u, rem_b + (b_voff[q] - (M16_BIAS - 1024u * (q & 3))), 8u * chunk < rem);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0); // the loads above are the compiler's to wait for: keep them in front of the DMA pieces it cannot see
+        if (!(WG_ABLATE & 2)) {
+            if constexpr (TRANS_A) { pro_b(-2, 8); pro_b(1, 8); pro_b(2, 4); }
+            else { pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4); }
+        }
+    } else if (!(WG_ABLATE & 2)) {
         if constexpr (TRANS_A) { // full stages of A as well: A(0), B(0) | A(1), B(1), first half of B(2)
             pro_b(-1, 8); pro_b(0, 8);
             pro_b(-2, 8); pro_b(1, 8); pro_b(2, 4);
@@ -978,7 +1032,12 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // 32-bit DMA offsets within a tile: rows * ld * 2 bytes must stay below 2^31
     const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);
     // (N is free: B rows are clamped per column and the epilogues skip columns >= N)
-    const bool fast = (M % 8 == 0) && (K % BKH == 0) && K >= (uint32_t)BKH && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) &&
+    // K: any multiple of 8 with >= 3 whole stages (the 256 x 256 kernel: a K % 64 remainder is the accumulators' initial value, m16_tile);
+    // 64 or 128 (the 128 x 128 kernel, whole stages only). Everything else is zero-padded along K by the staging branch below.
+    const uint32_t krem = K % 64u;
+    const bool k_big = K % 8u == 0 && K - krem >= 192u, k_small = krem == 0 && K >= 64u;
+    const bool a_step_fits = trans || (uint64_t)m1.ld * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
+    const bool fast = (M % 8 == 0) && (k_big || k_small) && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) && a_step_fits &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
     if (fast) {
         g.tiles_m = (M + BM - 1) / BM;
@@ -1007,7 +1066,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 if (ns < 2) ns = 1;
             }
             bool want128 = false;
-            if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
+            if (!k_big) want128 = true; // K = 64 or 128: fewer than the three stages the big kernel's DMA pipeline runs ahead
+            else if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
             else if (tiles * nmats < (uint64_t)cus) {
                 const double w128 = (double)(tiles128 * nmats * ns) / cus, k128 = (double)(((K / 64u + ns - 1) / ns) * 64u);
                 const double est128 = (w128 <= 1.0 ? k128 * 0.00875 : w128 * k128 * 0.0108) + 6.0 + slabs(ns);
@@ -1033,30 +1093,28 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 }
             }
         }
-        // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split
+        if (!k_big) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: K = %u with %u matrices does not fit the 128 x 128 kernel's launch", K, nmats);
+        // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split. Every split is a
+        // whole number of stages and at least three of them (the DMA stream runs three stages ahead); the LAST one also takes the K % 64
+        // remainder.
         uint32_t nsplit = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
-#ifdef WG_F16_TRACE
-        if (getenv("WG_F16_NOSPLIT")) nsplit = 1; // timing experiments: fewer tiles than CUs on the big kernel, unsplit
-#endif
+        const uint32_t stages = K / 64u;
+        auto kps_of = [&](uint32_t ns) { return ((stages + ns - 1u) / ns) * 64u; };
+        while (nsplit > 1) {
+            const uint32_t kps = kps_of(nsplit), n = (K - krem + kps - 1u) / kps;
+            if (n == nsplit && kps >= 192u && K - krem - (n - 1u) * kps >= 192u) break;
+            nsplit = n < nsplit ? n : nsplit - 1u;
+        }
         g.nsplit = nsplit;
-        g.k_per_split = nsplit > 1 ? ((K / BKH + nsplit - 1) / nsplit) * BKH : K;
+        g.k_per_split = nsplit > 1 ? kps_of(nsplit) : K;
         g.part = nullptr;
         if (nsplit > 1) {
-            g.nsplit = nsplit = (K + g.k_per_split - 1) / g.k_per_split; // no empty splits
             void *ws = nullptr;
             if (int rc = wg_ctx_workspace(ctx, (size_t)nsplit * M * N * nmats * sizeof(float), &ws)) return rc;
             g.part = (float *)ws;
         }
         if ((uint64_t)nmats * nsplit > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
-        const dim3 grid((uint32_t)tiles, nmats * nsplit);
-#ifndef WG_F16_M16
-#define WG_F16_M16 1 // 1 = 16x16x32 MFMA kernel, 0 = 32x32x16 MFMA kernel
-#endif
-        // the 16x16x32 kernel stages B in full stages of 64 k and its DMA stream runs three stages ahead: every split (the last one may be
-        // shorter) must be a multiple of 64 k and >= 192 k
-        const uint32_t last_k = K - (nsplit - 1) * g.k_per_split;
-        const bool a_step_fits = trans || (uint64_t)g.lda * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
-        if (WG_F16_M16 && a_step_fits && g.k_per_split % 64u == 0 && last_k % 64u == 0 && last_k >= 192u && (nsplit == 1 || g.k_per_split >= 192u)) {
+        {
 #ifdef WG_F16_TRACE
             uint64_t *trace = nullptr;
             if (nsplit == 1) {
@@ -1123,11 +1181,10 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
                 if (r > 0 && r * 2u <= (uint32_t)cus) {
                     uint32_t sp = (uint32_t)cus / r;
-                    const uint32_t stages = K / 64u;
                     if (sp > stages / 3u) sp = stages / 3u; // >= 3 stages per split
                     while (sp >= 2) {
                         const uint32_t kps = ((stages + sp - 1) / sp) * 64u;
-                        const uint32_t n = (K + kps - 1) / kps, last = K - (n - 1) * kps;
+                        const uint32_t n = (K - krem + kps - 1) / kps, last = K - krem - (n - 1) * kps; // (the last split also takes the K % 64 remainder)
                         if (n >= 2 && last >= 192u && (size_t)n * r * 65536u * sizeof(float) <= (512ull << 20)) { tail = r; tail_split = n; tail_kps = kps; break; }
                         --sp;
                     }
@@ -1164,8 +1221,6 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 g.part = nullptr;
             }
 #endif
-        } else {
-            if (int rc = legacy_launch(ctx, trans, grid, g)) return rc;
         }
         WG_HIP_TRY(hipGetLastError());
         if (nsplit > 1) return wg_splitk_reduce(ctx, g.part, nsplit, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
@@ -1178,7 +1233,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // scratch and run the same call on those: HBM-bound passes over a few MB against a GEMM that re-reads them hundreds of times.
         // Only what does not qualify is copied: op(A) when K, M, its leading dimension or its alignment is off, B when K or its leading
         // dimension / alignment is, the output when M or its leading dimension / alignment is (N is free: columns are independent).
-        const bool k_ok = K % BKH == 0;
+        const bool k_ok = k_big || k_small; // (else: zero-padded to whole stages -- at least one, which the 128 x 128 kernel takes)
         const uint32_t Mp = (M + 7u) & ~7u, Kp = k_ok ? K : ((K + 63u) & ~63u);
         const bool a_ok = k_ok && M == Mp && m1.ld % 8 == 0 && al16(m1.ptr) && (nmats == 1 || m1.batch % 8 == 0);
         const bool b_ok = k_ok && m2.ld % 8 == 0 && al16(m2.ptr) && (nmats == 1 || m2.batch % 8 == 0);

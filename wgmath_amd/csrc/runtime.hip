@@ -72,6 +72,9 @@ int wg_ctx_check_async(wg_ctx *ctx) {
     return WG_OK;
 }
 
+int wg_ctx_stage_workspace(wg_ctx *ctx, size_t bytes, void **out) {
+    return grow_scratch(ctx, &ctx->stage_workspace, &ctx->stage_workspace_bytes, bytes, "staging workspace", out);
+}
 int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out) {
     return grow_scratch(ctx, &ctx->bal.scratch, &ctx->bal.scratch_bytes, bytes, "balance workspace", out);
 }
@@ -166,6 +169,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     if (ctx->workspace) (void)hipFree(ctx->workspace);
     if (ctx->tr_workspace) (void)hipFree(ctx->tr_workspace);
     if (ctx->pad_workspace) (void)hipFree(ctx->pad_workspace);
+    if (ctx->stage_workspace) (void)hipFree(ctx->stage_workspace);
     for (void *p : ctx->retired_scratch) (void)hipFree(p);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->tile_queues) (void)hipFree(ctx->tile_queues);

@@ -21,6 +21,8 @@ struct wg_ctx {
     size_t workspace_bytes = 0;
     void *tr_workspace = nullptr; // second scratch: transposed operand of the row-major GemmTr (lives across the GEMM that may use `workspace`)
     size_t tr_workspace_bytes = 0;
+    void *stage_workspace = nullptr; // fourth scratch: dense zero-padded copies of operator views that are not vec4-aligned (api.hip)
+    size_t stage_workspace_bytes = 0;
     void *pad_workspace = nullptr; // third scratch: zero-padded operand copies of f16 GEMMs whose shapes the MFMA kernels do not take as they are
     size_t pad_workspace_bytes = 0;
     int compute_units = 0;
@@ -92,6 +94,9 @@ int wg_ctx_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out);
 int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out);
+int wg_ctx_stage_workspace(wg_ctx *ctx, size_t bytes, void **out); // dense copies of views that are not vec4-aligned (api.hip)
+int wgk_stage_copy(wg_ctx *ctx, wg_dtype dtype, void *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd, const void *src,
+                   uint32_t ld_src, uint64_t src_batch, uint32_t rs, uint32_t cs, uint32_t nmats);
 int wgk_transpose(wg_ctx *ctx, wg_dtype dtype, uint32_t rows, uint32_t cols, uint32_t nmats, const void *src, uint32_t ld_src,
                   uint64_t src_batch, void *dst, uint32_t ld_dst, uint64_t dst_batch);
 
