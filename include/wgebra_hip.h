@@ -356,6 +356,11 @@ int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collec
 /* Pipelined steps (WG_GATHER_PEER_STAGED): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
  * exchange nothing of its own call can hide -- to the next call on the communicator, which runs it right after enqueueing its first Gemm
  * (wg_comm_join / _flush / _barrier / a call in another mode complete it too). `out` is then complete in stream order only after that. */
+/* One launch per step (default on): an f16 wg_gemm_sharded of at least one round of 256 x 256 tiles (WG_GATHER_RCCL, WG_GATHER_PEER_STAGED, panels
+ * of whole tiles) runs the rank's product as ONE kernel over all N-panels; the kernel writes each panel through to memory and raises a
+ * flag per panel that the exchange of that panel waits on (hipStreamWaitValue32), the relayouts follow the kernel. Results are bit for bit
+ * those of the panel-by-panel launches (on = 0), which every other product still uses. */
+int wg_comm_set_one_launch(wg_comm *comm, int on);
 int wg_comm_set_pipelined(wg_comm *comm, int on); /* (a step with ONE panel always completes in its call: deferring it would let a rank run two steps ahead of a peer) */
 int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */
 int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined into the context: all ranks' earlier exchanges are complete */

@@ -310,3 +310,77 @@ def test_two_ranks_one_gpu_staged_steps_with_changing_operands_and_shapes():
         p.join(60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+# --------------------------------------------------------------------------------------------------------
+# One launch per step with two ranks (two processes, one GPU): each rank's whole product is ONE kernel over all N-panels that raises a flag
+# per panel; the peer streams wait on the flags (hipStreamWaitValue32) and push the slots while the kernel is still running; operands
+# change every step, pipelined, no host synchronisation. Must equal the panel-by-panel launches bit for bit.
+# --------------------------------------------------------------------------------------------------------
+def _staged_one_launch_worker(rank, world, port, q):
+    try:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["GPU_MAX_HW_QUEUES"] = "16"
+        import torch  # noqa: F401  first: one HIP runtime per process
+        import torch.distributed as dist
+        import wgmath_amd as wg
+        from wgmath_amd.sharded import Comm, GatherMode
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        M, K, N, panel = 4096, 512, 8192 + 256, 2048  # 2048-row shards: 8 x 33 tiles >= 256; a ragged last panel
+        Mg = M // world
+        gpu = wg.GpuInstance.new(0)
+        dev, S = gpu.device(), wg.BufferUsages
+        U = S.STORAGE | S.COPY_SRC | S.COPY_DST
+        rng = np.random.default_rng(2024)
+        A = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        ta = wg.TensorBuilder.matrix(Mg, K, U).build_init(dev, np.ascontiguousarray(A[rank * Mg:(rank + 1) * Mg].reshape(-1, order="F")))
+        nsteps = 4
+        Bs = [(rng.random((K, N), dtype=np.float32) * 2 - 1).astype(np.float16) for _ in range(nsteps)]
+        tbs = [wg.TensorBuilder.matrix(K, N, U).build_init(dev, np.ascontiguousarray(B.reshape(-1, order="F"))) for B in Bs]
+        comm = Comm(gpu, world, rank, None)
+        pairs = [None] * world
+        dist.all_gather_object(pairs, comm.stage_export(2 * M * N * 2))
+        comm.set_peer_stages(pairs)
+        dist.barrier()
+        comm.set_pipelined(True)
+        results = {}
+        for one in (False, True):
+            comm.set_one_launch(one)
+            tcs = [wg.TensorBuilder.matrix(M, N, U).build_init(dev, np.full(M * N, np.nan, np.float16)) for _ in range(nsteps)]
+            for tb, tc in zip(tbs, tcs):
+                comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, panel)
+            comm.join()
+            results[one] = [tc.read(dev).view(np.uint16).copy() for tc in tcs]
+            comm.flush()
+            dist.barrier()
+        same = all(np.array_equal(x, y) for x, y in zip(results[False], results[True]))
+        A64 = A.astype(np.float64)
+        rows = np.unique(rng.integers(0, M, 64))
+        ok = True
+        for B, r in zip(Bs, results[True]):
+            got = r.view(np.float16).reshape(N, M).T[rows].astype(np.float64)
+            B64 = B.astype(np.float64)
+            truth, sabs = A64[rows] @ B64, np.abs(A64[rows]) @ np.abs(B64)
+            tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+            ok = ok and bool((np.abs(got - truth) <= tol).all())
+        q.put((rank, ok and same, f"values ok={ok}, one launch == panel launches: {same}"))
+        comm.close()
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, traceback.format_exc() + str(e)))
+
+
+def test_two_ranks_one_gpu_one_launch_per_step():
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port, world = ctx.Queue(), _free_port(), 2
+    procs = [ctx.Process(target=_staged_one_launch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"

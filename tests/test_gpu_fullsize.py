@@ -201,7 +201,56 @@ def test_addressing_beyond_4GiB(gpu):
 # (WG_GATHER_RCCL), on the unmasked 256-CU stream and on the 224-CU masked stream the multi-rank bench gives that engine, and the
 # panel-wise strided-output path of the peer-copy engine (WG_GATHER_PEER_COPY). >= 64 sampled rows x 512 columns against f64.
 # --------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("peer", None)])
+@pytest.mark.parametrize("engine", ["rccl", "staged"])
+@pytest.mark.parametrize("cus", [None, 248])
+@pytest.mark.parametrize("M,K,N,panel,bitwise", [(4096, 1024, 4096, 1024, True), (4096, 512 + 32, 8192, 4096, True), (8192, 512, 8192, 2048, True),
+                                                 (4096, 512 + 32, 4352, 1024, False), (2048, 768, 8448, 512, False)])
+def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus, M, K, N, panel, bitwise):
+    """wg_gemm_sharded's one-launch-per-step form (the rank's whole f16 product as ONE kernel that walks the N-panels, writes them through
+    to memory and raises a flag per panel; the panel's exchange waits on the flag with hipStreamWaitValue32, the relayouts follow) against
+    the panel-by-panel launches: the same tiles, the same accumulation chains -- bit for bit, ragged last panel and K remainder included,
+    on the full chip and on a 248-CU masked stream (31 CUs per XCD: viable now that nothing assumes 32), RCCL (1 rank) and staged engine.
+    (`bitwise` False: the panel launches of that shape are split along K -- few tiles per panel with a K remainder, or a launcher
+    estimate -- i.e. another summation order: both forms are then held to the f64 bound, and the one-launch form to itself.)"""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wg = _wg()
+    from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
+    inst = wg.GpuInstance.new(0, cu_count=cus) if cus else wg.GpuInstance.new(0)
+    dev = inst.device()
+    comm = Comm(inst, 1, 0, new_unique_id() if engine == "rccl" else None)
+    rng = np.random.default_rng(M + K + N + panel)
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
+    A = wg.TensorBuilder.matrix(M, K, S_ALL).build_init(dev, a)
+    B = wg.TensorBuilder.matrix(K, N, S_ALL).build_init(dev, b)
+    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.PEER_STAGED
+    if engine == "staged":
+        comm.stage_reserve(2 * M * N * 2)
+    res = []
+    for one in (False, True, True):
+        comm.set_one_launch(one)
+        C = wg.TensorBuilder.matrix(M, N, S_ALL).build_init(dev, np.full(M * N, np.nan, np.float16))
+        comm.sharded_gemm(C, A, B, 0, mode, panel)
+        comm.join()
+        inst.sync()
+        res.append(C.read(dev).view(np.uint16).copy())
+    assert not np.isnan(res[0].view(np.float16)).any()
+    assert np.array_equal(res[2], res[1])
+    if bitwise and cus is None:  # (on 248 CUs the panel launches of these shapes cut their last 8 tiles along K: another order)
+        assert np.array_equal(res[1], res[0])
+    A64, B64 = a.reshape(K, M).T.astype(np.float64), b.reshape(N, K).T.astype(np.float64)
+    rows = np.unique(rng.integers(0, M, 96))
+    truth, sabs = A64[rows] @ B64, np.abs(A64[rows]) @ np.abs(B64)
+    tol = U.f32_gate(K, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+    for r in res[:2]:
+        got = r.view(np.float16).reshape(N, M).T.astype(np.float64)
+        assert (np.abs(got[rows] - truth) <= tol).all()
+    comm.close()
+    inst.close()
+
+
+@pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("rccl", 248), ("peer", None)])
 def test_config5_gemm_f16_32768_sharded_entry_point(engine, cus):
     import os
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

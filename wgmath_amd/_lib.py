@@ -120,6 +120,7 @@ def _load() -> ctypes.CDLL:
         "wg_all_gather": (ci, [vp, ci, vp, u64, u64]),
         "wg_comm_join": (ci, [vp]),
         "wg_comm_set_pipelined": (ci, [vp, ci]),
+        "wg_comm_set_one_launch": (ci, [vp, ci]),
         "wg_comm_flush": (ci, [vp]),
         "wg_comm_barrier": (ci, [vp]),
         "wg_buf_ipc_export": (ci, [vp, vp]),

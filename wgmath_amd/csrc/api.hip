@@ -93,6 +93,18 @@ int gemv_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, wg_buf *out, const View &o
 
 } // namespace
 
+int wg_gemm_f16_panels(wg_ctx *ctx, bool tr, void *out_panel0, uint32_t ldc, const wg_buf *m1, wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape,
+                       const wgk_panels &panels) {
+    const View a = mk(m1_shape), b = mk(m2_shape);
+    const uint32_t m_rows = tr ? a.cols : a.rows, m_cols = tr ? a.rows : a.cols;
+    if (m_cols != b.rows || a.mats != 1 || b.mats != 1 || m1->bytes == 0 || m2->bytes == 0) return WG_ERR_UNSUPPORTED;
+    if (!vec4_ok(a) || !vec4_ok(b) || m_rows % 4 || m_cols % 4 || b.cols % 4) return WG_ERR_UNSUPPORTED;
+    if (int rc = check_bounds("Gemm", "m1", a, m1, WG_F16)) return rc;
+    if (int rc = check_bounds("Gemm", "m2", b, m2, WG_F16)) return rc;
+    const wgk_mat A = { elem_ptr(m1, a.offset, WG_F16), a.stride, a.stride_mat }, B = { elem_ptr(m2, b.offset, WG_F16), b.stride, b.stride_mat };
+    return wgk_gemm_f16(ctx, tr, m_rows, b.cols, m_cols, 1, (__half *)out_panel0, ldc, 0, A, B, 1.f, 0.f, &panels);
+}
+
 extern "C" {
 
 int wg_gemm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out, wg_view_shape out_shape, const wg_buf *m1,

@@ -176,6 +176,10 @@ struct wg_comm {
     uint32_t step = 0;
     uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
     uint32_t staged_npanels = 0;              // panels of that call (its sent_ev layout)
+    // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels that raises panel_sync[kMaxPanels + p] = seq when
+    // panel p is in memory; the exchange of panel p waits on that word (hipStreamWaitValue32) while the kernel works on the next panels
+    bool one_launch = true;
+    uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters, [kMaxPanels, 2 kMaxPanels): flags
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
@@ -392,6 +396,13 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
     return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es, c->nranks > 1 ? c->wait_err : nullptr);
 }
 
+int ensure_panel_sync(wg_comm *c) {
+    if (c->panel_sync) return WG_OK;
+    WG_HIP_TRY(hipMalloc((void **)&c->panel_sync, 2 * kMaxPanels * sizeof(uint32_t)));
+    WG_HIP_TRY(hipMemset(c->panel_sync, 0, 2 * kMaxPanels * sizeof(uint32_t)));
+    return WG_OK;
+}
+
 struct IpcHandle { // WG_IPC_HANDLE_BYTES
     hipIpcMemHandle_t h;
     uint64_t offset, bytes;
@@ -497,6 +508,7 @@ int wg_comm_destroy(wg_comm *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->pstage) (void)hipFree(c->pstage);
     if (c->pflags) (void)hipFree(c->pflags);
+    if (c->panel_sync) (void)hipFree(c->panel_sync);
     if (c->seq_src) (void)hipFree(c->seq_src);
     if (c->wait_err) {
         wg_ctx_unregister_async_error(c->ctx, c->wait_err);
@@ -514,6 +526,12 @@ int wg_comm_size(const wg_comm *c) { return c ? c->nranks : 0; }
 int wg_comm_has_collectives(const wg_comm *c) { return c && c->nccl ? 1 : 0; }
 const char *wg_comm_copy_engine(const wg_comm *c) { return !c || c->nranks < 2 ? "none" : (c->use_sdma ? "sdma-rect" : "hip2d"); }
 uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
+
+int wg_comm_set_one_launch(wg_comm *c, int on) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_one_launch: comm is NULL");
+    c->one_launch = on != 0;
+    return WG_OK;
+}
 
 int wg_comm_set_pipelined(wg_comm *c, int on) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_pipelined: comm is NULL");
@@ -799,6 +817,59 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
             return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->wait_err : nullptr);
         };
+        static const bool no_copy = getenv("WG_STAGED_NO_COPY") != nullptr; // tools/rank_emulation.py: one rank's compute + relayout alone
+        // ---- ONE launch per step (f16 products of at least one round of tiles): the kernel walks the panels left to right and raises a
+        // flag per panel; every peer stream waits on panel p's flag (hipStreamWaitValue32) and pushes the slot; the relayouts follow the
+        // kernel on the context's stream. No launch boundary, no ramp per panel, and the tile scheduler sees the rank's whole product.
+        if (c->one_launch && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
+            if (int rc = ensure_panel_sync(c)) return rc;
+            const uint32_t np_last = N - (npanels - 1u) * panel_cols;
+            wgk_panels pa;
+            pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
+            pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols; // (wraps: pointer arithmetic modulo 2^64)
+            pa.counters = c->panel_sync; pa.flags = c->panel_sync + kMaxPanels; pa.seq = seq;
+            // every slot of this parity is rewritten by the one kernel: the copies that left them two steps ago must be done
+            for (uint32_t p = 0; p < npanels; ++p)
+                for (uint32_t r = 0; r < P; ++r) {
+                    hipEvent_t e = c->sent_ev[((size_t)parity * npanels + p) * P + r];
+                    if (r != g && e) WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, e, 0));
+                }
+            const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->pstage + slot_elem(0, panel_cols, g) * es, mg, a_rows, a_shape, b, b_shape, pa);
+            if (rc1 == WG_OK) {
+                if (P > 1 && !no_copy) {
+                    for (uint32_t p = 0; p < npanels; ++p) {
+                        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                        const size_t off = slot_elem(c0, np, g) * es, bytes = (size_t)mg * np * es;
+                        for (uint32_t i = 1; i < P; ++i) {
+                            const uint32_t r = (g + i) % P;
+                            hipStream_t st = c->peer_stream[r];
+                            WG_HIP_TRY(hipStreamWaitValue32(st, pa.flags + p, seq, hipStreamWaitValueGte, 0xffffffffu));
+                            WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_stage[r]->ptr + off, (const char *)c->pstage + off, bytes, hipMemcpyDeviceToDevice, st));
+                            WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_flags[r]->ptr + ((size_t)g * kMaxPanels + p) * sizeof(uint32_t), c->seq_src + (seq % 64u),
+                                                      sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                            hipEvent_t &e = c->sent_ev[((size_t)parity * npanels + p) * P + r];
+                            if (!e) WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                            WG_HIP_TRY(hipEventRecord(e, st));
+                        }
+                        c->bytes_sent += (uint64_t)(P - 1) * bytes;
+                    }
+                }
+                if (int rc = run_pending(c)) return rc; // the previous call's deferred last panel: behind this call's kernel
+                const uint32_t upto = c->pipelined ? npanels - 1u : npanels;
+                for (uint32_t p = 0; p < upto; ++p)
+                    if (int rc = finish_panel(p)) return rc;
+                if (c->pipelined) {
+                    const uint32_t p = npanels - 1, c0 = p * panel_cols, np = N - c0;
+                    c->pending.on = true;
+                    c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
+                    c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
+                    c->pending.dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
+                    c->pending.ld = out_shape.stride; c->pending.es = es;
+                }
+                return WG_OK;
+            }
+            if (rc1 != WG_ERR_UNSUPPORTED) return rc1; // (unsupported: not that kind of product -- panel by panel below)
+        }
         for (uint32_t p = 0; p < npanels; ++p) {
             const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
             wg_view_shape bs = b_shape;
@@ -815,7 +886,6 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 if (r != g && e) WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, e, 0));
             }
             if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, &sbuf, os, a_rows, a_shape, b, bs)) return rc;
-            static const bool no_copy = getenv("WG_STAGED_NO_COPY") != nullptr; // tools/rank_emulation.py: one rank's compute + relayout alone
             if (P > 1 && !no_copy) {
                 WG_HIP_TRY(hipEventRecord(c->ev_ctx, ctx->stream));
                 const size_t off = slot_elem(c0, np, g) * es, bytes = (size_t)mg * np * es;
@@ -853,6 +923,55 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     }
 
     const bool staged = mode == WG_GATHER_RCCL && c->nccl != nullptr; // a 1-rank communicator still runs the whole path (tests)
+    // ---- RCCL engine, ONE launch per step (f16 products of at least one round of tiles): a staging cube for the whole step, the kernel raises
+    // a flag per panel, the communicator's stream waits on it (hipStreamWaitValue32) and all-gathers the panel while the kernel works on the
+    // next ones; the relayouts follow the kernel on the context's stream, each behind its panel's gather.
+    if (staged && c->one_launch && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0 && (uint64_t)M * N < (1ull << 32)) {
+        const size_t need = (size_t)M * N * es;
+        if (need > c->stage_bytes) {
+            WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
+            WG_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->stage) WG_HIP_TRY(hipFree(c->stage));
+            c->stage = nullptr;
+            c->stage_bytes = 0;
+            WG_HIP_TRY(hipMalloc(&c->stage, need));
+            c->stage_bytes = need;
+        }
+        if (int rc = ensure_panel_sync(c)) return rc;
+        while (c->ev_panel.size() < npanels) {
+            hipEvent_t e = nullptr;
+            WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_panel.push_back(e);
+        }
+        const uint32_t seq = ++c->step, np_last = N - (npanels - 1u) * panel_cols;
+        wgk_panels pa;
+        pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
+        pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols;
+        pa.counters = c->panel_sync; pa.flags = c->panel_sync + kMaxPanels; pa.seq = seq;
+        // (the cube is free: the previous call's relayouts precede this kernel on the context's stream, and this call's gathers only start
+        // on flags this kernel raises)
+        const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->stage + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
+        if (rc1 == WG_OK) {
+            for (uint32_t p = 0; p < npanels; ++p) {
+                const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                char *base = (char *)c->stage + (size_t)c0 * M * es;
+                WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.flags + p, seq, hipStreamWaitValueGte, 0xffffffffu));
+                ncclResult_t r = rccl().AllGather(base + (size_t)g * mg * np * es, base, (size_t)mg * np, ncclFloat16, c->nccl, c->stream);
+                if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
+                c->bytes_sent += (uint64_t)mg * np * es;
+                WG_HIP_TRY(hipEventRecord(c->ev_panel[p], c->stream));
+            }
+            for (uint32_t p = 0; p < npanels; ++p) {
+                const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, c->ev_panel[p], 0));
+                if (int rc = launch_cube_to_matrix(ctx, (const char *)c->stage + (size_t)c0 * M * es,
+                                                   (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es, mg, np, P, out_shape.stride, es))
+                    return rc;
+            }
+            return WG_OK;
+        }
+        if (rc1 != WG_ERR_UNSUPPORTED) return rc1;
+    }
     wg_buf stage_buf;
     if (staged) {
         const size_t need = 2 * (size_t)M * panel_cols * es;

@@ -133,8 +133,16 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // the sums + the loop's span go to the second 64 bytes of the tile's trace record (see tools/f16_trace.py)
     uint32_t q_a = 0, q_b = 0, q_c = 0, q_d = 0, s_vm = 0, s_bar = 0, s_probe = 0, m_vm = 0, m_bar = 0, n_adv = 0, loop_t0 = 0, loop_t1 = 0;
 #endif
-    uint32_t tm, tn;
-    tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    uint32_t tm, tn, panel = 0;
+    if (g.panel.cols) { // tiles are numbered panel by panel (PanelArgs); within a panel the usual XCD-aware order on the panel's own grid
+        const uint32_t id = bid + g.tile_base;
+        panel = __builtin_amdgcn_readfirstlane(min(id / g.panel.tiles, g.panel.npanels - 1u)); // (the division runs on the vector unit)
+        const uint32_t ptn = panel + 1u == g.panel.npanels ? g.panel.last_tn : g.panel.cols / 256u;
+        tile_of(id - panel * g.panel.tiles, g.tiles_m, ptn, tm, tn);
+        tn += panel * (g.panel.cols / 256u);
+    } else tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    panel = __builtin_amdgcn_readfirstlane(panel); // (all three are workgroup-uniform; said explicitly: they end up in scalar operands of the DMA asm)
+    tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     uint32_t k_begin = split * g.k_per_split;
@@ -171,6 +179,14 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
     _Float16 *C = g.c + z * g.c_batch;
+    const bool paneled = g.panel.cols != 0; // workgroup-uniform
+    if (paneled) { // the epilogue indexes columns globally: C + col * ldc; panel p's columns start at its own base
+        // (64-bit products run on the vector unit even when uniform: back to scalar registers by hand, C is pinned in SGPRs below)
+        const uint64_t off = (uint64_t)panel * g.panel.c_stride + (panel + 1u == g.panel.npanels ? g.panel.c_last_adjust : 0ull) - (uint64_t)panel * g.panel.cols * g.ldc;
+        C += ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+    }
+    uint32_t *panel_counter = g.panel.counters + panel, *panel_flag = g.panel.flags + panel;
+    uint32_t panel_seq = g.panel.seq, panel_goal = panel + 1u == g.panel.npanels ? g.tiles_m * g.panel.last_tn : g.panel.tiles;
     // Pin the epilogue's kernel arguments in SGPRs NOW: left alone, the compiler loads them (s_load, also an lgkmcnt event,
     // returning out of order with LDS reads) right in front of the main loop, and every counted LDS wait of the first
     // half-step then degrades to lgkmcnt(0).
@@ -723,12 +739,21 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             half8_t v;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-            if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+            if (paneled) // write-through to memory (system scope): when the store is acknowledged a copy engine may read it
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
+            else if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
         }
     }
 #ifndef WG_F16_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this tile (parked DMA pieces, stores) is in flight when the workgroup ends
 #endif
+    if (paneled) { // every wave's stores are in memory; the workgroup that finishes the panel's last tile raises its flag
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t done = __hip_atomic_fetch_add(panel_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (done == panel_goal) __hip_atomic_store(panel_flag, panel_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 #ifdef WG_F16_TRACE
     WG_TRACE_POINT(3);                       // all stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1014,8 +1039,8 @@ int pad_copy(wg_ctx *ctx, _Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, ui
 } // namespace
 
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta) {
-    if (M == 0 || N == 0 || nmats == 0) return WG_OK;
+                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha, float beta, const wgk_panels *panels) {
+    if (M == 0 || N == 0 || nmats == 0) return panels ? WG_ERR_UNSUPPORTED : WG_OK;
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: more than 65535 matrices in one call");
     GemmArgs g;
     g.a = (const _Float16 *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
@@ -1025,7 +1050,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.alpha = alpha; g.beta = beta;
     g.tile_base = 0; g.tail_tiles = 0;
     g.sched = nullptr; g.sched_tiles = 0;
-    g.calib = nullptr; g.bal = BalancePlan{};
+    g.calib = nullptr; g.bal = BalancePlan{}; g.panel = PanelArgs{};
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
@@ -1039,18 +1064,28 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const bool a_step_fits = trans || (uint64_t)m1.ld * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
     const bool fast = (M % 8 == 0) && (k_big || k_small) && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) && a_step_fits &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
+    if (panels && !(fast && k_big && nmats == 1 && alpha == 1.f && beta == 0.f && panels->cols && panels->cols % 256u == 0 && panels->cols < N &&
+                    (uint64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) >= (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256)))
+        return WG_ERR_UNSUPPORTED; // (no message: the caller falls back to one launch per panel)
     if (fast) {
         g.tiles_m = (M + BM - 1) / BM;
         g.tiles_n = (N + BN - 1) / BN;
         const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
         const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+        if (panels) {
+            const uint32_t ptn = panels->cols / 256u, np_ = (g.tiles_n + ptn - 1u) / ptn;
+            g.panel.cols = panels->cols; g.panel.npanels = np_; g.panel.tiles = g.tiles_m * ptn; g.panel.last_tn = g.tiles_n - (np_ - 1u) * ptn;
+            g.panel.c_stride = panels->c_stride; g.panel.c_last_adjust = panels->c_last_adjust;
+            g.panel.counters = panels->counters; g.panel.flags = panels->flags; g.panel.seq = panels->seq;
+            WG_HIP_TRY(hipMemsetAsync(panels->counters, 0, np_ * sizeof(uint32_t), ctx->stream));
+        }
         // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip) fills the chip with four times as many
         // tiles instead of split-K partial slabs, at ~2/3 of the big kernel's rate per busy CU. Estimates from measured rates
         // (profiles/r01_evidence.md section 12; us per k of one tile: 256 x 256 0.0234 with 8 us per workgroup of prologue + epilogue;
         // 128 x 128 0.00875 alone on a CU, 0.0108 each when several share it, + 6 us; f32 partial slabs written at ~3.5 TB/s + 3 us,
         // reduced at ~7 TB/s + 4 us). WG_F16_TILE=128|256 forces the choice (tests, experiments).
-        if (K % 64u == 0) {
+        if (K % 64u == 0 && !panels) {
             const double out_bytes = (double)M * N * nmats * 4.0;
             auto slabs = [&](uint32_t ns) { return ns > 1 ? ns * out_bytes / 3.5e6 + 3.0 + 4.0 + ns * out_bytes / 7.0e6 : 0.0; };
             GemmArgs t = g;
@@ -1097,7 +1132,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // split-K when the output has too few tiles for the chip (1 workgroup per CU): >= 8 half-steps (256 k) per split. Every split is a
         // whole number of stages and at least three of them (the DMA stream runs three stages ahead); the LAST one also takes the K % 64
         // remainder.
-        uint32_t nsplit = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
+        uint32_t nsplit = panels ? 1u : wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
         const uint32_t stages = K / 64u;
         auto kps_of = [&](uint32_t ns) { return ((stages + ns - 1u) / ns) * 64u; };
         while (nsplit > 1) {
@@ -1149,7 +1184,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 // WG_TUNE_F16_BALANCE: 0 never, 1 whenever the shape allows (tests: made-up rates until real ones exist), -1 by size.
                 const int bal_knob = ctx->tuning[WG_TUNE_F16_BALANCE];
                 const uint32_t S = gm.K / 64u;
-                if (bal_knob != 0 && !dyn && gm.nsplit == 1 && nmats == 1 && gm.tail_tiles == 0 && gm.tile_base == 0 && cus == 256 && ntiles >= 16u && ntiles < 8u * 65535u && S >= 8u) {
+                if (bal_knob != 0 && !dyn && gm.panel.cols == 0 && gm.nsplit == 1 && nmats == 1 && gm.tail_tiles == 0 && gm.tile_base == 0 && cus == 256 && ntiles >= 16u && ntiles < 8u * 65535u && S >= 8u) {
                     if (int rc = bal_prepare(ctx)) return rc;
                     wg_ctx::F16Balance &b = ctx->bal;
                     if (b.dev && ntiles >= (uint32_t)cus) gm.calib = b.dev; // full rounds only: a slot's rate with the whole chip busy
@@ -1177,7 +1212,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifndef WG_F16_TAIL_SPLIT
 #define WG_F16_TAIL_SPLIT 1
 #endif
-            if (WG_F16_TAIL_SPLIT && nsplit == 1 && nmats == 1 && tiles > (uint64_t)cus) {
+            if (WG_F16_TAIL_SPLIT && nsplit == 1 && nmats == 1 && tiles > (uint64_t)cus && !panels) {
                 const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
                 if (r > 0 && r * 2u <= (uint32_t)cus) {
                     uint32_t sp = (uint32_t)cus / r;

@@ -70,6 +70,20 @@ __host__ __device__ inline bool bal_decode(const BalancePlan &bp, uint32_t b, ui
     return true;
 }
 
+// N-panels with completion flags (the M-sharded Gemm of comm.hip as ONE launch per step): the output is written panel by panel -- panel p's
+// columns live at c + p * c_stride (+ c_last_adjust for the narrower last panel) with leading dimension ldc, i.e. the slots of a staging
+// cube or simply the columns of one matrix -- the tiles are numbered panel by panel, the epilogue stores write through to memory, and the
+// workgroup that completes a panel's last tile raises flags[p] = seq (system scope): a copy engine's stream waits on that word
+// (hipStreamWaitValue32) while the kernel is still working on the next panels.
+struct PanelArgs {
+    uint32_t cols;       // columns per panel (a multiple of 256); 0: off
+    uint32_t npanels, tiles, last_tn; // tiles of a full panel (tiles_m * cols / 256); tile columns of the last panel
+    uint64_t c_stride, c_last_adjust; // elements
+    uint32_t *counters;  // [npanels] tiles finished (zeroed ahead of the launch)
+    uint32_t *flags;     // [npanels]
+    uint32_t seq;
+};
+
 struct GemmArgs {
     const _Float16 *a; uint32_t lda; uint64_t a_batch;
     const _Float16 *b; uint32_t ldb; uint64_t b_batch;
@@ -89,6 +103,7 @@ struct GemmArgs {
     // per-XCD rate measurement (nullptr: off): calib[2 x] += main-loop time of a tile that ran on XCD x (100 MHz ticks), calib[2 x + 1] += its stages
     unsigned long long *calib;
     BalancePlan bal;
+    PanelArgs panel;
 #ifdef WG_F16_TRACE
     uint32_t trace_tiles; // timing experiment: records in `part` (gemm_f16.hip)
 #endif

@@ -136,8 +136,24 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
+// N-panels with completion flags (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
+// panel p's columns live at out + p * c_stride (+ c_last_adjust for the narrower last panel), leading dimension out_ld; flags[p] = seq
+// (system scope) once every tile of panel p is in memory. wgk_gemm_f16 returns WG_ERR_UNSUPPORTED -- silently -- when the product does
+// not take that path (shapes off the MFMA fast path, fewer tiles than CUs, ...): the caller then launches panel by panel.
+struct wgk_panels {
+    uint32_t cols;
+    uint64_t c_stride, c_last_adjust;
+    uint32_t *counters, *flags;
+    uint32_t seq;
+};
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
-                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
+                 __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f,
+                 const wgk_panels *panels = nullptr);
+
+// The f16 product out_rows (M x N) = op(m1) m2 as ONE launch over N-panels with completion flags (api.hip; the operator front-end's checks
+// on m1 / m2, then wgk_gemm_f16 with `panels`). WG_ERR_UNSUPPORTED without a message: not that kind of product, launch panel by panel.
+int wg_gemm_f16_panels(wg_ctx *ctx, bool tr, void *out_panel0, uint32_t ldc, const wg_buf *m1, wg_view_shape m1_shape, const wg_buf *m2, wg_view_shape m2_shape,
+                       const wgk_panels &panels);
 
 // split-K (splitk.hip)
 uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32_t min_units, uint64_t out_elems, uint64_t max_ws_bytes);
