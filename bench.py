@@ -952,9 +952,10 @@ def main():
         # CU partitioning between compute and communication. Every f16 GEMM workgroup needs a whole CU (160 KiB
         # LDS, 512 registers per lane), so RCCL's copy kernels, launched from a second queue while a GEMM grid is resident, only get CUs
         # when GEMM workgroups retire (tools/overlap_probe.py: they start ~0.75-1.4 ms late). For the RCCL engine the GEMM stream is
-        # therefore CU-masked to leave `comm_cus` CUs free (32 = one per shader engine of every XCD; masks that are not a multiple of 32
-        # unbalance the shader engines). The peer-copy engine moves the blocks with the SDMA engines: no mask, all 256 CUs compute.
-        comm_cus = int(os.environ.get("WG_BENCH_COMM_CUS", "32"))
+        # therefore CU-masked to leave `comm_cus` CUs free. Round 2 needed 32 of them (a mask had to take whole shader engines for the
+        # static tile map); the rank's product is ONE scheduler-driven launch per step now (wg_comm_set_one_launch) and 8 -- one CU per
+        # XCD -- are enough: 248 CUs compute. The copy engines of the staged / peer engines need none: all 256 CUs compute.
+        comm_cus = int(os.environ.get("WG_BENCH_COMM_CUS", "8"))
 
         def make_gpu(masked):
             if masked and comm_cus > 0 and total_cus > 2 * comm_cus:

@@ -356,10 +356,12 @@ int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collec
 /* Pipelined steps (WG_GATHER_PEER_STAGED): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
  * exchange nothing of its own call can hide -- to the next call on the communicator, which runs it right after enqueueing its first Gemm
  * (wg_comm_join / _flush / _barrier / a call in another mode complete it too). `out` is then complete in stream order only after that. */
-/* One launch per step (default on): an f16 wg_gemm_sharded of at least one round of 256 x 256 tiles (WG_GATHER_RCCL, WG_GATHER_PEER_STAGED, panels
- * of whole tiles) runs the rank's product as ONE kernel over all N-panels; the kernel writes each panel through to memory and raises a
- * flag per panel that the exchange of that panel waits on (hipStreamWaitValue32), the relayouts follow the kernel. Results are bit for bit
- * those of the panel-by-panel launches (on = 0), which every other product still uses. */
+/* One launch per step: an f16 wg_gemm_sharded of at least one round of 256 x 256 tiles (WG_GATHER_RCCL, WG_GATHER_PEER_STAGED, panels of whole
+ * tiles) can run the rank's product as ONE kernel over all N-panels; the kernel writes each panel through to memory, its waves count
+ * themselves into a per-panel word, the exchange of a panel waits for the full count (hipStreamWaitValue32) and the relayouts follow the
+ * kernel. Bit for bit the result of the panel-by-panel launches (whenever those are not split along K). on = 1 / 0 force it / the panel
+ * launches, on < 0 (default) decides by engine: RCCL on -- the scheduler-driven launch does not care how many CUs its stream has, so
+ * RCCL's copy kernels need only 8 of them instead of 32 --, staged off (measured 1-2 % slower than 16 synchronised one-round launches). */
 int wg_comm_set_one_launch(wg_comm *comm, int on);
 int wg_comm_set_pipelined(wg_comm *comm, int on); /* (a step with ONE panel always completes in its call: deferring it would let a rank run two steps ahead of a peer) */
 int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */

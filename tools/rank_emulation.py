@@ -57,32 +57,68 @@ for P in Ps:
             sent = (P - 1) * Mg * N * 2
             res[name]["bytes_pushed_per_step"] = sent
             res[name]["aggregate_push_gbs_if_fully_overlapped"] = round(sent / dt / 1e9, 1)
-    # the staged engine's compute side: panel Gemms into the staging cube + the relayout of every panel, copies switched off
-    # (WG_STAGED_NO_COPY) and the flags pre-set so that the wait kernels pass: what the contiguous per-link copies run BESIDE
-    if P > 1:
-        os.environ["WG_STAGED_NO_COPY"] = "1"
-        from wgmath_amd._lib import check, lib
-        st, fl = comm.stage_reserve(2 * M * N * 2)
-        ones = np.full(16 * 1024, 0x3fffffff, np.uint32)
-        check(lib.wg_buf_write(gpu._ctx.handle, fl, 0, ones.ctypes.data, ones.nbytes))
-        comm._stage = (st, fl)
-        comm.set_local_peer_stages([comm] * P)
+    # the staged engine's compute side: the rank's Gemm into the staging cube + the relayout of every panel, copies switched off
+    # (WG_STAGED_NO_COPY) and the flags pre-set so that the wait kernels pass: what the contiguous per-link copies run BESIDE.
+    # Panel by panel (round 2's form) and as ONE launch per step (round 3), on all 256 CUs; and on a 248-CU masked stream = the compute
+    # side of the RCCL engine (the same kernel + the same relayouts; RCCL's own copy kernels run on the 8 CUs left over).
+    def staged_side(inst, cm, a_t, b_t, c_t, one_launch):
+        cm.set_one_launch(one_launch)
         for _ in range(2):
-            comm.sharded_gemm(C, A, B, 0, GatherMode.PEER_STAGED, panel)
-        gpu.sync()
+            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panel)
+        inst.sync()
         t0 = time.perf_counter()
         for _ in range(STEPS):
-            comm.sharded_gemm(C, A, B, 0, GatherMode.PEER_STAGED, panel)
-        gpu.sync()
-        dt = (time.perf_counter() - t0) / STEPS
+            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panel)
+        inst.sync()
+        return (time.perf_counter() - t0) / STEPS
+
+    def prepare_staged(inst, cm):
+        from wgmath_amd._lib import check, lib
+        st, fl = cm.stage_reserve(2 * M * N * 2)
+        ones = np.full(16 * 1024, 0x3fffffff, np.uint32)
+        check(lib.wg_buf_write(inst._ctx.handle, fl, 0, ones.ctypes.data, ones.nbytes))
+        cm._stage = (st, fl)
+        cm.set_local_peer_stages([cm] * P)
+
+    if P > 1:
+        os.environ["WG_STAGED_NO_COPY"] = "1"
+        prepare_staged(gpu, comm)
         last = Mg * min(panel, N) * 2
-        res["staged_compute_and_relayout"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1),
-                                              "last_panel_bytes_per_peer": last}
+        for one, key in ((False, "staged_compute_and_relayout_panel_launches"), (True, "staged_compute_and_relayout")):
+            dt = staged_side(gpu, comm, A, B, C, one)
+            res[key] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "last_panel_bytes_per_peer": last,
+                        "one_launch_per_step": one}
     out["ranks"][str(P)] = res
     comm.close()
+    if P > 1:  # the RCCL engine's compute side: 248 of the 256 CUs
+        gpu2 = wg.GpuInstance.new(0, cu_count=248)
+        comm2 = Comm(gpu2, P, 0, None)
+        prepare_staged(gpu2, comm2)
+        dt = staged_side(gpu2, comm2, A, B, C, True)
+        res["rccl_compute_side_248_cus"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "stream_compute_units": 248}
+        comm2.close()
+        gpu2.close()
     del A, B, C, peers
     gpu.close()
-t1 = out["ranks"].get("1", {}).get("no_exchange", {}).get("ms_per_step")
+# the best single-GPU run: the plain 32768^3 Gemm (one launch, tile scheduler on) -- what every speed-up below is against
+gpu = wg.GpuInstance.new(0)
+dev, shapes, S = gpu.device(), wg.ViewShapeBuffers(), wg.BufferUsages
+A = bench.device_random(wg, gpu, (M, K), np.float16, 0xA000)
+B = bench.device_random(wg, gpu, (K, N), np.float16, 0xB000)
+C = wg.TensorBuilder.matrix(M, N, S.STORAGE).build(dev, np.float16)
+gemm = wg.Gemm.from_device(dev)
+enc = dev.create_command_encoder(); ps = enc.compute_pass("t1", None)
+for _ in range(2):
+    gemm.dispatch(dev, shapes, ps, C, A, B)
+gpu.sync()
+t0 = time.perf_counter()
+for _ in range(STEPS):
+    gemm.dispatch(dev, shapes, ps, C, A, B)
+gpu.sync()
+t1 = (time.perf_counter() - t0) / STEPS * 1e3
+out["single_gpu_best"] = {"ms_per_step": round(t1, 3), "tflops": round(2.0 * M * N * K / t1 / 1e9, 1), "what": "wg_gemm 32768^3, one launch, tile scheduler"}
+del A, B, C
+gpu.close()
 # measured beside busy SDMA engines (tools/cpp/sdma_probe2.cpp): Gemm slowdown with 1 / 3 / 7 engines at 60.7 GB/s each
 SLOW = {2: 1.006, 4: 1.023, 8: 1.048}
 ENGINE_GBS = 60.7
@@ -100,4 +136,11 @@ if t1:
                                               "note": "wg_comm_set_pipelined: only the last step of a run exposes its tail"}
             r["expected_staged"] = {"ms_per_step": round(t, 3), "link_ms_per_step_at_engine_rate": round(steady, 3), "exposed_tail_ms": round(tail, 3),
                                     "gemm_slowdown_beside_engines": SLOW.get(int(P), 1.05), "speedup_vs_1_gpu": round(t1 / t, 3)}
+        if "rccl_compute_side_248_cus" in r:
+            rc = r["rccl_compute_side_248_cus"]
+            steady = r["rows_per_rank"] * N * 2 / (ENGINE_GBS * 1e6)
+            tail = r["staged_compute_and_relayout"]["last_panel_bytes_per_peer"] / (ENGINE_GBS * 1e6)
+            t = max(rc["ms_per_step"] * SLOW.get(int(P), 1.05), steady) + tail
+            r["expected_rccl_248"] = {"ms_per_step": round(t, 3), "speedup_vs_1_gpu": round(t1 / t, 3),
+                                      "assumes": "RCCL's gather of a panel keeps up with the per-link rate measured for the copy engines (60.7 GB/s) on its 8 CUs; the last panel's gather is exposed"}
 print(json.dumps(out, indent=1))

@@ -176,10 +176,10 @@ struct wg_comm {
     uint32_t step = 0;
     uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
     uint32_t staged_npanels = 0;              // panels of that call (its sent_ev layout)
-    // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels that raises panel_sync[kMaxPanels + p] = seq when
-    // panel p is in memory; the exchange of panel p waits on that word (hipStreamWaitValue32) while the kernel works on the next panels
-    bool one_launch = true;
-    uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters, [kMaxPanels, 2 kMaxPanels): flags
+    // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels whose waves count themselves into panel_sync[p] as
+    // their stores reach memory; the exchange of panel p waits for the full count (hipStreamWaitValue32) while the kernel works on
+    int one_launch = -1;                      // -1: by engine (RCCL: on -- what lets its Gemm run on 248 CUs; staged: off -- measured 1-2 % slower there), 0 / 1
+    uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters of the panels (waves finished; zeroed ahead of every launch)
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
@@ -273,14 +273,14 @@ int nccl_fail(const char *what, ncclResult_t r) {
 }
 
 // cube [mg, np, P] (contiguous slots) -> columns of a column-major matrix: c[(j)*ldc + g*mg + i] = stage[(g*np + j)*mg + i], in units of V
-// `err` (may be null): the wait kernel's time-out word. Set => a slot of this cube never arrived: write NaN bit patterns (all ones: a NaN in
+// `err` (may be null): the wait kernel's device-side time-out word. Set => a slot of this cube never arrived: write NaN bit patterns (all ones: a NaN in
 // f16 and in f32) instead of whatever the slots hold, so that a result read before the error is reported cannot pass for data.
 template <typename V>
 __global__ __launch_bounds__(256) void cube_to_matrix_kernel(const V *__restrict__ stage, V *__restrict__ c, uint32_t mg_v, uint32_t np, uint64_t ldc_v,
                                                              const uint32_t *err) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x, g = blockIdx.z;
     if (i >= mg_v) return;
-    const bool poison = err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+    const bool poison = err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; // (a device word: see wait_flags_kernel)
     for (uint32_t j = blockIdx.y; j < np; j += gridDim.y) {
         V v;
         if (poison) __builtin_memset(&v, 0xff, sizeof v);
@@ -324,15 +324,19 @@ constexpr size_t kFlagBytes = (size_t)kMaxRanks * kMaxPanels * sizeof(uint32_t);
 // 30 s, WG_COMM_TIMEOUT_MS) and raises *err instead of hanging the queue. *err is sticky until the host has reported it: the relayout
 // behind a failed wait poisons its output (NaN bit patterns), every later wait fails fast, and wg_ctx_sync / wg_buf_read on the
 // context, wg_comm_flush / _join / _barrier and the next sharded call all return the error.
-__global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32_t self, uint32_t panel, uint32_t seq, uint32_t *err, uint64_t timeout_ticks) {
+// (`err` is pinned HOST memory, for the host to report; `err_dev` is its device-side twin, which the relayout kernels read -- thousands of
+// workgroups polling a host word over PCIe made a 0.4 ms relayout take 10 ms.)
+__global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32_t self, uint32_t panel, uint32_t seq, uint32_t *err, uint32_t *err_dev,
+                                  uint64_t timeout_ticks) {
     const uint32_t r = threadIdx.x;
     if (r >= nranks || r == self) return;
     const uint32_t *f = flags + (size_t)r * kMaxPanels + panel;
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return; // an earlier wait already gave up: fail fast
+    if (__hip_atomic_load(err_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return; // an earlier wait already gave up: fail fast
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while ((int32_t)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
         __builtin_amdgcn_s_sleep(64);
         if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+            __hip_atomic_store(err_dev, 1u + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(err, 1u + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
@@ -390,10 +394,10 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
     const wg_comm::Pending &q = c->pending;
     if (c->nranks > 1) {
         hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, c->ctx->stream, c->pflags, (uint32_t)c->nranks, (uint32_t)c->rank, q.panel, q.seq, c->wait_err,
-                           c->timeout_ticks);
+                           c->seq_src + 64, c->timeout_ticks);
         WG_HIP_TRY(hipGetLastError());
     }
-    return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es, c->nranks > 1 ? c->wait_err : nullptr);
+    return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es, c->nranks > 1 ? c->seq_src + 64 : nullptr);
 }
 
 int ensure_panel_sync(wg_comm *c) {
@@ -529,7 +533,7 @@ uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
 
 int wg_comm_set_one_launch(wg_comm *c, int on) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_one_launch: comm is NULL");
-    c->one_launch = on != 0;
+    c->one_launch = on < 0 ? -1 : (on != 0 ? 1 : 0);
     return WG_OK;
 }
 
@@ -672,8 +676,8 @@ int wg_comm_stage_reserve(wg_comm *c, size_t bytes, wg_buf **stage, wg_buf **fla
     }
     // each of these is tested on its own: a failed allocation leaves the others for the next attempt, never a half-built set in use
     if (!c->seq_src) {
-        WG_HIP_TRY(hipMalloc((void **)&c->seq_src, 64 * sizeof(uint32_t)));
-        WG_HIP_TRY(hipMemset(c->seq_src, 0, 64 * sizeof(uint32_t)));
+        WG_HIP_TRY(hipMalloc((void **)&c->seq_src, 128 * sizeof(uint32_t))); // 64 sequence words + (word 64) the wait kernels' device-side time-out word
+        WG_HIP_TRY(hipMemset(c->seq_src, 0, 128 * sizeof(uint32_t)));
     }
     if (!c->wait_err) {
         WG_HIP_TRY(hipHostMalloc((void **)&c->wait_err, 64, hipHostMallocDefault));
@@ -784,7 +788,10 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // cross-rank agreement beyond the one every step makes.
         const uint64_t half_elems = ((c->pstage_bytes / 2) & ~(size_t)15) / es;
         if (half_elems + (uint64_t)M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
-        if (int rc = wg_ctx_check_async(ctx)) return rc; // a wait of an earlier step gave up
+        if (int rc = wg_ctx_check_async(ctx)) { // a wait of an earlier step gave up: reported here; the device-side word is reset for a retry
+            (void)hipMemsetAsync(c->seq_src + 64, 0, sizeof(uint32_t), ctx->stream);
+            return rc;
+        }
         const uint64_t geom[4] = { M, N, panel_cols, es };
         if (memcmp(geom, c->staged_geom, sizeof geom) != 0) {
             // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything of
@@ -810,24 +817,24 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         auto finish_panel = [&](uint32_t p) -> int { // wait for the peers' slots of panel p, then relayout it into columns of `out`
             const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
             if (P > 1) {
-                hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err, c->timeout_ticks);
+                hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err, c->seq_src + 64, c->timeout_ticks);
                 WG_HIP_TRY(hipGetLastError());
             }
             const char *src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
             char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
-            return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->wait_err : nullptr);
+            return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->seq_src + 64 : nullptr);
         };
         static const bool no_copy = getenv("WG_STAGED_NO_COPY") != nullptr; // tools/rank_emulation.py: one rank's compute + relayout alone
         // ---- ONE launch per step (f16 products of at least one round of tiles): the kernel walks the panels left to right and raises a
         // flag per panel; every peer stream waits on panel p's flag (hipStreamWaitValue32) and pushes the slot; the relayouts follow the
         // kernel on the context's stream. No launch boundary, no ramp per panel, and the tile scheduler sees the rank's whole product.
-        if (c->one_launch && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
+        if (c->one_launch == 1 && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
             if (int rc = ensure_panel_sync(c)) return rc;
             const uint32_t np_last = N - (npanels - 1u) * panel_cols;
             wgk_panels pa;
             pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
             pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols; // (wraps: pointer arithmetic modulo 2^64)
-            pa.counters = c->panel_sync; pa.flags = c->panel_sync + kMaxPanels; pa.seq = seq;
+            pa.counters = c->panel_sync;
             // every slot of this parity is rewritten by the one kernel: the copies that left them two steps ago must be done
             for (uint32_t p = 0; p < npanels; ++p)
                 for (uint32_t r = 0; r < P; ++r) {
@@ -843,7 +850,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                         for (uint32_t i = 1; i < P; ++i) {
                             const uint32_t r = (g + i) % P;
                             hipStream_t st = c->peer_stream[r];
-                            WG_HIP_TRY(hipStreamWaitValue32(st, pa.flags + p, seq, hipStreamWaitValueGte, 0xffffffffu));
+                            WG_HIP_TRY(hipStreamWaitValue32(st, pa.counters + p, wgk_panel_goal(mg, np), hipStreamWaitValueGte, 0xffffffffu));
                             WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_stage[r]->ptr + off, (const char *)c->pstage + off, bytes, hipMemcpyDeviceToDevice, st));
                             WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_flags[r]->ptr + ((size_t)g * kMaxPanels + p) * sizeof(uint32_t), c->seq_src + (seq % 64u),
                                                       sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -926,7 +933,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     // ---- RCCL engine, ONE launch per step (f16 products of at least one round of tiles): a staging cube for the whole step, the kernel raises
     // a flag per panel, the communicator's stream waits on it (hipStreamWaitValue32) and all-gathers the panel while the kernel works on the
     // next ones; the relayouts follow the kernel on the context's stream, each behind its panel's gather.
-    if (staged && c->one_launch && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0 && (uint64_t)M * N < (1ull << 32)) {
+    if (staged && c->one_launch != 0 && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0 && (uint64_t)M * N < (1ull << 32)) {
         const size_t need = (size_t)M * N * es;
         if (need > c->stage_bytes) {
             WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -943,11 +950,11 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->ev_panel.push_back(e);
         }
-        const uint32_t seq = ++c->step, np_last = N - (npanels - 1u) * panel_cols;
+        const uint32_t np_last = N - (npanels - 1u) * panel_cols;
         wgk_panels pa;
         pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
         pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols;
-        pa.counters = c->panel_sync; pa.flags = c->panel_sync + kMaxPanels; pa.seq = seq;
+        pa.counters = c->panel_sync;
         // (the cube is free: the previous call's relayouts precede this kernel on the context's stream, and this call's gathers only start
         // on flags this kernel raises)
         const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->stage + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
@@ -955,7 +962,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             for (uint32_t p = 0; p < npanels; ++p) {
                 const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
                 char *base = (char *)c->stage + (size_t)c0 * M * es;
-                WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.flags + p, seq, hipStreamWaitValueGte, 0xffffffffu));
+                WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.counters + p, wgk_panel_goal(mg, np), hipStreamWaitValueGte, 0xffffffffu));
                 ncclResult_t r = rccl().AllGather(base + (size_t)g * mg * np * es, base, (size_t)mg * np, ncclFloat16, c->nccl, c->stream);
                 if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
                 c->bytes_sent += (uint64_t)mg * np * es;

@@ -185,8 +185,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         const uint64_t off = (uint64_t)panel * g.panel.c_stride + (panel + 1u == g.panel.npanels ? g.panel.c_last_adjust : 0ull) - (uint64_t)panel * g.panel.cols * g.ldc;
         C += ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
     }
-    uint32_t *panel_counter = g.panel.counters + panel, *panel_flag = g.panel.flags + panel;
-    uint32_t panel_seq = g.panel.seq, panel_goal = panel + 1u == g.panel.npanels ? g.tiles_m * g.panel.last_tn : g.panel.tiles;
+    uint32_t *panel_counter = g.panel.counters + panel;
     // Pin the epilogue's kernel arguments in SGPRs NOW: left alone, the compiler loads them (s_load, also an lgkmcnt event,
     // returning out of order with LDS reads) right in front of the main loop, and every counted LDS wait of the first
     // half-step then degrades to lgkmcnt(0).
@@ -739,21 +738,22 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             half8_t v;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-            if (paneled) // write-through to memory (system scope): when the store is acknowledged a copy engine may read it
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-            else if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+#ifndef WG_PANEL_STORE
+#define WG_PANEL_STORE 2 // write-through flavour of a paneled launch's stores: 1 = sc1 (agent scope), 2 = sc0 sc1 (system scope)
+#endif
+            if (paneled) { // write-through to memory: when the store is acknowledged a copy engine may read it
+                if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(cc + 32 * p) = v; // (timing experiments only: NOT visible to a copy engine in time)
+                else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
+            } else if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
         }
     }
 #ifndef WG_F16_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing of this tile (parked DMA pieces, stores) is in flight when the workgroup ends
 #endif
-    if (paneled) { // every wave's stores are in memory; the workgroup that finishes the panel's last tile raises its flag
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t done = __hip_atomic_fetch_add(panel_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (done == panel_goal) __hip_atomic_store(panel_flag, panel_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    if (paneled && lane == 0) // this wave's stores are in memory (vmcnt(0) above): one arrival per WAVE on the panel's counter, fire and forget --
+        // no barrier, no returned value; the panel's exchange waits for 4 x its tile count (hipStreamWaitValue32 on the counter itself)
+        __hip_atomic_fetch_add(panel_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 #ifdef WG_F16_TRACE
     WG_TRACE_POINT(3);                       // all stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1077,7 +1077,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             const uint32_t ptn = panels->cols / 256u, np_ = (g.tiles_n + ptn - 1u) / ptn;
             g.panel.cols = panels->cols; g.panel.npanels = np_; g.panel.tiles = g.tiles_m * ptn; g.panel.last_tn = g.tiles_n - (np_ - 1u) * ptn;
             g.panel.c_stride = panels->c_stride; g.panel.c_last_adjust = panels->c_last_adjust;
-            g.panel.counters = panels->counters; g.panel.flags = panels->flags; g.panel.seq = panels->seq;
+            g.panel.counters = panels->counters;
             WG_HIP_TRY(hipMemsetAsync(panels->counters, 0, np_ * sizeof(uint32_t), ctx->stream));
         }
         // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip) fills the chip with four times as many

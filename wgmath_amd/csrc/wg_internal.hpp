@@ -136,16 +136,18 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
-// N-panels with completion flags (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
-// panel p's columns live at out + p * c_stride (+ c_last_adjust for the narrower last panel), leading dimension out_ld; flags[p] = seq
-// (system scope) once every tile of panel p is in memory. wgk_gemm_f16 returns WG_ERR_UNSUPPORTED -- silently -- when the product does
-// not take that path (shapes off the MFMA fast path, fewer tiles than CUs, ...): the caller then launches panel by panel.
+// N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
+// panel p's columns live at out + p * c_stride (+ c_last_adjust for the narrower last panel), leading dimension out_ld; counters[p]
+// (zeroed on the stream ahead of the launch) reaches wgk_panel_goal(...) once every tile of panel p is in memory. wgk_gemm_f16 returns
+// WG_ERR_UNSUPPORTED -- silently -- when the product does not take that path (shapes off the MFMA fast path, fewer tiles than CUs, ...):
+// the caller then launches panel by panel.
 struct wgk_panels {
     uint32_t cols;
     uint64_t c_stride, c_last_adjust;
-    uint32_t *counters, *flags;
-    uint32_t seq;
+    uint32_t *counters;
 };
+// what counters[p] reads when panel p (np columns of an M-row product) is complete: one arrival per wave, 4 waves per 256 x 256 tile
+static inline uint32_t wgk_panel_goal(uint32_t M, uint32_t np) { return 4u * ((M + 255u) / 256u) * ((np + 255u) / 256u); }
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f,
                  const wgk_panels *panels = nullptr);

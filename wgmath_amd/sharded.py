@@ -226,9 +226,10 @@ class Comm:
         """Staged engine: defer each call's last panel (wait + relayout) to the next call / join(), hiding its exchange under the next step."""
         self._lib.check(self._lib.lib.wg_comm_set_pipelined(self._h, 1 if on else 0))
 
-    def set_one_launch(self, on: bool) -> None:
-        """f16 products of >= one round of tiles as ONE kernel over all N-panels with per-panel completion flags (default on); off = one launch per panel."""
-        self._lib.check(self._lib.lib.wg_comm_set_one_launch(self._h, 1 if on else 0))
+    def set_one_launch(self, on) -> None:
+        """f16 products of >= one round of tiles as ONE kernel over all N-panels with per-panel arrival counters: True / False force it / the
+        panel-by-panel launches, None = by engine (the default: RCCL on, staged off)."""
+        self._lib.check(self._lib.lib.wg_comm_set_one_launch(self._h, -1 if on is None else (1 if on else 0)))
 
     def join(self) -> None:
         self._lib.check(self._lib.lib.wg_comm_join(self._h))
