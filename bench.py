@@ -166,6 +166,8 @@ class GemmWorkload(Workload):
         comm, world = self.dist["comm"], self.world
         self.mode = mode
         cus = int(self.gpu.adapter().get("stream_compute_units") or self.gpu.adapter()["compute_units"])
+        if mode == "rccl" and self.dtype == "f16":
+            cus = int(self.gpu.adapter()["compute_units"])  # ONE scheduler-driven launch per step: panels need not be whole rounds of the masked stream
         self.panel_cols = plan_panel_cols(self.Mg, self.N, cus, tile=256 if self.dtype == "f16" else 128)
         self.npanels = -(-self.N // self.panel_cols)
         self.gather_mode = {"peer": GatherMode.PEER_COPY, "staged": GatherMode.PEER_STAGED}.get(mode, GatherMode.RCCL)

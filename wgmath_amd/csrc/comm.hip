@@ -179,7 +179,10 @@ struct wg_comm {
     // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels whose waves count themselves into panel_sync[p] as
     // their stores reach memory; the exchange of panel p waits for the full count (hipStreamWaitValue32) while the kernel works on
     int one_launch = -1;                      // -1: by engine (RCCL: on -- what lets its Gemm run on 248 CUs; staged: off -- measured 1-2 % slower there), 0 / 1
-    uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters of the panels (waves finished; zeroed ahead of every launch)
+    uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters of the panels: waves finished, RUNNING totals (a reset could overtake a
+                                              // copy stream that has not evaluated its wait yet -- and then waits for the NEXT step's kernel, which waits for
+                                              // the peer, which waits for this copy: found as a dead-lock with two processes on one GPU)
+    std::vector<uint32_t> panel_total;        // what panel_sync[p] reads once every launch enqueued so far has finished panel p
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
@@ -401,9 +404,21 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
 }
 
 int ensure_panel_sync(wg_comm *c) {
-    if (c->panel_sync) return WG_OK;
-    WG_HIP_TRY(hipMalloc((void **)&c->panel_sync, 2 * kMaxPanels * sizeof(uint32_t)));
-    WG_HIP_TRY(hipMemset(c->panel_sync, 0, 2 * kMaxPanels * sizeof(uint32_t)));
+    if (!c->panel_sync) {
+        WG_HIP_TRY(hipMalloc((void **)&c->panel_sync, kMaxPanels * sizeof(uint32_t)));
+        WG_HIP_TRY(hipMemset(c->panel_sync, 0, kMaxPanels * sizeof(uint32_t)));
+        c->panel_total.assign(kMaxPanels, 0u);
+    }
+    uint32_t mx = 0;
+    for (uint32_t t : c->panel_total) mx = t > mx ? t : mx;
+    if (mx > 0x60000000u) { // long before the 32-bit totals wrap: let everything that waits on them finish, start again from zero (hours apart)
+        WG_HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        WG_HIP_TRY(hipStreamSynchronize(c->stream));
+        for (hipStream_t st : c->peer_stream)
+            if (st) WG_HIP_TRY(hipStreamSynchronize(st));
+        WG_HIP_TRY(hipMemset(c->panel_sync, 0, kMaxPanels * sizeof(uint32_t)));
+        c->panel_total.assign(kMaxPanels, 0u);
+    }
     return WG_OK;
 }
 
@@ -843,6 +858,8 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 }
             const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->pstage + slot_elem(0, panel_cols, g) * es, mg, a_rows, a_shape, b, b_shape, pa);
             if (rc1 == WG_OK) {
+                for (uint32_t p = 0; p < npanels; ++p) // this launch's arrivals, on top of every earlier launch's
+                    c->panel_total[p] += wgk_panel_goal(mg, (N - p * panel_cols < panel_cols) ? N - p * panel_cols : panel_cols);
                 if (P > 1 && !no_copy) {
                     for (uint32_t p = 0; p < npanels; ++p) {
                         const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
@@ -850,7 +867,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                         for (uint32_t i = 1; i < P; ++i) {
                             const uint32_t r = (g + i) % P;
                             hipStream_t st = c->peer_stream[r];
-                            WG_HIP_TRY(hipStreamWaitValue32(st, pa.counters + p, wgk_panel_goal(mg, np), hipStreamWaitValueGte, 0xffffffffu));
+                            WG_HIP_TRY(hipStreamWaitValue32(st, pa.counters + p, c->panel_total[p], hipStreamWaitValueGte, 0xffffffffu));
                             WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_stage[r]->ptr + off, (const char *)c->pstage + off, bytes, hipMemcpyDeviceToDevice, st));
                             WG_HIP_TRY(hipMemcpyAsync((char *)c->peer_flags[r]->ptr + ((size_t)g * kMaxPanels + p) * sizeof(uint32_t), c->seq_src + (seq % 64u),
                                                       sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -962,7 +979,8 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             for (uint32_t p = 0; p < npanels; ++p) {
                 const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
                 char *base = (char *)c->stage + (size_t)c0 * M * es;
-                WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.counters + p, wgk_panel_goal(mg, np), hipStreamWaitValueGte, 0xffffffffu));
+                c->panel_total[p] += wgk_panel_goal(mg, np);
+                WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.counters + p, c->panel_total[p], hipStreamWaitValueGte, 0xffffffffu));
                 ncclResult_t r = rccl().AllGather(base + (size_t)g * mg * np * es, base, (size_t)mg * np, ncclFloat16, c->nccl, c->stream);
                 if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
                 c->bytes_sent += (uint64_t)mg * np * es;

@@ -1077,8 +1077,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             const uint32_t ptn = panels->cols / 256u, np_ = (g.tiles_n + ptn - 1u) / ptn;
             g.panel.cols = panels->cols; g.panel.npanels = np_; g.panel.tiles = g.tiles_m * ptn; g.panel.last_tn = g.tiles_n - (np_ - 1u) * ptn;
             g.panel.c_stride = panels->c_stride; g.panel.c_last_adjust = panels->c_last_adjust;
-            g.panel.counters = panels->counters;
-            WG_HIP_TRY(hipMemsetAsync(panels->counters, 0, np_ * sizeof(uint32_t), ctx->stream));
+            g.panel.counters = panels->counters; // (never reset here: they only ever grow, the caller waits for its own running totals)
         }
         // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip) fills the chip with four times as many
         // tiles instead of split-K partial slabs, at ~2/3 of the big kernel's rate per busy CU. Estimates from measured rates

@@ -74,13 +74,14 @@ __host__ __device__ inline bool bal_decode(const BalancePlan &bp, uint32_t b, ui
 // columns live at c + p * c_stride (+ c_last_adjust for the narrower last panel) with leading dimension ldc, i.e. the slots of a staging
 // cube or simply the columns of one matrix -- the tiles are numbered panel by panel, the epilogue stores write through to memory, and every
 // WAVE that has its stores acknowledged adds one to counters[p] (system scope, fire and forget): panel p is complete in memory when the
-// word reads 4 x its tile count. A copy engine's stream waits on exactly that (hipStreamWaitValue32) while the kernel is still working on
+// word has grown by 4 x its tile count. A copy engine's stream waits on exactly that (hipStreamWaitValue32) while the kernel is still working on
 // the next panels.
 struct PanelArgs {
     uint32_t cols;       // columns per panel (a multiple of 256); 0: off
     uint32_t npanels, tiles, last_tn; // tiles of a full panel (tiles_m * cols / 256); tile columns of the last panel
     uint64_t c_stride, c_last_adjust; // elements
-    uint32_t *counters;  // [npanels] waves finished (zeroed ahead of the launch)
+    uint32_t *counters;  // [npanels] waves finished, running totals over every launch (never reset between launches: a waiter of an earlier
+                         // launch may not have looked yet)
 };
 
 struct GemmArgs {

@@ -293,40 +293,56 @@ __global__ __launch_bounds__(kThreads) void gemv_combine_kernel(const float *__r
 }
 
 // ------------------------------------------------------------------------------------------------------
-// N, small matrices (a few MiB: launch-bound): ONE kernel, no partials. A workgroup owns 32 rows (8 lanes x float4 = 128-byte
-// row segments) and all columns: its 32 lane groups take columns g, g + 32, ... and are summed through LDS in a fixed order.
-// 1024 x 1024 (BASELINE config 1): 32 workgroups, one launch instead of split + combine.
+// N, small matrices (a few MiB: launch-bound): ONE kernel, no partials. A workgroup owns 4 RL rows (RL lanes x float4) and all columns:
+// its 256 / RL lane groups take columns g, g + 256 / RL, ... with up to 8 loads in flight per lane, are summed across the wave by
+// butterfly shuffles and across the four waves through LDS in a fixed order. RL is chosen so that even a 1024-row matrix gives the
+// chip >= 128 workgroups (1024 x 1024, BASELINE config 1: RL = 2, every lane's 8 columns in flight at once: one memory round trip
+// instead of eight -- the kernel was latency-bound at 32 workgroups of 32 rows).
+// gemv_small_rows is shared with the fused Gemv + Reduce below: same summation, same bits.
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <int RL, typename T>
+__device__ __forceinline__ float4 gemv_small_rows(const T *mp, uint32_t ldm, const T *vp, uint32_t k, float4 (*red)[8]) {
+    constexpr uint32_t G = 256u / RL; // column groups of the workgroup
+    const uint32_t rl = threadIdx.x & (RL - 1u), g = threadIdx.x / RL;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t c = g;
+    for (; c + 7u * G < k; c += 8u * G) { // 8 columns in flight per lane
+        float4 mv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mv[u] = load4s(mp + (uint64_t)(c + u * G) * ldm);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fma4(acc, mv[u], (float)vp[c + u * G]);
+    }
+    for (; c < k; c += G) fma4(acc, load4s(mp + (uint64_t)c * ldm), (float)vp[c]);
+#pragma unroll
+    for (int st = RL; st < 64; st <<= 1) { // the wave's 64 / RL groups, butterfly
+        acc.x += __shfl_xor(acc.x, st, 64); acc.y += __shfl_xor(acc.y, st, 64);
+        acc.z += __shfl_xor(acc.z, st, 64); acc.w += __shfl_xor(acc.w, st, 64);
+    }
+    if ((threadIdx.x & 63u) < (uint32_t)RL) red[threadIdx.x >> 6][rl] = acc;
+    __syncthreads();
+    float4 s = red[0][rl]; // (meaningful for threadIdx.x < RL)
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const float4 p = red[w][rl];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    return s;
+}
+// rows per workgroup = 4 RL: as few as gives the chip >= 128 workgroups
+static inline int gemv_small_rl(uint32_t rows_out) { return rows_out >= 4096u ? 8 : (rows_out >= 2048u ? 4 : 2); }
+
+template <int RL, typename T>
 __global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgsT<T> a) {
-    __shared__ float4 part[32][8];
-    const uint32_t rl = threadIdx.x & 7u, g = threadIdx.x >> 3; // row lane, column group
+    __shared__ float4 red[4][8];
+    const uint32_t rl = threadIdx.x & (RL - 1u);
     const uint32_t z = blockIdx.z, y = blockIdx.y;
-    const uint32_t row = blockIdx.x * 32u + 4u * rl;
+    const uint32_t row = blockIdx.x * (4u * RL) + 4u * rl;
     const bool row_ok = row < a.rows_out;
     const T *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
     const T *vp = a.v + z * a.v_batch + (uint64_t)y * a.ldv;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t c = g;
-    for (; c + 96u < a.k; c += 128u) { // 4 columns in flight per lane
-        const float4 m0 = load4s(mp + (uint64_t)c * a.ldm);
-        const float4 m1 = load4s(mp + (uint64_t)(c + 32u) * a.ldm);
-        const float4 m2 = load4s(mp + (uint64_t)(c + 64u) * a.ldm);
-        const float4 m3 = load4s(mp + (uint64_t)(c + 96u) * a.ldm);
-        fma4(acc, m0, (float)vp[c]); fma4(acc, m1, (float)vp[c + 32u]); fma4(acc, m2, (float)vp[c + 64u]); fma4(acc, m3, (float)vp[c + 96u]);
-    }
-    for (; c < a.k; c += 32u) fma4(acc, load4s(mp + (uint64_t)c * a.ldm), (float)vp[c]);
-    part[g][rl] = acc;
-    __syncthreads();
-    if (g == 0 && row_ok) {
-        float4 s = part[0][rl];
-#pragma unroll
-        for (int i = 1; i < 32; ++i) {
-            const float4 p = part[i][rl];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-        store4(a.out + z * a.dst_batch + (uint64_t)y * a.ld_dst + row, s);
-    }
+    const float4 s = gemv_small_rows<RL, T>(mp, a.ldm, vp, a.k, red);
+    if (threadIdx.x < (uint32_t)RL && row_ok) store4(a.out + z * a.dst_batch + (uint64_t)y * a.ld_dst + row, s);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -336,34 +352,15 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgsT<T> a) 
 // folds y in the reference's order: 128 virtual lanes, lane t takes y[t], y[t+128], ... ascending, then the 64..1 tree
 // (reduce.wgsl:68-87), mapped onto 32 lanes x float4 exactly like reduce_rows4 -- so the result has the bits of Gemv followed by Reduce.
 // ------------------------------------------------------------------------------------------------------
-template <int OP>
+template <int OP, int RL>
 __global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs a, unsigned *__restrict__ counter, float *__restrict__ result) {
-    __shared__ float4 part[32][8];
+    __shared__ float4 red[4][8];
     __shared__ unsigned is_last;
-    const uint32_t rl = threadIdx.x & 7u, g = threadIdx.x >> 3;
-    const uint32_t row = blockIdx.x * 32u + 4u * rl;
+    const uint32_t rl = threadIdx.x & (RL - 1u);
+    const uint32_t row = blockIdx.x * (4u * RL) + 4u * rl;
     const bool row_ok = row < a.rows_out;
-    const float *mp = a.m + (row_ok ? row : 0u);
-    const float *vp = a.v;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t c = g;
-    for (; c + 96u < a.k; c += 128u) {
-        const float4 m0 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm));
-        const float4 m1 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 32u) * a.ldm));
-        const float4 m2 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 64u) * a.ldm));
-        const float4 m3 = ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)(c + 96u) * a.ldm));
-        fma4(acc, m0, vp[c]); fma4(acc, m1, vp[c + 32u]); fma4(acc, m2, vp[c + 64u]); fma4(acc, m3, vp[c + 96u]);
-    }
-    for (; c < a.k; c += 32u) fma4(acc, ld_stream(reinterpret_cast<const float4 *>(mp + (uint64_t)c * a.ldm)), vp[c]);
-    part[g][rl] = acc;
-    __syncthreads();
-    if (g == 0 && row_ok) { // the same summation as gemv_n_small_kernel: y has the bits wg_gemv would have produced
-        float4 s = part[0][rl];
-#pragma unroll
-        for (int i = 1; i < 32; ++i) {
-            const float4 p = part[i][rl];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
+    const float4 s = gemv_small_rows<RL, float>(a.m + (row_ok ? row : 0u), a.ldm, a.v, a.k, red); // the same summation as gemv_n_small_kernel: y has the bits wg_gemv would have produced
+    if (threadIdx.x < (uint32_t)RL && row_ok) {
         *reinterpret_cast<float4 *>(a.out + row) = s;
         __threadfence(); // release: this workgroup's rows of y are visible device-wide (other XCDs' L2 included) before it is counted
     }
@@ -468,7 +465,11 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     // launch-bound sizes: one kernel without partials beats split + combine (1024 x 1024: 12.6 -> ~9 us per eager dispatch)
     if (uses_small_kernel(cus, trans, rows_out, k, nrhs, nsplit)) {
         a.part = nullptr; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
-        hipLaunchKernelGGL(gemv_n_small_kernel<T>, dim3(ceil_div(rows_out, 32u), nrhs, nmats), dim3(kThreads), 0, ctx->stream, a);
+        const int rl = gemv_small_rl(rows_out);
+        const dim3 sg(ceil_div(rows_out, 4u * (uint32_t)rl), nrhs, nmats);
+        if (rl == 8) hipLaunchKernelGGL((gemv_n_small_kernel<8, T>), sg, dim3(kThreads), 0, ctx->stream, a);
+        else if (rl == 4) hipLaunchKernelGGL((gemv_n_small_kernel<4, T>), sg, dim3(kThreads), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemv_n_small_kernel<2, T>), sg, dim3(kThreads), 0, ctx->stream, a);
         WG_HIP_TRY(hipGetLastError());
         return WG_OK;
     }
@@ -525,14 +526,22 @@ int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, fl
     a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = 0;
     a.rows_out = rows_out; a.k = k; a.nrhs = 1; a.k_per_split = k;
     a.out = y; a.part = nullptr; a.ld_dst = rows_out; a.dst_split = 0; a.dst_batch = 0;
-    const dim3 grid(ceil_div(rows_out, 32u)), block(kThreads);
+    const int rl = gemv_small_rl(rows_out);
+    const dim3 grid(ceil_div(rows_out, 4u * (uint32_t)rl)), block(kThreads);
+#define WG_SMALL_REDUCE(OP)                                                                                                          \
+    do {                                                                                                                             \
+        if (rl == 8) hipLaunchKernelGGL((gemv_n_small_reduce_kernel<OP, 8>), grid, block, 0, ctx->stream, a, counter, result);        \
+        else if (rl == 4) hipLaunchKernelGGL((gemv_n_small_reduce_kernel<OP, 4>), grid, block, 0, ctx->stream, a, counter, result);   \
+        else hipLaunchKernelGGL((gemv_n_small_reduce_kernel<OP, 2>), grid, block, 0, ctx->stream, a, counter, result);               \
+    } while (0)
     switch (op) {
-    case R_MIN: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_MIN>, grid, block, 0, ctx->stream, a, counter, result); break;
-    case R_MAX: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_MAX>, grid, block, 0, ctx->stream, a, counter, result); break;
-    case R_SUM: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_SUM>, grid, block, 0, ctx->stream, a, counter, result); break;
-    case R_PROD: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_PROD>, grid, block, 0, ctx->stream, a, counter, result); break;
-    default: hipLaunchKernelGGL(gemv_n_small_reduce_kernel<R_SQNORM>, grid, block, 0, ctx->stream, a, counter, result); break;
+    case R_MIN: WG_SMALL_REDUCE(R_MIN); break;
+    case R_MAX: WG_SMALL_REDUCE(R_MAX); break;
+    case R_SUM: WG_SMALL_REDUCE(R_SUM); break;
+    case R_PROD: WG_SMALL_REDUCE(R_PROD); break;
+    default: WG_SMALL_REDUCE(R_SQNORM); break;
     }
+#undef WG_SMALL_REDUCE
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

@@ -138,7 +138,8 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
 // N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
 // panel p's columns live at out + p * c_stride (+ c_last_adjust for the narrower last panel), leading dimension out_ld; counters[p]
-// (zeroed on the stream ahead of the launch) reaches wgk_panel_goal(...) once every tile of panel p is in memory. wgk_gemm_f16 returns
+// grows by wgk_panel_goal(...) per launch, complete once every tile of panel p is in memory (running totals, never reset by the kernel
+// or its launcher: the caller keeps the totals and waits for them). wgk_gemm_f16 returns
 // WG_ERR_UNSUPPORTED -- silently -- when the product does not take that path (shapes off the MFMA fast path, fewer tiles than CUs, ...):
 // the caller then launches panel by panel.
 struct wgk_panels {
