@@ -175,6 +175,8 @@ class GemmWorkload(Workload):
             handles = self.dist["all_gather_object"](comm.export_handle(self.C))
             comm.register_peers(self.C, handles)
             self._peers_registered = True
+        if mode == "rccl" and self.dtype == "f16":  # the one-launch form defers its last panel too (two cubes by step parity inside the library)
+            comm.set_pipelined(os.environ.get("WG_BENCH_PIPELINED", "1") != "0")
         if mode == "staged":  # two staging cubes (step parity) + flag array, exported to every peer
             pair = comm.stage_export(2 * self.M * self.N * np.dtype(self.np_dtype).itemsize)
             if world > 1:
@@ -200,7 +202,7 @@ class GemmWorkload(Workload):
 
     def finish(self):
         """End of a run of steps (inside the timed region): complete what pipelined steps deferred."""
-        if self.dist is not None and self.mode == "staged":
+        if self.dist is not None and self.mode in ("staged", "rccl"):
             self.dist["comm"].join()
 
     def close(self):
@@ -1078,7 +1080,7 @@ def main():
         par = f"m-shard x{world} + {engine}"
         cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels,
                      "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"]),
-                     "pipelined_steps": bool(DIST["mode"] == "staged" and os.environ.get("WG_BENCH_PIPELINED", "1") != "0")}
+                     "pipelined_steps": bool(DIST["mode"] in ("staged", "rccl") and os.environ.get("WG_BENCH_PIPELINED", "1") != "0")}
         if dist_report:
             cfg_extra.update(dist_report)
         if oversub:

@@ -353,7 +353,7 @@ uint64_t wg_comm_bytes_sent(const wg_comm *comm);     /* payload bytes this rank
  * communicator's stream, ordered after the work already enqueued on the context; the context does not wait (wg_comm_join). */
 int wg_all_gather(wg_comm *comm, wg_dtype dtype, wg_buf *buf, uint64_t first_elem, uint64_t elems_per_rank);
 int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collectives in flight (and completes a deferred last panel) */
-/* Pipelined steps (WG_GATHER_PEER_STAGED): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
+/* Pipelined steps (WG_GATHER_PEER_STAGED, and WG_GATHER_RCCL in its one-launch form): with on != 0 a wg_gemm_sharded call leaves the wait + relayout of its LAST panel -- the one
  * exchange nothing of its own call can hide -- to the next call on the communicator, which runs it right after enqueueing its first Gemm
  * (wg_comm_join / _flush / _barrier / a call in another mode complete it too). `out` is then complete in stream order only after that. */
 /* One launch per step: an f16 wg_gemm_sharded of at least one round of 256 x 256 tiles (WG_GATHER_RCCL, WG_GATHER_PEER_STAGED, panels of whole

@@ -250,6 +250,42 @@ def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus,
     inst.close()
 
 
+@pytest.mark.parametrize("engine", ["rccl", "staged"])
+def test_sharded_gemm_pipelined_steps_one_launch(engine):
+    """Pipelined steps of the one-launch form (each call's last panel completes behind the NEXT call's kernel; two staging cubes by step
+    parity), RCCL engine (1 rank) and staged engine: five back-to-back steps on different B and different outputs with no synchronisation
+    in between must each equal the unpipelined panel-by-panel result of the same operands."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wg = _wg()
+    from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
+    inst = wg.GpuInstance.new(0)
+    dev = inst.device()
+    comm = Comm(inst, 1, 0, new_unique_id() if engine == "rccl" else None)
+    M, K, N, panel = 8192, 512, 8192, 2048  # 256 tiles per panel: the panel launches are unsplit too (same accumulation chains)
+    rng = np.random.default_rng(77)
+    A = wg.TensorBuilder.matrix(M, K, S_ALL).build_init(dev, (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16))
+    Bs = [wg.TensorBuilder.matrix(K, N, S_ALL).build_init(dev, (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)) for _ in range(5)]
+    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.PEER_STAGED
+    if engine == "staged":
+        comm.stage_reserve(2 * M * N * 2)
+    res = {}
+    for one, pipe in ((False, False), (True, True)):
+        comm.set_one_launch(one)
+        comm.set_pipelined(pipe)
+        Cs = [wg.TensorBuilder.matrix(M, N, S_ALL).build_init(dev, np.full(M * N, np.nan, np.float16)) for _ in Bs]
+        for B, C in zip(Bs, Cs):
+            comm.sharded_gemm(C, A, B, 0, mode, panel)
+        comm.join()
+        inst.sync()
+        res[one] = [C.read(dev).view(np.uint16).copy() for C in Cs]
+    for i, (x, y) in enumerate(zip(res[False], res[True])):
+        assert not np.isnan(y.view(np.float16)).any(), f"step {i}: unwritten elements"
+        assert np.array_equal(x, y), f"step {i}: pipelined one-launch result differs from the panel launches"
+    comm.close()
+    inst.close()
+
+
 @pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("rccl", 248), ("peer", None)])
 def test_config5_gemm_f16_32768_sharded_entry_point(engine, cus):
     import os

@@ -188,6 +188,7 @@ struct wg_comm {
     bool pipelined = false;
     struct Pending {
         bool on = false;
+        hipEvent_t after = nullptr; // RCCL engine: the panel's gather (an event of the communicator's stream) instead of the peers' flags
         uint32_t seq = 0, panel = 0, mg = 0, np = 0;
         const char *src = nullptr;
         char *dst = nullptr;
@@ -395,6 +396,10 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
     if (!c->pending.on) return WG_OK;
     c->pending.on = false;
     const wg_comm::Pending &q = c->pending;
+    if (q.after) { // RCCL engine
+        WG_HIP_TRY(hipStreamWaitEvent(c->ctx->stream, q.after, 0));
+        return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es);
+    }
     if (c->nranks > 1) {
         hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, c->ctx->stream, c->pflags, (uint32_t)c->nranks, (uint32_t)c->rank, q.panel, q.seq, c->wait_err,
                            c->seq_src + 64, c->timeout_ticks);
@@ -786,7 +791,10 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     const size_t es = wg_dtype_size(dtype);
     WG_HIP_TRY(hipSetDevice(ctx->device));
 
-    if (mode != WG_GATHER_PEER_STAGED)
+    // (the RCCL engine's one-launch form completes a deferred last panel itself, behind its kernel)
+    const bool rccl_one = mode == WG_GATHER_RCCL && c->nccl != nullptr && c->one_launch != 0 && dtype == WG_F16 && (N + panel_cols - 1) / panel_cols > 1 &&
+                          panel_cols % 256u == 0 && 2ull * M * N < (1ull << 32);
+    if (mode != WG_GATHER_PEER_STAGED && !rccl_one)
         if (int rc = run_pending(c)) return rc;
     if (mode == WG_GATHER_PEER_STAGED) {
         // ---- contiguous per-link copies into the peers' staging cubes + flag, wait kernel + relayout on the receiving side ----
@@ -884,7 +892,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                     if (int rc = finish_panel(p)) return rc;
                 if (c->pipelined) {
                     const uint32_t p = npanels - 1, c0 = p * panel_cols, np = N - c0;
-                    c->pending.on = true;
+                    c->pending.on = true; c->pending.after = nullptr;
                     c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
                     c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
                     c->pending.dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
@@ -936,7 +944,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // still be reading that half) -- so a one-panel step completes in the call.
         if (c->pipelined && npanels > 1) {
             const uint32_t p = npanels - 1, c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
-            c->pending.on = true;
+            c->pending.on = true; c->pending.after = nullptr;
             c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
             c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
             c->pending.dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
@@ -947,12 +955,15 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     }
 
     const bool staged = mode == WG_GATHER_RCCL && c->nccl != nullptr; // a 1-rank communicator still runs the whole path (tests)
-    // ---- RCCL engine, ONE launch per step (f16 products of at least one round of tiles): a staging cube for the whole step, the kernel raises
-    // a flag per panel, the communicator's stream waits on it (hipStreamWaitValue32) and all-gathers the panel while the kernel works on the
-    // next ones; the relayouts follow the kernel on the context's stream, each behind its panel's gather.
-    if (staged && c->one_launch != 0 && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0 && (uint64_t)M * N < (1ull << 32)) {
-        const size_t need = (size_t)M * N * es;
+    // ---- RCCL engine, ONE launch per step (f16 products of at least one round of tiles): staging cubes for two whole steps (step parity, as
+    // the staged engine's), the kernel's waves count themselves into a word per panel, the communicator's stream waits for the full count
+    // (hipStreamWaitValue32) and all-gathers the panel while the kernel works on the next ones; the relayouts follow the kernel on the
+    // context's stream, each behind its panel's gather. Pipelined steps (wg_comm_set_pipelined) leave the last panel's relayout -- the one
+    // gather nothing of its own step hides -- to the next call, behind that call's kernel.
+    if (rccl_one) {
+        const size_t half = ((size_t)M * N * es + 255) & ~(size_t)255, need = 2 * half;
         if (need > c->stage_bytes) {
+            if (int rc = run_pending(c)) return rc;
             WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
             WG_HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->stage) WG_HIP_TRY(hipFree(c->stage));
@@ -962,40 +973,53 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             c->stage_bytes = need;
         }
         if (int rc = ensure_panel_sync(c)) return rc;
-        while (c->ev_panel.size() < npanels) {
+        while (c->ev_panel.size() < 2 * (size_t)npanels) {
             hipEvent_t e = nullptr;
             WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             c->ev_panel.push_back(e);
         }
-        const uint32_t np_last = N - (npanels - 1u) * panel_cols;
+        const uint32_t parity = (++c->step) & 1u, np_last = N - (npanels - 1u) * panel_cols;
+        char *cube = (char *)c->stage + (size_t)parity * half; // this step's cube; the other one may still be gathering its last panel
         wgk_panels pa;
         pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
         pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols;
         pa.counters = c->panel_sync;
-        // (the cube is free: the previous call's relayouts precede this kernel on the context's stream, and this call's gathers only start
-        // on flags this kernel raises)
-        const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->stage + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
+        // (this parity's cube is free: its last user's relayouts -- two steps ago, the deferred one included, see below -- precede this
+        // kernel on the context's stream, and this step's gathers only start on counts this kernel produces)
+        if (c->pending.on && c->pending.after && (c->pending.seq & 1u) == parity)
+            if (int rc = run_pending(c)) return rc; // (cannot happen with alternating parities; kept as a guard)
+        const int rc1 = wg_gemm_f16_panels(ctx, tr, cube + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
         if (rc1 == WG_OK) {
+            hipEvent_t *ev = c->ev_panel.data() + (size_t)parity * npanels;
             for (uint32_t p = 0; p < npanels; ++p) {
                 const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
-                char *base = (char *)c->stage + (size_t)c0 * M * es;
+                char *base = cube + (size_t)c0 * M * es;
                 c->panel_total[p] += wgk_panel_goal(mg, np);
                 WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.counters + p, c->panel_total[p], hipStreamWaitValueGte, 0xffffffffu));
                 ncclResult_t r = rccl().AllGather(base + (size_t)g * mg * np * es, base, (size_t)mg * np, ncclFloat16, c->nccl, c->stream);
                 if (r != ncclSuccess) return nccl_fail("ncclAllGather", r);
                 c->bytes_sent += (uint64_t)mg * np * es;
-                WG_HIP_TRY(hipEventRecord(c->ev_panel[p], c->stream));
+                WG_HIP_TRY(hipEventRecord(ev[p], c->stream));
             }
+            if (int rc = run_pending(c)) return rc; // the previous call's deferred last panel: behind this call's kernel
+            const uint32_t upto = c->pipelined ? npanels - 1u : npanels;
             for (uint32_t p = 0; p < npanels; ++p) {
                 const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
-                WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, c->ev_panel[p], 0));
-                if (int rc = launch_cube_to_matrix(ctx, (const char *)c->stage + (size_t)c0 * M * es,
-                                                   (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es, mg, np, P, out_shape.stride, es))
-                    return rc;
+                const char *src = cube + (size_t)c0 * M * es;
+                char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
+                if (p < upto) {
+                    WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[p], 0));
+                    if (int rc = launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es)) return rc;
+                } else {
+                    c->pending.on = true; c->pending.after = ev[p];
+                    c->pending.seq = c->step; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
+                    c->pending.src = src; c->pending.dst = dst; c->pending.ld = out_shape.stride; c->pending.es = es;
+                }
             }
             return WG_OK;
         }
         if (rc1 != WG_ERR_UNSUPPORTED) return rc1;
+        if (int rc = run_pending(c)) return rc; // panel by panel below
     }
     wg_buf stage_buf;
     if (staged) {
