@@ -141,6 +141,9 @@ if t1:
             steady = r["rows_per_rank"] * N * 2 / (ENGINE_GBS * 1e6)
             tail = r["staged_compute_and_relayout"]["last_panel_bytes_per_peer"] / (ENGINE_GBS * 1e6)
             t = max(rc["ms_per_step"] * SLOW.get(int(P), 1.05), steady) + tail
+            tp = max(rc["ms_per_step"] * SLOW.get(int(P), 1.05), steady)
+            r["expected_rccl_248_pipelined"] = {"ms_per_step": round(tp, 3), "speedup_vs_1_gpu": round(t1 / tp, 3),
+                                                "note": "wg_comm_set_pipelined: the last panel's gather + relayout run behind the next step's kernel"}
             r["expected_rccl_248"] = {"ms_per_step": round(t, 3), "speedup_vs_1_gpu": round(t1 / t, 3),
                                       "assumes": "RCCL's gather of a panel keeps up with the per-link rate measured for the copy engines (60.7 GB/s) on its 8 CUs; the last panel's gather is exposed"}
 print(json.dumps(out, indent=1))
