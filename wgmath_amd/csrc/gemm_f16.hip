@@ -1099,6 +1099,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 while (ns > 1 && (double)ns * out_bytes > (double)(512ull << 20)) --ns;
                 if (ns < 2) ns = 1;
             }
+#ifdef WG_T128_FORCE_NS
+            if (tiles128 * nmats <= (uint64_t)cus && K >= 1024u) ns = WG_T128_FORCE_NS; // experiment: K cut on a full round of 128 x 128 tiles
+#endif
             bool want128 = false;
             if (!k_big) want128 = true; // K = 64 or 128: fewer than the three stages the big kernel's DMA pipeline runs ahead
             else if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
