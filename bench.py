@@ -761,13 +761,17 @@ def engine_trials(args, rank, world):
     engine, all ranks' children of one engine rendezvous on their own port), with a time limit, BEFORE this process has touched the GPU
     (it never re-executes itself and starts children only while it is still GPU-free). An engine that fails is recorded with its
     error, one that HANGS (RCCL across ranks has never run on some nodes) with "timeout" after WG_BENCH_TRIAL_TIMEOUT seconds (default
-    240): its group is killed and the next engine is tried. Returns {engine: {"ms_per_step": float | None, "error": str | None}} as seen by
+    150): its group is killed and the next engine is tried. Returns {engine: {"ms_per_step": float | None, "error": str | None}} as seen by
     THIS rank; the ranks agree on the winner afterwards (max over ranks, failures = infinity)."""
-    limit = float(os.environ.get("WG_BENCH_TRIAL_TIMEOUT", "240"))
+    limit = float(os.environ.get("WG_BENCH_TRIAL_TIMEOUT", "150"))
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
     argv = [a for a in sys.argv[1:]]
     out = {}
     for k, mode in enumerate(ENGINES):
+        if mode == "peer" and world > 2:
+            # the rect-copy engine is the 2-rank engine (one rect-capable SDMA queue per direction, DESIGN.md section 6): not a candidate
+            out[mode] = {"ms_per_step": None, "error": "skipped: the SDMA rect-copy engine is for 2 ranks"}
+            continue
         env = dict(os.environ)
         env["MASTER_PORT"] = str(base_port + 1 + k)       # this engine's own rendezvous, hosted by rank 0's child
         env.pop("TORCHELASTIC_USE_AGENT_STORE", None)       # (the launcher agent's store only serves the original port)
