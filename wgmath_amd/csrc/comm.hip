@@ -178,6 +178,7 @@ struct wg_comm {
     uint32_t staged_npanels = 0;              // panels of that call (its sent_ev layout)
     // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels whose waves count themselves into panel_sync[p] as
     // their stores reach memory; the exchange of panel p waits for the full count (hipStreamWaitValue32) while the kernel works on
+    bool can_wait_value = false;              // hipDeviceAttributeCanUseStreamWaitValue: without it every product launches panel by panel
     int one_launch = -1;                      // -1: by engine (RCCL: on -- what lets its Gemm run on 248 CUs; staged: off -- measured 1-2 % slower there), 0 / 1
     uint32_t *panel_sync = nullptr;           // [0, kMaxPanels): arrival counters of the panels: waves finished, RUNNING totals (a reset could overtake a
                                               // copy stream that has not evaluated its wait yet -- and then waits for the NEXT step's kernel, which waits for
@@ -474,6 +475,11 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
         memcpy(&u, id, sizeof u);
         ncclResult_t r = R.CommInitRank(&c->nccl, nranks, u, rank);
         if (r != ncclSuccess) return fail(nccl_fail("ncclCommInitRank", r));
+    }
+    {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ctx->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        c->can_wait_value = can != 0;
     }
     if (const char *t = getenv("WG_COMM_TIMEOUT_MS")) { // read once, here: how long a receiver waits for a peer's slot before it reports the peer missing
         const long long ms = atoll(t);
@@ -792,7 +798,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     WG_HIP_TRY(hipSetDevice(ctx->device));
 
     // (the RCCL engine's one-launch form completes a deferred last panel itself, behind its kernel)
-    const bool rccl_one = mode == WG_GATHER_RCCL && c->nccl != nullptr && c->one_launch != 0 && dtype == WG_F16 && (N + panel_cols - 1) / panel_cols > 1 &&
+    const bool rccl_one = mode == WG_GATHER_RCCL && c->nccl != nullptr && c->one_launch != 0 && c->can_wait_value && dtype == WG_F16 && (N + panel_cols - 1) / panel_cols > 1 &&
                           panel_cols % 256u == 0 && 2ull * M * N < (1ull << 32);
     if (mode != WG_GATHER_PEER_STAGED && !rccl_one)
         if (int rc = run_pending(c)) return rc;
@@ -851,7 +857,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // ---- ONE launch per step (f16 products of at least one round of tiles): the kernel walks the panels left to right and raises a
         // flag per panel; every peer stream waits on panel p's flag (hipStreamWaitValue32) and pushes the slot; the relayouts follow the
         // kernel on the context's stream. No launch boundary, no ramp per panel, and the tile scheduler sees the rank's whole product.
-        if (c->one_launch == 1 && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
+        if (c->one_launch == 1 && c->can_wait_value && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
             if (int rc = ensure_panel_sync(c)) return rc;
             const uint32_t np_last = N - (npanels - 1u) * panel_cols;
             wgk_panels pa;
