@@ -854,9 +854,10 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->seq_src + 64 : nullptr);
         };
         static const bool no_copy = getenv("WG_STAGED_NO_COPY") != nullptr; // tools/rank_emulation.py: one rank's compute + relayout alone
-        // ---- ONE launch per step (f16 products of at least one round of tiles): the kernel walks the panels left to right and raises a
-        // flag per panel; every peer stream waits on panel p's flag (hipStreamWaitValue32) and pushes the slot; the relayouts follow the
-        // kernel on the context's stream. No launch boundary, no ramp per panel, and the tile scheduler sees the rank's whole product.
+        // ---- ONE launch per step (f16 products of at least one round of tiles; on request for this engine: wg_comm_set_one_launch): the kernel
+        // walks the panels left to right, its waves count themselves into a word per panel as their write-through stores reach memory; every
+        // peer stream waits for panel p's full count (hipStreamWaitValue32) and pushes the slot; the relayouts follow the kernel on the
+        // context's stream. The tile scheduler sees the rank's whole product.
         if (c->one_launch == 1 && c->can_wait_value && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
             if (int rc = ensure_panel_sync(c)) return rc;
             const uint32_t np_last = N - (npanels - 1u) * panel_cols;
