@@ -191,11 +191,11 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // half-step then degrades to lgkmcnt(0).
     float *part = unit_mode ? g.bal.part + (uint64_t)unit_pair * 65536u : g.part;
     float alpha = g.alpha, beta = g.beta;
-    uint32_t ldc = g.ldc;
+    uint32_t ldc = g.ldc, c_stream = g.c_stream;
     uint32_t *bal_flag = g.bal.flags + unit_pair;
     uint32_t bal_epoch = g.bal.epoch;
     unsigned long long *calib = g.calib;
-    asm volatile("" : "+s"(C), "+s"(part), "+s"(alpha), "+s"(beta), "+s"(ldc), "+s"(bal_flag), "+s"(bal_epoch), "+s"(calib));
+    asm volatile("" : "+s"(C), "+s"(part), "+s"(alpha), "+s"(beta), "+s"(ldc), "+s"(c_stream), "+s"(bal_flag), "+s"(bal_epoch), "+s"(calib));
 
     // ---- DMA addressing; ragged tiles: rows past the end are clamped to the last valid one (results discarded by the epilogue) ----
     // A half-stage = 16 pieces of 1 KiB, wave stages P = 4 wave + q; B full stage = 32 pieces, wave stages P = 8 wave + q.
@@ -745,7 +745,19 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
                 if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(cc + 32 * p) = v; // (timing experiments only: NOT visible to a copy engine in time)
                 else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
                 else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-            } else if (!(WG_ABLATE & 32)) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+            } else if (!(WG_ABLATE & 32)) {
+#ifndef WG_EPI_STORE
+#define WG_EPI_STORE -1 // -1: by GemmArgs::c_stream (shipped); experiments: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt for every launch
+#endif
+                if constexpr (WG_EPI_STORE == -1) {
+                    if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(cc + 32 * p), "v"(v) : "memory");
+                    else *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+                } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+                else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_t *>(cc + 32 * p));
+                else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
+                else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(cc + 32 * p), "v"(v) : "memory");
+            }
         }
     }
 #ifndef WG_F16_TRACE
@@ -1048,6 +1060,10 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.c = (_Float16 *)out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
+    {   // the result past the caches when it would push the operands out of the Infinity Cache (see GemmArgs::c_stream); beta != 0 reads C back
+        const uint64_t MiB = 1ull << 20, ab = ((uint64_t)M * K + (uint64_t)K * N) * nmats * 2u, cb = (uint64_t)M * N * nmats * 2u;
+        g.c_stream = (beta == 0.f && ab <= 256u * MiB && ab + cb > 256u * MiB) ? 1u : 0u;
+    }
     g.tile_base = 0; g.tail_tiles = 0;
     g.sched = nullptr; g.sched_tiles = 0;
     g.calib = nullptr; g.bal = BalancePlan{}; g.panel = PanelArgs{};

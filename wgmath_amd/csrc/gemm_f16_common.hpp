@@ -94,6 +94,9 @@ struct GemmArgs {
     uint32_t nsplit, k_per_split;
     float *part;
     float alpha, beta; // out = alpha * acc + beta * out (wg_gemm_ex)
+    // 1: the result is stored past the caches (`sc1 nt`): chosen by the launcher when the operands fit the 256 MiB Infinity Cache and the
+    // result on top of them would not -- the result then leaves the operands alone there (8192^3: +1.2 ... 2.8 %, profiles/r03_evidence.md section 8)
+    uint32_t c_stream;
     // "tail split" launches of the 16x16x32 kernel: tile id = tile_base + blockIdx.x; with tail_tiles > 0 the workgroup (tile, split)
     // writes its f32 partial tile to part[(split * tail_tiles + blockIdx.x) * 65536 + col_local * 256 + row_local]
     uint32_t tile_base, tail_tiles;
@@ -172,7 +175,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
         // 256 consecutive ids = one 16x16 super-tile; hardware deals ids round-robin to the 8 XCDs: XCD x gets a 4x8 patch
         const uint32_t super = bid >> 8, within = bid & 255u;
         const uint32_t xcd = within & 7u, local = within >> 3;
-        const uint32_t sm = super % (tiles_m / 16u), sn = super / (tiles_m / 16u);
+        const uint32_t sm = super % (tiles_m / 16u), sn = super / (tiles_m / 16u); // (a serpentine over the super-tile columns measured the same: r03 evidence 8)
         tm = sm * 16u + (xcd & 3u) * 4u + (local & 3u);
         tn = sn * 16u + (xcd >> 2) * 8u + (local >> 2);
     } else {
