@@ -1,0 +1,111 @@
+// Probe: what does the chip sustain on v_mfma_f32_16x16x32_f16 when NOTHING but the matrix cores works -- operands in registers, no LDS, no
+// loads -- at the package power cap? That is the ceiling any f16 Gemm on this part can approach (the 2.5 PFLOP/s "peak" assumes 2.4 GHz,
+// which the cap does not allow with non-zero operands).
+//   data 0: zero operands (the clock stays at its ceiling: measures the issue rate)   data 1: uniform random f16 in [-1, 1) per lane and fragment
+//   shape 0: 16x16x32 (the shipped kernel's instruction), wave tile 8 x 8 fragments like the Gemm   shape 1: 32x32x16, 4 x 4 fragments
+// One workgroup of 4 waves per CU (160 KiB of LDS claimed), `wgs` workgroups, each wave REPS x 64 (or 16) MFMAs into 256 accumulator registers.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/cpp/mfma_power_ceiling.hip -o tools/cpp/_bin/mfma_power_ceiling
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t mix(uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__device__ __forceinline__ half8 frag(uint32_t seed, int data) {
+    half8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t r = mix(seed * 8u + i + 0x9e3779b9u);
+        v[i] = data ? (_Float16)((float)(r >> 8) * (2.f / 16777216.f) - 1.f) : (_Float16)0.f;
+    }
+    return v;
+}
+
+template <int SHAPE>
+__global__ __launch_bounds__(256, 1) void burn(float *out, int reps, int data) {
+    extern __shared__ char smem[];
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    half8 a[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a[i] = frag(id * 16u + i, data); b[i] = frag(id * 16u + 8u + i, data); }
+    float s = 0.f;
+    if constexpr (SHAPE == 0) {
+        floatx4 acc[8][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[t][u] = floatx4{ 0.f, 0.f, 0.f, 0.f };
+        for (int r = 0; r < reps; ++r) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += acc[t][u][0] + acc[t][u][1] + acc[t][u][2] + acc[t][u][3];
+    } else {
+        floatx16 acc[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+        for (int r = 0; r < reps; ++r) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2 * t + kk], b[2 * u + kk], acc[t][u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s += acc[t][u][e];
+    }
+    if (s == 123.456f) out[id] = s; // (keeps the accumulators alive)
+    if (threadIdx.x == 0 && smem[0] == 77) out[0] = 1.f;
+}
+
+template <int SHAPE>
+int run(float *out, int wgs, int reps, int data, const char *label) {
+    CK(hipFuncSetAttribute((const void *)burn<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    burn<SHAPE><<<wgs, 256, 160 * 1024>>>(out, reps / 8, data); // warm-up
+    CK(hipDeviceSynchronize());
+    double best = 0, sum = 0; const int N = 5;
+    for (int i = 0; i < N; ++i) {
+        CK(hipEventRecord(e0));
+        burn<SHAPE><<<wgs, 256, 160 * 1024>>>(out, reps, data);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        // flops per wave per rep: 64 MFMAs x 2 x 16 x 16 x 32  ==  32 MFMAs x 2 x 32 x 32 x 16
+        const double fl = (double)wgs * 4.0 * reps * 64.0 * 2.0 * 16 * 16 * 32;
+        const double tf = fl / (ms * 1e-3) / 1e12;
+        best = tf > best ? tf : best; sum += tf;
+        if (i == N - 1) printf("%-34s %4d workgroups, %6.1f ms per launch: mean %7.1f, best %7.1f TFLOP/s (%.3f of 2500)\n", label, wgs, ms, sum / N, best, sum / N / 2500.0);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 60000; // ~50 ms per launch at 1.5 PFLOP/s with 256 workgroups
+    float *out; CK(hipMalloc((void **)&out, 1024 * 256 * 4));
+    for (int wgs : { 256, 248, 224, 128 }) {
+        if (run<0>(out, wgs, reps, 1, "16x16x32 random operands")) return 1;
+        if (wgs != 256) continue;
+        if (run<0>(out, wgs, reps, 0, "16x16x32 zero operands")) return 1;
+        if (run<1>(out, wgs, reps, 1, "32x32x16 random operands")) return 1;
+        if (run<1>(out, wgs, reps, 0, "32x32x16 zero operands")) return 1;
+    }
+    return 0;
+}
