@@ -761,9 +761,9 @@ def engine_trials(args, rank, world):
     engine, all ranks' children of one engine rendezvous on their own port), with a time limit, BEFORE this process has touched the GPU
     (it never re-executes itself and starts children only while it is still GPU-free). An engine that fails is recorded with its
     error, one that HANGS (RCCL across ranks has never run on some nodes) with "timeout" after WG_BENCH_TRIAL_TIMEOUT seconds (default
-    150): its group is killed and the next engine is tried. Returns {engine: {"ms_per_step": float | None, "error": str | None}} as seen by
+    240): its group is killed and the next engine is tried. Returns {engine: {"ms_per_step": float | None, "error": str | None}} as seen by
     THIS rank; the ranks agree on the winner afterwards (max over ranks, failures = infinity)."""
-    limit = float(os.environ.get("WG_BENCH_TRIAL_TIMEOUT", "150"))
+    limit = float(os.environ.get("WG_BENCH_TRIAL_TIMEOUT", "240"))
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
     argv = [a for a in sys.argv[1:]]
     out = {}
@@ -912,6 +912,9 @@ def main():
     trial_mode = os.environ.get("WG_BENCH_TRIAL")  # set: this process is one rank of ONE engine's trial (a child of engine_trials)
     trials = None
     if world > 1 and args.gather == "auto" and not trial_mode:
+        # (importing torch initialises no GPU; done HERE so that the first trial's clock does not run while a fresh box pages the image's
+        # libraries in -- 1-2 minutes the first time -- which would time the first engine out for no fault of its own)
+        import torch  # noqa: F401
         trials = engine_trials(args, rank, world)  # fresh child groups with time limits, while this process is still GPU-free
     if args.dry_run:
         return dry_run(args, rank, world, trials, trial_mode)
