@@ -295,6 +295,8 @@ GEMV_SHAPES = [
     (1024, 2048, 8, 1), (516, 772, 7, 2), (256, 1024, 9, 1), (1024, 512, 12, 2), (64, 128, 17, 1),
     # 9 .. 64 right-hand sides with >= 512 outputs and k >= 128: one pass on the few-column Gemm kernels
     (1024, 512, 12, 1), (1024, 516, 17, 2), (516, 1028, 40, 1), (1024, 640, 64, 1),
+    # GemvTr with one right-hand side (a half-wave per column): batches, ragged lengths, splits, the 64-KiB-column case of the older kernel
+    (12, 12, 1, 3), (1028, 36, 1, 2), (16384, 64, 1, 1), (40004, 68, 1, 1), (300000, 4, 1, 1), (2052, 4100, 1, 1),
 ]
 
 
@@ -1271,7 +1273,9 @@ def test_gemv_reduce_fused_single_launch(gpu, R, Cn):
 # (exactly converted) inputs and rounded once.
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("tr", [False, True])
-@pytest.mark.parametrize("R,Cn,nrhs,mats", [(1024, 2048, 1, 1), (256, 512, 3, 2), (4096, 8192, 1, 1), (132, 260, 2, 1)])
+@pytest.mark.parametrize("R,Cn,nrhs,mats", [(1024, 2048, 1, 1), (256, 512, 3, 2), (4096, 8192, 1, 1), (132, 260, 2, 1),
+                                           # one right-hand side: 16-byte loads where aligned (k % 8, batches), 8-byte loads otherwise, splits
+                                           (12, 12, 1, 3), (1028, 36, 1, 2), (40004, 68, 1, 1), (300000, 8, 1, 1), (16392, 20, 1, 1), (2056, 4100, 1, 1)])
 def test_gemv_f16(gpu, tr, R, Cn, nrhs, mats):
     wg = _wg()
     rng = np.random.default_rng(R + Cn + nrhs + tr)

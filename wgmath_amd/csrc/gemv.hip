@@ -237,6 +237,95 @@ __global__ __launch_bounds__(kThreads) void gemv_t_kernel(GemvArgsT<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// T, one right-hand side, the batched-Reduce shape (reduce.hip, reduce_rows4: 6.5 TB/s on the same matrix): a HALF-wave per column, lane p
+// takes rows 4 p + 128 i of this split -- 512 contiguous bytes (f32) per half-wave per load, U loads in flight per lane, the vector's
+// float4 beside each (the 8 half-waves of a workgroup read the same addresses: cache hits). 8 columns per workgroup.
+// grid = (column groups of 8, splits, nmats)
+// ------------------------------------------------------------------------------------------------------
+#ifndef WG_GEMVT_U
+#define WG_GEMVT_U 8
+#endif
+#ifndef WG_GEMVT_ROT
+#define WG_GEMVT_ROT 0 // 1: column c starts its sweep (c * 5) blocks of rows in and wraps around (de-phases the columns' streams)
+#endif
+typedef _Float16 wg_h8 __attribute__((ext_vector_type(8)));
+// E consecutive elements as floats (E = 4: load4 / load4s; E = 8: f16 only, one 16-byte load)
+template <int E, typename T> struct RowPiece { float f[E]; };
+template <int E, typename T>
+__device__ __forceinline__ RowPiece<E, T> piece_stream(const T *p) {
+    RowPiece<E, T> o;
+    if constexpr (E == 4) { const float4 v = load4s(p); o.f[0] = v.x; o.f[1] = v.y; o.f[2] = v.z; o.f[3] = v.w; }
+    else {
+        const wg_h8 v = GEMV_NT ? __builtin_nontemporal_load(reinterpret_cast<const wg_h8 *>(p)) : *reinterpret_cast<const wg_h8 *>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.f[i] = (float)v[i];
+    }
+    return o;
+}
+template <int E, typename T>
+__device__ __forceinline__ RowPiece<E, T> piece_cached(const T *p) {
+    RowPiece<E, T> o;
+    if constexpr (E == 4) { const float4 v = load4(p); o.f[0] = v.x; o.f[1] = v.y; o.f[2] = v.z; o.f[3] = v.w; }
+    else {
+        const wg_h8 v = *reinterpret_cast<const wg_h8 *>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.f[i] = (float)v[i];
+    }
+    return o;
+}
+template <typename T, int E>
+__global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
+    const uint32_t col = blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
+    const uint32_t p = threadIdx.x & 31u;
+    const uint32_t z = blockIdx.z;
+    if (col >= a.rows_out) return; // whole half-waves leave together; the shuffles below never cross halves
+    const uint32_t r_begin = blockIdx.y * a.k_per_split;
+    const uint32_t r_end = min(a.k, r_begin + a.k_per_split);
+    const T *mp = a.m + z * a.m_batch + (uint64_t)col * a.ldm;
+    const T *vp = a.v + z * a.v_batch;
+    constexpr int U = WG_GEMVT_U;
+    constexpr uint32_t kChunk = 32u * E;   // rows a half-wave covers per load
+    constexpr uint32_t kBlock = kChunk * U; // ... per trip
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    const uint32_t nblocks = (r_end - r_begin) / kBlock;
+    uint32_t rot = 0;
+    if constexpr (WG_GEMVT_ROT) rot = nblocks ? (col * 5u) % nblocks : 0u;
+    for (uint32_t i = 0; i < nblocks; ++i) {
+        uint32_t j = i + rot;
+        if (j >= nblocks) j -= nblocks;
+        const uint32_t r = r_begin + j * kBlock + E * p;
+        RowPiece<E, T> mv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) mv[u] = piece_stream<E, T>(mp + r + kChunk * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) xv[u] = piece_cached<E, T>(vp + r + kChunk * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] = fmaf(mv[u].f[e], xv[u].f[e], acc[e]);
+    }
+    // what is left of the range (< one trip): 4 rows per lane, 128 per half-wave (k % 4 == 0: a lane's 4 rows are all in or all out)
+    for (uint32_t r = r_begin + nblocks * kBlock + 4u * p; r < r_end; r += 128u) {
+        const float4 mv = load4s(mp + r), xv = load4(vp + r);
+        acc[0] = fmaf(mv.x, xv.x, acc[0]);
+        acc[1] = fmaf(mv.y, xv.y, acc[1]);
+        acc[2] = fmaf(mv.z, xv.z, acc[2]);
+        acc[3] = fmaf(mv.w, xv.w, acc[3]);
+    }
+    float s;
+    if constexpr (E == 4) s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    else s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+#pragma unroll
+    for (int sh = 16; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh, 64);
+    if (p == 0) {
+        const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + col;
+        if (a.part) a.part[off] = s; else a.out[off] = (T)s;
+    }
+}
+
 // out[r] = sum_{s < nsplit} partial[s][r] in a FIXED order. partial layout: [z][s][y][rows_out] dense.
 // A workgroup covers 4 float4 rows x 64 "split lanes": split lane j adds splits j, j+64, ... ascending (4 independent loads
 // in flight per trip), then the 16 split lanes of a wave are folded by a butterfly and the 4 waves ascending through LDS.
@@ -404,17 +493,33 @@ __global__ __launch_bounds__(kThreads) void gemv_n_small_reduce_kernel(GemvArgs 
 inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); }
 
 // blocks along the output, and how finely the contraction must be split to give every CU ~4 workgroups
-static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t gz) {
-    const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
+#ifndef WG_GEMVT_COLS
+#define WG_GEMVT_COLS 1 // 0: T with one right-hand side on the 4-columns-per-wave kernel as well (the form before round 3)
+#endif
+// T with ONE right-hand side runs on gemv_t_cols_kernel (a half-wave per column): measured over 17 shapes x 2 element types against the
+// 4-columns-per-wave kernel (tools/gemvtr_sweep.py, profiles/r03_evidence.md section 10): f32 -1...-40 % time (4096^2 16.5 -> 10 us, 65536 x 4096
+// 169 -> 162), f16 -5...-45 % (65536 x 4096 95 -> 83 us = 6.5 TB/s) -- except f32 columns exactly 64 KiB apart with k <= 16384 (16384 x 2048 ...
+// x 16384: +5...+13 %; 15360 and 17408 rows are fine, f16 and longer columns at that stride are fine), which stay on the old kernel.
+template <typename T>
+static bool uses_t_cols(bool trans, uint32_t nrhs, uint32_t k, uint32_t ldm) {
+    if (!WG_GEMVT_COLS || !trans || nrhs != 1) return false;
+    if (sizeof(T) == 4 && ldm % 16384u == 0 && k <= 16384u) return false;
+    return true;
+}
+template <typename T>
+static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t gz, uint32_t ldm) {
+    const bool cols = uses_t_cols<T>(trans, nrhs, k, ldm);
+    const uint32_t gx = cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
     const uint64_t blocks_xy = (uint64_t)gx * gz;
     const uint32_t max_split = k == 0 ? 1u : ceil_div(k, min_k_per_split);
     // ~4 workgroups per CU (measured at 1 / 2 / 4 per CU: GemvTr 65536 x 4096 5.4 / 6.0 / 6.4 TB/s; Gemv 4096 x 11008 43 / - / 33 us),
     // except a tall matrix with a short contraction whose row blocks alone give every CU a workgroup: splitting 65536 x 256 four ways
     // costs 18 us with the combine pass against 10 us unsplit.
-    uint32_t want = blocks_xy >= (uint64_t)cus * 4u ? 1u : ceil_div((uint32_t)cus * 4u, (uint32_t)blocks_xy);
+    const uint32_t per_cu = cols ? 2u : 4u; // (the half-wave-per-column kernel: 2 / 4 / 8 per CU measured the same within 2 %; fewer splits, smaller combine)
+    uint32_t want = blocks_xy >= (uint64_t)cus * per_cu ? 1u : ceil_div((uint32_t)cus * per_cu, (uint32_t)blocks_xy);
     if (!trans && blocks_xy >= (uint64_t)cus && k <= 1024u) want = 1u;
-    if (trans && blocks_xy >= 2ull * (uint64_t)cus) want = 1u; // T with >= 2 workgroups per CU already: 8192 x 8192 47 us unsplit, 57 split in two + combine
+    if (trans && !cols && blocks_xy >= 2ull * (uint64_t)cus) want = 1u; // T with >= 2 workgroups per CU already: 8192 x 8192 47 us unsplit, 57 split in two + combine
     uint32_t nsplit = want > max_split ? max_split : want;
     if (nsplit < 1u) nsplit = 1u;
     if (nsplit > 65535u) nsplit = 65535u;
@@ -437,8 +542,9 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/8) = %llu exceeds 65535", (unsigned long long)gz64);
     const uint32_t gz = (uint32_t)gz64;
 
-    const uint32_t gx = trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
-    uint32_t nsplit = plan_nsplit(cus, trans, rows_out, k, nrhs, gz);
+    const bool t_cols = uses_t_cols<T>(trans, nrhs, k, m.ld);
+    const uint32_t gx = t_cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
+    uint32_t nsplit = plan_nsplit<T>(cus, trans, rows_out, k, nrhs, gz, m.ld);
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
 
@@ -478,7 +584,17 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     // holds min(nrhs, 8) columns (a group of 3 uses tile 4, of 5..7 tile 8)
     const uint32_t per_group = nrhs < (uint32_t)kMaxRhs ? nrhs : (uint32_t)kMaxRhs;
     const int tile = per_group > 4 ? 8 : (per_group > 2 ? 4 : (int)per_group);
-    if (trans) {
+    if (t_cols) {
+        // f16: 16-byte loads (8 rows per lane) where every column, split and batch keeps them aligned; 8-byte loads (the view contract) otherwise
+        bool wide = false;
+        if constexpr (sizeof(T) == 2)
+            wide = (uintptr_t)a.m % 16 == 0 && (uintptr_t)a.v % 16 == 0 && a.ldm % 8 == 0 && a.k_per_split % 8 == 0 && (nmats == 1 || (a.m_batch % 8 == 0 && a.v_batch % 8 == 0));
+        if constexpr (sizeof(T) == 2) {
+            if (wide) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8>), grid, block, 0, ctx->stream, a);
+            else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4>), grid, block, 0, ctx->stream, a);
+        } else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4>), grid, block, 0, ctx->stream, a);
+    }
+    else if (trans) {
         if (tile == 1) hipLaunchKernelGGL((gemv_t_kernel<1, T>), grid, block, 0, ctx->stream, a);
         else if (tile == 2) hipLaunchKernelGGL((gemv_t_kernel<2, T>), grid, block, 0, ctx->stream, a);
         else if (tile == 4) hipLaunchKernelGGL((gemv_t_kernel<4, T>), grid, block, 0, ctx->stream, a);
@@ -520,7 +636,7 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 // tells the caller to run Gemv and Reduce as two launches. `y` is a scratch vector of rows_out floats, `counter` a zeroed device word.
 int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, float *y, wgk_mat m, wgk_mat v, unsigned *counter, float *result) {
     const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
-    if (k < 4u || !uses_small_kernel(cus, false, rows_out, k, 1, plan_nsplit(cus, false, rows_out, k, 1, 1))) return WG_ERR_UNSUPPORTED;
+    if (k < 4u || !uses_small_kernel(cus, false, rows_out, k, 1, plan_nsplit<float>(cus, false, rows_out, k, 1, 1, m.ld))) return WG_ERR_UNSUPPORTED;
     GemvArgs a;
     a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = 0;
     a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = 0;
