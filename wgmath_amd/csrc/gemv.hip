@@ -176,78 +176,6 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgsT<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// N, one right-hand side, 128-row blocks (experiment WG_GEMVN_HALF): lanes 0-31 and 32-63 of a wave take the even and the odd columns of
-// the wave's range -- two 512-byte segments per load instead of one of 1 KiB; the halves are added at the end.
-// grid = (blocks of 128 rows, splits, nmats)
-// ------------------------------------------------------------------------------------------------------
-#ifndef WG_GEMVN_HALF
-#define WG_GEMVN_HALF 0
-#endif
-#ifndef WG_GEMVN_HALF_NU
-#define WG_GEMVN_HALF_NU 8
-#endif
-template <typename T>
-__global__ __launch_bounds__(kThreads) void gemv_n1h_kernel(GemvArgsT<T> a) {
-    __shared__ float4 part[kWaves][32];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t p = lane & 31u, h = (uint32_t)lane >> 5;
-    const uint32_t z = blockIdx.z;
-    const uint32_t row = blockIdx.x * 128u + 4u * p;
-    const bool row_ok = row < a.rows_out;
-    const uint32_t c_begin = blockIdx.y * a.k_per_split;
-    const uint32_t c_end = min(a.k, c_begin + a.k_per_split);
-    const uint32_t ncol4 = (c_end - c_begin + 3u) / 4u;
-    const uint32_t per_wave = ((ncol4 + kWaves - 1) / kWaves) * 4u;
-    const uint32_t w_begin = min(c_end, c_begin + wave * per_wave);
-    const uint32_t w_end = min(c_end, w_begin + per_wave);
-    const T *mp = a.m + z * a.m_batch + (row_ok ? row : 0u);
-    const T *vp = a.v + z * a.v_batch;
-    constexpr int NU = WG_GEMVN_HALF_NU;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (uint32_t cb = w_begin; cb < w_end; cb += 64u) {
-        const float vv = (cb + lane < w_end) ? (float)vp[cb + lane] : 0.f; // 64 entries of v, one per lane
-        const T *col = mp + ((uint64_t)cb + h) * a.ldm;                    // this half's first column
-        const uint64_t ld2 = 2ull * a.ldm;
-        if (cb + 64u <= w_end) {
-#pragma unroll
-            for (int u0 = 0; u0 < 32; u0 += NU) {
-                float4 mv[NU];
-#pragma unroll
-                for (int u = 0; u < NU; ++u) mv[u] = load4s(col + (uint64_t)(u0 + u) * ld2);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const float ve = readlane_f(vv, 2 * (u0 + u)), vo = readlane_f(vv, 2 * (u0 + u) + 1);
-                    fma4(acc, mv[u], h ? vo : ve);
-                }
-            }
-        } else {
-            const int rem = (int)(w_end - cb); // wave-uniform, a multiple of 4 (k % 4 == 0)
-            for (int u = 0; 2 * u < rem; ++u) {
-                const bool in = 2 * u + (int)h < rem;
-                float4 mv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (in) mv = load4s(col + (uint64_t)u * ld2);
-                fma4(acc, mv, __shfl(vv, 2 * u + (int)h, 64));
-            }
-        }
-    }
-    // odd columns' half onto the even columns' half, then the 4 waves through LDS
-    acc.x += __shfl_down(acc.x, 32, 64); acc.y += __shfl_down(acc.y, 32, 64); acc.z += __shfl_down(acc.z, 32, 64); acc.w += __shfl_down(acc.w, 32, 64);
-    if (h == 0) part[wave][p] = acc;
-    __syncthreads();
-    if (wave == 0 && h == 0 && row_ok) {
-        float4 s = part[0][p];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w) {
-            const float4 q = part[w][p];
-            s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
-        }
-        const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + row;
-        if (a.part) store4(a.part + off, s); else store4(a.out + off, s);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // T: dst[c] = sum_r m[r, c] v[r],  4 columns per wave, rows of this split
 // grid = (column groups of 16, splits, nmats * rhs groups)
 // ------------------------------------------------------------------------------------------------------
@@ -588,7 +516,7 @@ static bool uses_t_cols(bool trans, uint32_t nrhs, uint32_t k, uint32_t ldm) {
 template <typename T>
 static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t gz, uint32_t ldm) {
     const bool cols = uses_t_cols<T>(trans, nrhs, k, ldm);
-    const uint32_t gx = cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, (WG_GEMVN_HALF && nrhs == 1) ? 128u : 256u);
+    const uint32_t gx = cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
     const uint64_t blocks_xy = (uint64_t)gx * gz;
     const uint32_t max_split = k == 0 ? 1u : ceil_div(k, min_k_per_split);
@@ -625,8 +553,7 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     const uint32_t gz = (uint32_t)gz64;
 
     const bool t_cols = uses_t_cols<T>(trans, nrhs, k, m.ld);
-    const bool n_half = WG_GEMVN_HALF && !trans && nrhs == 1;
-    const uint32_t gx = t_cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, n_half ? 128u : 256u);
+    const uint32_t gx = t_cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     uint32_t nsplit = plan_nsplit<T>(cus, trans, rows_out, k, nrhs, gz, m.ld);
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
     nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
@@ -682,8 +609,6 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
         else if (tile == 2) hipLaunchKernelGGL((gemv_t_kernel<2, T>), grid, block, 0, ctx->stream, a);
         else if (tile == 4) hipLaunchKernelGGL((gemv_t_kernel<4, T>), grid, block, 0, ctx->stream, a);
         else hipLaunchKernelGGL((gemv_t_kernel<8, T>), grid, block, 0, ctx->stream, a);
-    } else if (n_half) {
-        hipLaunchKernelGGL((gemv_n1h_kernel<T>), grid, block, 0, ctx->stream, a);
     } else {
         if (tile == 1) hipLaunchKernelGGL((gemv_n_kernel<1, T>), grid, block, 0, ctx->stream, a);
         else if (tile == 2) hipLaunchKernelGGL((gemv_n_kernel<2, T>), grid, block, 0, ctx->stream, a);
