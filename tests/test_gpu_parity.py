@@ -1208,6 +1208,32 @@ def test_reduce_fast(gpu, oracle_c, n, off):
         assert res.read(gpu.device())[0].tobytes() == got.tobytes()
 
 
+@pytest.mark.parametrize("n", [65536, 65540, 300007, (1 << 22) + 8])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_reduce_min_max_long_vector_bits(gpu, oracle_c, n, dtype):
+    """Min / Max of one long vector run on the two-pass kernels (order-free operations); the same data as TWO columns of a batched call runs
+    the reference-order kernels: the bits must agree -- signed zeros as the extreme value included (the min of a non-negative vector holding
+    both zeros, the max of a non-positive one) -- and agree with the oracle where the oracle's own answer does not depend on the order."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(n)
+    base = rng.random(n, dtype=np.float32).astype(dtype)
+    for sign, op, wop in ((1.0, wg.ReduceOp.Min, wo.MIN), (-1.0, wg.ReduceOp.Max, wo.MAX), (1.0, wg.ReduceOp.Max, wo.MAX), (-1.0, wg.ReduceOp.Min, wo.MIN)):
+        x = (base * dtype(sign)).astype(dtype)
+        idx = rng.integers(0, n, 64)
+        x[idx[:32]] = dtype(0.0)
+        x[idx[32:]] = dtype(-0.0)
+        two = np.concatenate([x, x])
+        t1, t2 = upload(gpu, (n,), x, dtype), upload(gpu, (n, 2), two, dtype)
+        r1, r2 = upload(gpu, (), np.full(1, np.nan, dtype), dtype), upload(gpu, (2,), np.full(2, np.nan, dtype), dtype)
+        red = wg.Reduce.new(gpu.device(), op)
+        run_pass(gpu, lambda p: (red.dispatch(gpu.device(), wg.ViewShapeBuffers(), p, t1, r1), red.dispatch_batched(gpu.device(), wg.ViewShapeBuffers(), p, t2, r2)))
+        a, b = r1.read(gpu.device()), r2.read(gpu.device())
+        assert a[0].tobytes() == b[0].tobytes() == b[1].tobytes(), f"{op.name} sign {sign} n={n} {np.dtype(dtype).name}: one vector {a[0]!r} vs batched {b!r}"
+        if (sign > 0) == (op == wg.ReduceOp.Max):  # the extreme value is not a zero: the oracle's answer is order-free too
+            ref = np.float32(oracle_c.reduce(wop, x.astype(np.float32), wo.Shape(n, 1, 1, n, n, 0)))
+            assert np.float32(a[0]) == ref
+
+
 @pytest.mark.parametrize("tr", [False, True])
 def test_gemv_reduce(gpu, tr):
     """reduce(op, op(m) v) in one call == Gemv then Reduce, bit for bit."""

@@ -372,6 +372,10 @@ static int reduce_dispatch(wg_ctx *ctx, int op, const T *b, uint32_t n, uint32_t
 // `results` has the element type of the input (Reduce::dispatch(value: GpuVectorView<T>, result: &GpuScalar<T>), reduce.rs:100-107)
 int wgk_reduce(wg_ctx *ctx, int op, wg_dtype dtype, const void *base, uint32_t n, uint32_t ncols, uint32_t nmats,
                uint32_t stride, uint32_t stride_mat, void *results) {
+    // Min / Max of ONE long vector: min and max of non-NaN floats do not depend on the order (v_min_f32 / v_max_f32 order -0 below +0 whatever the
+    // operand order), so the whole chip may stream it -- the two-pass kernels give the bits the reference's 128 chains give (1 Mi elements: 100 -> 7 us).
+    // Sum / Prod / SqNorm keep the reference's chains (wg_reduce_fast is the caller's explicit choice there).
+    if ((op == R_MIN || op == R_MAX) && (uint64_t)ncols * nmats == 1 && n >= 65536u) return wgk_reduce_fast(ctx, op, dtype, base, n, results);
     if (dtype == WG_F16) return reduce_dispatch(ctx, op, (const _Float16 *)base, n, ncols, nmats, stride, stride_mat, (_Float16 *)results);
     return reduce_dispatch(ctx, op, (const float *)base, n, ncols, nmats, stride, stride_mat, (float *)results);
 }
