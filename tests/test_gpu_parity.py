@@ -131,6 +131,10 @@ GEMM_SHAPES = [
     (16, 4096, 4096, 1), (64, 260, 1000, 2), (8, 128, 516, 1), (36, 1024, 2048, 1), (4, 512, 8192, 3),
     # K % 16 != 0 on interior tiles (extra zero-filled k-tile after the pipelined loop), alone, under split-K and under the tail split
     (512, 36, 256, 1), (768, 1044, 384, 2), (256, 4100, 128, 1), (4104, 268, 4104, 1), (3328, 520, 3328, 1),
+    # more than one wave of 2 x CUs tiles with a leftover (1280 = 2.5 waves; 17 x 83 ragged): the leftover tiles cut along K as their own launch
+    (4096, 256, 10240, 1), (4100, 272, 10500, 1),
+    # 65 .. 128 rows and more than 4096 columns: computed transposed on the tiled kernel (transposed copy of m1 for Gemm, transposed result)
+    (128, 256, 4224, 1), (72, 132, 5000, 2), (100, 1028, 4352, 1),
 ]
 
 

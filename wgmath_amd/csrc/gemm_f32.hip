@@ -515,6 +515,23 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // C^T (N x M) = op(B)^T op(A)^T, which is a GemmTr with few columns on m1' = m2 (K x N, already k-contiguous) and m2' = op(A)^T as
     // a K x M column-major matrix -- m1 itself for GemmTr, a transposed copy of the tiny m1 for Gemm -- followed by a transpose of the
     // small result. 16 x 4096 x 4096: 79 us on the 256 x 128 tiles, 34 us this way. beta needs the old output inside the product: not taken then.
+    // 65 .. 128 rows: a 256 x 128 tile would be at most half full; transposed, the product has <= 128 COLUMNS -- one full-width tile column of
+    // 256-row tiles -- at the price of a transposed copy of the small m1 (Gemm only) and a transpose of the small result: 128 x 11008 x 4096
+    // 249 -> 137 us, 128 x 14336 x 4096 305 -> 174 (vendor 117 on the first; profiles/r03_evidence.md section 11).
+    // (N <= 4096 has the 64-column panels below: 128 x 4096 x 4096 49 us there, 68 this way)
+    if (M > 64 && M <= 128 && N > 4096 && K >= 128 && beta == 0.f) {
+        const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
+        void *ws = nullptr;
+        if (int rc = wg_ctx_pad_workspace(ctx, (size_t)((at_elems + ct_elems) * nmats * sizeof(float)), &ws)) return rc;
+        float *at = (float *)ws, *ct = at + at_elems * nmats;
+        wgk_mat a2 = m1; // K x M, column m contiguous in k
+        if (!trans) {
+            if (int rc = wgk_transpose(ctx, WG_F32, M, K, nmats, m1.ptr, m1.ld, m1.batch, at, K, at_elems)) return rc;
+            a2 = wgk_mat{ at, K, at_elems };
+        }
+        if (int rc = wgk_gemm_f32(ctx, true, N, M, K, nmats, ct, N, ct_elems, m2, a2, alpha, 0.f)) return rc;
+        return wgk_transpose(ctx, WG_F32, N, M, nmats, ct, N, ct_elems, out, out_ld, out_batch);
+    }
     if (M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
         // the few-column GemmTr kernel takes m2' = op(A)^T either k-contiguous (GemmTr: m1 as it is) or with its columns contiguous (Gemm:
         // m1 as it is, "k-major"), and writes -- or its split-K reduce does -- straight into the transposed position: "row" n of C^T is
@@ -574,7 +591,34 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifndef WG_F32_TAIL_SPLIT
 #define WG_F32_TAIL_SPLIT 1
 #endif
-    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus) {
+    // More than one full wave of resident workgroups (2 per CU): the launch runs in waves of 2 x CUs tiles, K x 0.23 us each -- and the LAST
+    // wave costs that much however few tiles it holds: completion times have drifted apart by then, a CU that finishes its pair is handed two
+    // new workgroups at once, and the leftover r tiles end up two to a CU on r / 2 CUs (measured, K = 4096: 1024 tiles 1931 us, 1280 tiles
+    // 2801, 1536 tiles 2824 -- five tiles per CU cost six; profiles/r03_evidence.md section 11). So the r = tiles mod (2 x CUs) leftover tiles are
+    // cut along K into sp parts that run as their own launch (spread one per CU up to CUs workgroups: 0.136 us per k then, 0.23 per wave of
+    // 2 x CUs beyond), with the split count that minimises wave time + the partial tiles' write and ordered reduce.
+    bool tail_done = false;
+    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > 2ull * (uint64_t)cus) {
+        const uint64_t cap = 2ull * (uint64_t)cus;
+        const uint32_t r = (uint32_t)(tiles % cap);
+        if (r > 0 && nsplit == 1) {
+            const double pair = 2.0 * us_per_k, lone = 0.136;
+            double best_t = (double)K * pair * 0.97; // the leftover wave as it is (a split must pay for itself by a margin)
+            uint32_t best_sp = 1;
+            for (uint32_t sp = 2; sp <= 8 && ktiles / sp >= 8; ++sp) {
+                const double part_bytes = (double)sp * r * BM * BN * 4.0;
+                if (part_bytes > (double)(512ull << 20)) break;
+                const uint32_t kps = ((ktiles + sp - 1) / sp) * BK;
+                const uint64_t w = (uint64_t)r * sp, full = w / cap, rem = w % cap;
+                const double t = (double)full * kps * pair + (rem == 0 ? 0.0 : rem <= (uint64_t)cus ? kps * lone : kps * pair) +
+                                 (part_bytes / 3.5e6 + 3.0) + (4.0 + part_bytes / 7.0e6);
+                if (t < best_t) { best_t = t; best_sp = sp; }
+            }
+            if (best_sp > 1) { tail_r = r; tail_sp = best_sp; }
+            tail_done = true;
+        }
+    }
+    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus && !tail_done) {
         const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
         uint32_t sp = r ? (uint32_t)cus / r : 0;
         if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
