@@ -301,6 +301,8 @@ GEMV_SHAPES = [
     (1024, 512, 12, 1), (1024, 516, 17, 2), (516, 1028, 40, 1), (1024, 640, 64, 1),
     # GemvTr with one right-hand side (a half-wave per column): batches, ragged lengths, splits, the 64-KiB-column case of the older kernel
     (12, 12, 1, 3), (1028, 36, 1, 2), (16384, 64, 1, 1), (40004, 68, 1, 1), (300000, 4, 1, 1), (2052, 4100, 1, 1),
+    # 3 .. 8 right-hand sides on matrices past the launch-bound sizes: one pass on the matrix cores (few_rhs_as_gemm in gemv.hip)
+    (4096, 4096, 4, 1), (4096, 3072, 8, 1), (2048, 2304, 7, 1),
 ]
 
 
@@ -1305,7 +1307,9 @@ def test_gemv_reduce_fused_single_launch(gpu, R, Cn):
 @pytest.mark.parametrize("tr", [False, True])
 @pytest.mark.parametrize("R,Cn,nrhs,mats", [(1024, 2048, 1, 1), (256, 512, 3, 2), (4096, 8192, 1, 1), (132, 260, 2, 1),
                                            # one right-hand side: 16-byte loads where aligned (k % 8, batches), 8-byte loads otherwise, splits
-                                           (12, 12, 1, 3), (1028, 36, 1, 2), (40004, 68, 1, 1), (300000, 8, 1, 1), (16392, 20, 1, 1), (2056, 4100, 1, 1)])
+                                           (12, 12, 1, 3), (1028, 36, 1, 2), (40004, 68, 1, 1), (300000, 8, 1, 1), (16392, 20, 1, 1), (2056, 4100, 1, 1),
+                                           # 3 .. 8 right-hand sides past the launch-bound sizes: the f16 Gemm kernels
+                                           (8192, 4096, 3, 1), (4096, 2112, 8, 1), (4104, 6152, 5, 1)])
 def test_gemv_f16(gpu, tr, R, Cn, nrhs, mats):
     wg = _wg()
     rng = np.random.default_rng(R + Cn + nrhs + tr)

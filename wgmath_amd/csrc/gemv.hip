@@ -624,6 +624,18 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     return WG_OK;
 }
 
+// 3 .. 8 right-hand sides on a matrix that is not launch-bound: the GEMV kernels re-read the vectors once per matrix piece (GemvTr) or give every
+// right-hand side its own accumulators (f16 Gemv), and fall well behind one pass on the matrix cores -- measured against both and against the
+// vendor's skinny GEMMs (tools/misc_sweep.py, profiles/r03_evidence.md section 12): f16 GemvTr 65536 x 4096 x 8 373 -> 135 us, f32 GemvTr 4096^2 x 8
+// 33 -> 18 us, f16 Gemv 65536 x 4096 x 8 138 -> 123 us. Kept on the GEMV kernels: 2 right-hand sides, matrices under 48 MiB (one launch instead
+// of several), f32 Gemv (the N kernel streams 8 right-hand sides at 6.2 TB/s), and f32 GemvTr with >= 8 outputs per contracted row (212 vs 279 us).
+static bool few_rhs_as_gemm(bool trans, bool f16, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t es) {
+    const uint64_t bytes = (uint64_t)rows_out * k * es;
+    if (nrhs < 3u || bytes < ((nrhs >= 7u ? 16ull : 48ull) << 20)) return false; // (7-8 right-hand sides pay from 16 MiB: 4096^2 f16 x 8 26 -> 19 us)
+    if (trans) return f16 || (uint64_t)rows_out < 8ull * k;
+    return f16 || (nrhs >= 7u && bytes < (256ull << 20)); // f32 Gemv: only 7-8 right-hand sides on mid-size matrices (4096^2 x 8: 22.5 -> 19 us)
+}
+
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
@@ -631,12 +643,13 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
         // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): the same HBM-bound kernels on f16 elements (8-byte loads of 4 rows,
         // f32 accumulation in the same order, one rounding at the store; split partials stay f32). More than 8 right-hand sides are a
         // Gemm with few columns: the f16 Gemm kernels take any column count (one pass over the matrix on the matrix cores).
-        if (nrhs > (uint32_t)kMaxRhs) return wgk_gemm_f16(ctx, trans, rows_out, nrhs, k, nmats, (__half *)out, out_ld, out_batch, m, v, 1.f, 0.f);
+        if (nrhs > (uint32_t)kMaxRhs || few_rhs_as_gemm(trans, true, rows_out, k, nrhs, 2u))
+            return wgk_gemm_f16(ctx, trans, rows_out, nrhs, k, nmats, (__half *)out, out_ld, out_batch, m, v, 1.f, 0.f);
         return gemv_launch<_Float16>(ctx, trans, rows_out, k, nrhs, nmats, (_Float16 *)out, out_ld, out_batch, m, v);
     }
     // 9 .. 64 right-hand sides are a Gemm with few columns: one pass over the matrix on the matrix cores (gemm_f32_skinny.hip) instead of
     // one GEMV pass per 8 columns. (The 32-bit DMA offsets of that kernel must suffice for both operands, in both variants.)
-    if (nrhs > (uint32_t)kMaxRhs && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
+    if ((nrhs > (uint32_t)kMaxRhs || few_rhs_as_gemm(trans, false, rows_out, k, nrhs, 4u)) && nrhs <= 64u && rows_out >= 512u && k >= 128u &&
         (uint64_t)m.ld * 32u * 4u < (1ull << 31) && (uint64_t)v.ld * 64u * 4u < (1ull << 31))
         return wgk_gemm_f32_skinny(ctx, trans, rows_out, nrhs, k, nmats, (float *)out, out_ld, out_batch, m, v, 1.f, 0.f);
     return gemv_launch<float>(ctx, trans, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
