@@ -138,6 +138,19 @@ GEMM_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("M,K,N,mats", [(64, 64, 64, 9), (32, 32, 32, 12), (96, 200, 48, 5), (256, 256, 256, 3), (36, 44, 20, 7), (132, 36, 68, 4), (40, 32, 16, 6)])
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_small_batched_on_panels(gpu, oracle_c, M, K, N, mats, tr):
+    """Batches of small f32 matrices run on the 64-column panels of the few-column kernel when the launch plan expects that to pay (hundreds of
+    matrices); forced here (wg_ctx_set_tuning) so that a handful of matrices exercises the same kernel, and once more on the plan's own choice."""
+    for force in (1, -1):
+        old = gpu.set_tuning("f32_panels", force)
+        try:
+            test_gemm_shapes(gpu, oracle_c, M, K, N, mats, tr)
+        finally:
+            gpu.set_tuning("f32_panels", old)
+
+
 @pytest.mark.parametrize("M,K,N,mats", GEMM_SHAPES)
 @pytest.mark.parametrize("tr", [False, True])
 def test_gemm_shapes(gpu, oracle_c, M, K, N, mats, tr):

@@ -633,18 +633,22 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // Small outputs (few 256 x 128 tiles): 64-column panels of the few-column kernel (gemm_f32_skinny.hip) give 128 x 64 "tiles", eight
     // times as many, each streaming its rows through a wave-private ring at ~1.4 us per 32 k (+ ~2.5 us of pipeline fill per workgroup):
     // 1024^3 25 + 5 us instead of 33 + 7.
-    if (N > 64 && N <= 4096 && M >= 128 && K >= 128 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
+    // Batches of small matrices as well (M >= 32, N >= 16: a 256 x 128 tile is mostly empty there -- 64^3 x 1024 matrices 43 -> 25 us, 32^3 x 4096 84 -> 40).
+    if (((N > 64 && M >= 128 && K >= 128) || (nmats > 1 && N >= 16 && M >= 32 && K >= 32)) && N <= 4096 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
         const uint64_t wgs = (uint64_t)((M + 127u) / 128u) * ((N + 63u) / 64u) * nmats;
         double best_p = 1e30;
         uint32_t ns_p = 1;
-        for (uint32_t ns = 1; ns <= 8 && K / ns >= 128; ++ns) {
+        for (uint32_t ns = 1; ns <= 8 && (ns == 1 || K / ns >= 128); ++ns) {
             if ((double)ns * out_bytes > (double)(512ull << 20)) break;
             const double stages = (double)((K + ns - 1) / ns + 31u) / 32.0;
             const double t = rounds(wgs * ns) * (stages * 1.4 + 2.5) + (ns > 1 ? 4.0 + ns * out_bytes / 7.0e6 : 0.0); // (slab writes are in the per-stage figure)
             if (t < best_p) { best_p = t; ns_p = ns; }
         }
         const int force = ctx->tuning[WG_TUNE_F32_PANELS]; // experiments: 0 = never, 1 = whenever applicable
-        if ((force >= 0 ? force == 1 : best_p < 0.9 * best))
+        // (what the tiled plan's time above leaves out and short-K launches feel: ~3 us per round of workgroups and the output written at ~3.5 TB/s --
+        // 1024 x 1024 x 128 x 32 matrices: 59 us by the formula, 107 measured)
+        const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + (nsplit == 1 && tail_r == 0 ? out_bytes / 3.5e6 : 0.0);
+        if ((force >= 0 ? force == 1 : best_p < 0.95 * tiled))
             return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, 1u, false, ns_p);
     }
     float *part = nullptr;
