@@ -913,6 +913,40 @@ def test_gemm_f16_k_remainder(gpu, M, K, N, tr):
     assert np.array_equal(res[1].view(np.uint16), res[2].view(np.uint16)) and np.array_equal(res[1].view(np.uint16), res[3].view(np.uint16))
 
 
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N", [(128, 72, 128), (128, 136, 256), (1000, 1000, 1000), (520, 328, 264), (256, 4104, 128), (2048, 2056, 2048), (136, 120, 72)])
+def test_gemm_f16_k_remainder_small_tiles(gpu, M, K, N, tr):
+    """The same on the 128 x 128 kernel (outputs of fewer than one 256 x 256 tile per CU, K from 72 on): the remainder is its half-stages 0 and 1;
+    under split-K the last split owns it. Forced (wg_ctx_set_tuning) and on the launcher's own choice; NaN just past K in memory."""
+    wg = _wg()
+    rng = np.random.default_rng(M * 3 + K + N + int(tr))
+    KP = K + 8
+    if tr:
+        pa = np.full((M, KP), np.nan, np.float16); pa[:, :K] = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+        a_flat, a_view_shape = pa.reshape(-1), wg.ViewShape((K, M, 1), KP, KP * M, 0)
+        A64 = pa[:, :K].astype(np.float64)
+    else:
+        pa = np.full((KP, M), np.nan, np.float16); pa[:K] = (rng.random((K, M), dtype=np.float32) * 2 - 1).astype(np.float16)
+        a_flat, a_view_shape = pa.reshape(-1), wg.ViewShape((M, K, 1), M, M * KP, 0)
+        A64 = pa[:K].T.astype(np.float64)
+    pb = np.full((N, KP), np.nan, np.float16); pb[:, :K] = (rng.random((N, K), dtype=np.float32) * 2 - 1).astype(np.float16)
+    B64 = pb[:, :K].T.astype(np.float64)
+    ta, tb = upload(gpu, (a_flat.size,), a_flat, np.float16), upload(gpu, (pb.size,), pb.reshape(-1), np.float16)
+    va = wg.GpuTensorView(a_view_shape, ta, 2)
+    vb = wg.GpuTensorView(wg.ViewShape((K, N, 1), KP, KP * N, 0), tb, 2)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    old = gpu.get_tuning("f16_tile")
+    try:
+        for tile in (128, 0):
+            gpu.set_tuning("f16_tile", tile)
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, va, vb, variant))
+            f16_check(out.read(gpu.device()).reshape(N, M).T.copy(), A64, B64, K, f"K remainder, 128-tiles {tile}: {M}x{K}x{N} tr={tr}")
+    finally:
+        gpu.set_tuning("f16_tile", old)
+
+
 # --------------------------------------------------------------------------------------------------------
 # seeded fuzz over the f16 MFMA paths: random ragged sizes, strides, offsets, batches, both variants, alpha/beta
 # --------------------------------------------------------------------------------------------------------

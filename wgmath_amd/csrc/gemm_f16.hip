@@ -1074,9 +1074,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);
     // (N is free: B rows are clamped per column and the epilogues skip columns >= N)
     // K: any multiple of 8 with >= 3 whole stages (the 256 x 256 kernel: a K % 64 remainder is the accumulators' initial value, m16_tile);
-    // 64 or 128 (the 128 x 128 kernel, whole stages only). Everything else is zero-padded along K by the staging branch below.
+    // from one whole stage on (the 128 x 128 kernel, same treatment of the remainder). Everything else is zero-padded along K by the staging branch below.
     const uint32_t krem = K % 64u;
-    const bool k_big = K % 8u == 0 && K - krem >= 192u, k_small = krem == 0 && K >= 64u;
+    const bool k_big = K % 8u == 0 && K - krem >= 192u, k_small = K % 8u == 0 && K - krem >= 64u;
     const bool a_step_fits = trans || (uint64_t)m1.ld * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
     const bool fast = (M % 8 == 0) && (k_big || k_small) && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) && a_step_fits &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
@@ -1100,7 +1100,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // (profiles/r01_evidence.md section 12; us per k of one tile: 256 x 256 0.0234 with 8 us per workgroup of prologue + epilogue;
         // 128 x 128 0.00875 alone on a CU, 0.0108 each when several share it, + 6 us; f32 partial slabs written at ~3.5 TB/s + 3 us,
         // reduced at ~7 TB/s + 4 us). WG_F16_TILE=128|256 forces the choice (tests, experiments).
-        if (K % 64u == 0 && !panels) {
+        // (K % 64 != 0: the 128 x 128 kernel multiplies the remainder first, like the big one; it needs >= 64 whole k behind it)
+        if ((krem == 0 || K - krem >= 64u) && !panels) {
             const double out_bytes = (double)M * N * nmats * 4.0;
             auto slabs = [&](uint32_t ns) { return ns > 1 ? ns * out_bytes / 3.5e6 + 3.0 + 4.0 + ns * out_bytes / 7.0e6 : 0.0; };
             GemmArgs t = g;
@@ -1111,7 +1112,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             uint32_t ns = 1;
             if (tiles128 * nmats * 2u <= (uint64_t)cus) {
                 ns = (uint32_t)((uint64_t)cus / (tiles128 * nmats));
-                if (ns > K / 1024u) ns = K / 1024u;
+                if (ns > K / 1024u) ns = K / 1024u; // (whole stages per split; the last split also takes the K % 64 remainder)
                 while (ns > 1 && (double)ns * out_bytes > (double)(512ull << 20)) --ns;
                 if (ns < 2) ns = 1;
             }
@@ -1119,7 +1120,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             if (tiles128 * nmats <= (uint64_t)cus && K >= 1024u) ns = WG_T128_FORCE_NS; // experiment: K cut on a full round of 128 x 128 tiles
 #endif
             bool want128 = false;
-            if (!k_big) want128 = true; // K = 64 or 128: fewer than the three stages the big kernel's DMA pipeline runs ahead
+            if (!k_big) want128 = true; // fewer than the three whole stages the big kernel's DMA pipeline runs ahead
             else if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
             else if (tiles * nmats < (uint64_t)cus) {
                 const double w128 = (double)(tiles128 * nmats * ns) / cus, k128 = (double)(((K / 64u + ns - 1) / ns) * 64u);
@@ -1134,7 +1135,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 t.k_per_split = ns > 1 ? ((K / 64u + ns - 1) / ns) * 64u : K;
                 t.part = nullptr;
                 if (ns > 1) {
-                    t.nsplit = ns = (K + t.k_per_split - 1) / t.k_per_split;
+                    t.nsplit = ns = (K - krem + t.k_per_split - 1) / t.k_per_split;
                     void *ws = nullptr;
                     if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
                     t.part = (float *)ws;

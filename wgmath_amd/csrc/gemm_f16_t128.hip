@@ -65,7 +65,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const uint32_t m0 = tm * TM, n0 = tn * TN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split;
-    const uint32_t K_loc = min(g.K - k_begin, g.k_per_split);
+    // K remainder (K % 64, a multiple of 8; the last split owns it): multiplied FIRST, as two zero-padded half-stages written to LDS slots 0 and 1
+    // by ordinary loads + stores in exactly the image the DMA pieces would have left (m16_tile in gemm_f16.hip does the same); the DMA stream
+    // then starts at half-stage 2 = the first 32 k of this split (bases moved back by two half-stages below).
+    uint32_t K_loc = split + 1u == g.nsplit ? g.K - k_begin : g.k_per_split;
+    const uint32_t rem = K_loc & 63u;
+    K_loc -= rem;
+    const uint32_t rem_dk = K_loc; // the remainder's first k, relative to k_begin
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
 
@@ -94,8 +100,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);
-    const char *ga0 = (const char *)a_base - T_BIAS, *gb0 = (const char *)b_base - T_BIAS;
     const uint64_t a_step = TRANS_A ? 64u : (uint64_t)64u * g.lda; // bytes per half-stage (32 k)
+    const char *ga0 = (const char *)a_base - T_BIAS - (rem ? 2u * a_step : 0u), *gb0 = (const char *)b_base - T_BIAS - (rem ? 128u : 0u);
     auto issue = [&](uint32_t H, uint32_t slot_off) { // the 4 pieces of half-stage H into the slot at byte offset slot_off
         const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * 64u;
         t_set_m0(lds_wave + slot_off);
@@ -156,12 +162,41 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         }
     };
 
-    const uint32_t NH = K_loc / 32u; // half-steps; the launcher guarantees K_loc % 64 == 0 (NH even, >= 2)
+    const uint32_t NH = K_loc / 32u + (rem ? 2u : 0u); // half-steps (even, >= 2; with a remainder >= 4: the launcher leaves >= 64 whole k)
     // prologue: half-stages 0 .. min(5, NH) - 1; the first two must have landed before the first fragment reads / half-step 0
+    if (rem) {
+        auto put = [&](uint32_t dst, const char *src, bool valid) {
+            uintx4 v = { 0u, 0u, 0u, 0u };
+            if (valid) v = *reinterpret_cast<const uintx4 *>(src);
+            *(WG_AS3 uintx4 *)(uintptr_t)(dst + 16u * (uint32_t)lane) = v;
+        };
+        const char *ra = TRANS_A ? (const char *)(a_base + rem_dk) : (const char *)(a_base + (uint64_t)rem_dk * g.lda);
+        const char *rb = (const char *)(b_base + rem_dk);
 #pragma unroll
-    for (int h = 0; h < T_RING; ++h)
-        if ((uint32_t)h < NH) issue(h, h * T_SLOT);
-    if (NH >= 5) wait_dma_keep<12>(); else if (NH == 4) wait_dma_keep<8>(); else wait_dma_all();
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t P = 2u * wave + q, row = 16u * P + (lane >> 2);
+                // k-contiguous rows: the lane's 8 k are logical chunk (lane & 3) ^ G(key(row)) of the half-stage's 32
+                const uint32_t kb = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u));
+                uint32_t ka;
+                if constexpr (TRANS_A) ka = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row >> 3) & 3u)) & 3u));
+                else ka = 32u * h + 4u * P + ((lane >> 2) & 3u); // column-major A: the piece's k row
+                put(lds_wave + (uint32_t)h * T_SLOT + 1024u * q, ra + (uint64_t)h * a_step + (a_voff[q] - (T_BIAS - 1024u * q)), ka < rem);
+                put(lds_wave + (uint32_t)h * T_SLOT + 2048u + 1024u * q, rb + (uint64_t)h * 64u + (b_voff[q] - (T_BIAS - 1024u * (2 + q))), kb < rem);
+            }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0); // the loads above are the compiler's to wait for: keep them in front of the DMA pieces it cannot see
+#pragma unroll
+        for (int h = 2; h < T_RING; ++h)
+            if ((uint32_t)h < NH) issue(h, h * T_SLOT);
+        // (no DMA piece has to have landed yet: half-step 0 reads slots 0 and 1; its own counted wait covers half-stage 2)
+    } else {
+#pragma unroll
+        for (int h = 0; h < T_RING; ++h)
+            if ((uint32_t)h < NH) issue(h, h * T_SLOT);
+        if (NH >= 5) wait_dma_keep<12>(); else if (NH == 4) wait_dma_keep<8>(); else wait_dma_all();
+    }
     __syncthreads();
 #pragma unroll
     for (int op = 0; op < kOps; ++op) frag_op(smem, op, 0);
