@@ -712,6 +712,54 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
+#ifndef WG_PANEL_STORE
+#define WG_PANEL_STORE 2 // write-through flavour of a paneled launch's stores: 1 = sc1 (agent scope), 2 = sc0 sc1 (system scope)
+#endif
+#ifndef WG_EPI_STORE
+#define WG_EPI_STORE -1 // -1: by GemmArgs::c_stream (shipped); experiments: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt for every launch
+#endif
+    // (u, p) in the lane's own layout: rows row0 + 32 p .. + 7 of column n0 + 128 wn + 16 u + i16, alpha / beta applied, rounded once
+    auto pack = [&](int u, int p, bool ok, const _Float16 *cc) -> half8_t {
+        float r[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            r[q] = acc[2 * p][u][q];
+            r[4 + q] = acc[2 * p + 1][u][q];
+        }
+        if (alpha != 1.f) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] *= alpha;
+        }
+        if (beta != 0.f && ok) { // beta == 0 never reads C
+            const half8_t c = *reinterpret_cast<const half8_t *>(cc + 32 * p);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r[q] = fmaf(beta, (float)c[q], r[q]);
+        }
+        half8_t v;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
+        return v;
+    };
+    auto store8 = [&](_Float16 *dst, half8_t v) {
+        if (paneled) { // write-through to memory: when the store is acknowledged a copy engine may read it
+            if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v; // (timing experiments only: NOT visible to a copy engine in time)
+            else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+        } else if (!(WG_ABLATE & 32)) {
+            if constexpr (WG_EPI_STORE == -1) {
+                if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+                else *reinterpret_cast<half8_t *>(dst) = v;
+            } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v;
+            else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_t *>(dst));
+            else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+            else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+        }
+    };
+    // (A store instruction covers 16 columns x 64 bytes -- half lines -- and an idle CU gets a tile out four times faster when 16 consecutive lanes
+    // cover 256 contiguous bytes (tools/cpp/store_probe.hip). Both ways to that layout were built and measured in the kernel -- a DPP exchange between
+    // the halves of the 16-lane rows, and a round trip of the rounded tile through the idle LDS -- and neither paid: the stores of a tile boundary
+    // are bound by what the chip takes from 256 CUs at once, not by their issue; 8192 x 8192 x 512 92.5 -> 97 us: profiles/r03_evidence.md section 9.)
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const uint32_t col = n0 + 128u * wn + 16u * u + i16;
@@ -720,44 +768,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             if (!(full_tile || row0 + 32 * p < g.M)) continue; // 8 consecutive rows, all in or all out (M % 8 == 0)
-            float r[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r[q] = acc[2 * p][u][q];
-                r[4 + q] = acc[2 * p + 1][u][q];
-            }
-            if (alpha != 1.f) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) r[q] *= alpha;
-            }
-            if (beta != 0.f) { // beta == 0 never reads C
-                const half8_t c = *reinterpret_cast<const half8_t *>(cc + 32 * p);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) r[q] = fmaf(beta, (float)c[q], r[q]);
-            }
-            half8_t v;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-#ifndef WG_PANEL_STORE
-#define WG_PANEL_STORE 2 // write-through flavour of a paneled launch's stores: 1 = sc1 (agent scope), 2 = sc0 sc1 (system scope)
-#endif
-            if (paneled) { // write-through to memory: when the store is acknowledged a copy engine may read it
-                if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(cc + 32 * p) = v; // (timing experiments only: NOT visible to a copy engine in time)
-                else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-            } else if (!(WG_ABLATE & 32)) {
-#ifndef WG_EPI_STORE
-#define WG_EPI_STORE -1 // -1: by GemmArgs::c_stream (shipped); experiments: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc1 nt for every launch
-#endif
-                if constexpr (WG_EPI_STORE == -1) {
-                    if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(cc + 32 * p), "v"(v) : "memory");
-                    else *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
-                } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
-                else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_t *>(cc + 32 * p));
-                else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-                else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(cc + 32 * p), "v"(v) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(cc + 32 * p), "v"(v) : "memory");
-            }
+            store8(cc + 32 * p, pack(u, p, true, cc));
         }
     }
 #ifndef WG_F16_TRACE
