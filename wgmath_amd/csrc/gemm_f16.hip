@@ -1133,6 +1133,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             bool want128 = false;
             if (!k_big) want128 = true; // fewer than the three whole stages the big kernel's DMA pipeline runs ahead
             else if (ctx->tuning[WG_TUNE_F16_TILE]) want128 = ctx->tuning[WG_TUNE_F16_TILE] == 128;
+            else if (N <= 64u) want128 = true; // few columns: HBM-bound on op(A), and a 256-wide tile multiplies four times the padding (65536 x 8 x 4096: 140 -> 104 us, 131072 x 8 x 1024: 72 -> 41)
             else if (tiles * nmats < (uint64_t)cus) {
                 const double w128 = (double)(tiles128 * nmats * ns) / cus, k128 = (double)(((K / 64u + ns - 1) / ns) * 64u);
                 const double est128 = (w128 <= 1.0 ? k128 * 0.00875 : w128 * k128 * 0.0108) + 6.0 + slabs(ns);
