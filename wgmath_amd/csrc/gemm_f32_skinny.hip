@@ -27,6 +27,7 @@ struct SkinnyArgs {
     uint32_t crs;              // element stride between consecutive ROWS of the output (1; != 1: the caller wants it transposed, beta == 0)
     uint32_t M, N, K;
     uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
+    uint32_t rot;              // GemmTr: workgroups start their sweep over K at different stages (see the kernel)
 };
 
 __device__ __forceinline__ float comp4(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
@@ -114,10 +115,22 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     const uint64_t a_step = TRANS_A ? 128u : (uint64_t)128u * g.lda; // bytes per stage (32 k)
     const char *gb0 = (const char *)(B_KMAJ ? B : B + (uint64_t)col0 * g.ldb) - TR_BIAS;
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem + wave * (RING * STAGE_BYTES));
-    auto issue = [&](uint32_t st) { // stage st -> ring slot st % RING
-        const uint32_t dst = lds_wave + (st % RING) * STAGE_BYTES;
+#ifndef WG_SKINNY_ROT
+#define WG_SKINNY_ROT 1
+#endif
+    // GemmTr, whole stages only: every workgroup starts its sweep over K at its own stage and wraps around. All waves of the chip walk k at about the
+    // same pace; with k-contiguous rows a fixed number of KiB apart, "the same k of every row" is the same few memory channels for everybody
+    // (65536 x 8 x 4096 GemmTr: 3.8 TB/s; column-major A does not have this: its workgroups differ in the LOW address bits). Trip j of a wave works
+    // on stage (j + rot) mod nst; the sum over k is the same set of products in a rotated order (deterministic per workgroup). Only while m2's K range is
+    // small (<= 256 KiB, the launcher's g.rot): every workgroup re-reads it from L2, and in step they all read the same lines of it -- out of step a
+    // larger m2 stops being a broadcast (N = 64, K = 4096: 325 -> 423 us with the rotation; N = 8: 281 -> 228).
+    const uint32_t rot = (WG_SKINNY_ROT && TRANS_A && g.rot && last_chunks == 8u && nst > 1u) ? (uint32_t)(((uint64_t)blockIdx.x * 7u + blockIdx.y * 3u) % nst) : 0u; // (per workgroup: its four waves fetch the same stage of the small m2 together)
+    auto issue = [&](uint32_t trip) { // trip -> ring slot trip % RING; the stage it carries: (trip + rot) mod nst
+        const uint32_t dst = lds_wave + (trip % RING) * STAGE_BYTES;
+        uint32_t st = trip + rot;
+        if (st >= nst) st -= nst;
         const char *ga = ga0 + (uint64_t)st * a_step, *gb = gb0 + (uint64_t)st * b_step;
-        const bool tail = st + 1u == nst; // wave-uniform
+        const bool tail = rot == 0u && st + 1u == nst; // wave-uniform (with a rotation there is no partial stage)
         tr_set_m0(dst);
         tr_dma<0>(tail ? a_tail[0] : a_voff[0], ga); tr_dma<1024>(tail ? a_tail[1] : a_voff[1], ga);
         tr_dma<2048>(tail ? a_tail[2] : a_voff[2], ga); tr_dma<3072>(tail ? a_tail[3] : a_voff[3], ga);
@@ -257,6 +270,7 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = npanels;
+    g.rot = (uint64_t)(ns > 1 ? kps : K) * (N < 32u * (N <= 32 ? 1u : 2u) ? N : 32u * (N <= 32 ? 1u : 2u)) * 4u <= (256u << 10) ? 1u : 0u;
     const dim3 grid(row_blocks, ns, nmats * npanels);
     if (m2_kmajor) { // GemmTr only (the few-row route)
         if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
