@@ -169,7 +169,12 @@ __global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restr
         for (int p = 0; p < kLongPieces; ++p) red_dma16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + p * 1024));
     };
 
-    float acc[4] = { r_init<OP>(), r_init<OP>(), r_init<OP>(), r_init<OP>() };
+    // Consumers: waves 0 and 1, ONE chain per lane (chain t = 64 wave + lane folds x[t], x[t + 128], ... ascending -- reduce.wgsl:71-74): a slot's 32
+    // rows cost a lane 32 dependent operations and 16 two-row LDS reads. (Round 2 folded on 32 lanes x float4 of wave 0: four chains per lane, 37 GB/s,
+    // bound by what one wave pulls out of LDS; this form: 56 GB/s, ~19 cycles per element of a chain -- the dependent operation itself is ~10.)
+    const bool consumer = wave < 2;
+    const uint32_t t = 64u * (uint32_t)wave + (uint32_t)lane; // the chain (consumers only)
+    float acc = r_init<OP>();
     for (uint32_t s = 0; s < kLongSlots - 1 && s < nslots; ++s) issue(s);
     for (uint32_t s = 0; s < nslots; ++s) {
         // slot s has landed once at most the (up to 6) younger slots' pieces of this wave are still in flight
@@ -183,50 +188,32 @@ __global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restr
         case 1: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
-        __syncthreads(); // everyone's pieces of slot s are in LDS; the consumer has left slot s-1
+        __syncthreads(); // everyone's pieces of slot s are in LDS; the consumers have left slot s-1
         if (s + kLongSlots - 1 < nslots) issue(s + kLongSlots - 1); // refill the position slot s-1 occupied
-        if (wave == 0 && lane < 32) {
-            // (measured: 37 GB/s, bound by what ONE wave can pull out of LDS. Reading two rows per 64-lane ds_read_b128 and
-            // handing the upper half down with v_permlane32_swap, with the reads of slot s issued before slot s-1 is folded,
-            // was slower -- 17.6 GB/s: hipcc hoists the swaps onto the freshly read registers and serialises the lot.)
-            const float4 *rows = reinterpret_cast<const float4 *>(ring + (s % kLongSlots) * kLongSlotBytes) + lane;
-            float4 v[kLongSlotRows];
+        if (consumer) {
+            const float *rows = reinterpret_cast<const float *>(ring + (s % kLongSlots) * kLongSlotBytes) + t;
+            float v[kLongSlotRows];
 #pragma unroll
-            for (int r = 0; r < kLongSlotRows; ++r) v[r] = rows[r * 32];
+            for (int r = 0; r < kLongSlotRows; ++r) v[r] = rows[r * 128];
 #pragma unroll
-            for (int r = 0; r < kLongSlotRows; ++r) { // ascending rows: the per-lane chain of reduce.wgsl:71-74
-                acc[0] = r_ws<OP>(acc[0], v[r].x);
-                acc[1] = r_ws<OP>(acc[1], v[r].y);
-                acc[2] = r_ws<OP>(acc[2], v[r].z);
-                acc[3] = r_ws<OP>(acc[3], v[r].w);
-            }
+            for (int r = 0; r < kLongSlotRows; ++r) acc = r_ws<OP>(acc, v[r]); // ascending rows
+            // (reading slot s while folding slot s - 1 out of registers measured slower: 56 -> 50 GB/s)
         }
     }
-    if (wave != 0 || lane >= 32) return;
-    const uint32_t p = lane;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    for (uint32_t r = nslots * kLongSlotRows; r < full_rows; ++r) { // < 32 left-over full rows
-        const float4 v = x4[(uint64_t)r * 32u + p];
-        acc[0] = r_ws<OP>(acc[0], v.x);
-        acc[1] = r_ws<OP>(acc[1], v.y);
-        acc[2] = r_ws<OP>(acc[2], v.z);
-        acc[3] = r_ws<OP>(acc[3], v.w);
+    if (consumer) {
+        for (uint32_t r = nslots * kLongSlotRows; r < full_rows; ++r) acc = r_ws<OP>(acc, x[(uint64_t)r * 128u + t]); // < 32 left-over full rows
+        const uint32_t i0 = full_rows * 128u + t;
+        if (i0 < n) acc = r_ws<OP>(acc, x[i0]); // ragged last row
     }
-    {
-        const uint32_t i0 = full_rows * 128u + 4u * p;
+    // the 64 .. 1 tree of reduce.wgsl:76-87 over the 128 chains: stride 64 crosses the two consumer waves (LDS), the rest is inside wave 0
+    __shared__ float upper[64];
+    if (wave == 1) upper[lane] = acc;
+    __syncthreads();
+    if (wave != 0) return;
+    acc = r_red<OP>(acc, upper[lane]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (i0 + c < n) acc[c] = r_ws<OP>(acc[c], x[i0 + c]);
-    }
-#pragma unroll
-    for (int sft = 16; sft >= 1; sft >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = r_red<OP>(acc[c], __shfl_down(acc[c], sft, 32));
-    }
-    acc[0] = r_red<OP>(acc[0], acc[2]);
-    acc[1] = r_red<OP>(acc[1], acc[3]);
-    acc[0] = r_red<OP>(acc[0], acc[1]);
-    if (p == 0) results[q] = acc[0];
+    for (int sft = 32; sft >= 1; sft >>= 1) acc = r_red<OP>(acc, __shfl_down(acc, sft, 64));
+    if (lane == 0) results[q] = acc;
 }
 
 template <int OP, typename T>
