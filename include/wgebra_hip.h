@@ -233,8 +233,9 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
  *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122). Views that are not
  *                   vec4-aligned run on staged copies, as for wg_gemm.
  *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
- * dtype WG_F16 (extension): f16 elements, f32 accumulation, one rounding at the store -- the same HBM-bound kernels (> 8 right-hand
- * sides: the f16 Gemm kernels).
+ * dtype WG_F16 (extension): f16 elements, f32 accumulation, one rounding at the store -- the same HBM-bound kernels.
+ * Several right-hand sides: one pass over the matrix for all of them; from 9 on -- and from 3 on when the matrix is past the launch-bound
+ * sizes -- that pass runs on the Gemm kernels (same contract: f32 accumulation, results within the Gemv tolerance, deterministic).
  */
 int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype,
             wg_buf *out, wg_view_shape out_shape,
