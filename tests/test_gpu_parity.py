@@ -316,6 +316,8 @@ GEMV_SHAPES = [
     (12, 12, 1, 3), (1028, 36, 1, 2), (16384, 64, 1, 1), (40004, 68, 1, 1), (300000, 4, 1, 1), (2052, 4100, 1, 1),
     # 3 .. 8 right-hand sides on matrices past the launch-bound sizes: one pass on the matrix cores (few_rhs_as_gemm in gemv.hip)
     (4096, 4096, 4, 1), (4096, 3072, 8, 1), (2048, 2304, 7, 1),
+    # GemvTr, 2 .. 8 right-hand sides, >= 128 x CUs outputs, vectors in the LDS (gemv_t_lds_kernel); the transposed shape is the plain multi-vector Gemv
+    (64, 32768, 3, 1), (132, 33000, 8, 1), (260, 32772, 2, 2),
 ]
 
 

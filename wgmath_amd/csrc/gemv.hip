@@ -333,6 +333,70 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// T with 2 .. 8 right-hand sides and a SHORT contraction (k x nrhs floats fit the LDS): the small-batch product x^T W of a weight matrix stored
+// k x outputs. The vectors are staged once per workgroup into the LDS (as f32), then every half-wave streams ONE column of the matrix exactly
+// like gemv_t_cols_kernel and multiplies each 16-byte piece with the NRHS pieces of the vectors read from the LDS: no split of k, no combine
+// pass, the matrix read once. 1024 threads = 32 columns per workgroup (one workgroup per CU when the vectors take > 80 KiB).
+// grid = (column groups of 32, 1, nmats); dynamic LDS = k * NRHS * 4 bytes.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kLdsThreads = 1024;
+template <int NRHS, typename T>
+__global__ __launch_bounds__(kLdsThreads) void gemv_t_lds_kernel(GemvArgsT<T> a) {
+    extern __shared__ __attribute__((aligned(16))) float vs[]; // [y][k]
+    const uint32_t z = blockIdx.z;
+    const uint32_t kk = a.k; // % 4 == 0
+    const T *vp = a.v + z * a.v_batch;
+    for (uint32_t idx = threadIdx.x * 4u; idx < kk * (uint32_t)NRHS; idx += kLdsThreads * 4u) {
+        const uint32_t y = idx / kk, r = idx - y * kk; // (kk % 4 == 0: a thread's 4 entries belong to one vector)
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < a.nrhs) x = load4(vp + (uint64_t)y * a.ldv + r);
+        *reinterpret_cast<float4 *>(vs + idx) = x;
+    }
+    __syncthreads();
+    const uint32_t p = threadIdx.x & 31u, hw = threadIdx.x >> 5;
+    // persistent: the vectors are staged once, then the workgroup walks its column groups (group g, g + gridDim.x, ...). A half-wave takes FOUR
+    // adjacent columns: a piece of the vectors read from the LDS serves four pieces of the matrix (one column per half-wave made the kernel
+    // LDS-bound: 8 right-hand sides = 8 x the matrix's bytes out of the LDS, 4096 x 65536 x 8 320 us; this form: 2 x).
+    constexpr uint32_t kGroup = (kLdsThreads / 32) * 4; // 128 columns per workgroup and trip
+    for (uint32_t c0 = blockIdx.x * kGroup + hw * 4u; c0 < a.rows_out; c0 += gridDim.x * kGroup) { // rows_out % 4 == 0: a half-wave's 4 columns are all in or all out
+        const T *mp = a.m + z * a.m_batch + (uint64_t)c0 * a.ldm;
+        float acc[4][NRHS];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int y = 0; y < NRHS; ++y) acc[c][y] = 0.f;
+        for (uint32_t r = 4u * p; r < kk; r += 128u) {
+            float4 mv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mv[c] = load4s(mp + (uint64_t)c * a.ldm + r);
+#pragma unroll
+            for (int y = 0; y < NRHS; ++y) {
+                const float4 x = *reinterpret_cast<const float4 *>(vs + (uint32_t)y * kk + r);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]); acc[c][y] = fmaf(mv[c].y, x.y, acc[c][y]);
+                    acc[c][y] = fmaf(mv[c].z, x.z, acc[c][y]); acc[c][y] = fmaf(mv[c].w, x.w, acc[c][y]);
+                }
+            }
+        }
+#pragma unroll
+        for (int y = 0; y < NRHS; ++y) {
+            float s[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                s[c] = acc[c][y];
+#pragma unroll
+                for (int sh = 16; sh >= 1; sh >>= 1) s[c] += __shfl_xor(s[c], sh, 64);
+            }
+            if (p == 0 && (uint32_t)y < a.nrhs) {
+                T *o = a.out + z * a.dst_batch + (uint64_t)y * a.ld_dst + c0;
+                o[0] = (T)s[0]; o[1] = (T)s[1]; o[2] = (T)s[2]; o[3] = (T)s[3];
+            }
+        }
+    }
+}
+
 // out[r] = sum_{s < nsplit} partial[s][r] in a FIXED order. partial layout: [z][s][y][rows_out] dense.
 // A workgroup covers 4 float4 rows x 64 "split lanes": split lane j adds splits j, j+64, ... ascending (4 independent loads
 // in flight per trip), then the 16 split lanes of a wave are folded by a butterfly and the 4 waves ascending through LDS.
@@ -636,9 +700,48 @@ static bool few_rhs_as_gemm(bool trans, bool f16, uint32_t rows_out, uint32_t k,
     return f16 || (nrhs >= 7u && bytes < (256ull << 20)); // f32 Gemv: only 7-8 right-hand sides on mid-size matrices (4096^2 x 8: 22.5 -> 19 us)
 }
 
+#ifndef WG_GEMVT_LDS
+#define WG_GEMVT_LDS 1
+#endif
+// GemvTr with 2 .. 8 right-hand sides whose vectors fit the LDS (see gemv_t_lds_kernel): very many outputs (a vocabulary-sized projection of a small batch).
+template <typename T>
+static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, T *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
+    GemvArgsT<T> a;
+    a.m = (const T *)m.ptr; a.ldm = m.ld; a.m_batch = m.batch;
+    a.v = (const T *)v.ptr; a.ldv = v.ld; a.v_batch = v.batch;
+    a.rows_out = rows_out; a.k = k; a.nrhs = nrhs; a.k_per_split = k;
+    a.out = out; a.part = nullptr; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
+    const int tile = nrhs > 4 ? 8 : (nrhs > 2 ? 4 : 2);
+    const size_t lds = (size_t)k * tile * sizeof(float);
+    const uint32_t groups = ceil_div(rows_out, (kLdsThreads / 32) * 4), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const dim3 grid(groups < cus ? groups : cus, 1, nmats), block(kLdsThreads);
+#define WG_T_LDS(NR)                                                                                                                   \
+    do {                                                                                                                               \
+        static bool attr_set = false; /* (one context per device; the attribute is per function) */                                    \
+        if (!attr_set) { WG_HIP_TRY(hipFuncSetAttribute((const void *)gemv_t_lds_kernel<NR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_set = true; } \
+        hipLaunchKernelGGL((gemv_t_lds_kernel<NR, T>), grid, block, lds, ctx->stream, a);                                              \
+    } while (0)
+    if (tile == 8) WG_T_LDS(8); else if (tile == 4) WG_T_LDS(4); else WG_T_LDS(2);
+#undef WG_T_LDS
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
+// Measured (tools/misc_sweep.py): it pays where every CU gets at least one group of 128 columns -- f32 4096 x 65536 x 8: 212 us on the
+// 4-columns-per-wave kernel, 279 on the few-column Gemm kernel, 184 here (vendor 178) -- and loses below that (4096 x 11008 x 4: 86 groups for 256 CUs:
+// 46 vs 36 us); f16 gains nothing over the f16 Gemm kernels (120 vs 111 us). So: f32, outputs >= 128 x CUs.
+static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
+    if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
+    const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= 128ull * cus && rows_out % 4u == 0;
+}
+
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
+    if (uses_t_lds(ctx, trans, rows_out, k, nrhs, nmats, dtype == WG_F16 ? 2u : 4u)) {
+        if (dtype == WG_F16) return gemv_t_lds_launch<_Float16>(ctx, rows_out, k, nrhs, nmats, (_Float16 *)out, out_ld, out_batch, m, v);
+        return gemv_t_lds_launch<float>(ctx, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
+    }
     if (dtype == WG_F16) {
         // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): the same HBM-bound kernels on f16 elements (8-byte loads of 4 rows,
         // f32 accumulation in the same order, one rounding at the store; split partials stay f32). More than 8 right-hand sides are a
