@@ -767,7 +767,23 @@ def engine_trials(args, rank, world):
     base_port = int(os.environ.get("MASTER_PORT", "29500"))
     argv = [a for a in sys.argv[1:]]
     out = {}
+    # The ranks start every trial TOGETHER (a key-value store of their own, no process group, no GPU): an engine that fails at once on one rank
+    # and hangs on another would otherwise leave the first rank's next trial waiting for the second rank's child for most of ITS time limit --
+    # and the next engine would be written off as "timeout" for no fault of its own.
+    import datetime
+    from torch.distributed import TCPStore
+    store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base_port + 40, world, rank == 0, timeout=datetime.timedelta(seconds=limit + 300))
+
+    def together(tag):
+        store.add(tag, 1)
+        t_end = time.time() + limit + 120
+        while store.add(tag, 0) < world:  # (add 0 reads the counter)
+            if time.time() > t_end:
+                raise SystemExit(f"[bench] rank {rank}: the other ranks never reached engine trial {tag}")
+            time.sleep(0.05)
+
     for k, mode in enumerate(ENGINES):
+        together(f"trial{k}")
         if mode == "peer" and world > 2:
             # the rect-copy engine is the 2-rank engine (one rect-capable SDMA queue per direction): not a candidate
             out[mode] = {"ms_per_step": None, "error": "skipped: the SDMA rect-copy engine is for 2 ranks"}
