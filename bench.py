@@ -754,6 +754,7 @@ def run_group(cmd, env, limit_s):
 
 
 ENGINES = ["rccl", "staged", "peer"]
+_TRIAL_STORE = None
 
 
 def engine_trials(args, rank, world):
@@ -773,6 +774,8 @@ def engine_trials(args, rank, world):
     import datetime
     from torch.distributed import TCPStore
     store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base_port + 40, world, rank == 0, timeout=datetime.timedelta(seconds=limit + 300))
+    global _TRIAL_STORE
+    _TRIAL_STORE = store  # rank 0 hosts it: it must outlive every other rank's last poll, i.e. live as long as this process
 
     def together(tag):
         store.add(tag, 1)
@@ -1028,6 +1031,8 @@ def main():
         trial_report = None
         if trials is not None:  # the engines' trials ran as child groups (engine_trials): agree on the winner, build only that engine
             gather, trial_report = agree_on_engine(trials, lambda t: dist.all_reduce(t, op=dist.ReduceOp.MAX), "cpu" if oversub else f"cuda:{dev_index}")
+            if oversub and gather not in ("peer", "staged"):
+                gather = "staged"  # (ranks sharing a GPU: RCCL refuses that; its trial ran as the staged engine too)
         engines = {}  # mode -> (GpuInstance, Comm)
         for mode in (ENGINES if gather == "auto" else [gather]):
             g = make_gpu(masked=(mode == "rccl" and world > 1))
