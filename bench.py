@@ -773,11 +773,17 @@ def engine_trials(args, rank, world):
     # and the next engine would be written off as "timeout" for no fault of its own.
     import datetime
     from torch.distributed import TCPStore
-    store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base_port + 40, world, rank == 0, timeout=datetime.timedelta(seconds=limit + 300))
     global _TRIAL_STORE
-    _TRIAL_STORE = store  # rank 0 hosts it: it must outlive every other rank's last poll, i.e. live as long as this process
+    try:
+        store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), base_port + 40, world, rank == 0, timeout=datetime.timedelta(seconds=120))
+        _TRIAL_STORE = store  # rank 0 hosts it: it must outlive every other rank's last poll, i.e. live as long as this process
+    except Exception as e:  # noqa: BLE001 -- (port taken, ...): the trials still run, each rank on its own clock as before
+        store = None
+        log(f"[bench] rank {rank}: no store for the trials ({type(e).__name__}: {e}); trials start unsynchronised")
 
     def together(tag):
+        if store is None:
+            return
         store.add(tag, 1)
         t_end = time.time() + limit + 120
         while store.add(tag, 0) < world:  # (add 0 reads the counter)
