@@ -1009,7 +1009,7 @@ def main():
         def make_gpu(masked):
             if masked and comm_cus > 0 and total_cus > 2 * comm_cus:
                 try:
-                    return wg.GpuInstance.new(dev_index, cu_count=total_cus - comm_cus)
+                    return wg.GpuInstance.new(dev_index, cu_count=total_cus - comm_cus, one_xcd=os.environ.get("WG_BENCH_CU_MASK_SPREAD") != "1")
                 except Exception as e:  # no CU-masked stream on this runtime
                     log(f"[bench] CU-masked compute stream unavailable ({e}); using an unmasked stream")
             return wg.GpuInstance.new(dev_index)

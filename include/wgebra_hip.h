@@ -116,6 +116,11 @@ int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out);
  * share). For multi-GPU runs: the compute stream leaves a few CUs to the collective library's copy kernels. The tile / split
  * heuristics then plan for `cu_count` CUs. */
 int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out);
+/* Same, but the missing CUs (fewer than one XCD's worth) all come from ONE XCD: the other seven keep their 32 CUs and the L2 locality of
+ * the f16 Gemm's tile patches, and that kernel's tile scheduler lets them take the short XCD's tiles (248 CUs: 13.8 -> 13.5 ms per step of a
+ * rank's 8192 x 32768 x 32768 product). For a context that runs the sharded f16 Gemm beside a collective; kernels with a static
+ * tile -> XCD map run better on the evenly masked stream above. */
+int wg_ctx_create_with_cu_count_one_xcd(int device, uint32_t cu_count, wg_ctx **out);
 int wg_ctx_destroy(wg_ctx *ctx);
 /* queue.submit(..) + device.poll(PollType::wait()) (tensor.rs:304-312): block until all enqueued work is done. Also reports (once) an
  * error a kernel of this context raised asynchronously -- a sharded Gemm whose peer never delivered (WG_ERR_HIP); so does wg_buf_read. */

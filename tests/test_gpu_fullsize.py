@@ -202,7 +202,7 @@ def test_addressing_beyond_4GiB(gpu):
 # panel-wise strided-output path of the peer-copy engine (WG_GATHER_PEER_COPY). >= 64 sampled rows x 512 columns against f64.
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("engine", ["rccl", "staged"])
-@pytest.mark.parametrize("cus", [None, 248])
+@pytest.mark.parametrize("cus", [None, 248, -248])  # -248: the 8 missing CUs all from one XCD (wg_ctx_create_with_cu_count_one_xcd: what bench.py gives the RCCL engine)
 @pytest.mark.parametrize("M,K,N,panel,bitwise", [(4096, 1024, 4096, 1024, True), (4096, 512 + 32, 8192, 4096, True), (8192, 512, 8192, 2048, True),
                                                  (4096, 512 + 32, 4352, 1024, False), (2048, 768, 8448, 512, False)])
 def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus, M, K, N, panel, bitwise):
@@ -216,7 +216,7 @@ def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus,
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     wg = _wg()
     from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
-    inst = wg.GpuInstance.new(0, cu_count=cus) if cus else wg.GpuInstance.new(0)
+    inst = wg.GpuInstance.new(0, cu_count=abs(cus), one_xcd=cus < 0) if cus else wg.GpuInstance.new(0)
     dev = inst.device()
     comm = Comm(inst, 1, 0, new_unique_id() if engine == "rccl" else None)
     rng = np.random.default_rng(M + K + N + panel)

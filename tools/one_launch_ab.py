@@ -14,7 +14,7 @@ P = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cus = int(sys.argv[2]) if len(sys.argv) > 2 else None
 N = K = M = 32768
 Mg = M // P
-gpu = wg.GpuInstance.new(0, cu_count=cus) if cus else wg.GpuInstance.new(0)
+gpu = wg.GpuInstance.new(0, cu_count=cus, one_xcd=os.environ.get("WG_BENCH_CU_MASK_SPREAD") != "1") if cus else wg.GpuInstance.new(0)
 dev, S = gpu.device(), wg.BufferUsages
 A = bench.device_random(wg, gpu, (Mg, K), np.float16, 0xA000); B = bench.device_random(wg, gpu, (K, N), np.float16, 0xB000)
 C = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(dev, np.float16)

@@ -91,7 +91,7 @@ for P in Ps:
     out["ranks"][str(P)] = res
     comm.close()
     if P > 1:  # the RCCL engine's compute side: 248 of the 256 CUs
-        gpu2 = wg.GpuInstance.new(0, cu_count=248)
+        gpu2 = wg.GpuInstance.new(0, cu_count=248, one_xcd=os.environ.get("WG_BENCH_CU_MASK_SPREAD") != "1")  # as bench.py does for the RCCL engine
         comm2 = Comm(gpu2, P, 0, None)
         prepare_staged(gpu2, comm2)
         dt = staged_side(gpu2, comm2, A, B, C, True)

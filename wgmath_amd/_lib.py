@@ -76,6 +76,7 @@ def _load() -> ctypes.CDLL:
         "wg_ctx_create": (ci, [ci, pvp]),
         "wg_ctx_create_on_stream": (ci, [ci, vp, pvp]),
         "wg_ctx_create_with_cu_count": (ci, [ci, ctypes.c_uint32, ctypes.POINTER(vp)]),
+        "wg_ctx_create_with_cu_count_one_xcd": (ci, [ci, ctypes.c_uint32, ctypes.POINTER(vp)]),
         "wg_ctx_destroy": (ci, [vp]),
         "wg_ctx_sync": (ci, [vp]),
         "wg_ctx_device": (ci, [vp]),

@@ -1200,7 +1200,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             auto launch_tiles = [&](GemmArgs gm, uint32_t ntiles) -> int {
                 uint32_t nwg = ntiles;
                 const int sched_env = ctx->tuning[WG_TUNE_F16_SCHED]; // 0 / 1 force (tests), default: by size
-                const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)(WG_F16_SCHED_ROUNDS * cus));
+                // (a stream whose missing CUs all come from one XCD: that XCD cannot keep up with an eighth of the tiles -- the others take them from 2 rounds on)
+                const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)((ctx->uneven_xcds ? 2 : WG_F16_SCHED_ROUNDS) * cus));
                 if (dyn) {
                     if (!ctx->tile_queues) {
                         if (ctx->recording) return wg_set_error(WG_ERR_WORKSPACE, "Gemm: the tile queues are needed while recording: run the call once outside the recording first");

@@ -134,12 +134,10 @@ int wg_ctx_create_on_stream(int device, void *hip_stream, wg_ctx **out) {
     return ctx_create_common(device, (hipStream_t)hip_stream, false, out);
 }
 
-// A context whose stream may only use `cu_count` of the device's compute units (hipExtStreamCreateWithCUMask: the first
-// `cu_count` bits of the CU mask; the driver spreads mask bits round-robin over the XCDs, so every XCD loses the same number of
-// CUs). For multi-GPU runs: the GEMM stream leaves a few CUs free, so that the collective library's copy kernels (a second
+// A context whose stream may only use `cu_count` of the device's compute units (hipExtStreamCreateWithCUMask; which ones: below). For multi-GPU runs: the GEMM stream leaves a few CUs free, so that the collective library's copy kernels (a second
 // queue) start at once instead of waiting for a GEMM workgroup -- which needs a whole CU -- to retire. The kernels' tile/split
 // heuristics see `cu_count` CUs.
-int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out) {
+static int ctx_create_masked(int device, uint32_t cu_count, bool one_xcd, wg_ctx **out) {
     if (!out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create_with_cu_count: out is NULL");
     *out = nullptr;
     int n = wg_device_count();
@@ -151,16 +149,35 @@ int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out) {
     const uint32_t total = (uint32_t)prop.multiProcessorCount;
     if (cu_count == 0 || cu_count > total) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_create_with_cu_count: %u not in [1,%u]", cu_count, total);
     std::vector<uint32_t> mask((total + 31) / 32, 0u);
-    for (uint32_t i = 0; i < cu_count; ++i) mask[i / 32] |= 1u << (i % 32);
+    // Which CUs stay free: mask bit i belongs to XCD i % 8. Up to a whole XCD's worth, ALL of them come from the last XCD -- seven XCDs keep their
+    // 32 CUs and with them the 4 x 8 tile patches of the f16 Gemm in their L2 (the tile scheduler lets the others take the short XCD's tiles):
+    // 8192 x 32768 x 32768 on 248 CUs 13.80 -> 13.49 ms against one CU from every XCD (256 CUs: 13.17; profiles/r03_evidence.md section 3).
+    // Only on request (wg_ctx_create_with_cu_count_one_xcd): kernels with a static tile -> XCD map (everything but the big f16 Gemm) would wait
+    // for the short XCD. wg_ctx_create_with_cu_count spreads the missing CUs evenly, as does a request for a whole XCD's worth or more.
+    const uint32_t missing = total - cu_count;
+    const bool uneven = one_xcd && missing > 0 && missing < total / 8u; // (never a whole XCD)
+    if (uneven) {
+        for (auto &w : mask) w = 0xffffffffu;
+        if (total % 32) mask.back() = (1u << (total % 32)) - 1u;
+        for (uint32_t j = 0; j < missing; ++j) {
+            const uint32_t bit = 7u + 8u * j; // XCD 7's CUs
+            if (bit < total) mask[bit / 32] &= ~(1u << (bit % 32));
+        }
+    } else {
+        for (uint32_t i = 0; i < cu_count; ++i) mask[i / 32] |= 1u << (i % 32);
+    }
     hipStream_t stream = nullptr;
     hipError_t e = hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data());
     if (e != hipSuccess) return wg_set_error(WG_ERR_HIP, "hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e));
     int rc = ctx_create_common(device, stream, false, out);
     if (rc) { (void)hipStreamDestroy(stream); return rc; }
     (*out)->owns_stream = true;
+    (*out)->uneven_xcds = uneven;
     (*out)->compute_units = (int)cu_count;
     return WG_OK;
 }
+int wg_ctx_create_with_cu_count(int device, uint32_t cu_count, wg_ctx **out) { return ctx_create_masked(device, cu_count, false, out); }
+int wg_ctx_create_with_cu_count_one_xcd(int device, uint32_t cu_count, wg_ctx **out) { return ctx_create_masked(device, cu_count, true, out); }
 
 int wg_ctx_destroy(wg_ctx *ctx) {
     if (!ctx) return WG_OK;

@@ -26,6 +26,7 @@ struct wg_ctx {
     void *pad_workspace = nullptr; // third scratch: zero-padded operand copies of f16 GEMMs whose shapes the MFMA kernels do not take as they are
     size_t pad_workspace_bytes = 0;
     int compute_units = 0;
+    bool uneven_xcds = false; // CU-masked stream whose missing CUs all come from one XCD (runtime.hip): static tile -> XCD maps would wait for the short XCD
     unsigned *flags = nullptr;           // a few zeroed device words (arrival counters of fused epilogues), created on first use
     unsigned long long *tile_queues = nullptr; // f16 Gemm tile scheduler: 8 per-XCD queue words, 128 bytes apart (gemm_f16.hip), created on first use
     // f16 Gemm, calibrated shares across XCDs (gemm_f16.hip "balance"): measured relative time per stage of the workgroup slots b % 8,

@@ -247,13 +247,14 @@ class GpuInstance:
         self._queue = Queue(ctx)
 
     @staticmethod
-    def new(device_index: int = 0, stream: Optional[int] = None, cu_count: Optional[int] = None) -> "GpuInstance":
+    def new(device_index: int = 0, stream: Optional[int] = None, cu_count: Optional[int] = None, one_xcd: bool = False) -> "GpuInstance":
         """`cu_count`: create the context on a CU-masked stream that may use only that many compute units (multi-GPU runs leave a
-        few CUs to the collective library's copy kernels)."""
+        few CUs to the collective library's copy kernels); `one_xcd`: take the missing CUs from one XCD (wg_ctx_create_with_cu_count_one_xcd)."""
         _lib.assert_single_hip_runtime()
         h = ctypes.c_void_p()
         if cu_count is not None:
-            check(lib.wg_ctx_create_with_cu_count(device_index, int(cu_count), ctypes.byref(h)))
+            create = lib.wg_ctx_create_with_cu_count_one_xcd if one_xcd else lib.wg_ctx_create_with_cu_count
+            check(create(device_index, int(cu_count), ctypes.byref(h)))
             inst = GpuInstance(_Ctx(h.value, device_index))
             inst._stream_compute_units = int(cu_count)
             return inst
