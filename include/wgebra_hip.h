@@ -35,7 +35,8 @@
 extern "C" {
 #endif
 
-#define WGEBRA_HIP_ABI_VERSION 2
+#define WGEBRA_HIP_ABI_VERSION 3 /* 3: the SDMA rect-copy exchange engine (gather mode 1, wg_comm_copy_engine, wg_gemm_sharded's peer_out) is gone;
+                                    wg_comm_reported_size, wg_debug_*; non-vec4 views compute staged; async time-outs surface in wg_ctx_sync */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* status codes                                                                                      */
@@ -147,6 +148,18 @@ int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in
  * 1-thread kernel enqueued just before). Stand-in for a collective library's copy kernel when studying queue interleaving.
  */
 int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_ticks);
+/* What the chip did while a kernel ran (the role of GpuTimestamps, timestamps.rs:226-230, for a power-capped part: a time alone does not say
+ * whether a slow run was a slow kernel or a slow clock).
+ * wg_debug_clock_begin / _end bracket whatever is enqueued between them on the context's stream with two stamp kernels (s_memtime -- shader
+ * clock ticks -- against s_memrealtime -- 100 MHz --, per XCD): _end synchronises the stream and returns the MEAN shader clock over the
+ * bracketed interval in GHz (mean / min / max over the XCDs; any of the last three pointers may be NULL) and the interval's length. Nothing
+ * is added to the bracketed kernels and nothing runs beside them.
+ * wg_debug_mfma_ceiling runs v_mfma_f32_16x16x32_f16 alone (random operands in registers, no LDS or memory traffic, one 4-wave workgroup per
+ * CU of the context's stream) for at least min_seconds (0 < s <= 30) and returns its TFLOP/s and mean shader clock: what the package power cap
+ * leaves the matrix cores when nothing else draws power -- the ceiling of any f16 Gemm on this part. */
+int wg_debug_clock_begin(wg_ctx *ctx);
+int wg_debug_clock_end(wg_ctx *ctx, double *ghz_mean, double *ghz_min, double *ghz_max, double *seconds);
+int wg_debug_mfma_ceiling(wg_ctx *ctx, double min_seconds, double *tflops, double *clock_ghz);
 
 /*
  * Kernel-selection knobs of a context (tests and experiments; production code never needs them). The launchers choose between
@@ -330,14 +343,14 @@ typedef struct wg_comm wg_comm; /* one rank of a group of contexts (one context 
 typedef enum wg_gather_mode {
     WG_GATHER_RCCL = 0,      /* per N-panel: Gemm into a staging cube [M/P, np, P], in-place ncclAllGather (RCCL over xGMI) on the
                                 communicator's stream beside the next panel's Gemm, then an HBM-bound relayout into columns of C */
-    WG_GATHER_PEER_COPY = 1, /* per N-panel: Gemm straight into this rank's rows of C, then the SDMA engines push that strided block
-                                into every peer's C (no compute units, no relayout); completion: wg_comm_flush + a barrier */
+    /* 1 was WG_GATHER_PEER_COPY (Gemm straight into C + hsa_amd_memory_async_copy_rect pushes by a helper thread): removed in ABI 3 -- one
+       rect-capable SDMA queue per direction made it a 2-rank engine at best, and it could hang two processes sharing a GPU at 32768^3 */
     WG_GATHER_NONE = 2,      /* this rank's rows of C only */
     WG_GATHER_PEER_STAGED = 3 /* per N-panel: Gemm into slot g of this rank's staging cube, one CONTIGUOUS copy per peer (the runtime's
                                 peer-to-peer path: that link's own SDMA engine, no compute units) into the same slot of the peer's cube + a
                                 sequence-number flag; the receiver's stream waits on the flags (one-wave kernel) and relayouts the panel into
                                 C. Stream-ordered end to end, no barrier: the cubes are double-buffered by step parity. Needs
-                                wg_comm_stage_reserve + wg_comm_set_peer_stages. The engine for P > 2 (one rect-capable SDMA queue per GPU).
+                                wg_comm_stage_reserve + wg_comm_set_peer_stages. The copy-engine exchange for any P.
                                 The HIP runtime folds a process's streams onto 4 hardware queues unless GPU_MAX_HW_QUEUES says otherwise: give
                                 a rank's process >= 3 + P of them, or its copies queue up behind its Gemms instead of running beside them
                                 (correct either way; two ranks driven from ONE thread on one device need it for progress) */
@@ -346,14 +359,14 @@ typedef enum wg_gather_mode {
 /* ncclGetUniqueId: call on one rank, ship the WG_COMM_ID_BYTES bytes to the others out of band (env, file, MPI, a torch store). */
 int wg_comm_unique_id(void *id);
 /* Rank `rank` of `nranks`, bound to `ctx` (its device, its stream). id != NULL: ncclCommInitRank (collective: every rank must call).
- * id == NULL: no collective library -- peer copies only, the caller brings its own barrier. librccl / libhsa-runtime64 are bound
- * at run time; the library itself links only the HIP runtime. */
+ * id == NULL: no collective library -- staged peer copies only, the caller brings its own barrier. librccl is bound at run time;
+ * the library itself links only the HIP runtime. */
 int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **out);
 int wg_comm_destroy(wg_comm *comm);
 int wg_comm_rank(const wg_comm *comm);
 int wg_comm_size(const wg_comm *comm);
 int wg_comm_has_collectives(const wg_comm *comm);
-const char *wg_comm_copy_engine(const wg_comm *comm); /* "sdma-rect" | "hip2d" | "none" */
+int wg_comm_reported_size(const wg_comm *comm, int *count); /* ncclCommCount: the rank count the collective library itself reports (0 without one) */
 uint64_t wg_comm_bytes_sent(const wg_comm *comm);     /* payload bytes this rank contributed / pushed so far */
 /* In-place all-gather of elements [first, first + nranks*per_rank) of `buf` (rank r owns [first + r*per_rank, +per_rank)) on the
  * communicator's stream, ordered after the work already enqueued on the context; the context does not wait (wg_comm_join). */
@@ -392,14 +405,12 @@ int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_s
 /*
  * out (M x N, one matrix, on EVERY rank) = op(A) * B with A sharded on M: `a_rows` is this rank's row block of op(A)
  * (M/P x K; WG_GEMM_TR*: stored K x M/P), `b` (K x N) is replicated. N is cut into panels of `panel_cols` columns (0 = default)
- * and panel i's exchange overlaps panel i+1's Gemm. peer_out[r] (WG_GATHER_PEER_COPY only) is rank r's `out` buffer as addressable
- * from this process (wg_buf_ipc_open, or the buffer itself when the ranks share a process); peer_out[rank] is ignored.
- * On return everything is enqueued: WG_GATHER_RCCL and WG_GATHER_PEER_STAGED -- `out` is complete in context-stream order; WG_GATHER_PEER_COPY -- this rank's
- * rows are complete in stream order, the peers' rows after every rank's wg_comm_flush + a barrier (wg_comm_barrier does both), which
- * must also separate two calls that write the same `out`. DIM_MISMATCH as Gemm (gemm.rs:91-95) with M = P * rows(a_rows).
+ * and panel i's exchange overlaps panel i+1's Gemm.
+ * On return everything is enqueued: `out` is complete in context-stream order (WG_GATHER_NONE: this rank's rows only).
+ * DIM_MISMATCH as Gemm (gemm.rs:91-95) with M = P * rows(a_rows).
  */
 int wg_gemm_sharded(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols,
-                    wg_buf *out, wg_view_shape out_shape, wg_buf *const *peer_out,
+                    wg_buf *out, wg_view_shape out_shape,
                     const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -2,9 +2,11 @@
 // process -- what a Rust caller of the boundary would do:
 //   1. a 1-rank RCCL communicator: unique id -> wg_comm_create -> wg_all_gather round trip -> wg_gemm_sharded(WG_GATHER_RCCL), i.e.
 //      staging cube + ncclAllGather + cube_to_matrix relayout, against a host f64 product;
-//   2. two ranks in ONE process on one device (two contexts, two communicators without a collective library), WG_GATHER_PEER_COPY:
-//      each rank's Gemm writes its rows of its own C and the copy engine pushes them into the other rank's C; both results must be
-//      the plain M x N product. (RCCL refuses two ranks on one device, so the 2-rank collective itself needs a multi-GPU node.)
+//   2. two ranks in ONE process on one device (two contexts, two communicators without a collective library), WG_GATHER_PEER_STAGED:
+//      each rank's Gemm writes its slot of its staging cube, one contiguous copy per peer carries it over, the receiver waits on the
+//      flags and relayouts; both results must be the plain M x N product. (RCCL refuses two ranks on one device, so the 2-rank
+//      collective itself needs a multi-GPU node.) Also: a peer that misses a step (time-out -> error in wg_ctx_sync -> clean retry),
+//      and pipelined one-launch RCCL steps whose shapes alternate.
 //   3. wg_cube_to_matrix on a hand-made cube (exact), wg_buf_ipc_export on a wrapped interior pointer (offset carried).
 // f32 and f16, Gemm and GemmTr, ragged last panel. Exit code 0 and "ALL OK" on success.
 #include <cmath>
@@ -77,56 +79,13 @@ template <typename T> static void rccl_one_rank(wg_ctx *ctx, wg_comm *comm, bool
     CK(wg_buf_create(ctx, (size_t)M * N * sizeof(T), USAGE, &c));
     CK(wg_buf_fill_zero(ctx, c));
     const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
-    CK(wg_gemm_sharded(comm, v, dt<T>::v, WG_GATHER_RCCL, panel, c, mat(M, N), nullptr, a, tr ? mat(K, M) : mat(M, K), b, mat(K, N)));
+    CK(wg_gemm_sharded(comm, v, dt<T>::v, WG_GATHER_RCCL, panel, c, mat(M, N), a, tr ? mat(K, M) : mat(M, K), b, mat(K, N)));
     std::vector<T> got((size_t)M * N);
     CK(wg_buf_read(ctx, c, 0, got.data(), got.size() * sizeof(T)));
     char what[128];
     std::snprintf(what, sizeof what, "rccl 1-rank %s %s %ux%ux%u panel %u", sizeof(T) == 2 ? "f16" : "f32", tr ? "GemmTr" : "Gemm", M, N, K, panel);
     check_product(what, got, A, tr, B, M, N, K);
     wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
-}
-
-template <typename T> static void peer_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel) {
-    const uint32_t P = 2, mg = M / P;
-    wg_ctx *ctx[2] = { nullptr, nullptr };
-    wg_comm *comm[2] = { nullptr, nullptr };
-    wg_buf *a[2] = {}, *b[2] = {}, *c[2] = {};
-    auto A = rnd<T>((size_t)M * K, 21), B = rnd<T>((size_t)K * N, 22);
-    for (uint32_t g = 0; g < P; ++g) {
-        CK(wg_ctx_create(0, &ctx[g]));
-        CK(wg_comm_create(ctx[g], P, g, nullptr, &comm[g]));
-        auto Ag = row_block(A, tr, M, K, g, mg);
-        CK(wg_buf_create_init(ctx[g], Ag.data(), Ag.size() * sizeof(T), USAGE, &a[g]));
-        CK(wg_buf_create_init(ctx[g], B.data(), B.size() * sizeof(T), USAGE, &b[g]));
-        CK(wg_buf_create(ctx[g], (size_t)M * N * sizeof(T), USAGE, &c[g]));
-        CK(wg_buf_fill_zero(ctx[g], c[g]));
-        CK(wg_ctx_sync(ctx[g]));
-    }
-    const wg_gemm_variant v = tr ? WG_GEMM_TR : WG_GEMM;
-    for (int rep = 0; rep < 2; ++rep) { // twice: the second call reuses events / signals and overwrites the same C
-        for (uint32_t g = 0; g < P; ++g) {
-            wg_buf *peers[2] = { c[0], c[1] };
-            CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_COPY, panel, c[g], mat(M, N), peers, a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
-        }
-        for (uint32_t g = 0; g < P; ++g) {
-            CK(wg_ctx_sync(ctx[g]));
-            CK(wg_comm_flush(comm[g])); // (the caller's barrier would follow here when the ranks are processes)
-        }
-    }
-    for (uint32_t g = 0; g < P; ++g) {
-        std::vector<T> got((size_t)M * N);
-        CK(wg_buf_read(ctx[g], c[g], 0, got.data(), got.size() * sizeof(T)));
-        char what[160];
-        std::snprintf(what, sizeof what, "peer-copy (%s) rank %u of 2 %s %s %ux%ux%u panel %u", wg_comm_copy_engine(comm[g]), g, sizeof(T) == 2 ? "f16" : "f32",
-                      tr ? "GemmTr" : "Gemm", M, N, K, panel);
-        check_product(what, got, A, tr, B, M, N, K);
-        EXPECT(wg_comm_bytes_sent(comm[g]) == 2ull * mg * N * sizeof(T), "bytes_sent %llu", (unsigned long long)wg_comm_bytes_sent(comm[g]));
-    }
-    for (uint32_t g = 0; g < P; ++g) {
-        wg_comm_destroy(comm[g]);
-        wg_buf_destroy(a[g]); wg_buf_destroy(b[g]); wg_buf_destroy(c[g]);
-        wg_ctx_destroy(ctx[g]);
-    }
 }
 
 // two ranks in one process, WG_GATHER_PEER_STAGED: staging cubes + contiguous per-peer copies + flags + wait kernel + relayout, three steps
@@ -152,7 +111,7 @@ template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t
     for (int rep = 0; rep < 3; ++rep) {
         for (uint32_t g = 0; g < P; ++g) {
             CK(wg_buf_fill_zero(ctx[g], c[g]));
-            CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[g], mat(M, N), nullptr, a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
+            CK(wg_gemm_sharded(comm[g], v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[g], mat(M, N), a[g], tr ? mat(K, mg) : mat(mg, K), b[g], mat(K, N)));
         }
     }
     if (pipelined)
@@ -169,7 +128,7 @@ template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t
     { // unregistered peers are an error, not a hang
         wg_comm *lone = nullptr;
         CK(wg_comm_create(ctx[0], P, 0, nullptr, &lone));
-        EXPECT(wg_gemm_sharded(lone, v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[0], mat(M, N), nullptr, a[0], tr ? mat(K, mg) : mat(mg, K), b[0], mat(K, N)) == WG_ERR_INVALID_ARG,
+        EXPECT(wg_gemm_sharded(lone, v, dt<T>::v, WG_GATHER_PEER_STAGED, panel, c[0], mat(M, N), a[0], tr ? mat(K, mg) : mat(mg, K), b[0], mat(K, N)) == WG_ERR_INVALID_ARG,
                "PEER_STAGED without staging cubes must be rejected");
         wg_comm_destroy(lone);
     }
@@ -178,6 +137,93 @@ template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t
         wg_buf_destroy(a[g]); wg_buf_destroy(b[g]); wg_buf_destroy(c[g]);
         wg_ctx_destroy(ctx[g]);
     }
+}
+
+
+// A peer that does not show up: rank 0 runs step 1 alone with a short time-out. Its wait kernel gives up, the panel is poisoned, and the
+// error surfaces in wg_ctx_sync -- which must leave the communicator usable: rank 1 then runs its step 1 late (rank 0's slots are there),
+// both run step 2, and both results are the plain product with no further error. (Round-3 review: only wg_gemm_sharded used to clear the
+// device-side time-out word, so an error reported by wg_ctx_sync poisoned every later step silently.)
+static void staged_timeout_and_retry() {
+    typedef _Float16 T;
+    const uint32_t P = 2, M = 1024, N = 1024, K = 256, mg = M / P, panel = 512;
+    setenv("WG_COMM_TIMEOUT_MS", "300", 1); // read when a communicator is created
+    wg_ctx *ctx[2] = { nullptr, nullptr };
+    wg_comm *comm[2] = { nullptr, nullptr };
+    wg_buf *a[2] = {}, *b[2] = {}, *c[2] = {}, *st[2] = {}, *fl[2] = {};
+    auto A = rnd<T>((size_t)M * K, 41), B = rnd<T>((size_t)K * N, 42);
+    for (uint32_t g = 0; g < P; ++g) {
+        CK(wg_ctx_create(0, &ctx[g]));
+        CK(wg_comm_create(ctx[g], P, g, nullptr, &comm[g]));
+        auto Ag = row_block(A, false, M, K, g, mg);
+        CK(wg_buf_create_init(ctx[g], Ag.data(), Ag.size() * sizeof(T), USAGE, &a[g]));
+        CK(wg_buf_create_init(ctx[g], B.data(), B.size() * sizeof(T), USAGE, &b[g]));
+        CK(wg_buf_create(ctx[g], (size_t)M * N * sizeof(T), USAGE, &c[g]));
+        CK(wg_comm_stage_reserve(comm[g], 2 * (size_t)M * N * sizeof(T), &st[g], &fl[g]));
+    }
+    unsetenv("WG_COMM_TIMEOUT_MS");
+    for (uint32_t g = 0; g < P; ++g) CK(wg_comm_set_peer_stages(comm[g], st, fl));
+    auto step = [&](uint32_t g) { return wg_gemm_sharded(comm[g], WG_GEMM, WG_F16, WG_GATHER_PEER_STAGED, panel, c[g], mat(M, N), a[g], mat(mg, K), b[g], mat(K, N)); };
+    EXPECT(step(0) == WG_OK, "step 1 of rank 0: %s", wg_last_error_string());
+    const int rc = wg_ctx_sync(ctx[0]); // rank 1 never sent: the wait gives up after 300 ms
+    EXPECT(rc == WG_ERR_HIP && std::strstr(wg_last_error_string(), "did not arrive") != nullptr, "time-out must surface in wg_ctx_sync: rc %d, %s", rc, wg_last_error_string());
+    { // ... and what rank 0 holds for rank 1's rows is poison, not stale data
+        std::vector<T> got((size_t)M * N);
+        CK(wg_buf_read(ctx[0], c[0], 0, got.data(), got.size() * sizeof(T)));
+        size_t nan = 0;
+        for (uint32_t j = 0; j < N; ++j)
+            for (uint32_t i = mg; i < M; ++i) nan += std::isnan((float)got[(size_t)j * M + i]) ? 1 : 0;
+        EXPECT(nan == (size_t)mg * N, "poisoned rows: %zu of %zu are NaN", nan, (size_t)mg * N);
+    }
+    EXPECT(wg_ctx_sync(ctx[0]) == WG_OK, "a reported time-out is a cleared time-out: %s", wg_last_error_string());
+    EXPECT(step(1) == WG_OK, "step 1 of rank 1 (late): %s", wg_last_error_string());
+    for (int rep = 0; rep < 2; ++rep) // step 2 and 3 on both ranks
+        for (uint32_t g = 0; g < P; ++g) EXPECT(step(g) == WG_OK, "step %d of rank %u: %s", rep + 2, g, wg_last_error_string());
+    for (uint32_t g = 0; g < P; ++g) {
+        EXPECT(wg_ctx_sync(ctx[g]) == WG_OK, "sync after the retry, rank %u: %s", g, wg_last_error_string());
+        std::vector<T> got((size_t)M * N);
+        CK(wg_buf_read(ctx[g], c[g], 0, got.data(), got.size() * sizeof(T)));
+        char what[96];
+        std::snprintf(what, sizeof what, "staged retry after a time-out, rank %u", g);
+        check_product(what, got, A, false, B, M, N, K);
+        EXPECT(wg_comm_flush(comm[g]) == WG_OK, "flush: %s", wg_last_error_string());
+    }
+    for (uint32_t g = 0; g < P; ++g) {
+        wg_comm_destroy(comm[g]);
+        wg_buf_destroy(a[g]); wg_buf_destroy(b[g]); wg_buf_destroy(c[g]);
+        wg_ctx_destroy(ctx[g]);
+    }
+}
+
+// Pipelined one-launch RCCL steps whose shapes alternate (small, big, small, big): a step's last panel is still waiting for its relayout in
+// its own cube while the next step's kernel -- enqueued first -- writes the other cube. The cubes sit at fixed offsets, so a smaller step
+// cannot land on the bigger previous step's cube (round-3 review: offsets used to follow the CURRENT step's M * N).
+static void rccl_pipelined_alternating_shapes(wg_ctx *ctx, wg_comm *comm) {
+    typedef _Float16 T;
+    const uint32_t K = 256, shapes[4][3] = { { 4096, 4096, 1024 }, { 4096, 5120, 1024 }, { 4096, 4096, 2048 }, { 4096, 5120, 1280 } }; // M, N, panel_cols (>= 256 tiles each)
+    auto A = rnd<T>((size_t)4096 * K, 51), B = rnd<T>((size_t)K * 5120, 52);
+    wg_buf *a = nullptr, *b = nullptr, *c[4] = {};
+    CK(wg_buf_create_init(ctx, A.data(), A.size() * sizeof(T), USAGE, &a));
+    CK(wg_buf_create_init(ctx, B.data(), B.size() * sizeof(T), USAGE, &b));
+    CK(wg_comm_set_pipelined(comm, 1));
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t M = shapes[s][0], N = shapes[s][1];
+        CK(wg_buf_create(ctx, (size_t)M * N * sizeof(T), USAGE, &c[s]));
+        CK(wg_buf_fill_zero(ctx, c[s]));
+        CK(wg_gemm_sharded(comm, WG_GEMM, WG_F16, WG_GATHER_RCCL, shapes[s][2], c[s], mat(M, N), a, mat(M, K), b, mat(K, N)));
+    }
+    CK(wg_comm_join(comm));
+    for (int s = 0; s < 4; ++s) {
+        const uint32_t M = shapes[s][0], N = shapes[s][1];
+        std::vector<T> got((size_t)M * N), Bs(B.begin(), B.begin() + (size_t)K * N);
+        CK(wg_buf_read(ctx, c[s], 0, got.data(), got.size() * sizeof(T)));
+        char what[96];
+        std::snprintf(what, sizeof what, "rccl pipelined, alternating shapes: step %d (%ux%u)", s, M, N);
+        check_product(what, got, A, false, Bs, M, N, K);
+        wg_buf_destroy(c[s]);
+    }
+    CK(wg_comm_set_pipelined(comm, 0));
+    wg_buf_destroy(a); wg_buf_destroy(b);
 }
 
 static void cube_relayout(wg_ctx *ctx) {
@@ -213,14 +259,14 @@ static void errors_and_export(wg_ctx *ctx) {
     CK(wg_buf_create(ctx, 64 * 128 * 4, USAGE, &b));
     CK(wg_buf_create(ctx, 512 * 128 * 4, USAGE, &c));
     // M = 2 * rows(a_rows) must hold; K and N must match (gemm.rs:91-95 on the sharded operands)
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(500, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_DIM_MISMATCH, "M != P * rows");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(500, 128), a, mat(256, 64), b, mat(64, 128)) == WG_ERR_DIM_MISMATCH, "M != P * rows");
     EXPECT(std::strstr(wg_last_error_string(), "Gemm: dimension mismatch.") != nullptr, "message: %s", wg_last_error_string());
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(60, 128)) == WG_ERR_DIM_MISMATCH, "K mismatch");
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 6, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_PRECONDITION, "panel_cols not a multiple of 4");
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_RCCL, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_UNSUPPORTED, "RCCL mode without a unique id");
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_PEER_COPY, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "peer mode without peers");
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, (wg_gather_mode)9, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "unknown mode");
-    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), nullptr, a, mat(256, 64), b, mat(64, 128)) == WG_OK, "local-only mode: %s", wg_last_error_string());
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), a, mat(256, 64), b, mat(60, 128)) == WG_ERR_DIM_MISMATCH, "K mismatch");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 6, c, mat(512, 128), a, mat(256, 64), b, mat(64, 128)) == WG_ERR_PRECONDITION, "panel_cols not a multiple of 4");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_RCCL, 0, c, mat(512, 128), a, mat(256, 64), b, mat(64, 128)) == WG_ERR_UNSUPPORTED, "RCCL mode without a unique id");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, (wg_gather_mode)1, 0, c, mat(512, 128), a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "gather mode 1 (the removed rect-copy engine)");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, (wg_gather_mode)9, 0, c, mat(512, 128), a, mat(256, 64), b, mat(64, 128)) == WG_ERR_INVALID_ARG, "unknown mode");
+    EXPECT(wg_gemm_sharded(comm, WG_GEMM, WG_F32, WG_GATHER_NONE, 0, c, mat(512, 128), a, mat(256, 64), b, mat(64, 128)) == WG_OK, "local-only mode: %s", wg_last_error_string());
     EXPECT(wg_all_gather(comm, WG_F32, c, 0, 16) == WG_ERR_UNSUPPORTED && wg_comm_barrier(comm) == WG_ERR_UNSUPPORTED, "collectives without a library");
     // export of a wrapped interior pointer: the handle names the base allocation and carries the offset
     wg_buf *inner = nullptr;
@@ -267,16 +313,19 @@ int main() {
     rccl_one_rank<float>(ctx, comm, true, 512, 768, 256, 512); // ragged last panel
     rccl_one_rank<_Float16>(ctx, comm, false, 1024, 1280, 512, 512);
     rccl_one_rank<_Float16>(ctx, comm, true, 1024, 1280, 512, 0);
+    {
+        int reported = -1;
+        EXPECT(wg_comm_reported_size(comm, &reported) == WG_OK && reported == 1, "ncclCommCount: %d (%s)", reported, wg_last_error_string());
+    }
+    rccl_pipelined_alternating_shapes(ctx, comm);
     wg_comm_destroy(comm);
 
-    peer_two_ranks<float>(false, 512, 768, 256, 256);
-    peer_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
-    peer_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
     staged_two_ranks<float>(false, 512, 768, 256, 256);
     staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
     staged_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
     staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512, /*pipelined=*/true);
     staged_two_ranks<float>(true, 512, 768, 256, 256, /*pipelined=*/true);
+    staged_timeout_and_retry();
     wg_ctx_destroy(ctx);
     if (failures == 0) std::printf("ALL OK\n");
     return failures ? 1 : 0;

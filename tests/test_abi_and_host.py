@@ -21,7 +21,9 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, f"include/wgebra_hip.h declares symbols the library does not export: {missing}"
     assert set(declared) == set(_lib.lib._wg_signatures), "the ctypes binding and the header disagree on the entry points"
-    assert _lib.lib.wg_abi_version() == 2  # 2: + WG_ERR_WORKSPACE, the multi-GPU section (wg_comm_*, wg_gemm_sharded)
+    # 3: the SDMA rect-copy exchange engine is gone (gather mode 1, wg_comm_copy_engine, peer_out), + wg_comm_reported_size, wg_debug_clock_*, wg_debug_mfma_ceiling
+    hdr = open(_lib.HEADER_PATH).read()
+    assert _lib.lib.wg_abi_version() == _lib.ABI_VERSION == 3 and f"#define WGEBRA_HIP_ABI_VERSION {_lib.ABI_VERSION} " in hdr
 
 
 def test_exported_symbols_are_plain_c():
@@ -317,17 +319,20 @@ def test_multi_gpu_entry_points_reject_null_handles_without_a_device():
     L, S = _lib.lib, _lib.ViewShapeC()
     out = ctypes.c_void_p()
     assert L.wg_comm_create(None, 2, 0, None, ctypes.byref(out)) == _lib.WG_ERR_INVALID_ARG and not out.value
-    assert L.wg_gemm_sharded(None, 0, 0, 0, 0, None, S, None, None, S, None, S) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_gemm_sharded(None, 0, 0, 0, 0, None, S, None, S, None, S) == _lib.WG_ERR_INVALID_ARG
     assert b"NULL" in L.wg_last_error_string()
     assert L.wg_all_gather(None, 0, None, 0, 0) == _lib.WG_ERR_INVALID_ARG
     assert L.wg_cube_to_matrix(None, 0, None, S, None, S) == _lib.WG_ERR_INVALID_ARG
     assert L.wg_comm_stage_reserve(None, 0, ctypes.byref(out), ctypes.byref(out)) == _lib.WG_ERR_INVALID_ARG
     assert L.wg_comm_barrier(None) == _lib.WG_ERR_INVALID_ARG and L.wg_comm_flush(None) == _lib.WG_ERR_INVALID_ARG
-    assert L.wg_comm_size(None) == 0 and L.wg_comm_rank(None) == -1 and L.wg_comm_copy_engine(None) == b"none"
+    assert L.wg_comm_size(None) == 0 and L.wg_comm_rank(None) == -1 and L.wg_comm_reported_size(None, None) == _lib.WG_ERR_INVALID_ARG
     assert L.wg_comm_destroy(None) == _lib.WG_OK
+    d = ctypes.c_double()
+    assert L.wg_debug_clock_begin(None) == _lib.WG_ERR_INVALID_ARG and L.wg_debug_clock_end(None, ctypes.byref(d), None, None, None) == _lib.WG_ERR_INVALID_ARG
+    assert L.wg_debug_mfma_ceiling(None, 1.0, ctypes.byref(d), None) == _lib.WG_ERR_INVALID_ARG
     # the gather modes the Python mirror names are the header's
     from wgmath_amd.sharded import GatherMode
     hdr = open(_lib.HEADER_PATH).read()
-    for name, val in (("WG_GATHER_RCCL", GatherMode.RCCL), ("WG_GATHER_PEER_COPY", GatherMode.PEER_COPY), ("WG_GATHER_NONE", GatherMode.NONE),
-                      ("WG_GATHER_PEER_STAGED", GatherMode.PEER_STAGED)):
+    for name, val in (("WG_GATHER_RCCL", GatherMode.RCCL), ("WG_GATHER_NONE", GatherMode.NONE), ("WG_GATHER_PEER_STAGED", GatherMode.PEER_STAGED)):
         assert f"{name} = {val}" in hdr
+    assert "WG_GATHER_PEER_COPY =" not in hdr and not hasattr(GatherMode, "PEER_COPY")  # the SDMA rect-copy engine is gone (ABI 3)

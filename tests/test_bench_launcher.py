@@ -29,6 +29,13 @@ def test_self_launch_two_ranks_dry_run():
     assert line["config"]["all_gather_bytes_per_step"] == 64 * 96 * 4
     assert line["scaling"] == "strong" and line["higher_is_better"] is True
     assert "dry-run" in line["data"]
+    # what a multi-rank line says about its CU split and about the rank count the collective library itself reports (none in a dry run)
+    assert line["config"]["comm_compute_units"] in (0, 4, 8) and line["config"]["rccl_reported_ranks"] == 0
+
+
+def test_rccl_engine_variants_leave_4_and_8_compute_units():
+    import bench
+    assert bench.ENGINES == ["rccl", "rccl_cus4", "staged"] and bench.ENGINE_COMM_CUS == {"rccl": 8, "rccl_cus4": 4}
 
 
 def test_self_launch_fails_cleanly_without_enough_gpus():
@@ -51,22 +58,24 @@ def test_failing_rank_fails_the_launch():
 def test_hanging_engine_trial_times_out_and_the_next_engine_runs():
     """--gather auto with N > 1 ranks: every exchange engine's trial runs as a fresh child group with a time limit, started by ranks that
     have not touched the GPU. Here (dry run) rank 1 of the FIRST engine's trial sleeps forever -- what a collective that never completes
-    looks like -- and the second engine's trial fails on rank 0: the launch must still print ONE JSON line, from the third engine, well
-    inside the limits, with both failures recorded."""
+    looks like -- and the second engine's trial (the RCCL engine again, with 4 CUs left to its kernels) fails on rank 0: the launch must still
+    print ONE JSON line, from the third engine, well inside the limits, with both failures recorded."""
     import time
     t0 = time.time()
     r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--gather", "auto",
-             env={"WG_BENCH_DRY_HANG": "rccl:1", "WG_BENCH_DRY_FAIL": "staged:0", "WG_BENCH_TRIAL_TIMEOUT": "25", "WG_BENCH_LAUNCH_TIMEOUT": "300"})
+             env={"WG_BENCH_DRY_HANG": "rccl:1", "WG_BENCH_DRY_FAIL": "rccl_cus4:0", "WG_BENCH_TRIAL_TIMEOUT": "25", "WG_BENCH_LAUNCH_TIMEOUT": "300"})
     assert r.returncode == 0, r.stdout + r.stderr
     assert time.time() - t0 < 240
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     cfg = line["config"]
-    assert cfg["gather_engine"] == "peer" and cfg["chosen"] == "peer"
+    assert cfg["gather_engine"] == "staged" and cfg["chosen"] == "staged"
     assert cfg["engine_trials"]["rccl"] == {"ms_per_step": None, "error": "timeout"}
-    assert cfg["engine_trials"]["staged"]["ms_per_step"] is None and cfg["engine_trials"]["staged"]["error"]
-    assert cfg["engine_trials"]["peer"]["ms_per_step"] > 0
+    assert cfg["engine_trials"]["rccl_cus4"]["ms_per_step"] is None and cfg["engine_trials"]["rccl_cus4"]["error"]
+    assert cfg["engine_trials"]["staged"]["ms_per_step"] > 0
+    assert set(cfg["engine_trials"]) == {"rccl", "rccl_cus4", "staged"}  # the RCCL engine is tried with 8 and with 4 CUs left to its kernels
+    assert cfg["comm_compute_units"] == 0 and cfg["rccl_reported_ranks"] == 0  # staged engine: every CU computes; the dry run has no RCCL
     assert cfg["ranks"] == 2 and cfg["all_gather_bytes_per_step"] == 64 * 96 * 4  # the contract's fields are still there
 
 
@@ -74,7 +83,7 @@ def test_every_engine_hanging_fails_the_launch_in_bounded_time():
     import time
     t0 = time.time()
     r = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--gather", "auto",
-             env={"WG_BENCH_DRY_HANG": "rccl:0,staged:1,peer:0", "WG_BENCH_TRIAL_TIMEOUT": "10", "WG_BENCH_LAUNCH_TIMEOUT": "200"})
+             env={"WG_BENCH_DRY_HANG": "rccl:0,rccl_cus4:1,staged:0", "WG_BENCH_TRIAL_TIMEOUT": "10", "WG_BENCH_LAUNCH_TIMEOUT": "200"})
     assert r.returncode != 0
     assert time.time() - t0 < 150
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -101,84 +101,11 @@ def test_sharded_gemm_two_ranks_one_gpu():
 
 
 # --------------------------------------------------------------------------------------------------------
-# The product path of the multi-rank run, two processes on ONE GPU: wg_comm (no collective library: RCCL refuses two ranks on one
-# device), the output buffers exchanged as IPC handles (wg_buf_ipc_export / _open), wg_gemm_sharded(WG_GATHER_PEER_COPY): every rank's
-# Gemm writes its rows of its own M x N C and the copy engine pushes them into the peer's C. Both ranks must hold the plain
-# column-major product -- a GpuMatrix any Gemm::dispatch operand can consume (gemm.rs:65-74), which is then fed to one.
-# --------------------------------------------------------------------------------------------------------
-def _peer_worker(rank, world, port, engine, q):
-    try:
-        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        os.environ["WG_PEER_COPY_ENGINE"] = engine
-        import torch  # first: one HIP runtime per process
-        import torch.distributed as dist
-        import wgmath_amd as wg
-        from wgmath_amd.sharded import Comm, GatherMode
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        M, N, K = 1024, 1536, 512
-        Mg = M // world
-        gpu = wg.GpuInstance.new(0)
-        dev, S = gpu.device(), wg.BufferUsages
-        rng = np.random.default_rng(99)
-        A = (rng.random((M, K), dtype=np.float32) * 2 - 1).astype(np.float16)
-        B = (rng.random((K, N), dtype=np.float32) * 2 - 1).astype(np.float16)
-        ta = wg.TensorBuilder.matrix(Mg, K, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(A[rank * Mg:(rank + 1) * Mg].reshape(-1, order="F")))
-        tb = wg.TensorBuilder.matrix(K, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ascontiguousarray(B.reshape(-1, order="F")))
-        tc = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.full(M * N, np.nan, np.float16))
-        comm = Comm(gpu, world, rank, None)
-        handles = [None] * world
-        dist.all_gather_object(handles, comm.export_handle(tc))
-        comm.register_peers(tc, handles)
-        dist.barrier()  # every rank's C is allocated, initialised and mapped before anyone pushes into it
-        for _ in range(2):
-            comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_COPY, 512)
-            gpu.sync()
-            comm.flush()
-            dist.barrier()
-        got = tc.read(dev).reshape(M, N, order="F").astype(np.float64)
-        A64, B64 = A.astype(np.float64), B.astype(np.float64)
-        truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
-        tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
-        ok = bool((np.abs(got - truth) <= tol).all())
-        # the gathered C is an ordinary GpuMatrix: use it as the m1 of another Gemm (C^T C would overflow f16: scale by a thin m2)
-        thin = (rng.random((N, 8), dtype=np.float32) / N).astype(np.float16)
-        tt = wg.TensorBuilder.matrix(N, 8, S.STORAGE | S.COPY_DST).build_init(dev, np.ascontiguousarray(thin.reshape(-1, order="F")))
-        to = wg.TensorBuilder.matrix(M, 8, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.zeros(M * 8, np.float16))
-        p = dev.create_command_encoder().compute_pass("use", None)
-        wg.Gemm.from_device(dev).dispatch(dev, wg.ViewShapeBuffers(), p, to, tc, tt)
-        used = to.read(dev).reshape(M, 8, order="F").astype(np.float64)
-        ref = tc.read(dev).reshape(M, N, order="F").astype(np.float64) @ thin.astype(np.float64)
-        ok2 = bool(np.abs(used - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3)
-        dist.barrier()
-        q.put((rank, ok and ok2, f"engine {comm.copy_engine}, sent {comm.bytes_sent} B, product ok={ok}, consumable ok={ok2}"))
-        comm.close()
-        dist.destroy_process_group()
-    except Exception as e:  # pragma: no cover
-        import traceback
-        q.put((rank, False, traceback.format_exc() + str(e)))
-
-
-@pytest.mark.parametrize("engine", ["sdma", "hip2d"])
-def test_two_ranks_one_gpu_peer_copy_gives_a_plain_matrix(engine):
-    import multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q, port, world = ctx.Queue(), _free_port(), 2
-    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, engine, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(60)
-    for rank, ok, msg in res:
-        assert ok, f"rank {rank}: {msg}"
-    assert any(("sdma-rect" if engine == "sdma" else "hip2d") in m for _, _, m in res)
-
-
-# --------------------------------------------------------------------------------------------------------
-# The engine for more than two ranks (WG_GATHER_PEER_STAGED), two processes on one GPU: staging cubes + flag arrays exchanged as IPC
-# handles, contiguous per-peer copies + sequence-number flags, wait kernel + relayout on the receiving stream -- and NO host
-# synchronisation or barrier between three back-to-back steps (stream-ordered, double-buffered by step parity).
+# The copy-engine exchange (WG_GATHER_PEER_STAGED), two processes on one GPU (RCCL refuses two ranks on one device): staging cubes +
+# flag arrays exchanged as IPC handles (wg_buf_ipc_export / _open), contiguous per-peer copies + sequence-number flags, wait kernel +
+# relayout on the receiving stream -- and NO host synchronisation or barrier between three back-to-back steps (stream-ordered,
+# double-buffered by step parity). Both ranks must hold the plain column-major product -- a GpuMatrix any Gemm::dispatch operand can
+# consume (gemm.rs:65-74), which is then fed to one.
 # --------------------------------------------------------------------------------------------------------
 def _staged_worker(rank, world, port, q):
     try:
@@ -215,9 +142,18 @@ def _staged_worker(rank, world, port, q):
         truth, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
         tol = 2 * 2.0 * np.sqrt(K) * 2.0 ** -24 * sabs + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
         ok = bool((np.abs(got - truth) <= tol).all())
+        # the gathered C is an ordinary GpuMatrix: use it as the m1 of another Gemm (C^T C would overflow f16: scale by a thin m2)
+        thin = (rng.random((N, 8), dtype=np.float32) / N).astype(np.float16)
+        tt = wg.TensorBuilder.matrix(N, 8, S.STORAGE | S.COPY_DST).build_init(dev, np.ascontiguousarray(thin.reshape(-1, order="F")))
+        to = wg.TensorBuilder.matrix(M, 8, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.zeros(M * 8, np.float16))
+        p = dev.create_command_encoder().compute_pass("use", None)
+        wg.Gemm.from_device(dev).dispatch(dev, wg.ViewShapeBuffers(), p, to, tc, tt)
+        used = to.read(dev).reshape(M, 8, order="F").astype(np.float64)
+        ref = tc.read(dev).reshape(M, N, order="F").astype(np.float64) @ thin.astype(np.float64)
+        ok2 = bool(np.abs(used - ref).max() <= 2.0 ** -9 * np.abs(ref).max() + 1e-3)
         comm.flush()
         dist.barrier()
-        q.put((rank, ok, f"sent {comm.bytes_sent} B, product ok={ok}"))
+        q.put((rank, ok and ok2, f"sent {comm.bytes_sent} B, product ok={ok}, consumable ok={ok2}"))
         comm.close()
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
@@ -384,3 +320,65 @@ def test_two_ranks_one_gpu_one_launch_per_step():
         p.join(60)
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+# --------------------------------------------------------------------------------------------------------
+# BASELINE config 5 at FULL size with two ranks: f16 32768^3, M-sharded over two processes that share the one GPU, through the bench's own
+# launcher (one JSON line, rank 0's sanity check reads rows the OTHER rank computed). The size at which the removed SDMA rect-copy engine
+# used to hang; the staged engine must finish well inside the limit.
+# --------------------------------------------------------------------------------------------------------
+def test_two_processes_one_gpu_config5_full_size_staged():
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WG_BENCH_OVERSUBSCRIBE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", WG_BENCH_LAUNCH_TIMEOUT="600")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--gather", "staged", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["workload"] == "gemm_f16_32768" and line["config"]["gather_engine"] == "staged"
+    assert line["config"]["all_gather_bytes_per_step"] == 16384 * 32768 * 2 and line["value"] > 100.0
+
+
+# --------------------------------------------------------------------------------------------------------
+# The bench line itself (tests/test_bench_launcher.py checks the launcher on CPU; these need the GPU): the single-GPU line ends with the scalar
+# `targets` object and carries the clock measured in the run + the MFMA-only ceiling; the communicator path (WG_BENCH_FORCE_DIST=1: RCCL with
+# one rank) reports the rank count RCCL itself gives and the CU split.
+# --------------------------------------------------------------------------------------------------------
+def _bench_line(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_line_ends_with_targets_and_carries_the_measured_clock():
+    line = _bench_line("--workload", "gemm_f16_8192", "--steps", "20", "--warmup", "5", "--no-secondary", "--no-cpu-baseline")
+    assert list(line)[-1] == "targets" and all(not isinstance(v, (dict, list)) for v in line["targets"].values())
+    rf, t = line["roofline"], line["targets"]
+    assert 0.8 < rf["clock_ghz_measured"] < 2.6 and rf["clock_ghz_xcd_min_max"][0] <= rf["clock_ghz_measured"] <= rf["clock_ghz_xcd_min_max"][1]
+    assert 1200.0 < rf["mfma_only_ceiling_tflops"] < 2600.0 and 0.3 < rf["frac_of_ceiling"] < 1.05
+    assert abs(rf["frac_at_measured_clock"] - rf["frac"] * 2.4 / rf["clock_ghz_measured"]) < 2e-3
+    assert t["c3_gemm_f16_8192_tflops"] == round(line["value"], 1) and t["c3_gemm_f16_8192_frac"] == rf["frac"] and t["c3_gemm_f16_8192_ghz"] == rf["clock_ghz_measured"]
+    assert line["config"]["c3_gemm_f16_8192_tflops"] == t["c3_gemm_f16_8192_tflops"]  # flat scalars in `config` too
+    assert 0 < line["checks"]["parity_max_ulp_vs_f64_f16_gemm"] <= 1.0  # one rounding of an f32 accumulation: within an f16 ulp of f64
+
+
+def test_bench_communicator_path_reports_rccl_rank_count_and_cu_split():
+    line = _bench_line("--workload", "gemm_f16_8192", "--gather", "rccl", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline",
+                       env={"WG_BENCH_FORCE_DIST": "1"})
+    cfg = line["config"]
+    assert cfg["gather_engine"] == "rccl" and cfg["ranks"] == 1
+    assert cfg["rccl_reported_ranks"] == 1  # ncclCommCount through wg_comm_reported_size
+    assert cfg["comm_compute_units"] == 0 and cfg["stream_compute_units"] == cfg["compute_units"]  # one rank: nothing to leave to RCCL
+    assert list(line)[-1] == "targets"

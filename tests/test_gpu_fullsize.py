@@ -199,7 +199,7 @@ def test_addressing_beyond_4GiB(gpu):
 # config 5: f16 GEMM 32768^3 through the M-sharded entry point (wg_gemm_sharded). One GPU here, so one rank -- but the whole
 # path: a real RCCL communicator created through the C ABI, staging cube + ncclAllGather + cube_to_matrix relayout per N-panel
 # (WG_GATHER_RCCL), on the unmasked 256-CU stream and on the 224-CU masked stream the multi-rank bench gives that engine, and the
-# panel-wise strided-output path of the peer-copy engine (WG_GATHER_PEER_COPY). >= 64 sampled rows x 512 columns against f64.
+# panel-wise strided-output path straight into C (WG_GATHER_NONE). >= 64 sampled rows x 512 columns against f64.
 # --------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("engine", ["rccl", "staged"])
 @pytest.mark.parametrize("cus", [None, 248, -248])  # -248: the 8 missing CUs all from one XCD (wg_ctx_create_with_cu_count_one_xcd: what bench.py gives the RCCL engine)
@@ -286,7 +286,7 @@ def test_sharded_gemm_pipelined_steps_one_launch(engine):
     inst.close()
 
 
-@pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("rccl", 248), ("peer", None)])
+@pytest.mark.parametrize("engine,cus", [("rccl", None), ("rccl", 224), ("rccl", 248), ("none", None)])
 def test_config5_gemm_f16_32768_sharded_entry_point(engine, cus):
     import os
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -303,7 +303,7 @@ def test_config5_gemm_f16_32768_sharded_entry_point(engine, cus):
     B = bench.device_random(wg, inst, (n, n), np.float16, 0xB000)
     C = wg.TensorBuilder.matrix(n, n, S_ALL).build(dev, np.float16)
     panel = bench.plan_panel_cols(n, n, cus or 256)
-    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.PEER_COPY
+    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.NONE  # NONE: the panel-wise strided-output path (one rank: all of C)
     comm.sharded_gemm(C, A, B, 0, mode, panel)
     comm.barrier()  # flush + 1-element all-reduce joined into the stream (what separates two steps of the bench)
     inst.sync()

@@ -1431,3 +1431,31 @@ def test_reduce_fast_f16(gpu, oracle_c, n, off):
             sabs = np.abs(xs).sum() if op == wg.ReduceOp.Sum else (xs * xs).sum()
             tol = n * 2.0 ** -24 * sabs + 2.0 ** -10 * abs(truth) + 2.0 ** -24
             assert abs(float(b) - truth) <= tol and abs(float(a) - truth) <= tol, (op, float(a), float(b), truth)
+
+
+@pytest.mark.parametrize("R,C", [(4096, 1004), (2048, 2500), (512, 68), (1024, 1000)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_gemv_inf_in_the_last_column_stays_inf(gpu, R, C, dtype):
+    """A wave's last < 64 columns are loaded in groups (gemv.hip); slots past the end re-load the last valid column and must contribute an exact
+    zero -- not (last column) x 0, which is NaN where that column holds an Inf. The reference kernel (gemv.wgsl:28-65) never touches a column
+    past the end: +-Inf in the last column gives +-Inf in that row, and no NaN anywhere (round-3 review)."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(R + C)
+    m = rng.random(R * C, dtype=np.float32).astype(dtype)
+    v = (rng.random(C, dtype=np.float32) + np.float32(0.5)).astype(dtype)
+    M2 = m.reshape(R, C, order="F")
+    M2[5, C - 1], M2[9, C - 1], M2[R - 1, C - 1] = np.inf, -np.inf, np.inf
+    tm, tv = upload(gpu, (R, C), m, dtype), upload(gpu, (C,), v, dtype)
+    out = upload(gpu, (R,), np.zeros(R, dtype), dtype)
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch(gpu.device(), shapes, p, out, tm, tv))
+    got = out.read(gpu.device()).astype(np.float64)
+    assert not np.isnan(got).any(), f"{int(np.isnan(got).sum())} NaN rows"
+    assert got[5] == np.inf and got[9] == -np.inf and got[R - 1] == np.inf
+    fin = np.ones(R, bool)
+    fin[[5, 9, R - 1]] = False
+    assert np.isfinite(got[fin]).all()
+    if dtype == np.float32:  # the restated kernel agrees on which rows are infinite
+        orc = np.zeros(R, np.float32)
+        wo.CLib().gemv(wo.GEMV, orc, wo.Shape(R), m, wo.Shape(R, C), v, wo.Shape(C))
+        assert np.array_equal(np.isinf(orc), np.isinf(got)) and not np.isnan(orc).any()

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """What ONE rank of a P-rank M-sharded f16 Gemm 32768^3 does, emulated on one GPU -- the measured inputs of DESIGN.md section 6's
-expected multi-GPU speed-up. Rank 0 of P computes its (M/P x N) row block panel by panel on all 256 CUs; with the peer-copy engine its
-SDMA engines push every panel's block into P-1 peer buffers -- here P-1 other buffers of the SAME device, so the local HBM sees the reads
-of the outgoing copies plus writes standing in for the incoming ones (the link is the part a single GPU cannot show: a same-device SDMA
-rect copy runs at ~60 GB/s, about the xGMI per-direction rate). Reports, per P: ms per step with no exchange, with the exchange, the
-exposed tail after the last Gemm, and the copy rate. Usage: python tools/rank_emulation.py [P ...] > gpurun_out/rank_emulation.json"""
+expected multi-GPU speed-up. Rank 0 of P computes its (M/P x N) row block panel by panel on all 256 CUs (no exchange), then the staged
+engine's compute side (Gemm into the staging cube + relayout of every panel, copies switched off: what the per-link SDMA copies run beside;
+the link itself is the part a single GPU cannot show). (The SDMA rect-copy engine this tool also emulated up to round 3 was removed in ABI 3.)
+Reports, per P: ms per step. Usage: python tools/rank_emulation.py [P ...] > gpurun_out/rank_emulation.json"""
 import json
 import os
 import sys
@@ -29,16 +28,10 @@ for P in Ps:
     A = bench.device_random(wg, gpu, (Mg, K), np.float16, 0xA000)
     B = bench.device_random(wg, gpu, (K, N), np.float16, 0xB000)
     C = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(dev, np.float16)
-    npeers = min(P - 1, 3)  # 3 stand-in buffers are enough to keep 3 engines busy; more peers reuse them round-robin
-    peers = [wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_DST).build(dev, np.float16) for _ in range(npeers)]
     comm = Comm(gpu, P, 0, None)
-    if P > 1:
-        comm.register_local_peers(C, [C] + [peers[i % npeers] for i in range(P - 1)])
     panel = bench.plan_panel_cols(Mg, N, 256)
-    res = {"rows_per_rank": Mg, "panel_cols": panel, "panels": -(-N // panel), "copy_engine": comm.copy_engine}
-    for mode, name in ((GatherMode.NONE, "no_exchange"), (GatherMode.PEER_COPY, "peer_copy")):
-        if P == 1 and mode == GatherMode.PEER_COPY:
-            continue
+    res = {"rows_per_rank": Mg, "panel_cols": panel, "panels": -(-N // panel)}
+    for mode, name in ((GatherMode.NONE, "no_exchange"),):
         for _ in range(2):
             comm.sharded_gemm(C, A, B, 0, mode, panel)
             gpu.sync(); comm.flush()
@@ -53,10 +46,6 @@ for P in Ps:
         dt = (time.perf_counter() - t0) / STEPS
         res[name] = {"ms_per_step": round(dt * 1e3, 3), "exposed_tail_ms": round(float(np.mean(tails)) * 1e3, 3),
                      "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1)}
-        if mode == GatherMode.PEER_COPY:
-            sent = (P - 1) * Mg * N * 2
-            res[name]["bytes_pushed_per_step"] = sent
-            res[name]["aggregate_push_gbs_if_fully_overlapped"] = round(sent / dt / 1e9, 1)
     # the staged engine's compute side: the rank's Gemm into the staging cube + the relayout of every panel, copies switched off
     # (WG_STAGED_NO_COPY) and the flags pre-set so that the wait kernels pass: what the contiguous per-link copies run BESIDE.
     # Panel by panel (round 2's form) and as ONE launch per step (round 3), on all 256 CUs; and on a 248-CU masked stream = the compute
@@ -98,7 +87,7 @@ for P in Ps:
         res["rccl_compute_side_248_cus"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "stream_compute_units": 248}
         comm2.close()
         gpu2.close()
-    del A, B, C, peers
+    del A, B, C
     gpu.close()
 # the best single-GPU run: the plain 32768^3 Gemm (one launch, tile scheduler on) -- what every speed-up below is against
 gpu = wg.GpuInstance.new(0)
@@ -124,8 +113,6 @@ SLOW = {2: 1.006, 4: 1.023, 8: 1.048}
 ENGINE_GBS = 60.7
 if t1:
     for P, r in out["ranks"].items():
-        if "peer_copy" in r:
-            r["expected_speedup_rect_engine"] = round(t1 / r["peer_copy"]["ms_per_step"], 3)
         if "staged_compute_and_relayout" in r:
             sc = r["staged_compute_and_relayout"]
             tail = sc["last_panel_bytes_per_peer"] / (ENGINE_GBS * 1e6)  # ms: the last panel's slot on one link, nothing left to hide it under

@@ -14,8 +14,9 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "wgebra_hip.h")
 # status codes (wg_status)
 WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_OF_BOUNDS, WG_ERR_HIP, \
     WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE, WG_ERR_WORKSPACE = range(9)
-WG_GATHER_RCCL, WG_GATHER_PEER_COPY, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 1, 2, 3
+WG_GATHER_RCCL, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 2, 3  # (1 was the SDMA rect-copy engine: removed in ABI 3)
 WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
+ABI_VERSION = 3  # == WGEBRA_HIP_ABI_VERSION (checked when the library is loaded, and against the header by tests/test_abi_and_host.py)
 WG_F32, WG_F16 = 0, 1
 WG_TUNE_F16_TILE, WG_TUNE_F16_SCHED, WG_TUNE_F32_SKINNY, WG_TUNE_F32_PANELS, WG_TUNE_F16_BALANCE = range(5)
 
@@ -66,6 +67,7 @@ def _load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C wgmath_amd/csrc`. There is no CPU fallback.")
     lib = ctypes.CDLL(LIB_PATH)
+    pd = ctypes.POINTER(ctypes.c_double)
     vp, cp, ci, u32, u64, sz = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_size_t
     pvp = ctypes.POINTER(vp)
     S = ViewShapeC
@@ -110,13 +112,16 @@ def _load() -> ctypes.CDLL:
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
         "wg_axpy": (ci, [vp, ctypes.c_float, ci, vp, S, vp, S]),
+        "wg_debug_clock_begin": (ci, [vp]),
+        "wg_debug_clock_end": (ci, [vp, pd, pd, pd, pd]),
+        "wg_debug_mfma_ceiling": (ci, [vp, ctypes.c_double, pd, pd]),
         "wg_comm_unique_id": (ci, [vp]),
         "wg_comm_create": (ci, [vp, ci, ci, vp, pvp]),
         "wg_comm_destroy": (ci, [vp]),
         "wg_comm_rank": (ci, [vp]),
         "wg_comm_size": (ci, [vp]),
         "wg_comm_has_collectives": (ci, [vp]),
-        "wg_comm_copy_engine": (cp, [vp]),
+        "wg_comm_reported_size": (ci, [vp, ctypes.POINTER(ci)]),
         "wg_comm_bytes_sent": (u64, [vp]),
         "wg_all_gather": (ci, [vp, ci, vp, u64, u64]),
         "wg_comm_join": (ci, [vp]),
@@ -129,7 +134,7 @@ def _load() -> ctypes.CDLL:
         "wg_comm_stage_reserve": (ci, [vp, sz, pvp, pvp]),
         "wg_comm_set_peer_stages": (ci, [vp, pvp, pvp]),
         "wg_cube_to_matrix": (ci, [vp, ci, vp, S, vp, S]),
-        "wg_gemm_sharded": (ci, [vp, ci, ci, ci, u32, vp, S, pvp, vp, S, vp, S]),
+        "wg_gemm_sharded": (ci, [vp, ci, ci, ci, u32, vp, S, vp, S, vp, S]),
         "wg_encoder_begin": (ci, [vp]),
         "wg_encoder_finish": (ci, [vp, pvp]),
         "wg_queue_submit": (ci, [vp, vp]),
@@ -146,6 +151,10 @@ def _load() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     lib._wg_signatures = sig
+    # a stale build of the library with every symbol this binding names but other semantics must not pass for the current one
+    if lib.wg_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} reports ABI version {lib.wg_abi_version()}, this binding is written for {ABI_VERSION} "
+                          f"(include/wgebra_hip.h: WGEBRA_HIP_ABI_VERSION): rebuild with `make -C wgmath_amd/csrc`")
     return lib
 
 

@@ -4,7 +4,9 @@
 // product of every rank is exactly Gemm::dispatch_generic (gemm.rs:65-127) on views of them.
 //
 //   rank g of P owns A_g = A[g*M/P .. (g+1)*M/P, :] (its own dense tensor), B is replicated, every rank ends with the full M x N C.
-//   N is cut into column panels; panel i's exchange runs while panel i+1 computes. Two exchange engines:
+//   N is cut into column panels; panel i's exchange runs while panel i+1 computes. Two exchange engines (a third, SDMA rect
+//   copies straight into the peers' C through hsa_amd_memory_async_copy_rect, was removed in ABI 3: one rect-capable queue per direction, and a hang with two
+//   processes on one GPU at 32768^3 that nothing in the HSA API let this library bound):
 //
 //   WG_GATHER_RCCL       the north star's primary. A row block of a column-major C is strided, a collective wants contiguous
 //                        ranges: the panel Gemm writes slot g of a staging cube [M/P, np, P] (GpuCube, stride_mat = M/P*np), one
@@ -12,13 +14,7 @@
 //                        relayout kernel (cube_to_matrix) scatters the cube into columns [c0, c0+np) of C. RCCL's copy kernels need
 //                        compute units; every f16 Gemm workgroup needs a whole one (so the caller may give the Gemm a CU-masked
 //                        context: wg_ctx_create_with_cu_count).
-//   WG_GATHER_PEER_COPY  no compute units and no relayout: the panel Gemm writes its row block straight into C (a strided view), and
-//                        the SDMA engines push that (M/P x np) block into every peer's C (hsa_amd_memory_async_copy_rect, the only
-//                        engine that copies strided blocks without a blit kernel: tools/cpp/sdma_probe.cpp), issued by a helper thread
-//                        as soon as the panel's event fires. ~60 GB/s per engine, one engine per peer: about the xGMI link rate.
-//
-//   WG_GATHER_PEER_STAGED  what P > 2 needs: ONE rect-capable SDMA queue per direction flag is all the HSA API exposes (measured: every
-//                        rect copy of an agent shares ~60 GB/s, tools/rank_emulation.py), but contiguous peer copies go to an SDMA engine
+//   WG_GATHER_PEER_STAGED  no compute units for the transfer: contiguous peer copies go to an SDMA engine
 //                        PER LINK (16 engines, 60.7 GB/s each, 7 at once 330 GB/s, Gemm beside 3 / 7 busy engines +2.3 % / +4.8 %:
 //                        tools/cpp/sdma_probe2.cpp). So: the panel Gemm writes slot g of a staging cube (as in RCCL mode), one contiguous
 //                        hipMemcpyAsync per peer (its own stream: the runtime's peer-to-peer path = that link's SDMA engine, no compute
@@ -27,23 +23,17 @@
 //                        relayout of that panel -- everything stream-ordered, no helper thread, no barrier: the staging cube is double-
 //                        buffered by step parity, and a rank cannot be more than one step ahead of a peer whose data it needs.
 //
-// RCCL and the HSA runtime are resolved at run time (dlopen): the library links only libamdhip64, and a process that already
+// RCCL is resolved at run time (dlopen): the library links only libamdhip64, and a process that already
 // loaded torch's bundled copies binds to those.
 #include "wg_internal.hpp"
 
 #include <dlfcn.h>
-#include <hsa/hsa.h>
-#include <hsa/hsa_ext_amd.h>
 #include <rccl/rccl.h> // types and enums only
 
-#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
-#include <deque>
-#include <mutex>
 #include <new>
 #include <string>
-#include <thread>
 
 namespace {
 
@@ -65,6 +55,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr; // optional
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -79,6 +70,7 @@ RcclApi &rccl() {
         a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(a.h, "ncclGetUniqueId");
         a.CommInitRank = (decltype(a.CommInitRank))dlsym(a.h, "ncclCommInitRank");
         a.CommDestroy = (decltype(a.CommDestroy))dlsym(a.h, "ncclCommDestroy");
+        a.CommCount = (decltype(a.CommCount))dlsym(a.h, "ncclCommCount");
         a.AllGather = (decltype(a.AllGather))dlsym(a.h, "ncclAllGather");
         a.AllReduce = (decltype(a.AllReduce))dlsym(a.h, "ncclAllReduce");
         a.GetErrorString = (decltype(a.GetErrorString))dlsym(a.h, "ncclGetErrorString");
@@ -87,53 +79,6 @@ RcclApi &rccl() {
     }();
     return api;
 }
-
-struct HsaApi {
-    void *h = nullptr;
-    hsa_status_t (*init)() = nullptr;
-    hsa_status_t (*signal_create)(hsa_signal_value_t, uint32_t, const hsa_agent_t *, hsa_signal_t *) = nullptr;
-    hsa_status_t (*signal_destroy)(hsa_signal_t) = nullptr;
-    void (*signal_store)(hsa_signal_t, hsa_signal_value_t) = nullptr;
-    hsa_signal_value_t (*signal_wait)(hsa_signal_t, hsa_signal_condition_t, hsa_signal_value_t, uint64_t, hsa_wait_state_t) = nullptr;
-    hsa_status_t (*copy_rect)(const hsa_pitched_ptr_t *, const hsa_dim3_t *, const hsa_pitched_ptr_t *, const hsa_dim3_t *, const hsa_dim3_t *,
-                              hsa_agent_t, hsa_amd_copy_direction_t, uint32_t, const hsa_signal_t *, hsa_signal_t) = nullptr;
-    hsa_status_t (*pointer_info)(const void *, hsa_amd_pointer_info_t *, void *(*)(size_t), uint32_t *, hsa_agent_t **) = nullptr;
-    hsa_status_t (*status_string)(hsa_status_t, const char **) = nullptr;
-    bool ok = false;
-};
-HsaApi &hsa() {
-    static HsaApi api = [] {
-        HsaApi a;
-        static const char *const names[] = { "libhsa-runtime64.so.1", "libhsa-runtime64.so", "/opt/rocm/lib/libhsa-runtime64.so.1", nullptr };
-        a.h = open_lib("WG_HSA_LIB", names);
-        if (!a.h) return a;
-        a.init = (decltype(a.init))dlsym(a.h, "hsa_init");
-        a.signal_create = (decltype(a.signal_create))dlsym(a.h, "hsa_signal_create");
-        a.signal_destroy = (decltype(a.signal_destroy))dlsym(a.h, "hsa_signal_destroy");
-        a.signal_store = (decltype(a.signal_store))dlsym(a.h, "hsa_signal_store_relaxed");
-        a.signal_wait = (decltype(a.signal_wait))dlsym(a.h, "hsa_signal_wait_scacquire");
-        a.copy_rect = (decltype(a.copy_rect))dlsym(a.h, "hsa_amd_memory_async_copy_rect");
-        a.pointer_info = (decltype(a.pointer_info))dlsym(a.h, "hsa_amd_pointer_info");
-        a.status_string = (decltype(a.status_string))dlsym(a.h, "hsa_status_string");
-        a.ok = a.init && a.signal_create && a.signal_destroy && a.signal_store && a.signal_wait && a.copy_rect && a.pointer_info && a.status_string;
-        if (a.ok && a.init() != HSA_STATUS_SUCCESS) a.ok = false; // reference-counted: HIP already initialised the same runtime
-        return a;
-    }();
-    return api;
-}
-
-struct Rect { // a strided block: `rows` pieces of `width` bytes, `pitch` bytes apart (a "row" of the copy is a matrix COLUMN)
-    void *dst;
-    size_t dpitch;
-    const void *src;
-    size_t spitch, width, rows;
-    int queue; // the HSA rect-copy API runs "host-to-device" and "device-to-host" copies on two different SDMA queues (60 GB/s each,
-               // concurrently: tools/cpp/sdma_probe2.cpp); device-to-device shares one of them. Peers alternate between the two.
-};
-struct CopyJob {
-    hipEvent_t after = nullptr; // issue once this event (recorded on the context's stream) has fired; nullptr = flush marker
-    std::vector<Rect> rects;
-};
 
 } // namespace
 
@@ -147,20 +92,6 @@ struct wg_comm {
     void *stage = nullptr;            // RCCL mode: two staging cubes
     size_t stage_bytes = 0;
     float *token = nullptr; // 1 float for the barrier's all-reduce
-    // peer copies
-    bool use_sdma = false;
-    hsa_agent_t agent = {};
-    hipStream_t copy_stream = nullptr; // fallback engine: hipMemcpy2DAsync (a blit kernel)
-    std::thread worker;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<CopyJob> jobs;
-    bool stop = false, busy = false;
-    uint64_t flushes_done = 0, flushes_asked = 0;
-    std::vector<hsa_signal_t> free_signals, inflight;
-    std::vector<hipEvent_t> free_events, used_events;
-    int async_status = WG_OK;
-    std::string async_error;
     uint64_t bytes_sent = 0; // payload this rank pushed or contributed since creation (diagnostics: wg_comm_bytes_sent)
     // staged peer copies (WG_GATHER_PEER_STAGED)
     void *pstage = nullptr;          // two staging cubes of the whole step (step parity), caller-sized: wg_comm_stage_reserve
@@ -175,7 +106,6 @@ struct wg_comm {
     uint64_t timeout_ticks = 3000000000ull; // wait kernel's patience in 100 MHz ticks (WG_COMM_TIMEOUT_MS at creation, default 30 s)
     uint32_t step = 0;
     uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
-    uint32_t staged_npanels = 0;              // panels of that call (its sent_ev layout)
     // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels whose waves count themselves into panel_sync[p] as
     // their stores reach memory; the exchange of panel p waits for the full count (hipStreamWaitValue32) while the kernel works on
     bool can_wait_value = false;              // hipDeviceAttributeCanUseStreamWaitValue: without it every product launches panel by panel
@@ -199,79 +129,6 @@ struct wg_comm {
 };
 
 namespace {
-
-void worker_fail(wg_comm *c, int status, const std::string &msg) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    if (c->async_status == WG_OK) {
-        c->async_status = status;
-        c->async_error = msg;
-    }
-}
-
-void worker_main(wg_comm *c) {
-    (void)hipSetDevice(c->ctx->device);
-    HsaApi &H = hsa();
-    for (;;) {
-        CopyJob job;
-        {
-            std::unique_lock<std::mutex> lk(c->mu);
-            c->cv_work.wait(lk, [&] { return c->stop || !c->jobs.empty(); });
-            if (c->jobs.empty()) return; // stop requested and nothing left
-            job = std::move(c->jobs.front());
-            c->jobs.pop_front();
-            c->busy = true;
-        }
-        if (job.after) {
-            hipError_t e = hipEventSynchronize(job.after);
-            if (e != hipSuccess) worker_fail(c, WG_ERR_HIP, std::string("peer copy: hipEventSynchronize failed: ") + hipGetErrorString(e));
-            for (const Rect &r : job.rects) {
-                hsa_signal_t sig;
-                {
-                    std::lock_guard<std::mutex> lk(c->mu);
-                    if (c->free_signals.empty()) {
-                        sig.handle = 0;
-                    } else {
-                        sig = c->free_signals.back();
-                        c->free_signals.pop_back();
-                    }
-                }
-                if (sig.handle == 0 && H.signal_create(1, 0, nullptr, &sig) != HSA_STATUS_SUCCESS) {
-                    worker_fail(c, WG_ERR_HIP, "peer copy: hsa_signal_create failed");
-                    continue;
-                }
-                H.signal_store(sig, 1);
-                hsa_pitched_ptr_t d = { r.dst, r.dpitch, r.dpitch * r.rows }, s = { (void *)r.src, r.spitch, r.spitch * r.rows };
-                hsa_dim3_t off = { 0, 0, 0 }, range = { (uint32_t)r.width, (uint32_t)r.rows, 1 };
-                hsa_status_t st = H.copy_rect(&d, &off, &s, &off, &range, c->agent, (r.queue & 1) ? hsaHostToDevice : hsaDeviceToHost, 0, nullptr, sig);
-                if (st != HSA_STATUS_SUCCESS) {
-                    const char *m = nullptr;
-                    H.status_string(st, &m);
-                    worker_fail(c, WG_ERR_HIP, std::string("peer copy: hsa_amd_memory_async_copy_rect failed: ") + (m ? m : "?"));
-                    std::lock_guard<std::mutex> lk(c->mu);
-                    c->free_signals.push_back(sig);
-                    continue;
-                }
-                std::lock_guard<std::mutex> lk(c->mu);
-                c->inflight.push_back(sig);
-            }
-            std::lock_guard<std::mutex> lk(c->mu);
-            c->busy = false;
-        } else { // flush: every copy issued so far has landed
-            std::vector<hsa_signal_t> w;
-            {
-                std::lock_guard<std::mutex> lk(c->mu);
-                w.swap(c->inflight);
-            }
-            for (hsa_signal_t s : w)
-                while (H.signal_wait(s, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_BLOCKED) >= 1) {}
-            std::lock_guard<std::mutex> lk(c->mu);
-            for (hsa_signal_t s : w) c->free_signals.push_back(s);
-            c->busy = false;
-            c->flushes_done++;
-            c->cv_done.notify_all();
-        }
-    }
-}
 
 int nccl_fail(const char *what, ncclResult_t r) {
     return wg_set_error(WG_ERR_HIP, "%s failed: %s", what, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
@@ -352,44 +209,10 @@ __global__ void wait_flags_kernel(const uint32_t *flags, uint32_t nranks, uint32
 // a kernel argument, so nothing the host may overwrite later is read at execution time)
 __global__ void set_word_kernel(uint32_t *dst, uint32_t v) { *dst = v; }
 
-hipEvent_t take_event(wg_comm *c) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    hipEvent_t e = nullptr;
-    if (!c->free_events.empty()) {
-        e = c->free_events.back();
-        c->free_events.pop_back();
-    }
-    if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-    c->used_events.push_back(e);
-    return e;
-}
-
 int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far has landed
     for (hipStream_t st : c->peer_stream)
         if (st) WG_HIP_TRY(hipStreamSynchronize(st));
     if (int rc = wg_ctx_check_async(c->ctx)) return rc; // a wait kernel gave up (reported once, then cleared)
-    if (c->nranks > 1 && c->use_sdma && c->worker.joinable()) {
-        std::unique_lock<std::mutex> lk(c->mu);
-        c->jobs.push_back(CopyJob());
-        const uint64_t want = ++c->flushes_asked;
-        c->cv_work.notify_one();
-        c->cv_done.wait(lk, [&] { return c->flushes_done >= want; });
-        for (hipEvent_t e : c->used_events) c->free_events.push_back(e);
-        c->used_events.clear();
-        if (c->async_status != WG_OK) {
-            const int st = c->async_status;
-            const std::string msg = c->async_error;
-            c->async_status = WG_OK;
-            c->async_error.clear();
-            lk.unlock();
-            return wg_set_error(st, "%s", msg.c_str());
-        }
-    } else if (c->copy_stream) {
-        WG_HIP_TRY(hipStreamSynchronize(c->copy_stream));
-        std::lock_guard<std::mutex> lk(c->mu);
-        for (hipEvent_t e : c->used_events) c->free_events.push_back(e);
-        c->used_events.clear();
-    }
     return WG_OK;
 }
 
@@ -485,23 +308,6 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
         const long long ms = atoll(t);
         if (ms > 0) c->timeout_ticks = (uint64_t)ms * 100000ull;
     }
-    // peer-copy engine: SDMA rect copies through the HSA runtime unless WG_PEER_COPY_ENGINE=hip2d (or HSA cannot be bound)
-    const char *eng = getenv("WG_PEER_COPY_ENGINE");
-    if (nranks > 1 && !(eng && strcmp(eng, "hip2d") == 0)) {
-        HsaApi &H = hsa();
-        if (H.ok) {
-            hsa_amd_pointer_info_t info;
-            memset(&info, 0, sizeof info);
-            info.size = sizeof info;
-            if (H.pointer_info(c->token, &info, nullptr, nullptr, nullptr) == HSA_STATUS_SUCCESS && info.agentOwner.handle != 0) {
-                c->agent = info.agentOwner;
-                c->use_sdma = true;
-                c->worker = std::thread(worker_main, c);
-            }
-        }
-    }
-    if (nranks > 1 && !c->use_sdma && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess)
-        return fail(wg_set_error(WG_ERR_HIP, "wg_comm_create: copy stream creation failed"));
     *out = c;
     return WG_OK;
 }
@@ -509,27 +315,13 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
 int wg_comm_destroy(wg_comm *c) {
     if (!c) return WG_OK;
     (void)hipSetDevice(c->ctx->device);
-    if (c->worker.joinable()) {
-        (void)comm_flush(c);
-        {
-            std::lock_guard<std::mutex> lk(c->mu);
-            c->stop = true;
-        }
-        c->cv_work.notify_all();
-        c->worker.join();
-    }
+    for (hipStream_t st : c->peer_stream)
+        if (st) (void)hipStreamSynchronize(st);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->copy_stream) {
-        (void)hipStreamSynchronize(c->copy_stream);
-        (void)hipStreamDestroy(c->copy_stream);
-    }
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
-    for (hsa_signal_t s : c->free_signals) (void)hsa().signal_destroy(s);
-    for (hsa_signal_t s : c->inflight) (void)hsa().signal_destroy(s);
-    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->used_events) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_panel) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_panel)
+        if (e) (void)hipEventDestroy(e);
     if (c->ev_ctx) (void)hipEventDestroy(c->ev_ctx);
     if (c->ev_comm) (void)hipEventDestroy(c->ev_comm);
     for (hipStream_t st : c->peer_stream)
@@ -554,7 +346,15 @@ int wg_comm_destroy(wg_comm *c) {
 int wg_comm_rank(const wg_comm *c) { return c ? c->rank : -1; }
 int wg_comm_size(const wg_comm *c) { return c ? c->nranks : 0; }
 int wg_comm_has_collectives(const wg_comm *c) { return c && c->nccl ? 1 : 0; }
-const char *wg_comm_copy_engine(const wg_comm *c) { return !c || c->nranks < 2 ? "none" : (c->use_sdma ? "sdma-rect" : "hip2d"); }
+int wg_comm_reported_size(const wg_comm *c, int *count) {
+    if (!c || !count) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_reported_size: NULL argument");
+    *count = 0;
+    if (!c->nccl) return WG_OK;
+    if (!rccl().CommCount) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_comm_reported_size: this librccl has no ncclCommCount");
+    ncclResult_t r = rccl().CommCount(c->nccl, count);
+    if (r != ncclSuccess) return nccl_fail("ncclCommCount", r);
+    return WG_OK;
+}
 uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
 
 int wg_comm_set_one_launch(wg_comm *c, int on) {
@@ -708,7 +508,11 @@ int wg_comm_stage_reserve(wg_comm *c, size_t bytes, wg_buf **stage, wg_buf **fla
     if (!c->wait_err) {
         WG_HIP_TRY(hipHostMalloc((void **)&c->wait_err, 64, hipHostMallocDefault));
         *c->wait_err = 0;
-        wg_ctx_register_async_error(c->ctx, c->wait_err, "Gemm (sharded): a peer's slot did not arrive within the communicator's time-out (peer gone, or its buffers not registered): rank");
+        // (the device-side twin, seq_src + 64, is registered with it: whichever call reports the time-out -- wg_ctx_sync, wg_buf_read, this
+        // communicator's calls -- clears BOTH words, the device one in context-stream order, so the next step runs clean instead of failing fast
+        // and poisoning its output without ever raising the host word again)
+        wg_ctx_register_async_error(c->ctx, c->wait_err, "Gemm (sharded): a peer's slot did not arrive within the communicator's time-out (peer gone, or its buffers not registered): rank",
+                                    c->seq_src + 64);
     }
     c->stage_buf.ctx = c->ctx; c->stage_buf.ptr = c->pstage; c->stage_buf.bytes = c->pstage_bytes; c->stage_buf.usage = WG_USAGE_STORAGE; c->stage_buf.owned = false;
     c->flags_buf.ctx = c->ctx; c->flags_buf.ptr = c->pflags; c->flags_buf.bytes = kFlagBytes; c->flags_buf.usage = WG_USAGE_STORAGE; c->flags_buf.owned = false;
@@ -764,11 +568,11 @@ int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_s
 // the M-sharded Gemm
 // ---------------------------------------------------------------------------------------------------------------
 int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols, wg_buf *out, wg_view_shape out_shape,
-                    wg_buf *const *peer_out, const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
+                    const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
     if (!c || !out || !a_rows || !b) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): NULL argument");
     if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown dtype %d", (int)dtype);
     if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
-    if ((int)mode < 0 || (int)mode > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown gather mode %d", (int)mode);
+    if ((int)mode < 0 || (int)mode > 3 || (int)mode == 1) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown gather mode %d", (int)mode);
     wg_ctx *ctx = c->ctx;
     if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): cannot be recorded");
     const bool tr = variant == WG_GEMM_TR || variant == WG_GEMM_TR_FAST;
@@ -782,12 +586,6 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     if (M == 0 || N == 0) return WG_OK;
     if (mg % 4 || N % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): the row block (%u rows) and N=%u must be multiples of 4 (vec4 views, shape.wgsl:64-66)", mg, N);
     if (mode == WG_GATHER_RCCL && P > 1 && !c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): WG_GATHER_RCCL needs a communicator created with a unique id");
-    if (mode == WG_GATHER_PEER_COPY && P > 1) {
-        if (!peer_out) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): WG_GATHER_PEER_COPY needs peer_out[rank] for every other rank");
-        for (uint32_t r = 0; r < P; ++r)
-            if (r != g && (!peer_out[r] || peer_out[r]->bytes < out->bytes))
-                return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): peer_out[%u] is missing or smaller than `out`", r);
-    }
     if (panel_cols == 0) { // default: ~8 panels of whole 256-column tiles, so that all but the last exchange hides under a Gemm
         panel_cols = N >= 2048 ? ((N / 8 + 255u) / 256u) * 256u : N;
     }
@@ -817,10 +615,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // cross-rank agreement beyond the one every step makes.
         const uint64_t half_elems = ((c->pstage_bytes / 2) & ~(size_t)15) / es;
         if (half_elems + (uint64_t)M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
-        if (int rc = wg_ctx_check_async(ctx)) { // a wait of an earlier step gave up: reported here; the device-side word is reset for a retry
-            (void)hipMemsetAsync(c->seq_src + 64, 0, sizeof(uint32_t), ctx->stream);
-            return rc;
-        }
+        if (int rc = wg_ctx_check_async(ctx)) return rc; // a wait of an earlier step gave up: reported here (both words cleared: the next call is a clean retry)
         const uint64_t geom[4] = { M, N, panel_cols, es };
         if (memcmp(geom, c->staged_geom, sizeof geom) != 0) {
             // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything of
@@ -968,24 +763,32 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     // context's stream, each behind its panel's gather. Pipelined steps (wg_comm_set_pipelined) leave the last panel's relayout -- the one
     // gather nothing of its own step hides -- to the next call, behind that call's kernel.
     if (rccl_one) {
-        const size_t half = ((size_t)M * N * es + 255) & ~(size_t)255, need = 2 * half;
-        if (need > c->stage_bytes) {
+        // The two step-parity cubes sit at FIXED offsets -- 0 and half of the reserved size -- whatever the shape of a step (as the staged engine's):
+        // with pipelined steps the previous call's last panel may still be gathering into ITS cube, laid out for ITS M x N, while this call's kernel
+        // (enqueued before that panel's relayout) writes the other one; halves computed from this call's M * N would overlap it when shapes alternate.
+        const size_t cube_bytes = ((size_t)M * N * es + 255) & ~(size_t)255;
+        if (2 * cube_bytes > c->stage_bytes) {
             if (int rc = run_pending(c)) return rc;
             WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
             WG_HIP_TRY(hipStreamSynchronize(c->stream));
             if (c->stage) WG_HIP_TRY(hipFree(c->stage));
             c->stage = nullptr;
             c->stage_bytes = 0;
-            WG_HIP_TRY(hipMalloc(&c->stage, need));
-            c->stage_bytes = need;
+            WG_HIP_TRY(hipMalloc(&c->stage, 2 * cube_bytes));
+            c->stage_bytes = 2 * cube_bytes;
         }
+        const size_t half = (c->stage_bytes / 2) & ~(size_t)255;
         if (int rc = ensure_panel_sync(c)) return rc;
-        while (c->ev_panel.size() < 2 * (size_t)npanels) {
-            hipEvent_t e = nullptr;
-            WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_panel.push_back(e);
+        if (npanels > kMaxPanels) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): more than %u panels", kMaxPanels);
+        const uint32_t parity = (++c->step) & 1u;
+        // the events of a parity live at [kMaxPanels * (1 + parity), +npanels): also independent of the step's shape (a deferred panel keeps its own
+        // event handle), and clear of [0, kMaxPanels), the panel-by-panel form's events
+        if (c->ev_panel.size() < 3 * (size_t)kMaxPanels) c->ev_panel.resize(3 * (size_t)kMaxPanels, nullptr);
+        for (uint32_t p = 0; p < npanels; ++p) {
+            hipEvent_t &e = c->ev_panel[(size_t)kMaxPanels * (1u + parity) + p];
+            if (!e) WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        const uint32_t parity = (++c->step) & 1u, np_last = N - (npanels - 1u) * panel_cols;
+        const uint32_t np_last = N - (npanels - 1u) * panel_cols;
         char *cube = (char *)c->stage + (size_t)parity * half; // this step's cube; the other one may still be gathering its last panel
         wgk_panels pa;
         pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
@@ -997,7 +800,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             if (int rc = run_pending(c)) return rc; // (cannot happen with alternating parities; kept as a guard)
         const int rc1 = wg_gemm_f16_panels(ctx, tr, cube + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
         if (rc1 == WG_OK) {
-            hipEvent_t *ev = c->ev_panel.data() + (size_t)parity * npanels;
+            hipEvent_t *ev = c->ev_panel.data() + (size_t)kMaxPanels * (1u + parity);
             for (uint32_t p = 0; p < npanels; ++p) {
                 const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
                 char *base = cube + (size_t)c0 * M * es;
@@ -1041,11 +844,10 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             c->stage_bytes = need;
         }
         stage_buf.ctx = ctx; stage_buf.ptr = c->stage; stage_buf.bytes = c->stage_bytes; stage_buf.usage = 0; stage_buf.owned = false; stage_buf.host_pinned = false;
-        while (c->ev_panel.size() < npanels) {
-            hipEvent_t e = nullptr;
-            WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_panel.push_back(e);
-        }
+        if (npanels > kMaxPanels) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): more than %u panels", kMaxPanels);
+        if (c->ev_panel.size() < npanels) c->ev_panel.resize(npanels, nullptr);
+        for (uint32_t p = 0; p < npanels; ++p)
+            if (!c->ev_panel[p]) WG_HIP_TRY(hipEventCreateWithFlags(&c->ev_panel[p], hipEventDisableTiming));
     }
 
     auto relayout = [&](uint32_t p) -> int { // panel p's cube -> columns of `out`, once its all-gather is done
@@ -1085,33 +887,6 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             if (off >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): output view exceeds u32 element indexing");
             os.offset = (uint32_t)off;
             if (int rc = wg_gemm_ex(ctx, variant, dtype, 1.f, 0.f, out, os, a_rows, a_shape, b, bs)) return rc;
-            if (mode == WG_GATHER_PEER_COPY && P > 1) {
-                hipEvent_t ev = take_event(c);
-                if (!ev) return wg_set_error(WG_ERR_HIP, "Gemm (sharded): event creation failed");
-                WG_HIP_TRY(hipEventRecord(ev, ctx->stream));
-                const size_t blk = off * es, pitch = (size_t)out_shape.stride * es, width = (size_t)mg * es;
-                if (c->use_sdma) {
-                    CopyJob job;
-                    job.after = ev;
-                    for (uint32_t r = 1; r < P; ++r) { // start with the next rank: every peer's link is busy from the first job on
-                        const uint32_t peer = (g + r) % P;
-                        job.rects.push_back(Rect{ (char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np, (int)r });
-                    }
-                    {
-                        std::lock_guard<std::mutex> lk(c->mu);
-                        c->jobs.push_back(std::move(job));
-                    }
-                    c->cv_work.notify_one();
-                } else {
-                    WG_HIP_TRY(hipStreamWaitEvent(c->copy_stream, ev, 0));
-                    for (uint32_t r = 1; r < P; ++r) {
-                        const uint32_t peer = (g + r) % P;
-                        WG_HIP_TRY(hipMemcpy2DAsync((char *)peer_out[peer]->ptr + blk, pitch, (const char *)out->ptr + blk, pitch, width, np, hipMemcpyDeviceToDevice,
-                                                    c->copy_stream));
-                    }
-                }
-                c->bytes_sent += (uint64_t)(P - 1) * width * np;
-            }
         }
     }
     if (staged) return relayout(npanels - 1); // the only exposed exchange

@@ -140,14 +140,19 @@ __global__ __launch_bounds__(kThreads) void gemv_n_kernel(GemvArgsT<T> a) {
                     for (int y = 0; y < NRHS; ++y) fma4(acc[y], mv[u], readlane_f(vv[y], u8 + u));
             }
         } else {
-            // < 64 columns left in this wave's range: the same groups of GEMV_NU loads in flight -- a column past the end is the last
-            // valid one again, multiplied by the zero its v entry was given above (one load at a time here cost the mid-size shapes,
+            // < 64 columns left in this wave's range: the same groups of GEMV_NU loads in flight -- a column past the end re-loads the last
+            // valid one and is zeroed (one load at a time here cost the mid-size shapes,
             // whose waves own fewer than 64 columns, up to 30 %: profiles/r03_evidence.md section 10)
             const int rem = (int)(w_end - cb); // wave-uniform, >= 1
             for (int u8 = 0; u8 < rem; u8 += GEMV_NU) {
                 float4 mv[GEMV_NU];
 #pragma unroll
-                for (int u = 0; u < GEMV_NU; ++u) mv[u] = load4s(col + (uint64_t)min(u8 + u, rem - 1) * ld4);
+                for (int u = 0; u < GEMV_NU; ++u) {
+                    mv[u] = load4s(col + (uint64_t)min(u8 + u, rem - 1) * ld4); // (the load still issues: a valid address)
+                    // ... but a padded slot contributes an exact zero, not (last column) x 0: an Inf or NaN in the last column must not
+                    // reach rows through slots the reference kernel never touches (gemv.wgsl:28-65 stops at the last column)
+                    if (u8 + u >= rem) mv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
 #pragma unroll
                 for (int u = 0; u < GEMV_NU; ++u)
 #pragma unroll
@@ -717,8 +722,12 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
     const dim3 grid(groups < cus ? groups : cus, 1, nmats), block(kLdsThreads);
 #define WG_T_LDS(NR)                                                                                                                   \
     do {                                                                                                                               \
-        static bool attr_set = false; /* (one context per device; the attribute is per function) */                                    \
-        if (!attr_set) { WG_HIP_TRY(hipFuncSetAttribute((const void *)gemv_t_lds_kernel<NR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_set = true; } \
+        /* per context (= per device and stream), per instantiation: a process may hold contexts on several devices */                \
+        const uint32_t bit = 1u << ((NR == 8 ? 0 : NR == 4 ? 1 : 2) + (sizeof(T) == 2 ? 3 : 0));                                       \
+        if (!(ctx->func_attr_bits & bit)) {                                                                                            \
+            WG_HIP_TRY(hipFuncSetAttribute((const void *)gemv_t_lds_kernel<NR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            ctx->func_attr_bits |= bit;                                                                                                \
+        }                                                                                                                              \
         hipLaunchKernelGGL((gemv_t_lds_kernel<NR, T>), grid, block, lds, ctx->stream, a);                                              \
     } while (0)
     if (tile == 8) WG_T_LDS(8); else if (tile == 4) WG_T_LDS(4); else WG_T_LDS(2);
@@ -732,7 +741,7 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
 static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
     if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
     const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= 128ull * cus && rows_out % 4u == 0;
+    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= 128ull * cus && rows_out % 4u == 0 && k % 4u == 0;
 }
 
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,

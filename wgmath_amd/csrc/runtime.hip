@@ -56,7 +56,7 @@ int wg_ctx_tr_workspace(wg_ctx *ctx, size_t bytes, void **out) {
 int wg_ctx_pad_workspace(wg_ctx *ctx, size_t bytes, void **out) {
     return grow_scratch(ctx, &ctx->pad_workspace, &ctx->pad_workspace_bytes, bytes, "padding workspace", out);
 }
-void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what) { ctx->async_errors.push_back({ word, what }); }
+void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what, uint32_t *dev_word) { ctx->async_errors.push_back({ word, what, dev_word }); }
 void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word) {
     for (size_t i = 0; i < ctx->async_errors.size(); ++i)
         if (ctx->async_errors[i].word == word) { ctx->async_errors.erase(ctx->async_errors.begin() + (long)i); return; }
@@ -66,6 +66,8 @@ int wg_ctx_check_async(wg_ctx *ctx) {
         const uint32_t v = *(volatile uint32_t *)e.word;
         if (v) {
             *(volatile uint32_t *)e.word = 0;
+            // the device-side twin (what the kernels themselves test) is cleared with it, in stream order: a reported error is a cleared error
+            if (e.dev_word) (void)hipMemsetAsync(e.dev_word, 0, sizeof(uint32_t), ctx->stream);
             return wg_set_error(WG_ERR_HIP, "%s %u", e.what, v - 1u);
         }
     }
@@ -124,7 +126,10 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
         { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
         { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE } };
     for (const auto &k : knobs)
-        if (const char *v = getenv(k.env)) ctx->tuning[k.key] = atoi(v);
+        if (const char *v = getenv(k.env)) {
+            // the same validation as wg_ctx_set_tuning: a value the knob does not take is ignored (with a note), never silently reinterpreted
+            if (wg_ctx_set_tuning(ctx, k.key, atoi(v)) != WG_OK) fprintf(stderr, "libwgebra_hip: ignoring %s=%s (%s)\n", k.env, v, wg_last_error_string());
+        }
     *out = ctx;
     return WG_OK;
 }
@@ -195,6 +200,7 @@ int wg_ctx_destroy(wg_ctx *ctx) {
     if (ctx->bal.dev) (void)hipFree(ctx->bal.dev);
     if (ctx->bal.host) (void)hipHostFree(ctx->bal.host);
     if (ctx->bal.scratch) (void)hipFree(ctx->bal.scratch);
+    if (ctx->debug_stamps) (void)hipHostFree(ctx->debug_stamps);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return WG_OK;

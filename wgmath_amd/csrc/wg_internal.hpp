@@ -44,14 +44,17 @@ struct wg_ctx {
         size_t scratch_bytes = 0;
     } bal;
     int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
+    bool debug_clock_open = false;
+    uint32_t func_attr_bits = 0;         // hipFuncSetAttribute calls already made for this context's device (gemv.hip: GemvTr's 128 KiB dynamic LDS)
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
     // pinned host words that kernels of this context's stream raise when something went wrong asynchronously (a communicator's wait
     // kernel timing out on a peer): checked -- reported once, then cleared -- by wg_ctx_sync, wg_buf_read and the communicator's calls
-    struct AsyncError { uint32_t *word; const char *what; };
+    struct AsyncError { uint32_t *word; const char *what; uint32_t *dev_word; };
     std::vector<AsyncError> async_errors;
 };
-void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what);
+void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what, uint32_t *dev_word = nullptr); // dev_word: a device-side twin cleared with it
 void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word);
 int wg_ctx_check_async(wg_ctx *ctx); // WG_ERR_HIP + message "<what> <word - 1>" if a registered word is set (and clears it)
 

@@ -3,8 +3,8 @@
 Two layers:
   * `Comm` / `sharded_gemm` -- the product path: thin ctypes callers of the C ABI's multi-GPU section (include/wgebra_hip.h:
     wg_comm_*, wg_gemm_sharded). RCCL is driven by the library itself (no torch needed); every rank ends with a plain M x N
-    column-major GpuMatrix. Exchange engines: RCCL all-gather of a staging cube + relayout, or SDMA peer copies of the strided
-    row blocks straight into every peer's C (csrc/comm.hip).
+    column-major GpuMatrix. Exchange engines: RCCL all-gather of a staging cube + relayout, or contiguous SDMA peer copies of the
+    cube's slots (one engine per link) + relayout (csrc/comm.hip).
   * `MShardPlan` / `ShardedGemm` -- the planner and the cube-layout driver with injected GEMM / collective (pure host arithmetic,
     runs under gloo in the CPU tests): the gathered result stays a GpuCube per panel, no relayout.
 
@@ -166,7 +166,6 @@ class ShardedGemm:
 # ---------------------------------------------------------------------------------------------------------------------
 class GatherMode:
     RCCL = 0       # staging cube + in-place ncclAllGather per panel + relayout into C (wg_gather_mode WG_GATHER_RCCL)
-    PEER_COPY = 1  # Gemm straight into C's rows, SDMA pushes the strided block to every peer's C (WG_GATHER_PEER_COPY)
     NONE = 2
     PEER_STAGED = 3  # Gemm into a staging cube, one contiguous copy per peer link + flag, wait kernel + relayout on the receiver (WG_GATHER_PEER_STAGED)
 
@@ -207,8 +206,11 @@ class Comm:
     __del__ = close
 
     @property
-    def copy_engine(self) -> str:
-        return self._lib.lib.wg_comm_copy_engine(self._h).decode()
+    def reported_size(self) -> int:
+        """ncclCommCount: the rank count the collective library itself reports (0 for a communicator without one)."""
+        n = ctypes.c_int(0)
+        self._lib.check(self._lib.lib.wg_comm_reported_size(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     @property
     def has_collectives(self) -> bool:
@@ -239,41 +241,6 @@ class Comm:
 
     def barrier(self) -> None:
         self._lib.check(self._lib.lib.wg_comm_barrier(self._h))
-
-    # -- peer buffers (one process per GPU): export mine, open everyone else's ---------------------------------------
-    def export_handle(self, tensor) -> bytes:
-        buf = ctypes.create_string_buffer(self._lib.WG_IPC_HANDLE_BYTES)
-        self._lib.check(self._lib.lib.wg_buf_ipc_export(tensor._h, buf))
-        return buf.raw
-
-    def register_peers(self, tensor, handles: List[bytes]) -> None:
-        """handles[r] = rank r's export_handle(its output tensor) (handles[self.rank] is ignored). After this, `tensor` can be the
-        output of sharded_gemm(..., mode=GatherMode.PEER_COPY)."""
-        arr = (ctypes.c_void_p * self.nranks)()
-        opened = []
-        for r, hb in enumerate(handles):
-            if r == self.rank:
-                arr[r] = tensor._h.value
-                continue
-            b = ctypes.c_void_p()
-            self._lib.check(self._lib.lib.wg_buf_ipc_open(self.gpu._ctx.handle, ctypes.create_string_buffer(hb, self._lib.WG_IPC_HANDLE_BYTES), ctypes.byref(b)))
-            arr[r] = b.value
-            opened.append(b)
-        self._peers[id(tensor)] = (arr, opened)
-
-    def release_peers(self, tensor) -> None:
-        """Unmap the peers' buffers registered for `tensor` (call before the owners free them; every rank's copies must be done: flush + barrier)."""
-        ent = self._peers.pop(id(tensor), None)
-        if ent is not None:
-            for b in ent[1]:
-                self._lib.lib.wg_buf_destroy(b)
-
-    def register_local_peers(self, tensor, tensors) -> None:
-        """The ranks share this process (tests): peer r's output is `tensors[r]` itself."""
-        arr = (ctypes.c_void_p * self.nranks)()
-        for r, t in enumerate(tensors):
-            arr[r] = t._h.value
-        self._peers[id(tensor)] = (arr, [])
 
     # -- staged peer copies (GatherMode.PEER_STAGED): the communicator's staging cubes + flag array ---------------------------
     def stage_reserve(self, nbytes: int):
@@ -332,11 +299,5 @@ class Comm:
         when `out` is complete)."""
         from .wgcore import as_view, wg_dtype
         ov, av, bv = as_view(out), as_view(a_rows), as_view(b)
-        peers = None
-        if mode == GatherMode.PEER_COPY and self.nranks > 1:
-            ent = self._peers.get(id(ov.buffer()))
-            if ent is None:
-                raise ValueError("PEER_COPY: call register_peers(out, handles) first")
-            peers = ent[0]
         self._lib.check(self._lib.lib.wg_gemm_sharded(self._h, int(variant), wg_dtype(ov.dtype), int(mode), int(panel_cols), ov.buffer()._h, ov.shape().to_c(),
-                                                      peers, av.buffer()._h, av.shape().to_c(), bv.buffer()._h, bv.shape().to_c()))
+                                                      av.buffer()._h, av.shape().to_c(), bv.buffer()._h, bv.shape().to_c()))

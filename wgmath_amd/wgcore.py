@@ -238,6 +238,23 @@ class Queue:
         check(lib.wg_buf_write(self._ctx.handle, tensor._h, offset_bytes, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
 
 
+class ClockProbe:
+    """wg_debug_clock_begin / _end around whatever is enqueued in between on the instance's stream (see GpuInstance.clock_probe)."""
+
+    def __init__(self, gpu):
+        self._gpu = gpu
+        self._open = lib.wg_debug_clock_begin(gpu._ctx.handle) == _lib.WG_OK  # a diagnostic: never takes the measured run down with it
+
+    def end(self):
+        if not self._open:
+            return None
+        self._open = False
+        mean, lo, hi, secs = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        if lib.wg_debug_clock_end(self._gpu._ctx.handle, ctypes.byref(mean), ctypes.byref(lo), ctypes.byref(hi), ctypes.byref(secs)) != _lib.WG_OK:
+            return None
+        return {"mean": mean.value, "min": lo.value, "max": hi.value, "seconds": secs.value}
+
+
 class GpuInstance:
     """gpu.rs:7-78.  `GpuInstance.new()` picks device 0; one instance == one GPU == one in-order stream."""
 
@@ -293,6 +310,18 @@ class GpuInstance:
 
     def sync(self) -> None:
         check(lib.wg_ctx_sync(self._ctx.handle))
+
+    # -- diagnostics (wg_debug_*): what the chip did while a kernel ran; the role GpuTimestamps (timestamps.rs:226-230) plays for time ----------
+    def clock_probe(self) -> "ClockProbe":
+        """Stamps the context's stream now (wg_debug_clock_begin); `.end()` stamps it again, synchronises and returns the mean shader clock of
+        the interval in GHz as {"mean", "min", "max"} over the XCDs (+ "seconds"), or None if the probe could not run."""
+        return ClockProbe(self)
+
+    def mfma_ceiling(self, min_seconds: float = 0.5) -> dict:
+        """v_mfma_f32_16x16x32_f16 alone on random in-register operands for `min_seconds`: {"tflops", "clock_ghz"} (wg_debug_mfma_ceiling)."""
+        tf, ghz = ctypes.c_double(), ctypes.c_double()
+        check(lib.wg_debug_mfma_ceiling(self._ctx.handle, float(min_seconds), ctypes.byref(tf), ctypes.byref(ghz)))
+        return {"tflops": tf.value, "clock_ghz": ghz.value}
 
     def close(self) -> None:
         self._ctx.close()
