@@ -1459,3 +1459,91 @@ def test_gemv_inf_in_the_last_column_stays_inf(gpu, R, C, dtype):
         orc = np.zeros(R, np.float32)
         wo.CLib().gemv(wo.GEMV, orc, wo.Shape(R), m, wo.Shape(R, C), v, wo.Shape(C))
         assert np.array_equal(np.isinf(orc), np.isinf(got)) and not np.isnan(orc).any()
+
+
+# --------------------------------------------------------------------------------------------------------
+# The mid-size f32 tile family (gemm_f32_mid.hip, whole K per workgroup): 128 x 128, 128 x 64, 64 x 128 tiles on 2 x 2 waves -- the same k-ordered
+# fmaf chain per element whatever the tile: bit for bit against each other and against gemm_f32.hip's unsplit result -- and 64 x 64, 64 x 32,
+# 32 x 64 tiles whose four waves split K, (p0 + p2) + (p1 + p3): bit for bit among themselves. Every tile shape forced (WG_TUNE_F32_MID) over
+# ragged M / N, a K remainder, batches and both variants, against the oracle and f64.
+# --------------------------------------------------------------------------------------------------------
+MID_TILES = [128128, 128064, 64128]
+MID_KW_TILES = [64064, 64032, 32064]
+MID_SHAPES = [(256, 256, 256, 1), (512, 128, 384, 1), (1024, 512, 1024, 1), (132, 64, 68, 1), (260, 200, 324, 3), (64, 32, 64, 5), (1000, 1000, 1000, 1),
+              (4, 36, 4, 2), (2048, 48, 2048, 1), (96, 96, 160, 2)]
+
+
+@pytest.mark.parametrize("M,K,N,mats", MID_SHAPES)
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f32_mid_tiles(gpu, oracle_c, M, K, N, mats, tr):
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M * 7919 + K * 31 + N + mats + int(tr))
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    s1 = wo.Shape(K, M, mats) if tr else wo.Shape(M, K, mats)
+    s2, so = wo.Shape(K, N, mats), wo.Shape(M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    orc = np.zeros(M * N * mats, np.float32)
+    oracle_c.gemm(int(variant), orc, so, a, s1, b, s2)
+    m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a)
+    m2 = upload(gpu, (K, N, mats), b)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    A, B = wo.view(a, s1), wo.view(b, s2)
+    results = {}
+    for knob in MID_TILES + MID_KW_TILES + [1, 0]:  # every tile; the estimate's own tile; the family off (gemm_f32.hip and friends)
+        old = gpu.set_tuning("f32_mid", knob)
+        try:
+            out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float32))
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            got = out.read(gpu.device())
+        finally:
+            gpu.set_tuning("f32_mid", old)
+        results[knob] = got
+        for t in range(mats):
+            amk = A[:, :, t].T if tr else A[:, :, t]
+            truth, sabs = wo.gemm_f64(amk, B[:, :, t])
+            g_t = wo.view(got, so)[:, :, t]
+            U.assert_close_f64(g_t, truth, K, sabs, f"mid tile {knob}: gemm {M}x{K}x{N} mat {t} tr={tr} vs f64")
+            U.assert_close_oracle(g_t, wo.view(orc, so)[:, :, t], K, sabs, f"mid tile {knob} vs oracle")
+    for knob in MID_TILES[1:]:
+        U.assert_bits_equal(results[knob], results[MID_TILES[0]], f"mid tile {knob} vs 128 x 128: {M}x{K}x{N} tr={tr}")
+    for knob in MID_KW_TILES[1:]:
+        U.assert_bits_equal(results[knob], results[MID_KW_TILES[0]], f"k-split tile {knob} vs 64 x 64: {M}x{K}x{N} tr={tr}")
+    assert results[1].tobytes() in (results[MID_TILES[0]].tobytes(), results[MID_KW_TILES[0]].tobytes())  # the estimate's tile is one of the two
+
+
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f32_mid_equals_the_big_tile_unsplit(gpu, tr):
+    """4096 x 4096 x 256: 512 of gemm_f32.hip's 256 x 128 tiles (no K cut) against the 128 x 128 family: the same chain per element, bit for bit;
+    and alpha / beta through the family's epilogue against the two-step form."""
+    wg = _wg()
+    M = N = 4096
+    K = 256
+    rng = np.random.default_rng(5 + int(tr))
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float32)
+    c0 = (rng.random(M * N, dtype=np.float32) * 2 - 1).astype(np.float32)
+    m1, m2 = upload(gpu, (K, M) if tr else (M, K), a), upload(gpu, (K, N), b)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    got = {}
+    for knob in (0, 128128, 64128):
+        old = gpu.set_tuning("f32_mid", knob)
+        try:
+            out = upload(gpu, (M, N), np.full(M * N, np.nan, np.float32))
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            got[knob] = out.read(gpu.device())
+            if knob:
+                from wgmath_amd._lib import check, lib
+                from wgmath_amd.wgcore import as_view
+                oc = upload(gpu, (M, N), c0)
+                ov, av, bv = as_view(oc), as_view(m1), as_view(m2)
+                check(lib.wg_gemm_ex(gpu._ctx.handle, int(variant), 0, 0.5, -2.0, ov.buffer()._h, ov.shape().to_c(), av.buffer()._h, av.shape().to_c(),
+                                     bv.buffer()._h, bv.shape().to_c()))
+                exp = np.float32(0.5) * got[knob]
+                exp = np.float32(-2.0) * c0 + exp  # fmaf(beta, c, alpha * acc): -2 c is exact, so one rounding either way
+                U.assert_bits_equal(oc.read(gpu.device()), exp.astype(np.float32), f"alpha/beta through the mid family (tile {knob})")
+        finally:
+            gpu.set_tuning("f32_mid", old)
+    U.assert_bits_equal(got[128128], got[0], "128 x 128 family vs the 256 x 128 tile")
+    U.assert_bits_equal(got[64128], got[0], "64 x 128 tiles vs the 256 x 128 tile")

@@ -630,6 +630,36 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             if (t < best) { best = t; nsplit = 1; tail_r = r; tail_sp = sp; }
         }
     }
+    // Mid-size outputs: the small-tile family (gemm_f32_mid.hip) -- more tiles instead of a K cut or a detour over the few-column kernel.
+    // Model, calibrated on tools/f32_mid_sweep.py (profiles/r04_f32_mid_sweep.txt): tiles are dealt round-robin, the busiest CU works through
+    // ceil(tiles / CUs) of them, each at the matrix cores' rate (157.3 TFLOP/s / 256 per CU) less a loop cost by tile (barriers, issue, what
+    // co-resident workgroups do not cover) plus ~1-1.5 us of its own (first fills, last stores, the k-split tiles' reduction); ~3 us per launch.
+    //   2 x 2-wave tiles: 128 x 64 (+12 %), 64 x 128 (+20 %), 128 x 128 (+17 %, only while every CU gets at most one: three of them sharing a CU
+    //   measured far worse, 4096^3 1409 us against 969 on 128 x 64);
+    //   k-split tiles: 64 x 64 (+4 %; GemmTr with a power-of-two leading dimension >= 1024 and several tiles per CU +30 %: 2048^3 148 us against
+    //   124 for Gemm -- every row segment of a tile then comes from the same few memory channels), 64 x 32 / 32 x 64 (+8 %); with more than one
+    //   round only from K = 256 up (their per-tile reduction does not amortise over a handful of k-tiles: 128^3 x 256 matrices 21 us against 16).
+    double mid_est = 1e30;
+    int mid_bm = 0, mid_bn = 0;
+    const int mid_knob = ctx->tuning[WG_TUNE_F32_MID];
+    if (mid_knob != 0 && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
+        const bool pow2_ld = trans && m1.ld >= 1024u && (m1.ld & (m1.ld - 1u)) == 0;
+        // { bm, bn, k-split family, loop cost in per cent, us per tile }
+        static const int cand[6][5] = { { 128, 64, 0, 12, 10 }, { 64, 128, 0, 20, 10 }, { 64, 64, 1, 4, 15 }, { 64, 32, 1, 8, 15 }, { 32, 64, 1, 8, 15 }, { 128, 128, 0, 17, 10 } };
+        for (const auto &c : cand) {
+            if (mid_knob > 1 && mid_knob != c[0] * 1000 + c[1]) continue;
+            const uint64_t t = (uint64_t)((M + c[0] - 1) / c[0]) * ((N + c[1] - 1) / c[1]) * nmats;
+            const double r = rounds(t);
+            if (mid_knob <= 1) {
+                if (c[0] == 128 && c[1] == 128 && r > 1.0) continue;
+                if (c[2] && r > 1.0 && K < 256) continue;
+            }
+            const double loop = 1.0 + 0.01 * ((c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) ? 30 : c[3]);
+            const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
+            const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
+            if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; }
+        }
+    }
     // Small outputs (few 256 x 128 tiles): 64-column panels of the few-column kernel (gemm_f32_skinny.hip) give 128 x 64 "tiles", eight
     // times as many, each streaming its rows through a wave-private ring at ~1.4 us per 32 k (+ ~2.5 us of pipeline fill per workgroup):
     // 1024^3 25 + 5 us instead of 33 + 7.
@@ -648,8 +678,14 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // (what the tiled plan's time above leaves out and short-K launches feel: ~3 us per round of workgroups and the output written at ~3.5 TB/s --
         // 1024 x 1024 x 128 x 32 matrices: 59 us by the formula, 107 measured)
         const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + (nsplit == 1 && tail_r == 0 ? out_bytes / 3.5e6 : 0.0);
-        if ((force >= 0 ? force == 1 : best_p < 0.95 * tiled))
+        const bool mid_wins = mid_bm && (mid_knob >= 1 || (force != 1 && mid_est < 0.97 * best_p && mid_est < 0.97 * (tiled + 5.0)));
+        if (!mid_wins && (force >= 0 ? force == 1 : best_p < 0.95 * tiled))
             return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, 1u, false, ns_p);
+    }
+    if (mid_bm) {
+        const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + (nsplit == 1 && tail_r == 0 ? out_bytes / 3.5e6 : 0.0) + 5.0; // (+ launch and drain)
+        if (mid_knob >= 1 || mid_est < 0.97 * tiled)
+            return wgk_gemm_f32_mid(ctx, trans, mid_bm, mid_bn, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }
     float *part = nullptr;
     g.nsplit = nsplit;

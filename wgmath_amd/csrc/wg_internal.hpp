@@ -43,7 +43,7 @@ struct wg_ctx {
         void *scratch = nullptr;            // raw f32 accumulator tiles of the prefix units (grow-only)
         size_t scratch_bytes = 0;
     } bal;
-    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
     bool debug_clock_open = false;
     uint32_t func_attr_bits = 0;         // hipFuncSetAttribute calls already made for this context's device (gemv.hip: GemvTr's 128 KiB dynamic LDS)
@@ -138,6 +138,11 @@ int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, fl
 
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
+// gemm_f32_mid.hip: bm x bn tiles (128 x 128, 128 x 64, 64 x 128 on 2 x 2 waves; 64 x 64, 64 x 32, 32 x 64 with K split over the waves), whole K per workgroup;
+// _ok: the shapes / strides it takes
+bool wgk_gemm_f32_mid_ok(uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, wgk_mat m1, wgk_mat m2);
+int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
+                     wgk_mat m1, wgk_mat m2, float alpha, float beta);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
 // N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
