@@ -174,9 +174,9 @@ typedef enum wg_tuning {
     WG_TUNE_F32_PANELS = 3,  /* -1 = by estimate, 0 / 1: 64-column panels of the few-column kernel for small square f32 products */
     WG_TUNE_F16_BALANCE = 4, /* calibrated per-XCD shares (K-prefix units) for f16 products of few rounds: 0 = off (default: measured not to pay on
                                 MI355X, gemm_f16.hip), -1 = measure slot rates and let the planner decide, 1 = the tests' fixed pattern */
-    WG_TUNE_F32_MID = 5,     /* the mid-size f32 tile family (gemm_f32_mid.hip: 128 x 128, 128 x 64, 64 x 128 tiles on 2 x 2 waves; 64 x 64, 64 x 32, 32 x 64
-                                with K split over the workgroup's waves; no slabs, no second launch): -1 = by estimate (default), 0 = never, 1 = whenever
-                                applicable with the estimate's tile, 128128 / 128064 / 64128 / 64064 / 64032 / 32064 = that tile (tests) */
+    WG_TUNE_F32_MID = 5,     /* the mid-size f32 tile family (gemm_f32_mid.hip: 128 x 128, 128 x 64, 64 x 128 tiles on 2 x 2 waves; 96 x 96, 96 x 64, 64 x 96, 64 x 64, 64 x 32,
+                                32 x 64 with K split over the workgroup's waves; no slabs, no second launch): -1 = by estimate (default), 0 = never, 1 = whenever
+                                applicable with the estimate's tile, 128128 / 128064 / 64128 / 96096 / 96064 / 64096 / 64064 / 64032 / 32064 = that tile (tests) */
     WG_TUNE_COUNT_ = 6
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);

@@ -1468,7 +1468,7 @@ def test_gemv_inf_in_the_last_column_stays_inf(gpu, R, C, dtype):
 # ragged M / N, a K remainder, batches and both variants, against the oracle and f64.
 # --------------------------------------------------------------------------------------------------------
 MID_TILES = [128128, 128064, 64128]
-MID_KW_TILES = [64064, 64032, 32064]
+MID_KW_TILES = [64064, 64032, 32064, 96096, 96064, 64096]
 MID_SHAPES = [(256, 256, 256, 1), (512, 128, 384, 1), (1024, 512, 1024, 1), (132, 64, 68, 1), (260, 200, 324, 3), (64, 32, 64, 5), (1000, 1000, 1000, 1),
               (4, 36, 4, 2), (2048, 48, 2048, 1), (96, 96, 160, 2)]
 

@@ -23,7 +23,7 @@ SHAPES = [(512, 512, 512, 1), (768, 768, 768, 1), (1024, 1024, 1024, 1), (1000, 
 if sys.argv[1:]:
     SHAPES = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
     SHAPES = [s if len(s) == 4 else s + (1,) for s in SHAPES]
-KNOBS = [0, 128128, 128064, 64128, 64064, 64032, 32064, -1]
+KNOBS = [0, 128128, 128064, 64128, 64064, 64032, 32064, 96096, 96064, -1]
 
 
 def reps_for(M, N, K, B):
@@ -76,7 +76,7 @@ def vendor(M, N, K, B, tr):
     return best
 
 
-print("# us per call: gemm_f32.hip plan | 128x128 | 128x64 | 64x128 | 64x64 | 64x32 | 32x64 | launcher's choice | vendor ; choice/vendor")
+print("# us per call: gemm_f32.hip plan | 128x128 | 128x64 | 64x128 | 64x64 | 64x32 | 32x64 | 96x96 | 96x64 | launcher's choice | vendor ; choice/vendor")
 for (M, N, K, B) in SHAPES:
     for tr in (False, True):
         ts = [ours(M, N, K, B, tr, k) * 1e6 for k in KNOBS]

@@ -28,6 +28,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) works on a contiguous band of tiles.
 #include "wg_internal.hpp"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -616,6 +617,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             }
             if (best_sp > 1) { tail_r = r; tail_sp = best_sp; }
             tail_done = true;
+            // what this plan takes: the full waves of 2 x CUs tiles, then the leftover wave -- as it is, or cut along K
+            best = (double)(tiles / cap) * K * pair + (best_sp > 1 ? best_t : (double)K * pair);
         }
     }
     if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus && !tail_done) {
@@ -636,16 +639,20 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // co-resident workgroups do not cover) plus ~1-1.5 us of its own (first fills, last stores, the k-split tiles' reduction); ~3 us per launch.
     //   2 x 2-wave tiles: 128 x 64 (+12 %), 64 x 128 (+20 %), 128 x 128 (+17 %, only while every CU gets at most one: three of them sharing a CU
     //   measured far worse, 4096^3 1409 us against 969 on 128 x 64);
-    //   k-split tiles: 64 x 64 (+4 %; GemmTr with a power-of-two leading dimension >= 1024 and several tiles per CU +30 %: 2048^3 148 us against
-    //   124 for Gemm -- every row segment of a tile then comes from the same few memory channels), 64 x 32 / 32 x 64 (+8 %); with more than one
-    //   round only from K = 256 up (their per-tile reduction does not amortise over a handful of k-tiles: 128^3 x 256 matrices 21 us against 16).
+    //   k-split tiles: 64 x 64 (GemmTr with a power-of-two leading dimension >= 1024 and several tiles per CU +30 %: 2048^3 148 us against
+    //   124 for Gemm -- every row segment of a tile then comes from the same few memory channels), 96 x 96 / 96 x 64 / 64 x 96 (sizes that
+    //   are multiples of 96: 1536^3 is 256 tiles of 96 x 96 -- 58 us against 70 on 64 x 64 and the vendor's 62), 64 x 32 / 32 x 64; with more
+    //   than one round only from K = 256 up (their per-tile reduction does not amortise over a handful of k-tiles: 128^3 x 256 matrices 21 us against 16).
     double mid_est = 1e30;
     int mid_bm = 0, mid_bn = 0;
     const int mid_knob = ctx->tuning[WG_TUNE_F32_MID];
-    if (mid_knob != 0 && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
+    // Mid-size means mid-size: from ~4 tiles of 256 x 128 per CU on, this file's kernel runs at 93-96 % of the matrix cores' rate and the small
+    // tiles' extra barriers and fills only cost (8192^3: 7287 us here, 7980 on 64 x 64 tiles).
+    if (mid_knob != 0 && (mid_knob >= 1 || tiles * nmats <= 4ull * (uint64_t)cus) && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
         const bool pow2_ld = trans && m1.ld >= 1024u && (m1.ld & (m1.ld - 1u)) == 0;
-        // { bm, bn, k-split family, loop cost in per cent, us per tile }
-        static const int cand[6][5] = { { 128, 64, 0, 12, 10 }, { 64, 128, 0, 20, 10 }, { 64, 64, 1, 4, 15 }, { 64, 32, 1, 8, 15 }, { 32, 64, 1, 8, 15 }, { 128, 128, 0, 17, 10 } };
+        // { bm, bn, k-split family, loop cost in per cent (2 x 2-wave tiles; k-split tiles: on top of the curve below), tenths of a us per tile }
+        static const int cand[9][5] = { { 128, 64, 0, 12, 10 }, { 64, 128, 0, 20, 10 }, { 64, 64, 1, 0, 15 }, { 96, 96, 1, 3, 20 }, { 96, 64, 1, 3, 18 }, { 64, 96, 1, 3, 18 },
+                                        { 64, 32, 1, 4, 27 }, { 32, 64, 1, 4, 27 }, { 128, 128, 0, 17, 10 } };
         for (const auto &c : cand) {
             if (mid_knob > 1 && mid_knob != c[0] * 1000 + c[1]) continue;
             const uint64_t t = (uint64_t)((M + c[0] - 1) / c[0]) * ((N + c[1] - 1) / c[1]) * nmats;
@@ -654,7 +661,10 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 if (c[0] == 128 && c[1] == 128 && r > 1.0) continue;
                 if (c[2] && r > 1.0 && K < 256) continue;
             }
-            const double loop = 1.0 + 0.01 * ((c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) ? 30 : c[3]);
+            // k-split tiles: one workgroup alone on a CU leaves its barriers uncovered (+16 %: 1024^3, 1536^3); co-resident ones cover each other
+            // (+5 % at 4 rounds) until the small tiles' traffic shows (+9 % at 16 rounds, +13 % at 64: 2048^3 / 4096^3 / 8192^3 on 64 x 64)
+            double loop = c[2] ? (r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r)) + 0.01 * c[3] : 1.0 + 0.01 * c[3];
+            if (c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) loop = 1.30;
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
             if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; }

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kThreads, (WT_M * WT_N == 4 ? 2 : 3)) void gemm_f32
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Small tiles: 64 x 64, 64 x 32, 32 x 64 -- the four waves of a workgroup SHARE one block tile and split K between them.
+// Small tiles: 96 x 96, 96 x 64, 64 x 96, 64 x 64, 64 x 32, 32 x 64 -- the four waves of a workgroup SHARE one block tile and split K between them.
 // Why: with 2 x 2 waves a 64 x 64 block leaves every wave ONE 32 x 32 accumulator, i.e. one dependent MFMA chain and a barrier every 8
 // MFMAs (measured 63-70 % of the matrix cores' rate with one workgroup per CU: 1024^3 25 us against the vendor's 19.5). Here every wave
 // holds the whole block (WT_M x WT_N independent accumulators) and multiplies ITS quarter of every k-tile: k-tile 32, wave w takes the 8 k of
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
     };
 
     // ---- this wave's fragments of one k-tile: chunk 2 wave + h, steps s = 0..3; two register sets (tile parity) ----
-    typedef typename std::conditional<WT_M == 2, floatx2, float>::type a_nn_t;
+    struct a_nn_t { float v[WT_M]; }; // WT_M consecutive m (one per M-tile)
     a_nn_t af_nn[2][4];
     float4 af_tn[2][WT_M], bf[2][WT_N];
     const int chunk = 2 * wave + h;
@@ -370,7 +370,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
         const float *Bs = As + A_TILE;
         if constexpr (!TRANS_A) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) af_nn[set][s] = *reinterpret_cast<const a_nn_t *>(&As[(4 * chunk + s) * BM + WT_M * i]);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < WT_M; ++t) af_nn[set][s].v[t] = As[(4 * chunk + s) * BM + WT_M * i + t];
         } else {
 #pragma unroll
             for (int t = 0; t < WT_M; ++t) {
@@ -386,8 +388,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
     };
     auto a_of = [&](int set, int s, int t) -> float {
         if constexpr (TRANS_A) return comp(af_tn[set][t], s);
-        else if constexpr (WT_M == 2) return af_nn[set][s][t];
-        else return af_nn[set][s];
+        else return af_nn[set][s].v[t];
     };
     auto mfma_step = [&](int set, int s) {
 #pragma unroll
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             for (int u = 0; u < WT_N; ++u) add(wave, t, u); // p0 + p2, p1 + p3
     }
     __syncthreads();
-    constexpr int U_SPLIT = WT_N == 2 ? 1 : 0; // 1: wave 1 keeps the columns u = 1 and hands u = 0 over, wave 0 the other way round
+    constexpr int U_SPLIT = WT_N == 2 ? 1 : 0; // 1: wave 1 keeps the columns u = 1 and hands u = 0 over, wave 0 the other way round (else: all to wave 0)
     if (wave < 2) {
 #pragma unroll
         for (int t = 0; t < WT_M; ++t)
@@ -530,13 +531,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
         float *cc = C + (uint64_t)col * g.ldc;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            if constexpr (!TRANS_A && WT_M == 2) {
+            if constexpr (!TRANS_A && WT_M > 1) {
+                // M-tile t holds rows WT_M r + t of the block: (e & 3, t) enumerate 4 WT_M consecutive rows from WT_M (8 gq + 4 h)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const uint32_t row = m0 + 16 * gq + 8 * h + 4 * p;
-                    if (row < g.M)
-                        store_c(cc + row, make_float4(acc[0][u][4 * gq + 2 * p], acc[1][u][4 * gq + 2 * p], acc[0][u][4 * gq + 2 * p + 1], acc[1][u][4 * gq + 2 * p + 1]),
-                                g.alpha, g.beta);
+                for (int p = 0; p < WT_M; ++p) {
+                    const uint32_t row = m0 + WT_M * (8 * gq + 4 * h) + 4 * p;
+                    auto val = [&](int n) { return acc[n % WT_M][u][4 * gq + n / WT_M]; };
+                    if (row < g.M) store_c(cc + row, make_float4(val(4 * p), val(4 * p + 1), val(4 * p + 2), val(4 * p + 3)), g.alpha, g.beta);
                 }
             } else {
 #pragma unroll
@@ -592,5 +593,8 @@ int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32
     if (bm == 64 && bn == 64) return launch_kw<2, 2>(ctx, trans, nmats, g);
     if (bm == 64 && bn == 32) return launch_kw<2, 1>(ctx, trans, nmats, g);
     if (bm == 32 && bn == 64) return launch_kw<1, 2>(ctx, trans, nmats, g);
+    if (bm == 96 && bn == 96) return launch_kw<3, 3>(ctx, trans, nmats, g);
+    if (bm == 96 && bn == 64) return launch_kw<3, 2>(ctx, trans, nmats, g);
+    if (bm == 64 && bn == 96) return launch_kw<2, 3>(ctx, trans, nmats, g);
     return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: no %d x %d f32 tile", bm, bn);
 }
