@@ -16,8 +16,11 @@
 //   * svd (2, 3)             (svd2/3.wgsl)    : M = U diag(S) Vt, S >= 0 in descending order;
 //   * Quat, Rot2, Sim2, Sim3 (quat/rot2/sim2/sim3.wgsl): unit quaternion (x, y, z, w), 2-D rotation (cos, sin), similarities
 //                                               x -> scale * R x + t, with the reference's function names.
-// Results agree with the reference within its own test tolerances (relative 1e-3 / 1e-4 against nalgebra); they are not
-// bit-identical (different but equivalent algorithms for QR, eigen and SVD).
+// Results agree with the reference within its own test tolerances (relative 1e-3 / 1e-4 against nalgebra). The CLOSED-FORM functions -- inv2/3/4,
+// cholesky, lu, Rot2, Quat, Sim2, Sim3 -- follow the reference's WGSL expression by expression, every product and sum rounded separately (no FMA
+// contraction: WGG_EXACT below), so that on the same inputs they give the bits the WGSL text gives when read that way (left to right, `dot` and
+// `cross` as their defining formulas: tests/golden/wgsl_exec_geometry.npz, made by running the reference's .wgsl files through oracle/wgsl_exec.py).
+// QR, eigen and SVD are different but equivalent algorithms and are not bit-identical.
 #pragma once
 
 #include <math.h>
@@ -27,6 +30,14 @@
 #define WGG_FN __host__ __device__ inline
 #else
 #define WGG_FN inline
+#endif
+// First statement of a function whose results are pinned to the WGSL text: a * b + c stays a rounded product and a rounded sum whatever
+// -ffp-contract the including translation unit was built with. (g++ has no per-function switch: its host builds of the pinned functions are
+// compiled with -ffp-contract=off, tests/test_geometry.py.)
+#if defined(__clang__)
+#define WGG_EXACT _Pragma("clang fp contract(off)")
+#else
+#define WGG_EXACT
 #endif
 
 namespace wgebra {
@@ -83,61 +94,74 @@ WGG_FN Vec<N> mul(const Mat<N> &a, const Vec<N> &x) {
 // ---------------------------------------------------------------------------------------------------------------
 // inverse (inv.wgsl:8-88): adjugate / determinant
 // ---------------------------------------------------------------------------------------------------------------
-WGG_FN Mat2 inv2(const Mat2 &m) {
+WGG_FN Mat2 inv2(const Mat2 &m) { // inv.wgsl:8-18
+    WGG_EXACT
+    Mat2 adj;
+    adj.c[0][0] = m.c[1][1];
+    adj.c[0][1] = -m.c[0][1];
+    adj.c[1][0] = -m.c[1][0];
+    adj.c[1][1] = m.c[0][0];
     const float det = m.c[0][0] * m.c[1][1] - m.c[1][0] * m.c[0][1];
     const float s = 1.f / det;
-    Mat2 r;
-    r.c[0][0] = m.c[1][1] * s;
-    r.c[0][1] = -m.c[0][1] * s;
-    r.c[1][0] = -m.c[1][0] * s;
-    r.c[1][1] = m.c[0][0] * s;
-    return r;
-}
-WGG_FN Mat3 inv3(const Mat3 &m) {
-    // cofactors of the transposed matrix; a(r, c) = m.c[c][r]
-    auto a = [&](int r, int c) { return m.c[c][r]; };
-    Mat3 adj;
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-            const int r1 = (r + 1) % 3, r2 = (r + 2) % 3, c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-            adj.c[r][c] = a(r1, c1) * a(r2, c2) - a(r1, c2) * a(r2, c1); // cofactor (r, c) lands at (c, r) of the adjugate
-        }
-    const float det = a(0, 0) * adj.c[0][0] + a(0, 1) * adj.c[0][1] + a(0, 2) * adj.c[0][2];
-    const float s = 1.f / det;
-    for (int j = 0; j < 3; ++j)
-        for (int i = 0; i < 3; ++i) adj.c[j][i] *= s;
+    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i) adj.c[j][i] = adj.c[j][i] * s;
     return adj;
 }
-WGG_FN Mat4 inv4(const Mat4 &m) {
-    // Laplace expansion with the six 2x2 minors of the two row pairs
-    auto a = [&](int r, int c) { return m.c[c][r]; };
-    const float s0 = a(0, 0) * a(1, 1) - a(1, 0) * a(0, 1), s1 = a(0, 0) * a(1, 2) - a(1, 0) * a(0, 2);
-    const float s2 = a(0, 0) * a(1, 3) - a(1, 0) * a(0, 3), s3 = a(0, 1) * a(1, 2) - a(1, 1) * a(0, 2);
-    const float s4 = a(0, 1) * a(1, 3) - a(1, 1) * a(0, 3), s5 = a(0, 2) * a(1, 3) - a(1, 2) * a(0, 3);
-    const float c5 = a(2, 2) * a(3, 3) - a(3, 2) * a(2, 3), c4 = a(2, 1) * a(3, 3) - a(3, 1) * a(2, 3);
-    const float c3 = a(2, 1) * a(3, 2) - a(3, 1) * a(2, 2), c2 = a(2, 0) * a(3, 3) - a(3, 0) * a(2, 3);
-    const float c1 = a(2, 0) * a(3, 2) - a(3, 0) * a(2, 2), c0 = a(2, 0) * a(3, 1) - a(3, 0) * a(2, 1);
-    const float det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+WGG_FN Mat3 inv3(const Mat3 &m) { // inv.wgsl:24-43
+    WGG_EXACT
+    const float(&a)[3][3] = m.c; // a[col][row] == WGSL m[col][row]
+    Mat3 adj;
+    adj.c[0][0] = (a[1][1] * a[2][2] - a[2][1] * a[1][2]);
+    adj.c[1][0] = -(a[1][0] * a[2][2] - a[2][0] * a[1][2]);
+    adj.c[2][0] = (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    adj.c[0][1] = -(a[0][1] * a[2][2] - a[2][1] * a[0][2]);
+    adj.c[1][1] = (a[0][0] * a[2][2] - a[2][0] * a[0][2]);
+    adj.c[2][1] = -(a[0][0] * a[2][1] - a[2][0] * a[0][1]);
+    adj.c[0][2] = (a[0][1] * a[1][2] - a[1][1] * a[0][2]);
+    adj.c[1][2] = -(a[0][0] * a[1][2] - a[1][0] * a[0][2]);
+    adj.c[2][2] = (a[0][0] * a[1][1] - a[1][0] * a[0][1]);
+    const float det = (a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
     const float s = 1.f / det;
-    Mat4 r;
-    auto set = [&](int rr, int cc, float v) { r.c[cc][rr] = v * s; };
-    set(0, 0, a(1, 1) * c5 - a(1, 2) * c4 + a(1, 3) * c3);
-    set(0, 1, -a(0, 1) * c5 + a(0, 2) * c4 - a(0, 3) * c3);
-    set(0, 2, a(3, 1) * s5 - a(3, 2) * s4 + a(3, 3) * s3);
-    set(0, 3, -a(2, 1) * s5 + a(2, 2) * s4 - a(2, 3) * s3);
-    set(1, 0, -a(1, 0) * c5 + a(1, 2) * c2 - a(1, 3) * c1);
-    set(1, 1, a(0, 0) * c5 - a(0, 2) * c2 + a(0, 3) * c1);
-    set(1, 2, -a(3, 0) * s5 + a(3, 2) * s2 - a(3, 3) * s1);
-    set(1, 3, a(2, 0) * s5 - a(2, 2) * s2 + a(2, 3) * s1);
-    set(2, 0, a(1, 0) * c4 - a(1, 1) * c2 + a(1, 3) * c0);
-    set(2, 1, -a(0, 0) * c4 + a(0, 1) * c2 - a(0, 3) * c0);
-    set(2, 2, a(3, 0) * s4 - a(3, 1) * s2 + a(3, 3) * s0);
-    set(2, 3, -a(2, 0) * s4 + a(2, 1) * s2 - a(2, 3) * s0);
-    set(3, 0, -a(1, 0) * c3 + a(1, 1) * c1 - a(1, 2) * c0);
-    set(3, 1, a(0, 0) * c3 - a(0, 1) * c1 + a(0, 2) * c0);
-    set(3, 2, -a(3, 0) * s3 + a(3, 1) * s1 - a(3, 2) * s0);
-    set(3, 3, a(2, 0) * s3 - a(2, 1) * s1 + a(2, 2) * s0);
-    return r;
+    for (int j = 0; j < 3; ++j)
+        for (int i = 0; i < 3; ++i) adj.c[j][i] = adj.c[j][i] * s;
+    return adj;
+}
+WGG_FN Mat4 inv4(const Mat4 &m) { // inv.wgsl:49-88
+    WGG_EXACT
+    const float(&a)[4][4] = m.c;
+    const float sf00 = a[2][2] * a[3][3] - a[3][2] * a[2][3], sf01 = a[2][1] * a[3][3] - a[3][1] * a[2][3];
+    const float sf02 = a[2][1] * a[3][2] - a[3][1] * a[2][2], sf03 = a[2][0] * a[3][3] - a[3][0] * a[2][3];
+    const float sf04 = a[2][0] * a[3][2] - a[3][0] * a[2][2], sf05 = a[2][0] * a[3][1] - a[3][0] * a[2][1];
+    const float sf06 = a[1][2] * a[3][3] - a[3][2] * a[1][3], sf07 = a[1][1] * a[3][3] - a[3][1] * a[1][3];
+    const float sf08 = a[1][1] * a[3][2] - a[3][1] * a[1][2], sf09 = a[1][0] * a[3][3] - a[3][0] * a[1][3];
+    const float sf10 = a[1][0] * a[3][2] - a[3][0] * a[1][2], sf11 = a[1][1] * a[3][3] - a[3][1] * a[1][3];
+    const float sf12 = a[1][0] * a[3][1] - a[3][0] * a[1][1], sf13 = a[1][2] * a[2][3] - a[2][2] * a[1][3];
+    const float sf14 = a[1][1] * a[2][3] - a[2][1] * a[1][3], sf15 = a[1][1] * a[2][2] - a[2][1] * a[1][2];
+    const float sf16 = a[1][0] * a[2][3] - a[2][0] * a[1][3], sf17 = a[1][0] * a[2][2] - a[2][0] * a[1][2];
+    const float sf18 = a[1][0] * a[2][1] - a[2][0] * a[1][1];
+    Mat4 adj;
+    adj.c[0][0] = (a[1][1] * sf00 - a[1][2] * sf01 + a[1][3] * sf02);
+    adj.c[1][0] = -(a[1][0] * sf00 - a[1][2] * sf03 + a[1][3] * sf04);
+    adj.c[2][0] = (a[1][0] * sf01 - a[1][1] * sf03 + a[1][3] * sf05);
+    adj.c[3][0] = -(a[1][0] * sf02 - a[1][1] * sf04 + a[1][2] * sf05);
+    adj.c[0][1] = -(a[0][1] * sf00 - a[0][2] * sf01 + a[0][3] * sf02);
+    adj.c[1][1] = (a[0][0] * sf00 - a[0][2] * sf03 + a[0][3] * sf04);
+    adj.c[2][1] = -(a[0][0] * sf01 - a[0][1] * sf03 + a[0][3] * sf05);
+    adj.c[3][1] = (a[0][0] * sf02 - a[0][1] * sf04 + a[0][2] * sf05);
+    adj.c[0][2] = (a[0][1] * sf06 - a[0][2] * sf07 + a[0][3] * sf08);
+    adj.c[1][2] = -(a[0][0] * sf06 - a[0][2] * sf09 + a[0][3] * sf10);
+    adj.c[2][2] = (a[0][0] * sf11 - a[0][1] * sf09 + a[0][3] * sf12);
+    adj.c[3][2] = -(a[0][0] * sf08 - a[0][1] * sf10 + a[0][2] * sf12);
+    adj.c[0][3] = -(a[0][1] * sf13 - a[0][2] * sf14 + a[0][3] * sf15);
+    adj.c[1][3] = (a[0][0] * sf13 - a[0][2] * sf16 + a[0][3] * sf17);
+    adj.c[2][3] = -(a[0][0] * sf14 - a[0][1] * sf16 + a[0][3] * sf18);
+    adj.c[3][3] = (a[0][0] * sf15 - a[0][1] * sf17 + a[0][2] * sf18);
+    const float det = (a[0][0] * adj.c[0][0] + a[0][1] * adj.c[1][0] + a[0][2] * adj.c[2][0] + a[0][3] * adj.c[3][0]);
+    const float s = 1.f / det;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) adj.c[j][i] = adj.c[j][i] * s;
+    return adj;
 }
 template <int N>
 WGG_FN Mat<N> inv(const Mat<N> &m);
@@ -153,11 +177,12 @@ WGG_FN Mat4 inv<4>(const Mat4 &m) { return inv4(m); }
 // ---------------------------------------------------------------------------------------------------------------
 template <int N>
 WGG_FN Mat<N> cholesky(const Mat<N> &x) {
+    WGG_EXACT
     Mat<N> m = x;
     for (int j = 0; j < N; ++j) {
         for (int k = 0; k < j; ++k) {
-            const float f = m.c[k][j]; // L(j, k)
-            for (int l = j; l < N; ++l) m.c[j][l] -= f * m.c[k][l];
+            const float factor = -m.c[k][j]; // -L(j, k)
+            for (int l = j; l < N; ++l) m.c[j][l] = m.c[j][l] + factor * m.c[k][l];
         }
         const float d = sqrtf(m.c[j][j]);
         m.c[j][j] = d;
@@ -180,6 +205,7 @@ struct LU {
 };
 template <int N>
 WGG_FN LU<N> lu(const Mat<N> &x) {
+    WGG_EXACT
     LU<N> r;
     r.lu = x;
     r.p.len = 0;
@@ -199,11 +225,11 @@ WGG_FN LU<N> lu(const Mat<N> &x) {
             ++r.p.len;
             for (int cc = 0; cc < N; ++cc) { const float t = m.c[cc][i]; m.c[cc][i] = m.c[cc][piv]; m.c[cc][piv] = t; }
         }
-        const float d = m.c[i][i];
-        for (int rr = i + 1; rr < N; ++rr) m.c[i][rr] /= d;
+        const float inv_diag = 1.f / m.c[i][i]; // lu.wgsl:84-99: the pivot's reciprocal, then products (not divisions)
+        for (int rr = i + 1; rr < N; ++rr) m.c[i][rr] = m.c[i][rr] * inv_diag;
         for (int cc = i + 1; cc < N; ++cc) {
-            const float u = m.c[cc][i];
-            for (int rr = i + 1; rr < N; ++rr) m.c[cc][rr] -= m.c[i][rr] * u;
+            const float pivot = m.c[cc][i];
+            for (int rr = i + 1; rr < N; ++rr) m.c[cc][rr] = m.c[cc][rr] - pivot * m.c[i][rr];
         }
     }
     return r;
@@ -407,9 +433,18 @@ WGG_FN Rot2 identity() { return Rot2{ 1.f, 0.f }; }
 WGG_FN Rot2 fromAngle(float angle) { return Rot2{ cosf(angle), sinf(angle) }; }
 WGG_FN float angle(Rot2 r) { return atan2f(r.sin, r.cos); }
 WGG_FN Rot2 inv(Rot2 r) { return Rot2{ r.cos, -r.sin }; }
-WGG_FN Rot2 mul(Rot2 a, Rot2 b) { return Rot2{ a.cos * b.cos - a.sin * b.sin, a.sin * b.cos + a.cos * b.sin }; }
-WGG_FN Vec<2> mulVec(Rot2 r, Vec<2> v) { return Vec<2>{ { r.cos * v.v[0] - r.sin * v.v[1], r.sin * v.v[0] + r.cos * v.v[1] } }; }
-WGG_FN Vec<2> invMulVec(Rot2 r, Vec<2> v) { return Vec<2>{ { r.cos * v.v[0] + r.sin * v.v[1], -r.sin * v.v[0] + r.cos * v.v[1] } }; }
+WGG_FN Rot2 mul(Rot2 a, Rot2 b) { // rot2.wgsl:61-65
+    WGG_EXACT
+    return Rot2{ a.cos * b.cos - a.sin * b.sin, a.sin * b.cos + a.cos * b.sin };
+}
+WGG_FN Vec<2> mulVec(Rot2 r, Vec<2> v) { // rot2.wgsl:68-70
+    WGG_EXACT
+    return Vec<2>{ { r.cos * v.v[0] - r.sin * v.v[1], r.sin * v.v[0] + r.cos * v.v[1] } };
+}
+WGG_FN Vec<2> invMulVec(Rot2 r, Vec<2> v) { // rot2.wgsl:73-75
+    WGG_EXACT
+    return Vec<2>{ { r.cos * v.v[0] + r.sin * v.v[1], -r.sin * v.v[0] + r.cos * v.v[1] } };
+}
 WGG_FN Mat2 toMatrix(Rot2 r) {
     Mat2 m;
     m.c[0][0] = r.cos; m.c[0][1] = r.sin;
@@ -425,36 +460,61 @@ struct Quat {
     float x, y, z, w;
 };
 namespace quat {
+// WGSL builtins as their defining formulas, left to right (what oracle/wgsl_exec.py evaluates)
+WGG_FN float dot3(const float *a, const float *b) { WGG_EXACT return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+WGG_FN Vec<3> cross3(const float *a, const float *b) {
+    WGG_EXACT
+    return Vec<3>{ { a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1] } };
+}
 WGG_FN Quat identity() { return Quat{ 0.f, 0.f, 0.f, 1.f }; }
-WGG_FN Quat fromScaledAxis(Vec<3> aa) { // rotation of |aa| radians about aa / |aa|
-    const float a2 = aa.v[0] * aa.v[0] + aa.v[1] * aa.v[1] + aa.v[2] * aa.v[2];
-    if (a2 == 0.f) return identity();
-    const float a = sqrtf(a2), s = sinf(0.5f * a) / a;
-    return Quat{ aa.v[0] * s, aa.v[1] * s, aa.v[2] * s, cosf(0.5f * a) };
+WGG_FN Quat fromScaledAxis(Vec<3> aa) { // quat.wgsl:16-28: rotation of |aa| radians about aa / |aa|
+    WGG_EXACT
+    const float angle = sqrtf(dot3(aa.v, aa.v));
+    if (angle == 0.f) return identity();
+    const float hs = sinf(angle / 2.f), hc = cosf(angle / 2.f);
+    return Quat{ (aa.v[0] / angle) * hs, (aa.v[1] / angle) * hs, (aa.v[2] / angle) * hs, hc };
 }
 WGG_FN Vec<3> imag(Quat q) { return Vec<3>{ { q.x, q.y, q.z } }; }
 WGG_FN Quat inv(Quat q) { return Quat{ -q.x, -q.y, -q.z, q.w }; } // conjugate (unit quaternion)
-WGG_FN Quat mul(Quat a, Quat b) {
-    return Quat{ a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x,
-                 a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z };
+WGG_FN Quat mul(Quat l, Quat r) { // quat.wgsl:73-77
+    WGG_EXACT
+    const float lv[3] = { l.x, l.y, l.z }, rv[3] = { r.x, r.y, r.z };
+    const float scalar = l.w * r.w - dot3(lv, rv);
+    const Vec<3> c = cross3(lv, rv);
+    return Quat{ c.v[0] + l.w * rv[0] + r.w * lv[0], c.v[1] + l.w * rv[1] + r.w * lv[1], c.v[2] + l.w * rv[2] + r.w * lv[2], scalar };
 }
-WGG_FN Quat renormalizeFast(Quat q) { // one Newton step of 1/sqrt(|q|^2) around 1
-    const float n2 = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
-    const float f = 0.5f * (3.f - n2);
+WGG_FN Quat renormalizeFast(Quat q) { // quat.wgsl:59-62: one Newton step of 1/sqrt(|q|^2) around 1
+    WGG_EXACT
+    const float sq_norm = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    const float f = 0.5f * (3.f - sq_norm);
     return Quat{ q.x * f, q.y * f, q.z * f, q.w * f };
 }
-WGG_FN Vec<3> mulVec(Quat q, Vec<3> v) { // v + 2 w (u x v) + 2 u x (u x v), u = imag(q)
-    const float tx = 2.f * (q.y * v.v[2] - q.z * v.v[1]), ty = 2.f * (q.z * v.v[0] - q.x * v.v[2]), tz = 2.f * (q.x * v.v[1] - q.y * v.v[0]);
-    return Vec<3>{ { v.v[0] + q.w * tx + (q.y * tz - q.z * ty), v.v[1] + q.w * ty + (q.z * tx - q.x * tz), v.v[2] + q.w * tz + (q.x * ty - q.y * tx) } };
+WGG_FN Vec<3> mulVec(Quat q, Vec<3> v) { // quat.wgsl:80-84: t = 2 (u x v); t w + u x t + v
+    WGG_EXACT
+    const float u[3] = { q.x, q.y, q.z };
+    Vec<3> t = cross3(u, v.v);
+    for (int i = 0; i < 3; ++i) t.v[i] = t.v[i] * 2.f;
+    const Vec<3> c = cross3(u, t.v);
+    return Vec<3>{ { t.v[0] * q.w + c.v[0] + v.v[0], t.v[1] * q.w + c.v[1] + v.v[1], t.v[2] * q.w + c.v[2] + v.v[2] } };
 }
-WGG_FN Vec<3> invMulVec(Quat q, Vec<3> v) { return mulVec(inv(q), v); }
-WGG_FN Mat3 toMatrix(Quat q) {
-    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, xy = q.x * q.y, xz = q.x * q.z, yz = q.y * q.z, wx = q.w * q.x, wy = q.w * q.y,
-                wz = q.w * q.z;
+WGG_FN Vec<3> invMulVec(Quat q, Vec<3> v) { // quat.wgsl:87-91: the same with -w
+    WGG_EXACT
+    const float u[3] = { q.x, q.y, q.z };
+    Vec<3> t = cross3(u, v.v);
+    for (int i = 0; i < 3; ++i) t.v[i] = t.v[i] * 2.f;
+    const Vec<3> c = cross3(u, t.v);
+    const float nw = -q.w;
+    return Vec<3>{ { t.v[0] * nw + c.v[0] + v.v[0], t.v[1] * nw + c.v[1] + v.v[1], t.v[2] * nw + c.v[2] + v.v[2] } };
+}
+WGG_FN Mat3 toMatrix(Quat q) { // quat.wgsl:31-54 -- ww + ii - jj - kk on the diagonal (NOT 1 - 2 (jj + kk): the two differ for the drifted,
+    WGG_EXACT                  // non-unit quaternions renormalizeFast exists for)
+    const float i = q.x, j = q.y, k = q.z, w = q.w;
+    const float ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+    const float ij = i * j * 2.f, wk = w * k * 2.f, wj = w * j * 2.f, ik = i * k * 2.f, jk = j * k * 2.f, wi = w * i * 2.f;
     Mat3 m;
-    m.c[0][0] = 1.f - 2.f * (yy + zz); m.c[0][1] = 2.f * (xy + wz);       m.c[0][2] = 2.f * (xz - wy);
-    m.c[1][0] = 2.f * (xy - wz);       m.c[1][1] = 1.f - 2.f * (xx + zz); m.c[1][2] = 2.f * (yz + wx);
-    m.c[2][0] = 2.f * (xz + wy);       m.c[2][1] = 2.f * (yz - wx);       m.c[2][2] = 1.f - 2.f * (xx + yy);
+    m.c[0][0] = ww + ii - jj - kk; m.c[0][1] = wk + ij;           m.c[0][2] = ik - wj;
+    m.c[1][0] = ij - wk;           m.c[1][1] = ww - ii + jj - kk; m.c[1][2] = wi + jk;
+    m.c[2][0] = wj + ik;           m.c[2][1] = jk - wi;           m.c[2][2] = ww - ii - jj + kk;
     return m;
 }
 } // namespace quat
@@ -469,16 +529,30 @@ struct Sim2 {
 };
 namespace sim2 {
 WGG_FN Sim2 identity() { return Sim2{ rot2::identity(), Vec<2>{ { 0.f, 0.f } }, 1.f }; }
-WGG_FN Vec<2> mulVec(const Sim2 &s, Vec<2> v) { Vec<2> r = rot2::mulVec(s.rotation, v); r.v[0] *= s.scale; r.v[1] *= s.scale; return r; }
+WGG_FN Vec<2> mulVec(const Sim2 &s, Vec<2> v) { WGG_EXACT Vec<2> r = rot2::mulVec(s.rotation, v); r.v[0] = r.v[0] * s.scale; r.v[1] = r.v[1] * s.scale; return r; } // sim2.wgsl:57-59
 WGG_FN Vec<2> mulUnitVec(const Sim2 &s, Vec<2> v) { return rot2::mulVec(s.rotation, v); }
-WGG_FN Vec<2> mulPt(const Sim2 &s, Vec<2> p) { Vec<2> r = mulVec(s, p); r.v[0] += s.translation.v[0]; r.v[1] += s.translation.v[1]; return r; }
-WGG_FN Vec<2> invMulVec(const Sim2 &s, Vec<2> v) { Vec<2> r = rot2::invMulVec(s.rotation, v); r.v[0] /= s.scale; r.v[1] /= s.scale; return r; }
+WGG_FN Vec<2> mulPt(const Sim2 &s, Vec<2> p) { // sim2.wgsl:42-44: R (p scale) + t
+    WGG_EXACT
+    const Vec<2> r = rot2::mulVec(s.rotation, Vec<2>{ { p.v[0] * s.scale, p.v[1] * s.scale } });
+    return Vec<2>{ { r.v[0] + s.translation.v[0], r.v[1] + s.translation.v[1] } };
+}
+WGG_FN Vec<2> invMulVec(const Sim2 &s, Vec<2> v) { WGG_EXACT Vec<2> r = rot2::invMulVec(s.rotation, v); r.v[0] = r.v[0] / s.scale; r.v[1] = r.v[1] / s.scale; return r; }
 WGG_FN Vec<2> invMulUnitVec(const Sim2 &s, Vec<2> v) { return rot2::invMulVec(s.rotation, v); }
-WGG_FN Vec<2> invMulPt(const Sim2 &s, Vec<2> p) { return invMulVec(s, Vec<2>{ { p.v[0] - s.translation.v[0], p.v[1] - s.translation.v[1] } }); }
-WGG_FN Sim2 mul(const Sim2 &a, const Sim2 &b) { return Sim2{ rot2::mul(a.rotation, b.rotation), mulPt(a, b.translation), a.scale * b.scale }; }
-WGG_FN Sim2 inv(const Sim2 &s) {
-    Vec<2> t = rot2::invMulVec(s.rotation, s.translation);
-    return Sim2{ rot2::inv(s.rotation), Vec<2>{ { -t.v[0] / s.scale, -t.v[1] / s.scale } }, 1.f / s.scale };
+WGG_FN Vec<2> invMulPt(const Sim2 &s, Vec<2> p) { // sim2.wgsl:47-49
+    WGG_EXACT
+    return invMulVec(s, Vec<2>{ { p.v[0] - s.translation.v[0], p.v[1] - s.translation.v[1] } });
+}
+WGG_FN Sim2 mul(const Sim2 &a, const Sim2 &b) { // sim2.wgsl:21-25: t_a + (R_a t_b) scale_a
+    WGG_EXACT
+    const Vec<2> r = rot2::mulVec(a.rotation, b.translation);
+    return Sim2{ rot2::mul(a.rotation, b.rotation), Vec<2>{ { a.translation.v[0] + r.v[0] * a.scale, a.translation.v[1] + r.v[1] * a.scale } }, a.scale * b.scale };
+}
+WGG_FN Sim2 inv(const Sim2 &s) { // sim2.wgsl:34-39: R^-1 (-t) times the RECIPROCAL scale
+    WGG_EXACT
+    const float scale = 1.f / s.scale;
+    const Rot2 rotation = rot2::inv(s.rotation);
+    const Vec<2> t = rot2::mulVec(rotation, Vec<2>{ { -s.translation.v[0], -s.translation.v[1] } });
+    return Sim2{ rotation, Vec<2>{ { t.v[0] * scale, t.v[1] * scale } }, scale };
 }
 WGG_FN Sim2 invMul(const Sim2 &a, const Sim2 &b) { return mul(inv(a), b); }
 } // namespace sim2
@@ -490,18 +564,31 @@ struct Sim3 {
 };
 namespace sim3 {
 WGG_FN Sim3 identity() { return Sim3{ quat::identity(), Vec<3>{ { 0.f, 0.f, 0.f } }, 1.f }; }
-WGG_FN Vec<3> mulVec(const Sim3 &s, Vec<3> v) { Vec<3> r = quat::mulVec(s.rotation, v); for (int i = 0; i < 3; ++i) r.v[i] *= s.scale; return r; }
+WGG_FN Vec<3> mulVec(const Sim3 &s, Vec<3> v) { WGG_EXACT Vec<3> r = quat::mulVec(s.rotation, v); for (int i = 0; i < 3; ++i) r.v[i] = r.v[i] * s.scale; return r; }
 WGG_FN Vec<3> mulUnitVec(const Sim3 &s, Vec<3> v) { return quat::mulVec(s.rotation, v); }
-WGG_FN Vec<3> mulPt(const Sim3 &s, Vec<3> p) { Vec<3> r = mulVec(s, p); for (int i = 0; i < 3; ++i) r.v[i] += s.translation.v[i]; return r; }
-WGG_FN Vec<3> invMulVec(const Sim3 &s, Vec<3> v) { Vec<3> r = quat::invMulVec(s.rotation, v); for (int i = 0; i < 3; ++i) r.v[i] /= s.scale; return r; }
+WGG_FN Vec<3> mulPt(const Sim3 &s, Vec<3> p) { // sim3.wgsl:40-42: R (p scale) + t
+    WGG_EXACT
+    const Vec<3> r = quat::mulVec(s.rotation, Vec<3>{ { p.v[0] * s.scale, p.v[1] * s.scale, p.v[2] * s.scale } });
+    return Vec<3>{ { r.v[0] + s.translation.v[0], r.v[1] + s.translation.v[1], r.v[2] + s.translation.v[2] } };
+}
+WGG_FN Vec<3> invMulVec(const Sim3 &s, Vec<3> v) { WGG_EXACT Vec<3> r = quat::invMulVec(s.rotation, v); for (int i = 0; i < 3; ++i) r.v[i] = r.v[i] / s.scale; return r; }
 WGG_FN Vec<3> invMulUnitVec(const Sim3 &s, Vec<3> v) { return quat::invMulVec(s.rotation, v); }
-WGG_FN Vec<3> invMulPt(const Sim3 &s, Vec<3> p) {
+WGG_FN Vec<3> invMulPt(const Sim3 &s, Vec<3> p) { // sim3.wgsl:45-47
+    WGG_EXACT
     return invMulVec(s, Vec<3>{ { p.v[0] - s.translation.v[0], p.v[1] - s.translation.v[1], p.v[2] - s.translation.v[2] } });
 }
-WGG_FN Sim3 mul(const Sim3 &a, const Sim3 &b) { return Sim3{ quat::mul(a.rotation, b.rotation), mulPt(a, b.translation), a.scale * b.scale }; }
-WGG_FN Sim3 inv(const Sim3 &s) {
-    Vec<3> t = quat::invMulVec(s.rotation, s.translation);
-    return Sim3{ quat::inv(s.rotation), Vec<3>{ { -t.v[0] / s.scale, -t.v[1] / s.scale, -t.v[2] / s.scale } }, 1.f / s.scale };
+WGG_FN Sim3 mul(const Sim3 &a, const Sim3 &b) { // sim3.wgsl:19-23
+    WGG_EXACT
+    const Vec<3> r = quat::mulVec(a.rotation, b.translation);
+    return Sim3{ quat::mul(a.rotation, b.rotation),
+                 Vec<3>{ { a.translation.v[0] + r.v[0] * a.scale, a.translation.v[1] + r.v[1] * a.scale, a.translation.v[2] + r.v[2] * a.scale } }, a.scale * b.scale };
+}
+WGG_FN Sim3 inv(const Sim3 &s) { // sim3.wgsl:26-31
+    WGG_EXACT
+    const float scale = 1.f / s.scale;
+    const Quat rotation = quat::inv(s.rotation);
+    const Vec<3> t = quat::mulVec(rotation, Vec<3>{ { -s.translation.v[0], -s.translation.v[1], -s.translation.v[2] } });
+    return Sim3{ rotation, Vec<3>{ { t.v[0] * scale, t.v[1] * scale, t.v[2] * scale } }, scale };
 }
 WGG_FN Sim3 invMul(const Sim3 &a, const Sim3 &b) { return mul(inv(a), b); }
 } // namespace sim3

@@ -650,6 +650,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // tiles' extra barriers and fills only cost (8192^3: 7287 us here, 7980 on 64 x 64 tiles).
     if (mid_knob != 0 && (mid_knob >= 1 || tiles * nmats <= 4ull * (uint64_t)cus) && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
         const bool pow2_ld = trans && m1.ld >= 1024u && (m1.ld & (m1.ld - 1u)) == 0;
+        const bool pow2_ldb = m2.ld >= 8192u && (m2.ld & (m2.ld - 1u)) == 0; // rows of m2 a large power of two apart: the small tiles' row segments share few channels
         // { bm, bn, k-split family, loop cost in per cent (2 x 2-wave tiles; k-split tiles: on top of the curve below), tenths of a us per tile }
         static const int cand[9][5] = { { 128, 64, 0, 12, 10 }, { 64, 128, 0, 20, 10 }, { 64, 64, 1, 0, 15 }, { 96, 96, 1, 3, 20 }, { 96, 64, 1, 3, 18 }, { 64, 96, 1, 3, 18 },
                                         { 64, 32, 1, 4, 27 }, { 32, 64, 1, 4, 27 }, { 128, 128, 0, 17, 10 } };
@@ -665,6 +666,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             // (+5 % at 4 rounds) until the small tiles' traffic shows (+9 % at 16 rounds, +13 % at 64: 2048^3 / 4096^3 / 8192^3 on 64 x 64)
             double loop = c[2] ? (r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r)) + 0.01 * c[3] : 1.0 + 0.01 * c[3];
             if (c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) loop = 1.30;
+            if (c[2] && pow2_ldb) loop += 0.10; // 1024 x 1024 x 32768: 536 us on 64 x 32 tiles against 486 for this file's split-K plan
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
             if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; }
@@ -688,12 +690,14 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // (what the tiled plan's time above leaves out and short-K launches feel: ~3 us per round of workgroups and the output written at ~3.5 TB/s --
         // 1024 x 1024 x 128 x 32 matrices: 59 us by the formula, 107 measured)
         const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + (nsplit == 1 && tail_r == 0 ? out_bytes / 3.5e6 : 0.0);
-        const bool mid_wins = mid_bm && (mid_knob >= 1 || (force != 1 && mid_est < 0.97 * best_p && mid_est < 0.97 * (tiled + 5.0)));
+        // (the mid estimate leaves the output's write time out, like `best`: compared with the tiled plan WITHOUT that term)
+        const double tiled_m = best + rounds(tiles * nmats * nsplit) * 3.0 + 5.0;
+        const bool mid_wins = mid_bm && (mid_knob >= 1 || (force != 1 && mid_est < 0.97 * best_p && mid_est < 0.97 * tiled_m));
         if (!mid_wins && (force >= 0 ? force == 1 : best_p < 0.95 * tiled))
             return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, 1u, false, ns_p);
     }
     if (mid_bm) {
-        const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + (nsplit == 1 && tail_r == 0 ? out_bytes / 3.5e6 : 0.0) + 5.0; // (+ launch and drain)
+        const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + 5.0; // (+ launch and drain; the output's write time is on neither side)
         if (mid_knob >= 1 || mid_est < 0.97 * tiled)
             return wgk_gemm_f32_mid(ctx, trans, mid_bm, mid_bn, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }
