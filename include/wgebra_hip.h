@@ -138,7 +138,10 @@ int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int
  */
 typedef enum wg_geom_op {
     WG_GEOM_INV = 0, WG_GEOM_CHOLESKY = 1, WG_GEOM_LU = 2, WG_GEOM_QR = 3, WG_GEOM_SYM_EIGEN = 4, WG_GEOM_SVD = 5,
-    WG_GEOM_ROT2 = 6, WG_GEOM_QUAT = 7, WG_GEOM_SIM2 = 8, WG_GEOM_SIM3 = 9
+    WG_GEOM_ROT2 = 6, WG_GEOM_QUAT = 7, WG_GEOM_SIM2 = 8, WG_GEOM_SIM3 = 9,
+    /* the transform functions one by one on raw coordinates (a non-unit quaternion, a (cos, sin) pair that is no rotation): the items the
+       fixtures executed from the reference's WGSL text hold (tests/golden/wgsl_exec_geometry.npz); FROM = quat::fromScaledAxis + rot2::fromAngle */
+    WG_GEOM_QUAT_RAW = 10, WG_GEOM_ROT2_RAW = 11, WG_GEOM_SIM2_RAW = 12, WG_GEOM_SIM3_RAW = 13, WG_GEOM_FROM = 14
 } wg_geom_op;
 int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in, wg_buf *out, uint32_t count);
 

@@ -20,6 +20,13 @@ module-scope `const`, `var<uniform>`, `var<storage,...>`, `var<workgroup>`, func
 `@builtin(global_invocation_id | local_invocation_id | workgroup_id)`, `let`/`var`, assignment and compound assignment, `x++`,
 `if`/`else`, `for`, `return`, calls, `vec4`, `mat4x4`, `mat4x4f`, `transpose`, `min`, `max`, member access, indexing, and the
 function redirection the Rust side performs through naga_oil's `Redirector` (reduce.rs:74-91, op_assign.rs:59-63).
+
+Round 4: the geometry shader library (crates/wgebra/src/geometry/{inv,quat,rot2,sim2,sim3,cholesky,lu}.wgsl) runs through the same
+translator -- called function by function (`call_fn`), no entry point: vec2/3/4 and mat2x2/3x3/4x4 values with mixed-argument constructors and
+swizzles, `dot` / `cross` / `length` as their defining formulas (left to right, every product and sum rounded to f32), `sqrt` correctly rounded,
+`sin` / `cos` rounded from float64, zero-value constructors (`Rot2()`), `var x: T;`, element writes `m[i][j] = ..`, `ptr<function, T>`
+parameters (`&m`, `(*m)`), `continue`, struct member writes, and the textual macro substitution (DIM, MAT, NROWS, ...) the Rust side does
+through naga_oil shader defs (cholesky.rs, lu.rs). tests/golden/make_wgsl_geometry_golden.py writes the fixtures.
 """
 from __future__ import annotations
 
@@ -113,6 +120,109 @@ def load(arr, i):
     return v.copy() if isinstance(v, np.ndarray) else v
 
 
+def op_neg(a):
+    if _is_int(a):
+        return (-a) & M32
+    return np.negative(_num(a))  # (0 - x would turn -0.0 into +0.0)
+
+
+def fn_vec(n, *args):
+    """vecN(...): a splat, N scalars, or any mix of scalars and shorter vectors (vec4(axis * hs, hc))."""
+    flat = []
+    for a in args:
+        if isinstance(a, np.ndarray):
+            flat.extend(a.tolist() if a.dtype != np.float32 else list(a))
+        else:
+            flat.append(a)
+    if not flat:
+        return np.zeros(n, f32)
+    if len(flat) == 1:
+        return np.full(n, _num(flat[0]), f32)
+    assert len(flat) == n, (n, args)
+    return np.array([_num(x) for x in flat], f32)
+
+
+def fn_mat(n, *cols):
+    """matNxN(col0, col1, ...) (columns) or matNxN() = zeros. Stored as an (N, N) array of COLUMNS: m[c][r]."""
+    if not cols:
+        return np.zeros((n, n), f32)
+    if len(cols) == n * n:
+        return np.array([_num(x) for x in cols], f32).reshape(n, n)
+    assert len(cols) == n, (n, cols)
+    return np.stack([np.asarray(c, f32) for c in cols])
+
+
+_SW = {"x": 0, "y": 1, "z": 2, "w": 3}
+
+
+def member(obj, name):
+    if isinstance(obj, np.ndarray):
+        idx = [_SW[ch] for ch in name]
+        return obj[idx[0]] if len(idx) == 1 else obj[idx].copy()
+    return getattr(obj, name)
+
+
+def setmember(obj, name, value):
+    if isinstance(obj, np.ndarray):
+        obj[_SW[name]] = value
+    else:
+        setattr(obj, name, value)
+
+
+def copyval(v):
+    """WGSL values are copied on `let` / `var` (arrays and structs are mutable objects here)."""
+    if isinstance(v, np.ndarray):
+        return v.copy()
+    if isinstance(v, Struct):
+        return Struct(v._fields, [copyval(getattr(v, f)) for f in v._fields])
+    if isinstance(v, list):
+        return list(v)
+    return v
+
+
+def fn_dot(a, b):
+    r = a[0] * b[0]
+    for k in range(1, len(a)):
+        r = r + a[k] * b[k]
+    return r
+
+
+def fn_cross(a, b):
+    return np.array([a[1] * b[2] - b[1] * a[2], a[2] * b[0] - b[2] * a[0], a[0] * b[1] - b[0] * a[1]], f32)
+
+
+def fn_sqrt(x):
+    return np.sqrt(_num(x))  # IEEE: correctly rounded
+
+
+def fn_length(v):
+    return np.sqrt(fn_dot(v, v))
+
+
+def fn_sin(x):
+    return f32(np.sin(np.float64(_num(x))))
+
+
+def fn_cos(x):
+    return f32(np.cos(np.float64(_num(x))))
+
+
+def fn_abs(x):
+    return abs(x) if _is_int(x) else np.abs(_num(x))
+
+
+def fn_sign(x):
+    return np.sign(_num(x))
+
+
+def fn_f32(x):
+    return f32(x)
+
+
+def fn_u32(x):
+    return int(x) & M32
+
+
 class Vec3:
     __slots__ = ("x", "y", "z")
 
@@ -123,6 +233,7 @@ class Vec3:
 class Struct:
     def __init__(self, fields, values):
         assert len(fields) == len(values), (fields, values)
+        self._fields = list(fields)
         for f, v in zip(fields, values):
             setattr(self, f, v)
 
@@ -134,6 +245,7 @@ TOKEN = re.compile(r"\s*(?:(//[^\n]*)|(\d+\.\d*(?:[eE][+-]?\d+)?f?|\d+[eE][+-]?\
 
 
 def preprocess(src: str, defs: set) -> str:
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)  # block comments
     out, stack = [], []
     for line in src.splitlines():
         s = line.strip()
@@ -168,10 +280,13 @@ def tokenize(src: str):
 class Module:
     """One WGSL file translated to Python. `imports` maps an alias (e.g. 'Shape') to another Module."""
 
-    def __init__(self, src: str, imports: dict | None = None, defs: set | None = None, redirect: dict | None = None):
+    def __init__(self, src: str, imports: dict | None = None, defs: set | None = None, redirect: dict | None = None, subst: dict | None = None):
         self.imports = imports or {}
         self.redirect = redirect or {}
         self.structs, self.consts, self.globals_, self.functions, self.entries = {}, {}, {}, {}, {}
+        self.struct_types = {}
+        for k, v in (subst or {}).items():  # naga_oil shader defs with values (cholesky.rs / lu.rs): whole identifiers only
+            src = re.sub(r"\b" + re.escape(k) + r"\b", v, src)
         lines = []
         for line in preprocess(src, defs or set()).splitlines():
             s = line.strip()
@@ -184,10 +299,45 @@ class Module:
         self._parse_module()
         self.ns = {"op_add": op_add, "op_sub": op_sub, "op_mul": op_mul, "op_div": op_div, "load": load, "Struct": Struct,
                    "fn_transpose": fn_transpose, "fn_min": fn_min, "fn_max": fn_max, "fn_vec4": fn_vec4, "fn_mat4x4": fn_mat4x4,
-                   "f32": f32, "M32": M32, "MOD": self}
+                   "f32": f32, "M32": M32, "MOD": self, "op_neg": op_neg, "fn_vec": fn_vec, "fn_mat": fn_mat, "member": member,
+                   "setmember": setmember, "copyval": copyval, "fn_dot": fn_dot, "fn_cross": fn_cross, "fn_sqrt": fn_sqrt,
+                   "fn_length": fn_length, "fn_sin": fn_sin, "fn_cos": fn_cos, "fn_abs": fn_abs, "fn_sign": fn_sign, "fn_f32": fn_f32,
+                   "fn_u32": fn_u32, "zero_of": self.zero_of}
         for alias, mod in self.imports.items():
             self.ns["IMP_" + alias] = mod
         exec("\n".join(self.py), self.ns)
+
+    def zero_of(self, ty: str):
+        """The zero value of a WGSL type (`var x: T;`, `T()`)."""
+        ty = ty.replace(" ", "")
+        m = re.fullmatch(r"vec(\d)(?:<(\w+)>|f|u|i)?", ty)
+        if m:
+            n, el = int(m.group(1)), (m.group(2) or ("f32" if ty.endswith("f") or ty == "vec" + m.group(1) else "u32"))
+            return np.zeros(n, f32) if el == "f32" else [0] * n
+        m = re.fullmatch(r"mat(\d)x(\d)(?:<f32>|f)?", ty)
+        if m:
+            return np.zeros((int(m.group(1)), int(m.group(2))), f32)
+        if ty in ("f32",):
+            return f32(0)
+        if ty in ("u32", "i32"):
+            return 0
+        if ty == "bool":
+            return False
+        if "::" in ty:
+            alias, name = ty.split("::")
+            return self.imports[alias].zero_of(name)
+        if ty in self.structs:
+            return Struct(self.structs[ty], [self.zero_of(t) for t in self.struct_types[ty]])
+        raise TypeError(f"no zero value for type {ty!r}")
+
+    def call_fn(self, name: str, *args):
+        """Runs function `name` (not an entry point) to completion and returns its value. Arguments are copied (value semantics)."""
+        gen = self.ns["F_" + name](None, *[copyval(a) for a in args])
+        try:
+            while True:
+                next(gen)
+        except StopIteration as e:
+            return e.value
 
     # -- token helpers
     def peek(self, k=0):
@@ -246,14 +396,15 @@ class Module:
                 self.next()
                 name = self.next()
                 self.expect("{")
-                fields = []
+                fields, ftypes = [], []
                 while not self.accept("}"):
                     self.skip_attrs()
                     fields.append(self.next())
                     self.expect(":")
-                    self.parse_type()
+                    ftypes.append(self.parse_type())
                     self.accept(",")
                 self.structs[name] = fields
+                self.struct_types[name] = ftypes
             elif t == "const":
                 self.next()
                 name = self.next()
@@ -322,12 +473,14 @@ class Module:
         if t in ("let", "var"):
             self.next()
             name = self.next()
-            if self.accept(":"):
-                self.parse_type()
+            ty = self.parse_type() if self.accept(":") else None
+            if self.peek() != "=":  # `var adj: mat2x2<f32>;` -- zero-initialised
+                scope.declare(name)
+                return [f"{scope.local(name)} = zero_of({ty!r})"]
             self.expect("=")
             rhs = self.parse_expr(scope)
             scope.declare(name)  # after the right-hand side: `let shape = f(shape)` reads the outer `shape`
-            return [f"{scope.local(name)} = {rhs}"]
+            return [f"{scope.local(name)} = copyval({rhs})"]
         lhs = self.parse_postfix(scope, lvalue=True)
         t = self.peek()
         if t in ("=", "+=", "-=", "*=", "/="):
@@ -367,8 +520,10 @@ class Module:
             self.expect(";")
             upd = self.parse_simple(inner) if self.peek() != ")" else []
             self.expect(")")
-            body = self.parse_block(inner, ind + 1)
-            return [pad + s for s in init] + [f"{pad}while {cond}:"] + body + [f"{pad}    {s}" for s in upd]
+            body = self.parse_block(inner, ind + 2)
+            # `continue` must still run the update: the body sits in a one-trip loop and `continue` leaves that one
+            return ([pad + s for s in init] + [f"{pad}while {cond}:", f"{pad}    for _once in (0,):"] + (body or [f"{pad}        pass"]) +
+                    [f"{pad}    {s}" for s in upd])
         if t == "return":
             self.next()
             if self.accept(";"):
@@ -376,6 +531,9 @@ class Module:
             e = self.parse_expr(scope)
             self.expect(";")
             return [f"{pad}return {e}"]
+        if t == "continue":
+            self.next(); self.expect(";")
+            return [f"{pad}break"]
         if t == "workgroupBarrier":
             self.next(); self.expect("("); self.expect(")"); self.expect(";")
             return [f"{pad}yield"]
@@ -410,7 +568,9 @@ class Module:
 
     def parse_unary(self, scope):
         if self.accept("-"):
-            return f"op_sub(0, {self.parse_unary(scope)})"
+            return f"op_neg({self.parse_unary(scope)})"
+        if self.accept("&") or self.accept("*"):  # ptr<function, T>: arrays and structs are references here already
+            return self.parse_postfix(scope).ref()
         if self.accept("!"):
             return f"(not {self.parse_unary(scope)})"
         return self.parse_postfix(scope).read()
@@ -433,7 +593,7 @@ class Module:
             if self.peek() == "::":
                 self.next()
                 alias, t = t, self.next()
-            if self.peek() == "<" and t in ("vec4", "mat4x4", "array"):  # explicit template arguments: vec4<f32>(...)
+            if self.peek() == "<" and re.fullmatch(r"vec\d|mat\dx\d|array", t):  # explicit template arguments: vec4<f32>(...)
                 self.parse_type_args()
             if self.peek() == "(":
                 self.next()
@@ -446,11 +606,11 @@ class Module:
                 node = scope.resolve(alias, t)
         while True:
             if self.accept("."):
-                node = LV(f"{node.read()}.{self.next()}", attr=True)
+                node = LV(None, obj=node, attr=self.next())
             elif self.accept("["):
                 idx = self.parse_expr(scope)
                 self.expect("]")
-                node = LV(None, base=node.read(), index=idx)
+                node = LV(None, base=node, index=idx)
             else:
                 return node
 
@@ -464,18 +624,28 @@ class Module:
     def call(self, scope, alias, name, args):
         a = ", ".join(args)
         if alias is None:
-            if name in ("vec4", "vec4f"):
+            if name in ("vec4", "vec4f") and len(args) in (1, 4):
                 return f"fn_vec4({a})"
-            if name in ("mat4x4", "mat4x4f"):
+            if name in ("mat4x4", "mat4x4f") and len(args) in (0, 4):
                 return f"fn_mat4x4({a})"
-            if name in ("transpose", "min", "max"):
+            m = re.fullmatch(r"vec(\d)f?", name)
+            if m:
+                return f"fn_vec({m.group(1)}{', ' if a else ''}{a})"
+            m = re.fullmatch(r"mat(\d)x\1f?", name)
+            if m:
+                return f"fn_mat({m.group(1)}{', ' if a else ''}{a})"
+            if name in ("transpose", "min", "max", "dot", "cross", "sqrt", "length", "sin", "cos", "abs", "sign", "f32", "u32"):
                 return f"fn_{name}({a})"
             if name in self.structs:
+                if not args:
+                    return f"zero_of({name!r})"
                 return f"Struct({self.structs[name]!r}, [{a}])"
             name = self.redirect.get(name, name)
             return f"(yield from F_{name}(G{', ' if a else ''}{a}))"
         mod = self.imports[alias]
         if name in mod.structs:
+            if not args:
+                return f"IMP_{alias}.zero_of({name!r})"
             return f"Struct({mod.structs[name]!r}, [{a}])"
         return f"(yield from IMP_{alias}.ns['F_{name}'](None{', ' if a else ''}{a}))"
 
@@ -548,19 +718,31 @@ class Module:
 
 
 class LV:
-    """An expression that may also be assigned to."""
+    """An expression that may also be assigned to: a name, `base[index]`, or `obj.member` (swizzle reads on vectors, fields on structs)."""
 
-    def __init__(self, expr, base=None, index=None, attr=False, scalar_global=False):
-        self.expr, self.base, self.index, self.attr, self.scalar_global = expr, base, index, attr, scalar_global
+    def __init__(self, expr, base=None, index=None, obj=None, attr=None, scalar_global=False):
+        self.expr, self.base, self.index, self.obj, self.attr, self.scalar_global = expr, base, index, obj, attr, scalar_global
+
+    def ref(self):
+        """The object itself (no copy): what an element write or a `&x` argument needs."""
+        if self.base is not None:
+            return f"{self.base.ref()}[{self.index}]"
+        if self.obj is not None:
+            return f"member({self.obj.ref()}, {self.attr!r})"
+        return self.expr
 
     def read(self):
         if self.base is not None:
-            return f"load({self.base}, {self.index})"
+            return f"load({self.base.ref()}, {self.index})"
+        if self.obj is not None:
+            return f"member({self.obj.ref()}, {self.attr!r})"
         return self.expr + ("[0]" if self.scalar_global else "")
 
     def write(self, rhs):
         if self.base is not None:
-            return f"{self.base}[{self.index}] = {rhs}"
+            return f"{self.base.ref()}[{self.index}] = {rhs}"
+        if self.obj is not None:
+            return f"setmember({self.obj.ref()}, {self.attr!r}, {rhs})"
         if self.scalar_global:
             return f"{self.expr}[0] = {rhs}"
         return f"{self.expr} = {rhs}"

@@ -13,11 +13,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LEN = 345
-OPS = dict(INV=0, CHOLESKY=1, LU=2, QR=3, SYM_EIGEN=4, SVD=5, ROT2=6, QUAT=7, SIM2=8, SIM3=9)
+OPS = dict(INV=0, CHOLESKY=1, LU=2, QR=3, SYM_EIGEN=4, SVD=5, ROT2=6, QUAT=7, SIM2=8, SIM3=9, QUAT_RAW=10, ROT2_RAW=11, SIM2_RAW=12, SIM3_RAW=13, FROM=14)
 
 
 def out_floats(op, n):
-    return {0: n * n, 1: n * n, 2: n * n + 2 * n + 1, 3: 2 * n * n, 4: n * n + n, 5: 2 * n * n + n, 6: 11, 7: 19, 8: 14, 9: 25}[op]
+    return {0: n * n, 1: n * n, 2: n * n + 2 * n + 1, 3: 2 * n * n, 4: n * n + n, 5: 2 * n * n + n, 6: 11, 7: 19, 8: 14, 9: 25, 10: 27, 11: 12, 12: 18, 13: 28, 14: 6}[op]
 
 
 @pytest.fixture(scope="module")
@@ -26,7 +26,7 @@ def host_apply():
     os.makedirs(build, exist_ok=True)
     so = os.path.join(build, "libgeom_host.so")
     src = os.path.join(ROOT, "tests", "cpp", "geometry_host.cpp")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-o", so, src], check=True)
     lib = ctypes.CDLL(so)
     lib.geom_apply_host.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
 
@@ -210,3 +210,44 @@ def test_geometry_gpu_vs_host(gpu, host_apply):
                 x = m.reshape(64, n * n).astype(np.float32)
             a, b = gapply(op, n, x), host_apply(op, n, x)
             assert np.allclose(a, b, rtol=2e-4, atol=2e-5), f"op {op} dim {n}: GPU and host builds differ by {np.abs(a - b).max()}"
+
+
+# --------------------------------------------------------------------------------------------------------
+# Pinned to the reference's WGSL TEXT: tests/golden/wgsl_exec_geometry.npz holds seeded inputs and what crates/wgebra/src/geometry/
+# {inv,cholesky,lu,quat,rot2,sim2,sim3}.wgsl return when executed by oracle/wgsl_exec.py (left to right, every product and sum rounded,
+# dot / cross as their defining formulas; generator: tests/golden/make_wgsl_geometry_golden.py). The header's closed-form functions follow the
+# same expressions with contraction off: 0 ulp for everything built from + - * / sqrt -- non-unit quaternions and (cos, sin) pairs that are no
+# rotations included --, <= 2 ulp where sin / cos enter (fromScaledAxis, fromAngle: the fixture rounds them from float64).
+# --------------------------------------------------------------------------------------------------------
+def max_ulp(a, b):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    ia, ib = a.view(np.int32).astype(np.int64), b.view(np.int32).astype(np.int64)
+    ia, ib = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia), np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return int(np.abs(ia - ib).max())
+
+
+def run_wgsl_pinned(apply):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wgsl_exec_geometry.npz"))
+    for n in (2, 3, 4):
+        for op in ("INV", "CHOLESKY", "LU"):
+            key = f"{op.lower()}{n}"
+            got = apply(OPS[op], n, g[key + "_in"])
+            assert got.tobytes() == g[key + "_out"].tobytes(), f"{key}: {max_ulp(got, g[key + '_out'])} ulp from the executed WGSL (must be 0)"
+    for op, key in (("QUAT_RAW", "quat_raw"), ("ROT2_RAW", "rot2_raw"), ("SIM2_RAW", "sim2_raw"), ("SIM3_RAW", "sim3_raw")):
+        got = apply(OPS[op], 0, g[key + "_in"])
+        exp = g[key + "_out"]
+        bad = np.argwhere(got.view(np.uint32) != exp.view(np.uint32))
+        assert bad.size == 0, f"{key}: {len(bad)} values differ from the executed WGSL, first at item/field {bad[0]}: {got[tuple(bad[0])]!r} vs {exp[tuple(bad[0])]!r}"
+    got, exp = apply(OPS["FROM"], 0, g["from_in"]), g["from_out"]
+    assert np.array_equal(got[0, :4], np.array([0, 0, 0, 1], np.float32))  # the zero axis is the identity (quat.wgsl:20-22)
+    # sin / cos: within 2 ulp of the correctly rounded value at the SCALE of the result's vector (|sin| near 0 has tiny ulps of its own)
+    assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= 2 * 2.0 ** -24, np.abs(got - exp).max()
+
+
+def test_closed_form_functions_match_the_executed_wgsl_host(host_apply):
+    run_wgsl_pinned(host_apply)
+
+
+@pytest.mark.gpu
+def test_closed_form_functions_match_the_executed_wgsl_gpu(gpu):
+    run_wgsl_pinned(gpu_apply_factory(gpu))

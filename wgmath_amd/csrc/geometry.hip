@@ -11,12 +11,15 @@
 //   QUAT          : in 2 scaled axes + vec3 (9)  -> out mul (4) + mulVec (3) + invMulVec (3) + toMatrix (9) = 19
 //   SIM2          : in 2 x (angle, t.x, t.y, scale) + pt (10) -> out mul (4: angle, t, scale) + inv (4) + mulPt (2) + invMulPt (2) + mulVec (2) = 14
 //   SIM3          : in 2 x (axis(3), t(3), scale) + pt (17)   -> out mul (quat 4, t 3, scale 1) + inv (8) + mulPt (3) + invMulPt (3) + mulVec (3) = 25
+// The transform functions one by one on RAW coordinates (what tests/golden/wgsl_exec_geometry.npz, executed from the reference's WGSL text, holds;
+// layouts in geometry_items.hpp raw_item): QUAT_RAW 11 -> 27, ROT2_RAW 6 -> 12, SIM2_RAW 12 -> 18, SIM3_RAW 19 -> 28, FROM (scaled axis + angle) 4 -> 6.
 #include "wg_internal.hpp"
 
 #include "geometry_items.hpp"
 
 namespace {
-static_assert(WG_GEOM_INV == wgg_items::OP_INV && WG_GEOM_SVD == wgg_items::OP_SVD && WG_GEOM_SIM3 == wgg_items::OP_SIM3, "op numbering");
+static_assert(WG_GEOM_INV == wgg_items::OP_INV && WG_GEOM_SVD == wgg_items::OP_SVD && WG_GEOM_SIM3 == wgg_items::OP_SIM3 &&
+                  WG_GEOM_QUAT_RAW == wgg_items::OP_QUAT_RAW && WG_GEOM_FROM == wgg_items::OP_FROM, "op numbering");
 
 template <int N>
 __global__ void geom_mat_kernel(int op, const float *__restrict__ in, float *__restrict__ out, uint32_t count, uint32_t out_stride) {
@@ -26,14 +29,16 @@ __global__ void geom_mat_kernel(int op, const float *__restrict__ in, float *__r
 __global__ void geom_transform_kernel(int op, const float *__restrict__ in, float *__restrict__ out, uint32_t count, uint32_t in_stride,
                                       uint32_t out_stride) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) wgg_items::transform_item(op, in + (uint64_t)i * in_stride, out + (uint64_t)i * out_stride);
+    if (i >= count) return;
+    if (op >= wgg_items::OP_QUAT_RAW) wgg_items::raw_item(op, in + (uint64_t)i * in_stride, out + (uint64_t)i * out_stride);
+    else wgg_items::transform_item(op, in + (uint64_t)i * in_stride, out + (uint64_t)i * out_stride);
 }
 } // namespace
 
 extern "C" int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in, wg_buf *out, uint32_t count) {
     if (!ctx || !in || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_geometry_apply: NULL argument");
-    if ((int)op < 0 || (int)op > WG_GEOM_SIM3) return wg_set_error(WG_ERR_INVALID_ARG, "wg_geometry_apply: unknown op %d", (int)op);
-    const bool is_mat = op <= WG_GEOM_SVD;
+    if ((int)op < 0 || (int)op > WG_GEOM_FROM) return wg_set_error(WG_ERR_INVALID_ARG, "wg_geometry_apply: unknown op %d", (int)op);
+    const bool is_mat = (int)op <= WG_GEOM_SVD;
     if (is_mat && (dim < 2 || dim > 4)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_geometry_apply: dim %u not in 2..4", dim);
     if (op == WG_GEOM_SVD && dim == 4) return wg_set_error(WG_ERR_UNSUPPORTED, "wg_geometry_apply: the reference has svd2 and svd3 only");
     if (count == 0) return WG_OK;

@@ -5,7 +5,10 @@
 
 namespace wgg_items {
 using namespace wgebra::geometry;
-enum { OP_INV = 0, OP_CHOLESKY = 1, OP_LU = 2, OP_QR = 3, OP_SYM_EIGEN = 4, OP_SVD = 5, OP_ROT2 = 6, OP_QUAT = 7, OP_SIM2 = 8, OP_SIM3 = 9 };
+enum { OP_INV = 0, OP_CHOLESKY = 1, OP_LU = 2, OP_QR = 3, OP_SYM_EIGEN = 4, OP_SVD = 5, OP_ROT2 = 6, OP_QUAT = 7, OP_SIM2 = 8, OP_SIM3 = 9,
+       // the transform functions one by one on RAW coordinates (a quaternion that is not unit, a (cos, sin) pair that is no rotation): what the
+       // fixtures executed from the reference's WGSL text hold (tests/golden/wgsl_exec_geometry.npz)
+       OP_QUAT_RAW = 10, OP_ROT2_RAW = 11, OP_SIM2_RAW = 12, OP_SIM3_RAW = 13, OP_FROM = 14 };
 
 template <int N>
 WGG_FN Mat<N> load_mat(const float *p) {
@@ -92,6 +95,56 @@ WGG_FN void transform_item(int op, const float *p, float *o) {
     }
 }
 
+WGG_FN void raw_item(int op, const float *p, float *o) {
+    if (op == OP_QUAT_RAW) { // in: a (x, y, z, w), b, v;  out: mul(a, b), mulVec(a, v), invMulVec(a, v), toMatrix(a), renormalizeFast(a), inv(a)
+        const Quat a{ p[0], p[1], p[2], p[3] }, b{ p[4], p[5], p[6], p[7] };
+        const Vec<3> v{ { p[8], p[9], p[10] } };
+        const Quat ab = quat::mul(a, b), rn = quat::renormalizeFast(a), ai = quat::inv(a);
+        const Vec<3> r1 = quat::mulVec(a, v), r2 = quat::invMulVec(a, v);
+        o[0] = ab.x; o[1] = ab.y; o[2] = ab.z; o[3] = ab.w;
+        for (int k = 0; k < 3; ++k) { o[4 + k] = r1.v[k]; o[7 + k] = r2.v[k]; }
+        store_mat<3>(o + 10, quat::toMatrix(a));
+        o[19] = rn.x; o[20] = rn.y; o[21] = rn.z; o[22] = rn.w;
+        o[23] = ai.x; o[24] = ai.y; o[25] = ai.z; o[26] = ai.w;
+    } else if (op == OP_ROT2_RAW) { // in: a (cos, sin), b, v;  out: mul, mulVec, invMulVec, toMatrix, inv
+        const Rot2 a{ p[0], p[1] }, b{ p[2], p[3] };
+        const Vec<2> v{ { p[4], p[5] } };
+        const Rot2 ab = rot2::mul(a, b), ai = rot2::inv(a);
+        const Vec<2> r1 = rot2::mulVec(a, v), r2 = rot2::invMulVec(a, v);
+        o[0] = ab.cos; o[1] = ab.sin; o[2] = r1.v[0]; o[3] = r1.v[1]; o[4] = r2.v[0]; o[5] = r2.v[1];
+        store_mat<2>(o + 6, rot2::toMatrix(a));
+        o[10] = ai.cos; o[11] = ai.sin;
+    } else if (op == OP_SIM2_RAW) { // in: a (cos, sin, tx, ty, scale), b, pt;  out: mul, inv (5 each), mulPt, invMulPt, mulVec, invMulVec
+        const Sim2 a{ Rot2{ p[0], p[1] }, Vec<2>{ { p[2], p[3] } }, p[4] }, b{ Rot2{ p[5], p[6] }, Vec<2>{ { p[7], p[8] } }, p[9] };
+        const Vec<2> pt{ { p[10], p[11] } };
+        const Sim2 ab = sim2::mul(a, b), ai = sim2::inv(a);
+        const Sim2 *two[2] = { &ab, &ai };
+        for (int k = 0; k < 2; ++k) {
+            o[5 * k] = two[k]->rotation.cos; o[5 * k + 1] = two[k]->rotation.sin;
+            o[5 * k + 2] = two[k]->translation.v[0]; o[5 * k + 3] = two[k]->translation.v[1]; o[5 * k + 4] = two[k]->scale;
+        }
+        const Vec<2> q1 = sim2::mulPt(a, pt), q2 = sim2::invMulPt(a, pt), q3 = sim2::mulVec(a, pt), q4 = sim2::invMulVec(a, pt);
+        o[10] = q1.v[0]; o[11] = q1.v[1]; o[12] = q2.v[0]; o[13] = q2.v[1]; o[14] = q3.v[0]; o[15] = q3.v[1]; o[16] = q4.v[0]; o[17] = q4.v[1];
+    } else if (op == OP_SIM3_RAW) { // in: a (q[4], t[3], scale), b, pt;  out: mul, inv (8 each), mulPt, invMulPt, mulVec, invMulVec
+        const Sim3 a{ Quat{ p[0], p[1], p[2], p[3] }, Vec<3>{ { p[4], p[5], p[6] } }, p[7] };
+        const Sim3 b{ Quat{ p[8], p[9], p[10], p[11] }, Vec<3>{ { p[12], p[13], p[14] } }, p[15] };
+        const Vec<3> pt{ { p[16], p[17], p[18] } };
+        const Sim3 ab = sim3::mul(a, b), ai = sim3::inv(a);
+        const Sim3 *two[2] = { &ab, &ai };
+        for (int k = 0; k < 2; ++k) {
+            o[8 * k] = two[k]->rotation.x; o[8 * k + 1] = two[k]->rotation.y; o[8 * k + 2] = two[k]->rotation.z; o[8 * k + 3] = two[k]->rotation.w;
+            for (int c = 0; c < 3; ++c) o[8 * k + 4 + c] = two[k]->translation.v[c];
+            o[8 * k + 7] = two[k]->scale;
+        }
+        const Vec<3> q1 = sim3::mulPt(a, pt), q2 = sim3::invMulPt(a, pt), q3 = sim3::mulVec(a, pt), q4 = sim3::invMulVec(a, pt);
+        for (int c = 0; c < 3; ++c) { o[16 + c] = q1.v[c]; o[19 + c] = q2.v[c]; o[22 + c] = q3.v[c]; o[25 + c] = q4.v[c]; }
+    } else if (op == OP_FROM) { // in: scaled axis (3), angle;  out: quat::fromScaledAxis (4), rot2::fromAngle (2)
+        const Quat q = quat::fromScaledAxis(Vec<3>{ { p[0], p[1], p[2] } });
+        const Rot2 r = rot2::fromAngle(p[3]);
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; o[4] = r.cos; o[5] = r.sin;
+    }
+}
+
 WGG_FN unsigned out_floats(int op, unsigned n) {
     switch (op) {
     case OP_INV: case OP_CHOLESKY: return n * n;
@@ -103,6 +156,11 @@ WGG_FN unsigned out_floats(int op, unsigned n) {
     case OP_QUAT: return 19;
     case OP_SIM2: return 14;
     case OP_SIM3: return 25;
+    case OP_QUAT_RAW: return 27;
+    case OP_ROT2_RAW: return 12;
+    case OP_SIM2_RAW: return 18;
+    case OP_SIM3_RAW: return 28;
+    case OP_FROM: return 6;
     }
     return 0;
 }
@@ -112,6 +170,11 @@ WGG_FN unsigned in_floats(int op, unsigned n) {
     case OP_QUAT: return 9;
     case OP_SIM2: return 10;
     case OP_SIM3: return 17;
+    case OP_QUAT_RAW: return 11;
+    case OP_ROT2_RAW: return 6;
+    case OP_SIM2_RAW: return 12;
+    case OP_SIM3_RAW: return 19;
+    case OP_FROM: return 4;
     default: return n * n;
     }
 }

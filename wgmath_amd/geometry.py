@@ -19,10 +19,17 @@ class GeomOp(enum.IntEnum):
     QUAT = 7
     SIM2 = 8
     SIM3 = 9
+    QUAT_RAW = 10  # the transform functions one by one on raw coordinates (layouts: csrc/geometry_items.hpp raw_item)
+    ROT2_RAW = 11
+    SIM2_RAW = 12
+    SIM3_RAW = 13
+    FROM = 14      # quat::fromScaledAxis + rot2::fromAngle
 
 
-_FIXED_IN = {GeomOp.ROT2: 4, GeomOp.QUAT: 9, GeomOp.SIM2: 10, GeomOp.SIM3: 17}
-_FIXED_OUT = {GeomOp.ROT2: 11, GeomOp.QUAT: 19, GeomOp.SIM2: 14, GeomOp.SIM3: 25}
+_FIXED_IN = {GeomOp.ROT2: 4, GeomOp.QUAT: 9, GeomOp.SIM2: 10, GeomOp.SIM3: 17, GeomOp.QUAT_RAW: 11, GeomOp.ROT2_RAW: 6, GeomOp.SIM2_RAW: 12,
+             GeomOp.SIM3_RAW: 19, GeomOp.FROM: 4}
+_FIXED_OUT = {GeomOp.ROT2: 11, GeomOp.QUAT: 19, GeomOp.SIM2: 14, GeomOp.SIM3: 25, GeomOp.QUAT_RAW: 27, GeomOp.ROT2_RAW: 12, GeomOp.SIM2_RAW: 18,
+              GeomOp.SIM3_RAW: 28, GeomOp.FROM: 6}
 
 
 def in_floats(op: GeomOp, dim: int = 0) -> int:
