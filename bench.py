@@ -178,11 +178,11 @@ class GemmWorkload(Workload):
         self.trans = trans  # GemmTr: m1 is stored K x M (op(A) = m1^T)
         self.np_dtype = np.float32 if dtype == "f32" else np.float16
         self.kernel = "gemm_f32_kernel" if dtype == "f32" else "gemm_f16_m16_kernel"
-        # mid-size outputs: f16 runs the 128 x 128 kernel; f32 cuts K in two and `kernel_ms` spans both launches
+        # mid-size outputs: f16 runs the 128 x 128 kernel; f32 the mid-size tile family (no K cut since round 4)
         if dtype == "f16" and (M // 256) * (N // 256) < 256 and M * N <= 2560 * 2560:
             self.kernel = "gemm_f16_t128_kernel"
         if dtype == "f32" and (M // 256) * (N // 128) < 256 and M == N == K == 2048:
-            self.kernel = "gemm_f32_kernel + splitk_reduce_kernel"
+            self.kernel = "gemm_f32_mid_kw_kernel" if not trans else "gemm_f32_mid_kernel"  # the mid-size tile family: 64 x 64 k-split tiles (GemmTr: 128 x 64)
 
     def setup(self, wg, gpu, rank, world):
         self.wg, self.gpu, self.rank, self.world = wg, gpu, rank, world
@@ -602,11 +602,11 @@ DIST_SECONDARY = [("gemv_f32_4096x65536", 2000), ("gemvtr_f32_65536x4096", 2000)
 
 
 def _pmc_row(workload: str):
-    """The workload's row of the tracked counter summary: profiles/r03_pmc.csv (tools/pmc_r03.sh: ONE rocprofv3 run per workload, separate
+    """The workload's row of the tracked counter summary: profiles/r04_pmc.csv (tools/pmc.sh: ONE rocprofv3 run per workload, separate
     --pmc passes, --kernel-trace only), else the previous round's. Static, measured on the builder's box -- every field taken from it
     carries `_profiled` in its name (or says so in `traffic_source`)."""
     import csv
-    for fn in ("r03_pmc.csv", "r02_pmc.csv"):
+    for fn in ("r04_pmc.csv", "r03_pmc.csv", "r02_pmc.csv"):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             with open(path) as f:

@@ -29,7 +29,7 @@ for wl in wls:
             if did not in seen:
                 seen.add(did)
                 dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    cand = {k: sum(v) for k, v in dur.items() if not any(s in k for s in ("Memset", "memset", "fill", "Copy", "copy", "now_kernel"))}
+    cand = {k: sum(v) for k, v in dur.items() if not any(s in k for s in ("Memset", "memset", "fill", "Copy", "copy", "now_kernel", "mfma_only_kernel", "clock_stamp_kernel"))}
     if not cand:
         continue
     k = max(cand, key=cand.get)

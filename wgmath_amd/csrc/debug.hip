@@ -21,16 +21,16 @@ constexpr uint32_t kStampBlocks = 64; // 8 per XCD if the dispatcher deals them 
 
 struct Stamp {
     uint64_t memtime, realtime;
-    uint32_t xcc, pad;
+    uint32_t xcc, hw; // hw: HW_REG_HW_ID bits [15:8] = cu [11:8], sh [12], se [15:13] -- where on the XCD the stamp was taken
 };
 
 __global__ void clock_stamp_kernel(Stamp *out) {
     if (threadIdx.x != 0) return;
     Stamp s;
     s.xcc = __builtin_amdgcn_s_getreg((20 /* HW_REG_XCC_ID */) | (0 << 6) | ((4 - 1) << 11)) & 7u;
+    s.hw = (__builtin_amdgcn_s_getreg((4 /* HW_REG_HW_ID */) | (0 << 6) | ((16 - 1) << 11)) >> 8) & 0xffu;
     s.memtime = __builtin_amdgcn_s_memtime();
     s.realtime = __builtin_amdgcn_s_memrealtime();
-    s.pad = 0;
     out[blockIdx.x] = s;
 }
 
@@ -110,18 +110,32 @@ int wg_debug_clock_end(wg_ctx *ctx, double *ghz_mean, double *ghz_min, double *g
     WG_HIP_TRY(hipGetLastError());
     WG_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->debug_clock_open = false;
+    // Per XCD: the MEDIAN of (d memtime / d memrealtime) over the stamp pairs taken at the same place (same CU of that XCD; any pair of the XCD
+    // when no CU was hit on both sides), pairs outside 0.2 .. 3.5 GHz dropped -- a CU's shader-clock counter is not guaranteed to have run
+    // through the interval (seen once on hardware: one pair 11 orders of magnitude off, the others fine).
     double sum = 0, lo = 1e30, hi = 0, secs = 0;
     int n = 0;
-    for (uint32_t x = 0; x < 8; ++x) { // per XCD: its first stamp before against its first stamp after
-        const Stamp *a = nullptr, *b = nullptr;
-        for (uint32_t i = 0; i < kStampBlocks && !a; ++i)
-            if (st[i].xcc == x) a = st + i;
-        for (uint32_t i = 0; i < kStampBlocks && !b; ++i)
-            if (st[kStampBlocks + i].xcc == x) b = st + kStampBlocks + i;
-        if (!a || !b || b->realtime <= a->realtime) continue;
-        const double ghz = (double)(b->memtime - a->memtime) / (double)(b->realtime - a->realtime) * 0.1; // ticks per 10 ns
+    for (uint32_t x = 0; x < 8; ++x) {
+        double cand[2][kStampBlocks * 4];
+        int nc[2] = { 0, 0 };
+        double t = 0;
+        for (uint32_t i = 0; i < kStampBlocks; ++i)
+            for (uint32_t j = 0; j < kStampBlocks; ++j) {
+                const Stamp &a = st[i], &b = st[kStampBlocks + j];
+                if (a.xcc != x || b.xcc != x || b.realtime <= a.realtime || b.memtime <= a.memtime) continue;
+                const double ghz = (double)(b.memtime - a.memtime) / (double)(b.realtime - a.realtime) * 0.1; // ticks per 10 ns
+                if (!(ghz > 0.2 && ghz < 3.5)) continue;
+                const int same = a.hw == b.hw ? 0 : 1;
+                if (nc[same] < (int)(kStampBlocks * 4)) cand[same][nc[same]++] = ghz;
+                t = (double)(b.realtime - a.realtime) * 1e-8;
+            }
+        const int w = nc[0] > 0 ? 0 : 1;
+        if (nc[w] == 0) continue;
+        for (int p = 1; p < nc[w]; ++p) // (insertion sort: a few dozen values)
+            for (int q = p; q > 0 && cand[w][q] < cand[w][q - 1]; --q) { const double tmp = cand[w][q]; cand[w][q] = cand[w][q - 1]; cand[w][q - 1] = tmp; }
+        const double ghz = cand[w][nc[w] / 2];
         sum += ghz; lo = ghz < lo ? ghz : lo; hi = ghz > hi ? ghz : hi;
-        secs += (double)(b->realtime - a->realtime) * 1e-8;
+        secs += t;
         ++n;
     }
     if (n == 0) return wg_set_error(WG_ERR_HIP, "wg_debug_clock_end: no XCD was stamped on both sides");
