@@ -2,7 +2,7 @@
 // f16 operands, f32 accumulation on the matrix cores, ONE rounding (RNE) to f16 at the end.
 //
 // This file: the shipped kernel (v_mfma_f32_16x16x32_f16, description below), the tail-split reduce and the launcher that picks
-// between it, the previous-generation 32x32x16 kernel and the generic fallback (both in gemm_f16_legacy.hip).
+// between it, the previous-generation 32x32x16 kernel and the generic fallback (both in gemm_f16_generic.hip).
 // Bound: MFMA (2.5 PFLOP/s dense peak); in practice the 1400 W package power cap (profiles/r01_evidence.md).
 #include "gemm_f16_common.hpp"
 

@@ -1,5 +1,5 @@
 // Shared by the f16 GEMM translation units (gemm_f16.hip: the shipped 16x16x32 kernel + launcher; gemm_f16_t128.hip: the 128 x 128
-// kernel; gemm_f16_legacy.hip: the generic fallback).
+// kernel; gemm_f16_generic.hip: the generic fallback).
 #pragma once
 #include "wg_internal.hpp"
 
@@ -184,7 +184,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
 }
 
 
-// launch wrapper of gemm_f16_legacy.hip (grid / arguments prepared by wgk_gemm_f16)
+// launch wrapper of gemm_f16_generic.hip (grid / arguments prepared by wgk_gemm_f16)
 int generic_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
 // gemm_f16_t128.hip: 128 x 128 tiles (g.tiles_m / g.tiles_n count those), grid = (tiles, nmats * nsplit); K per split % 64 == 0
 int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
