@@ -19,7 +19,7 @@
 // Results agree with the reference within its own test tolerances (relative 1e-3 / 1e-4 against nalgebra). The CLOSED-FORM functions -- inv2/3/4,
 // cholesky, lu, Rot2, Quat, Sim2, Sim3 -- follow the reference's WGSL expression by expression, every product and sum rounded separately (no FMA
 // contraction: WGG_EXACT below), so that on the same inputs they give the bits the WGSL text gives when read that way (left to right, `dot` and
-// `cross` as their defining formulas: tests/golden/wgsl_exec_geometry.npz, made by running the reference's .wgsl files through oracle/wgsl_exec.py).
+// `cross` as their defining formulas: tests/golden/wgsl_exec_geometry.npz, made by running the reference's .wgsl files through the tests' WGSL executor).
 // QR, eigen and SVD are different but equivalent algorithms and are not bit-identical.
 #pragma once
 
@@ -460,7 +460,7 @@ struct Quat {
     float x, y, z, w;
 };
 namespace quat {
-// WGSL builtins as their defining formulas, left to right (what oracle/wgsl_exec.py evaluates)
+// WGSL builtins as their defining formulas, left to right (what the tests' WGSL executor evaluates)
 WGG_FN float dot3(const float *a, const float *b) { WGG_EXACT return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 WGG_FN Vec<3> cross3(const float *a, const float *b) {
     WGG_EXACT

@@ -180,7 +180,9 @@ typedef enum wg_tuning {
     WG_TUNE_F32_MID = 5,     /* the mid-size f32 tile family (gemm_f32_mid.hip: 128 x 128, 128 x 64, 64 x 128 tiles on 2 x 2 waves; 96 x 96, 96 x 64, 64 x 96, 64 x 64, 64 x 32,
                                 32 x 64 with K split over the workgroup's waves; no slabs, no second launch): -1 = by estimate (default), 0 = never, 1 = whenever
                                 applicable with the estimate's tile, 128128 / 128064 / 64128 / 96096 / 96064 / 64096 / 64064 / 64032 / 32064 = that tile (tests) */
-    WG_TUNE_COUNT_ = 6
+    WG_TUNE_F32_MID_SPLIT = 6, /* K cut of the mid family's k-split tiles across workgroups (few tiles, long K: 64 x 4096 x 4096): 0 = by estimate (default), n >= 2 = n
+                                 splits whenever that family runs (tests) */
+    WG_TUNE_COUNT_ = 7
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);
 /* Diagnostics / tests (no device needed): the f16 Gemm's calibrated-shares plan for `tiles` whole 256 x 256 tiles of `stages` stages (64 k

@@ -435,6 +435,38 @@ def test_record_replay_and_timestamps(gpu):
     assert np.array_equal(a.slow_read(gpu), np.full(n, 20, np.float32))
 
 
+def test_objects_dropped_during_a_recording_are_freed_after_it(gpu):
+    """A tensor, a command buffer or a whole GpuInstance whose last reference goes away WHILE the thread records (Python's cyclic GC picks its
+    moment; a Rust drop at scope end) must not touch the HIP runtime then: hipFree / hipStreamSynchronize from the capturing thread are prohibited
+    and invalidate the capture. The destroy is queued and runs when the recording ends (wg_encoder_finish) -- the reference keeps a dropped
+    buffer alive until the submission that uses it retires. (Found as a flaky failure of the record / replay tests: the GC freed an earlier
+    test's tensor in the middle of a recording.)"""
+    import gc
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    n = 4096
+    a, b = upload(gpu, (n,), np.zeros(n, np.float32)), upload(gpu, (n,), np.ones(n, np.float32))
+    victims = [upload(gpu, (1 << 16,), np.zeros(1 << 16, np.float32)) for _ in range(4)]
+    other = wg.GpuInstance.new(0)  # a second context of this thread, with a buffer and a finished recording of its own
+    ob = wg.TensorBuilder.vector(n, wg.BufferUsages.STORAGE).build(other.device(), np.float32)
+    oenc = other.device().create_command_encoder(record=True)
+    ocb = oenc.finish()
+    add = wg.OpAssign.new(dev, wg.OpAssignVariant.Add)
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p:
+        add.dispatch(dev, shapes, p, a, b)
+        del victims, ob, ocb, oenc
+        other.close()
+        del other
+        gc.collect()  # every destroy call lands inside the recording
+        add.dispatch(dev, shapes, p, a, b)
+    cb = enc.finish()
+    for _ in range(3):
+        gpu.queue().submit([cb])
+    assert np.array_equal(a.read(dev), np.full(n, 6, np.float32))
+    gpu.sync()
+
+
 # --------------------------------------------------------------------------------------------------------
 # f16 Gemm (extension: no reference kernel -- contract defined in DESIGN.md: f16 in, f32 accumulate, one RNE rounding)
 # --------------------------------------------------------------------------------------------------------
@@ -1547,3 +1579,38 @@ def test_gemm_f32_mid_equals_the_big_tile_unsplit(gpu, tr):
             gpu.set_tuning("f32_mid", old)
     U.assert_bits_equal(got[128128], got[0], "128 x 128 family vs the 256 x 128 tile")
     U.assert_bits_equal(got[64128], got[0], "64 x 128 tiles vs the 256 x 128 tile")
+
+
+@pytest.mark.parametrize("M,K,N,mats,split", [(64, 4096, 4096, 1, 4), (4096, 4096, 64, 1, 4), (128, 1000, 192, 2, 3), (64, 96, 64, 1, 2), (256, 2048, 256, 1, 8)])
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f32_mid_split_k(gpu, oracle_c, M, K, N, mats, split, tr):
+    """Few tiles with a long K: the mid family's k-split tiles with K cut across workgroups (f32 slabs + the ordered reduce), forced through
+    WG_TUNE_F32_MID / _SPLIT, against the oracle and f64; and once on the launcher's own choice. (A split whose last part would hold no whole
+    k-tile is reduced: 64 x 96 x 64 in two parts of 64 + 32.)"""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + 3 * K + 5 * N + mats + int(tr))
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float32)
+    s1 = wo.Shape(K, M, mats) if tr else wo.Shape(M, K, mats)
+    s2, so = wo.Shape(K, N, mats), wo.Shape(M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    orc = np.zeros(M * N * mats, np.float32)
+    oracle_c.gemm(int(variant), orc, so, a, s1, b, s2)
+    m1, m2 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a), upload(gpu, (K, N, mats), b)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    A, B = wo.view(a, s1), wo.view(b, s2)
+    for knob, sp in ((64064, split), (64032, split), (-1, 0)):
+        old, old_s = gpu.set_tuning("f32_mid", knob), gpu.set_tuning("f32_mid_split", sp)
+        try:
+            out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float32))
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            got = out.read(gpu.device())
+        finally:
+            gpu.set_tuning("f32_mid", old)
+            gpu.set_tuning("f32_mid_split", old_s)
+        for t in range(mats):
+            amk = A[:, :, t].T if tr else A[:, :, t]
+            truth, sabs = wo.gemm_f64(amk, B[:, :, t])
+            g_t = wo.view(got, so)[:, :, t]
+            U.assert_close_f64(g_t, truth, K, sabs, f"mid tile {knob} split {sp}: gemm {M}x{K}x{N} mat {t} tr={tr} vs f64")
+            U.assert_close_oracle(g_t, wo.view(orc, so)[:, :, t], K, sabs, f"mid tile {knob} split {sp} vs oracle")

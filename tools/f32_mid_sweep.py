@@ -24,6 +24,8 @@ if sys.argv[1:]:
     SHAPES = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
     SHAPES = [s if len(s) == 4 else s + (1,) for s in SHAPES]
 KNOBS = [0, 128128, 128064, 64128, 64064, 64032, 32064, 96096, 96064, -1]
+if os.environ.get("SPLITS"):  # few tiles, long K: the 64 x 64 k-split tile with K cut across workgroups -- SPLITS="0 2 4 8" (knob f32_mid_split)
+    KNOBS = [0] + [(64064, int(x)) for x in os.environ["SPLITS"].split()] + [-1]
 
 
 def reps_for(M, N, K, B):
@@ -35,7 +37,11 @@ def ours(M, N, K, B, tr, knob):
     b = device_random(wg, gpu, (K, N, B), np.float32, 2)
     c = wg.TensorBuilder.tensor((M, N, B), S.STORAGE).build(dev, np.float32)
     variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    split = 0
+    if isinstance(knob, tuple):
+        knob, split = knob
     old = gpu.set_tuning("f32_mid", knob)
+    old_split = gpu.set_tuning("f32_mid_split", split)
 
     def run(n):
         enc = dev.create_command_encoder()
@@ -55,6 +61,7 @@ def ours(M, N, K, B, tr, knob):
             best = min(best, (time.perf_counter() - t0) / n)
     finally:
         gpu.set_tuning("f32_mid", old)
+        gpu.set_tuning("f32_mid_split", old_split)
     return best
 
 
@@ -76,6 +83,8 @@ def vendor(M, N, K, B, tr):
     return best
 
 
+if os.environ.get("SPLITS"):
+    print("# us per call: round-3 paths (knob 0) | 64x64 tile with K cut in " + " / ".join(os.environ["SPLITS"].split()) + " | launcher's choice | vendor")
 print("# us per call: gemm_f32.hip plan | 128x128 | 128x64 | 64x128 | 64x64 | 64x32 | 32x64 | 96x96 | 96x64 | launcher's choice | vendor ; choice/vendor")
 for (M, N, K, B) in SHAPES:
     for tr in (False, True):

@@ -520,7 +520,35 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // 256-row tiles -- at the price of a transposed copy of the small m1 (Gemm only) and a transpose of the small result: 128 x 11008 x 4096
     // 249 -> 137 us, 128 x 14336 x 4096 305 -> 174 (vendor 117 on the first; profiles/r03_evidence.md section 11).
     // (N <= 4096 has the 64-column panels below: 128 x 4096 x 4096 49 us there, 68 this way)
-    if (M > 64 && M <= 128 && N > 4096 && K >= 128 && beta == 0.f) {
+    const bool mid_forced = ctx->tuning[WG_TUNE_F32_MID] > 1; // (tests / sweeps: a forced tile of the mid family goes past the few-row / few-column paths)
+    // Few 64 x 64 tiles with a long K (64 x 4096 x 4096, 256 x 256 x 32768): the mid family's k-split tile with K cut across workgroups -- f32 slabs +
+    // the ordered reduce, but on tiles small enough that the slabs are small. Model (tools/f32_mid_sweep.py with SPLITS=..., profiles/r04_f32_split_sweep.txt):
+    // ceil(tiles x ns / CUs) rounds of a K / ns tile (+16 % alone on a CU, the co-resident curve beyond) + 1.5 us per tile + 3 us, slabs written at 3.5 TB/s,
+    // reduced at 7 TB/s + 4 us. Measured: 64 x 4096 x 4096 29 -> 26 us (vendor 25), 64 x 11008 x 4096 76 -> 57 (61), 256 x 256 x 32768 140 -> 43 (139).
+    const int cus0 = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    auto mid_split_plan = [&](double &est_out) -> uint32_t {
+        const uint64_t t64 = (uint64_t)((M + 63u) / 64u) * ((N + 63u) / 64u) * nmats;
+        uint32_t best_ns = 1;
+        est_out = 1e30;
+        if (K < 1024u || t64 * 2u > (uint64_t)cus0) return 1;
+        const double ob = (double)M * N * nmats * 4.0;
+        static const uint32_t opts[] = { 2, 3, 4, 6, 8, 12, 16, 24, 32 };
+        for (uint32_t ns : opts) {
+            if (K / ns < 256u || (uint64_t)nmats * ns > 65535u) break;
+            const double r = (double)((t64 * ns + (uint64_t)cus0 - 1) / (uint64_t)cus0);
+            const double loop = r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r);
+            const double kps = (double)((((K + 31u) / 32u + ns - 1u) / ns) * 32u);
+            const double est = r * (2.0 * 64 * 64 * kps / 614400.0 * loop + 1.5) + 3.0 + ns * ob / 3.5e6 + 4.0 + ns * ob / 7.0e6;
+            if (est < est_out) { est_out = est; best_ns = ns; }
+        }
+        return best_ns;
+    };
+    if (ctx->tuning[WG_TUNE_F32_MID] != 0 && !mid_forced && (M <= 64 || N <= 64) && M >= 48 && N >= 48 && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
+        double est;
+        const uint32_t ns = mid_split_plan(est);
+        if (ns > 1) return wgk_gemm_f32_mid(ctx, trans, 64, 64, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, ns);
+    }
+    if (!mid_forced && M > 64 && M <= 128 && N > 4096 && K >= 128 && beta == 0.f) {
         const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
         void *ws = nullptr;
         if (int rc = wg_ctx_pad_workspace(ctx, (size_t)((at_elems + ct_elems) * nmats * sizeof(float)), &ws)) return rc;
@@ -533,7 +561,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = wgk_gemm_f32(ctx, true, N, M, K, nmats, ct, N, ct_elems, m2, a2, alpha, 0.f)) return rc;
         return wgk_transpose(ctx, WG_F32, N, M, nmats, ct, N, ct_elems, out, out_ld, out_batch);
     }
-    if (M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
+    if (!mid_forced && M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
         // the few-column GemmTr kernel takes m2' = op(A)^T either k-contiguous (GemmTr: m1 as it is) or with its columns contiguous (Gemm:
         // m1 as it is, "k-major"), and writes -- or its split-K reduce does -- straight into the transposed position: "row" n of C^T is
         // column n of C (out_ld apart), "column" m is row m (adjacent). No copy of anything.
@@ -555,7 +583,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // few output columns (a matrix applied to a handful of vectors): HBM-bound on A, see gemm_f32_skinny.hip. wg_ctx_set_tuning(WG_TUNE_F32_SKINNY, 0) disables
     // it (experiments / tests of the tiled kernel on these shapes).
     // (32-bit DMA offsets within a 32-row / 32-k block of m1 and within the 64 columns of m2: both variants build them)
-    if (N <= 64 && M >= 512 && K >= 128 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
+    if (!mid_forced && N <= 64 && M >= 512 && K >= 128 && (uint64_t)m1.ld * 32u * 4u < (1ull << 31) && (uint64_t)m2.ld * 64u * 4u < (1ull << 31)) {
         if (ctx->tuning[WG_TUNE_F32_SKINNY] != 0) return wgk_gemm_f32_skinny(ctx, trans, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     }
     GemmArgs g;
@@ -645,6 +673,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     //   than one round only from K = 256 up (their per-tile reduction does not amortise over a handful of k-tiles: 128^3 x 256 matrices 21 us against 16).
     double mid_est = 1e30;
     int mid_bm = 0, mid_bn = 0;
+    uint32_t mid_ns = 1;
     const int mid_knob = ctx->tuning[WG_TUNE_F32_MID];
     // Mid-size means mid-size: from ~4 tiles of 256 x 128 per CU on, this file's kernel runs at 93-96 % of the matrix cores' rate and the small
     // tiles' extra barriers and fills only cost (8192^3: 7287 us here, 7980 on 64 x 64 tiles).
@@ -669,7 +698,12 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             if (c[2] && pow2_ldb) loop += 0.10; // 1024 x 1024 x 32768: 536 us on 64 x 32 tiles against 486 for this file's split-K plan
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
-            if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; }
+            if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; mid_ns = 1; }
+        }
+        if (mid_knob <= 1) { // few tiles, long K: the 64 x 64 tile with K cut across workgroups (mid_split_plan above)
+            double est;
+            const uint32_t ns = mid_split_plan(est);
+            if (ns > 1 && est < mid_est) { mid_est = est; mid_bm = 64; mid_bn = 64; mid_ns = ns; }
         }
     }
     // Small outputs (few 256 x 128 tiles): 64-column panels of the few-column kernel (gemm_f32_skinny.hip) give 128 x 64 "tiles", eight
@@ -699,7 +733,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     if (mid_bm) {
         const double tiled = best + rounds(tiles * nmats * nsplit) * 3.0 + 5.0; // (+ launch and drain; the output's write time is on neither side)
         if (mid_knob >= 1 || mid_est < 0.97 * tiled)
-            return wgk_gemm_f32_mid(ctx, trans, mid_bm, mid_bn, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
+            return wgk_gemm_f32_mid(ctx, trans, mid_bm, mid_bn, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, ctx->tuning[WG_TUNE_F32_MID_SPLIT] > 1 ? (uint32_t)ctx->tuning[WG_TUNE_F32_MID_SPLIT] : mid_ns);
     }
     float *part = nullptr;
     g.nsplit = nsplit;

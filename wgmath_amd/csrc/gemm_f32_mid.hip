@@ -39,6 +39,10 @@ struct MidArgs {
     uint32_t M, N, K;
     uint32_t tiles_m, tiles_n;
     float alpha, beta;
+    // split-K (k-split-wave tiles only; few tiles with a long K: 64 x 4096 x 4096): grid.y = nmats * nsplit, workgroup (z, s) covers
+    // k in [s * k_per_split, ..) -- a multiple of 32 -- and writes the f32 slab (z, s) of `c` ([z][s][N][M], ldc = M); wg_splitk_reduce adds
+    // them in ascending s and applies alpha / beta
+    uint32_t nsplit, k_per_split;
 };
 
 __device__ __forceinline__ void store_c(float *p, float4 v, float alpha, float beta) {
@@ -313,9 +317,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
 
     uint32_t tm, tn;
     tile_of(blockIdx.x, g.tiles_m, g.tiles_n, tm, tn);
-    const uint32_t m0 = tm * BM, n0 = tn * BN, z = blockIdx.y;
-    const float *A = g.a + z * g.a_batch, *B = g.b + z * g.b_batch;
-    float *C = g.c + z * g.c_batch;
+    const uint32_t m0 = tm * BM, n0 = tn * BN, z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
+    const uint32_t k_begin = split * g.k_per_split, K = min(g.K - k_begin, g.k_per_split); // (workgroup-uniform; K >= 32: launcher)
+    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda), *B = g.b + z * g.b_batch + k_begin;
+    float *C = g.c + ((uint64_t)z * g.nsplit + split) * g.c_batch;
 
     floatx16 acc[WT_M][WT_N];
 #pragma unroll
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             for (int u = 0; u < WT_N; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_of(set, s, t), comp(bf[set][u], s), acc[t][u], 0, 0, 0);
     };
 
-    const uint32_t nk = g.K / BK2; // whole k-tiles (>= 1: launcher); a K % 32 remainder follows the pipelined loop
+    const uint32_t nk = K / BK2; // whole k-tiles (>= 1: launcher); a K % 32 remainder follows the pipelined loop
     auto next_slot = [](uint32_t x) { return x + 1 == NRING ? 0u : x + 1; };
     static_assert(2 * NT >= PPW, "the second half of a tile has an MFMA for every piece");
     // Branch-free body (see the 2 x 2-wave kernel): every tile publishes "tile t + 1" and sends for "tile t + 3" into its own slot -- all of its
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
     wait_dma_keep<0>(); // the parked pieces: nothing may land once the ring is reused below
 
     // K % 32 != 0 (a multiple of 4): the last, partial k-tile through registers into slot 0, missing k zero-filled, multiplied like any other
-    if (nk * BK2 < g.K) {
+    if (nk * BK2 < K) {
         __syncthreads(); // every wave is done with the ring
         const uint32_t k0 = nk * BK2;
         float *As = smem, *Bs = smem + A_TILE;
@@ -448,13 +453,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             if constexpr (!TRANS_A) {
                 const uint32_t kr = (uint32_t)f / (BM / 4), m = min(4u * ((uint32_t)f % (BM / 4)), g.M - 4u - m0), k = k0 + kr;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)k * g.lda + m);
+                if (k < K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)k * g.lda + m);
                 *reinterpret_cast<float4 *>(&As[kr * BM + 4 * (f % (BM / 4))]) = v;
             } else {
                 const int mm = f >> 3, ch = f & 7;
                 const uint32_t k = k0 + 4u * ch, row = min((uint32_t)mm, g.M - 1u - m0);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)row * g.lda + k);
+                if (k < K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)row * g.lda + k);
                 *reinterpret_cast<float4 *>(&As[mm * BK2 + 4 * (ch ^ ((mm >> 1) & 7))]) = v;
             }
         }
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             const int nn = f >> 3, ch = f & 7;
             const uint32_t k = k0 + 4u * ch, row = min((uint32_t)nn, g.N - 1u - n0);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < g.K) v = *reinterpret_cast<const float4 *>(b_base + (uint64_t)row * g.ldb + k);
+            if (k < K) v = *reinterpret_cast<const float4 *>(b_base + (uint64_t)row * g.ldb + k);
             *reinterpret_cast<float4 *>(&Bs[nn * BK2 + 4 * (ch ^ ((nn >> 1) & 7))]) = v;
         }
         __syncthreads();
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
 
 template <int WT_M, int WT_N>
 int launch_kw(wg_ctx *ctx, bool trans, uint32_t nmats, const MidArgs &g) {
-    const dim3 grid(g.tiles_m * g.tiles_n, nmats), block(kThreads);
+    const dim3 grid(g.tiles_m * g.tiles_n, nmats * g.nsplit), block(kThreads);
     if (trans) hipLaunchKernelGGL((gemm_f32_mid_kw_kernel<true, WT_M, WT_N>), grid, block, 0, ctx->stream, g);
     else hipLaunchKernelGGL((gemm_f32_mid_kw_kernel<false, WT_M, WT_N>), grid, block, 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
@@ -577,24 +582,47 @@ bool wgk_gemm_f32_mid_ok(uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, wgk
 }
 
 int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
-                     wgk_mat m1, wgk_mat m2, float alpha, float beta) {
+                     wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t nsplit) {
+    const bool kw = !(bm == 128 || bn == 128);
+    if (nsplit > 1 && !kw) nsplit = 1; // (the 2 x 2-wave tiles have no split form)
+    uint32_t kps = K;
+    for (uint32_t want = nsplit; nsplit > 1; --want) { // whole k-tiles per split, no empty split, at least one whole k-tile in the last one
+        if (want <= 1) { nsplit = 1; kps = K; break; }
+        kps = (((K + 31u) / 32u + want - 1u) / want) * 32u;
+        const uint32_t n = (K + kps - 1u) / kps;
+        if (n > 1 && K - (n - 1u) * kps >= 32u) { nsplit = n; break; }
+    }
+    if ((uint64_t)nmats * nsplit > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: nmats * splits exceeds 65535");
     MidArgs g;
     g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.c = out; g.ldc = out_ld; g.c_batch = out_batch;
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
+    g.nsplit = nsplit > 1 ? nsplit : 1u; g.k_per_split = kps;
+    float *part = nullptr;
+    if (g.nsplit > 1) { // raw partial sums into f32 slabs; alpha / beta are applied by the ordered reduce
+        void *ws = nullptr;
+        if (int rc = wg_ctx_workspace(ctx, (size_t)g.nsplit * M * N * nmats * sizeof(float), &ws)) return rc;
+        part = (float *)ws;
+        g.c = part; g.ldc = M; g.c_batch = (uint64_t)M * N;
+        g.alpha = 1.f; g.beta = 0.f;
+    }
     g.tiles_m = (M + (uint32_t)bm - 1) / (uint32_t)bm;
     g.tiles_n = (N + (uint32_t)bn - 1) / (uint32_t)bn;
     if ((uint64_t)g.tiles_m * g.tiles_n > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
-    if (bm == 128 && bn == 128) return launch<2, 2>(ctx, trans, nmats, g);
-    if (bm == 128 && bn == 64) return launch<2, 1>(ctx, trans, nmats, g);
-    if (bm == 64 && bn == 128) return launch<1, 2>(ctx, trans, nmats, g);
-    if (bm == 64 && bn == 64) return launch_kw<2, 2>(ctx, trans, nmats, g);
-    if (bm == 64 && bn == 32) return launch_kw<2, 1>(ctx, trans, nmats, g);
-    if (bm == 32 && bn == 64) return launch_kw<1, 2>(ctx, trans, nmats, g);
-    if (bm == 96 && bn == 96) return launch_kw<3, 3>(ctx, trans, nmats, g);
-    if (bm == 96 && bn == 64) return launch_kw<3, 2>(ctx, trans, nmats, g);
-    if (bm == 64 && bn == 96) return launch_kw<2, 3>(ctx, trans, nmats, g);
-    return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: no %d x %d f32 tile", bm, bn);
+    int rc = WG_ERR_INVALID_ARG;
+    if (bm == 128 && bn == 128) rc = launch<2, 2>(ctx, trans, nmats, g);
+    else if (bm == 128 && bn == 64) rc = launch<2, 1>(ctx, trans, nmats, g);
+    else if (bm == 64 && bn == 128) rc = launch<1, 2>(ctx, trans, nmats, g);
+    else if (bm == 64 && bn == 64) rc = launch_kw<2, 2>(ctx, trans, nmats, g);
+    else if (bm == 64 && bn == 32) rc = launch_kw<2, 1>(ctx, trans, nmats, g);
+    else if (bm == 32 && bn == 64) rc = launch_kw<1, 2>(ctx, trans, nmats, g);
+    else if (bm == 96 && bn == 96) rc = launch_kw<3, 3>(ctx, trans, nmats, g);
+    else if (bm == 96 && bn == 64) rc = launch_kw<3, 2>(ctx, trans, nmats, g);
+    else if (bm == 64 && bn == 96) rc = launch_kw<2, 3>(ctx, trans, nmats, g);
+    else return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: no %d x %d f32 tile", bm, bn);
+    if (rc != WG_OK) return rc;
+    if (g.nsplit > 1) return wg_splitk_reduce(ctx, part, g.nsplit, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
+    return WG_OK;
 }

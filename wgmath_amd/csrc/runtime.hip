@@ -81,9 +81,27 @@ int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out) {
     return grow_scratch(ctx, &ctx->bal.scratch, &ctx->bal.scratch_bytes, bytes, "balance workspace", out);
 }
 
+namespace {
+thread_local int t_capturing = 0;                         // recordings open on this thread
+thread_local std::vector<std::function<void()>> t_deferred; // destroy calls that arrived meanwhile
+void capture_ended() {
+    if (t_capturing > 0 && --t_capturing == 0) {
+        std::vector<std::function<void()>> run;
+        run.swap(t_deferred);
+        for (auto &f : run) f();
+    }
+}
+} // namespace
+bool wg_defer_if_capturing(std::function<void()> fn) {
+    if (t_capturing == 0) return false;
+    t_deferred.push_back(std::move(fn));
+    return true;
+}
+
 extern "C" {
 
 int wg_abi_version(void) { return WGEBRA_HIP_ABI_VERSION; }
+
 const char *wg_last_error_string(void) { return g_last_error.c_str(); }
 
 int wg_device_count(void) {
@@ -124,7 +142,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
     // kernel-selection knobs: the environment is consulted here and nowhere on the dispatch path
     static const struct { const char *env; wg_tuning key; } knobs[] = {
         { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
-        { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID } };
+        { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID }, { "WG_F32_MID_SPLIT", WG_TUNE_F32_MID_SPLIT } };
     for (const auto &k : knobs)
         if (const char *v = getenv(k.env)) {
             // the same validation as wg_ctx_set_tuning: a value the knob does not take is ignored (with a note), never silently reinterpreted
@@ -186,6 +204,14 @@ int wg_ctx_create_with_cu_count_one_xcd(int device, uint32_t cu_count, wg_ctx **
 
 int wg_ctx_destroy(wg_ctx *ctx) {
     if (!ctx) return WG_OK;
+    if (!ctx->recording && wg_defer_if_capturing([ctx] { (void)wg_ctx_destroy(ctx); })) return WG_OK; // (another context of this thread is recording)
+    if (ctx->recording) { // destroyed in the middle of its own recording: end the capture first
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(ctx->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        ctx->recording = false;
+        capture_ended();
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->workspace) (void)hipFree(ctx->workspace);
@@ -252,6 +278,11 @@ int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value) {
     if (key == WG_TUNE_F16_TILE && value != 0 && value != 128 && value != 256)
         return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F16_TILE takes 0, 128 or 256, not %d", value);
     if (key == WG_TUNE_F32_MID && (value == 64064 || value == 64128 || value == 128064 || value == 128128 || value == 64032 || value == 32064 || value == 96096 || value == 96064 || value == 64096)) {
+        ctx->tuning[key] = value;
+        return WG_OK;
+    }
+    if (key == WG_TUNE_F32_MID_SPLIT) {
+        if (value < 0 || value == 1 || value > 64) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F32_MID_SPLIT takes 0 or 2..64, not %d", value);
         ctx->tuning[key] = value;
         return WG_OK;
     }
@@ -329,6 +360,7 @@ int wg_buf_wrap(wg_ctx *ctx, void *device_ptr, size_t bytes, wg_buf **out) {
 
 int wg_buf_destroy(wg_buf *buf) {
     if (!buf || buf->borrowed) return WG_OK;
+    if (wg_defer_if_capturing([buf] { (void)wg_buf_destroy(buf); })) return WG_OK; // (this thread is recording: after the recording)
     int rc = WG_OK;
     if (buf->owned && buf->ptr) {
         (void)hipSetDevice(buf->ctx->device);
@@ -408,6 +440,7 @@ int wg_encoder_begin(wg_ctx *ctx) {
     WG_HIP_TRY(hipSetDevice(ctx->device));
     WG_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->recording = true;
+    ++t_capturing;
     return WG_OK;
 }
 
@@ -417,7 +450,9 @@ int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out) {
     if (!ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: not recording");
     ctx->recording = false;
     hipGraph_t graph = nullptr;
-    WG_HIP_TRY(hipStreamEndCapture(ctx->stream, &graph));
+    const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
+    capture_ended(); // destroy calls that arrived while this thread was recording run now
+    WG_HIP_TRY(ec);
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (e != hipSuccess) {
@@ -445,6 +480,7 @@ int wg_queue_submit(wg_ctx *ctx, wg_cmdbuf *cmdbuf) {
 
 int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf) {
     if (!cmdbuf) return WG_OK;
+    if (wg_defer_if_capturing([cmdbuf] { (void)wg_cmdbuf_destroy(cmdbuf); })) return WG_OK;
     (void)hipSetDevice(cmdbuf->ctx->device);
     (void)hipStreamSynchronize(cmdbuf->ctx->stream);
     if (cmdbuf->exec) (void)hipGraphExecDestroy(cmdbuf->exec);
@@ -482,6 +518,7 @@ int wg_timestamps_create(wg_ctx *ctx, uint32_t capacity, wg_timestamps **out) {
 
 int wg_timestamps_destroy(wg_timestamps *ts) {
     if (!ts) return WG_OK;
+    if (wg_defer_if_capturing([ts] { (void)wg_timestamps_destroy(ts); })) return WG_OK;
     (void)hipSetDevice(ts->ctx->device);
     for (hipEvent_t e : ts->events)
         if (e) (void)hipEventDestroy(e);

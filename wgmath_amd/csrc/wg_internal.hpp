@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <vector>
 
 #include "../../include/wgebra_hip.h"
@@ -43,7 +44,7 @@ struct wg_ctx {
         void *scratch = nullptr;            // raw f32 accumulator tiles of the prefix units (grow-only)
         size_t scratch_bytes = 0;
     } bal;
-    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
     bool debug_clock_open = false;
     uint32_t func_attr_bits = 0;         // hipFuncSetAttribute calls already made for this context's device (gemv.hip: GemvTr's 128 KiB dynamic LDS)
@@ -54,6 +55,12 @@ struct wg_ctx {
     struct AsyncError { uint32_t *word; const char *what; uint32_t *dev_word; };
     std::vector<AsyncError> async_errors;
 };
+// A destroy call that arrives while THIS THREAD records a command buffer (hipStreamBeginCapture, thread-local mode) must not run now: hipFree /
+// hipStreamSynchronize from the capturing thread are prohibited and invalidate the capture. It happens -- a garbage-collected host object
+// (Python's cyclic GC, a Rust drop at scope end) owns a buffer or a command buffer -- and it is legal in the reference (wgpu keeps a dropped
+// buffer alive until the submission using it retires). Returns true if `fn` was queued: it then runs right after the recording ends
+// (wg_encoder_finish), otherwise the caller runs it itself.
+bool wg_defer_if_capturing(std::function<void()> fn);
 void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what, uint32_t *dev_word = nullptr); // dev_word: a device-side twin cleared with it
 void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word);
 int wg_ctx_check_async(wg_ctx *ctx); // WG_ERR_HIP + message "<what> <word - 1>" if a registered word is set (and clears it)
@@ -142,7 +149,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 // _ok: the shapes / strides it takes
 bool wgk_gemm_f32_mid_ok(uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, wgk_mat m1, wgk_mat m2);
 int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
-                     wgk_mat m1, wgk_mat m2, float alpha, float beta);
+                     wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t nsplit = 1);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
 // N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
