@@ -1614,3 +1614,35 @@ def test_gemm_f32_mid_split_k(gpu, oracle_c, M, K, N, mats, split, tr):
             g_t = wo.view(got, so)[:, :, t]
             U.assert_close_f64(g_t, truth, K, sabs, f"mid tile {knob} split {sp}: gemm {M}x{K}x{N} mat {t} tr={tr} vs f64")
             U.assert_close_oracle(g_t, wo.view(orc, so)[:, :, t], K, sabs, f"mid tile {knob} split {sp} vs oracle")
+
+
+@pytest.mark.parametrize("knob", MID_TILES + MID_KW_TILES)
+def test_gemm_f32_mid_strided_views(gpu, oracle_c, knob):
+    """Strided / offset views (GpuMatrix::columns / rows / GpuCubeView::matrix) through every tile of the mid family, nothing outside the output
+    view touched; and a larger strided case with a K remainder."""
+    old = gpu.set_tuning("f32_mid", knob)
+    try:
+        test_gemm_strided_views(gpu, oracle_c)
+        wg, wo = _wg(), _wo()
+        rng = np.random.default_rng(knob)
+        PR, PC = 400, 360
+        pa, pb = (rng.random(PR * PC * 2, dtype=np.float32) - 0.5).astype(np.float32), (rng.random(PR * PC * 2, dtype=np.float32) - 0.5).astype(np.float32)
+        po0 = rng.random(PR * PC * 2, dtype=np.float32)
+        ta, tb, to = upload(gpu, (PR, PC, 2), pa), upload(gpu, (PR, PC, 2), pb), upload(gpu, (PR, PC, 2), po0)
+        M, K, N = 196, 108, 132  # K % 32 = 12, K % 16 = 12: the remainder tile of both sub-families
+        a_view = ta.as_view().matrix(1).columns(8, K).rows(12, M)
+        b_view = tb.as_view().matrix(0).columns(20, N).rows(4, K)
+        o_view = to.as_view().matrix(1).columns(16, N).rows(24, M)
+        gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+        run_pass(gpu, lambda p: gemm.dispatch(gpu.device(), shapes, p, o_view, a_view, b_view))
+        got = to.read(gpu.device())
+        sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+        A, B = wo.view(pa, sh(a_view))[:, :, 0], wo.view(pb, sh(b_view))[:, :, 0]
+        truth, sabs = wo.gemm_f64(A, B)
+        U.assert_close_f64(wo.view(got, sh(o_view))[:, :, 0], truth, K, sabs, f"strided gemm, mid tile {knob}, vs f64")
+        mask = np.ones(po0.size, bool)
+        s = sh(o_view).resolved()
+        mask[(s.offset + np.arange(s.nrows)[:, None] + np.arange(s.ncols)[None, :] * s.stride).ravel()] = False
+        assert np.array_equal(got[mask], po0[mask]), f"mid tile {knob} wrote outside its output view"
+    finally:
+        gpu.set_tuning("f32_mid", old)

@@ -3,6 +3,7 @@
 // which the cap does not allow with non-zero operands).
 //   data 0: zero operands (the clock stays at its ceiling: measures the issue rate)   data 1: uniform random f16 in [-1, 1) per lane and fragment
 //   shape 0: 16x16x32 (the shipped kernel's instruction), wave tile 8 x 8 fragments like the Gemm   shape 1: 32x32x16, 4 x 4 fragments
+//   shape 2 / 3: 16x16x32 with TWO / FOUR consecutive MFMAs per accumulator (k-inner: does accumulator forwarding between dependent MFMAs save power?)
 // One workgroup of 4 waves per CU (160 KiB of LDS claimed), `wgs` workgroups, each wave REPS x 64 (or 16) MFMAs into 256 accumulator registers.
 // build: hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/cpp/mfma_power_ceiling.hip -o tools/cpp/_bin/mfma_power_ceiling
 #include <hip/hip_runtime.h>
@@ -44,6 +45,32 @@ __global__ __launch_bounds__(256, 1) void burn(float *out, int reps, int data) {
             for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int u = 0; u < 8; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b[u], acc[t][u], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += acc[t][u][0] + acc[t][u][1] + acc[t][u][2] + acc[t][u][3];
+    } else if constexpr (SHAPE == 2 || SHAPE == 3) {
+        constexpr int KI = SHAPE == 2 ? 2 : 4;
+        half8 a2[KI - 1][8], b2[KI - 1][8];
+#pragma unroll
+        for (int k = 0; k < KI - 1; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { a2[k][i] = frag(id * 64u + 16u * (k + 1) + i, data); b2[k][i] = frag(id * 64u + 16u * (k + 1) + 8u + i, data); }
+        floatx4 acc[8][8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[t][u] = floatx4{ 0.f, 0.f, 0.f, 0.f };
+        for (int r = 0; r < reps / KI; ++r) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t], b[u], acc[t][u], 0, 0, 0);
+#pragma unroll
+                    for (int k = 0; k < KI - 1; ++k) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[k][t], b2[k][u], acc[t][u], 0, 0, 0);
+                }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t)
@@ -106,6 +133,10 @@ int main(int argc, char **argv) {
         if (run<0>(out, wgs, reps, 0, "16x16x32 zero operands")) return 1;
         if (run<1>(out, wgs, reps, 1, "32x32x16 random operands")) return 1;
         if (run<1>(out, wgs, reps, 0, "32x32x16 zero operands")) return 1;
+        if (run<2>(out, wgs, reps, 1, "16x16x32 random, 2 per accumulator")) return 1;
+        if (run<2>(out, wgs, reps, 0, "16x16x32 zero,   2 per accumulator")) return 1;
+        if (run<3>(out, wgs, reps, 1, "16x16x32 random, 4 per accumulator")) return 1;
+        if (run<0>(out, wgs, reps, 1, "16x16x32 random operands (again)")) return 1;
     }
     return 0;
 }
