@@ -1646,3 +1646,29 @@ def test_gemm_f32_mid_strided_views(gpu, oracle_c, knob):
         assert np.array_equal(got[mask], po0[mask]), f"mid tile {knob} wrote outside its output view"
     finally:
         gpu.set_tuning("f32_mid", old)
+
+
+def test_encased_builders_and_into_inner(gpu):
+    """tensor.rs:132-173 (`build_uninit_encased`, `build_encase`) and :277-279 (`into_inner`): items of a shader struct travel in their storage layout --
+    here a structured dtype with the 16-byte alignment WGSL gives a vec3 member -- and `into_inner` keeps the allocation while consuming the tensor."""
+    import wgmath_amd as wg
+    S = wg.BufferUsages
+    item = np.dtype({"names": ["p", "id"], "formats": [(np.float32, 3), np.uint32], "offsets": [0, 12], "itemsize": 16})
+    host = np.zeros(37, item)
+    host["p"] = np.arange(37 * 3, dtype=np.float32).reshape(37, 3)
+    host["id"] = np.arange(37, dtype=np.uint32) * 7
+    t = wg.TensorBuilder.vector(37, S.STORAGE | S.COPY_SRC).build_encase(gpu.device(), host)
+    assert t.bytes_len() == 37 * 16
+    assert t.read_bytes(gpu.device()) == host.tobytes()
+    u = wg.TensorBuilder.vector(5, S.STORAGE).build_uninit_encased(gpu.device(), item)
+    assert u.bytes_len() == 80 and u.len() == 5
+    with pytest.raises(AssertionError, match="Incorrect number of elements"):
+        wg.TensorBuilder.vector(38, S.STORAGE).build_encase(gpu.device(), host)
+    ptr = t.device_ptr()
+    inner = t.into_inner()
+    assert isinstance(inner, wg.GpuBuffer) and inner.size == 37 * 16 and inner.device_ptr() == ptr
+    with pytest.raises(AssertionError, match="already consumed"):
+        t.into_inner()
+    del t  # the consumed tensor no longer owns anything: dropping it must not free the allocation
+    again = wg.GpuTensor.wrap(gpu.device(), inner.device_ptr(), (37 * 4,), np.uint32, keepalive=inner)
+    assert again.read_bytes(gpu.device()) == host.tobytes()

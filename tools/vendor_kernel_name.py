@@ -33,6 +33,31 @@ def run(n, layout, dtype=torch.float16, seconds=0.5):
     return 2.0 * n ** 3 / (e0.elapsed_time(e1) / iters) / 1e9
 
 
-for n, dt in ((8192, torch.float16), (2048, torch.float16), (4096, torch.float16), (2048, torch.float32), (1024, torch.float32)):
+import sys  # noqa: E402
+
+for n, dt in () if len(sys.argv) > 1 else ((8192, torch.float16), (2048, torch.float16), (4096, torch.float16), (2048, torch.float32), (1024, torch.float32)):
     for layout in ("nn", "tn"):
         print(f"vendor {str(dt).split('.')[-1]} {n}^3 {layout}: {run(n, layout, dt):8.1f} TFLOP/s", flush=True)
+
+
+def run_rect(M, N, K, seconds=0.3):
+    """GemmTr's layout (both operands k-contiguous), rectangular: column-major C (M x N) = row-major (N x K) @ (M x K)^T."""
+    x = (torch.rand(N, K, device="cuda") * 2 - 1).half()
+    y = (torch.rand(M, K, device="cuda") * 2 - 1).half().t()
+    c = torch.empty(N, M, device="cuda", dtype=torch.float16)
+    for _ in range(5):
+        torch.matmul(x, y, out=c)
+    torch.cuda.synchronize()
+    iters = max(20, int(seconds / (2.0 * M * N * K / 1.0e15 + 5e-6)))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(x, y, out=c)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for s in sys.argv[1:]:  # extra shapes MxNxK on the k-contiguous layout
+    M, N, K = (int(v) for v in s.split("x"))
+    print(f"vendor f16 tn {M}x{N}x{K}: {run_rect(M, N, K):8.1f} us", flush=True)

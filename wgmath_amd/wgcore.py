@@ -426,6 +426,40 @@ class TensorBuilder:
         return GpuTensor(device._ctx, h.value, self.shape, np.dtype(dtype), self.usage)
 
 
+    def build_uninit_encased(self, device: Device, item_dtype) -> "GpuTensor":
+        """tensor.rs:132-147: an uninitialised buffer of `len` items of a shader struct; `item_dtype` is the numpy structured dtype that carries the
+        struct's storage layout (its itemsize is the reference's `T::min_size()`, padding included)."""
+        return self.build(device, np.dtype(item_dtype))
+
+    def build_encase(self, device: Device, data) -> "GpuTensor":
+        """tensor.rs:164-173: items of a shader struct, uploaded in their storage layout. The reference serialises through `encase`; here the layout is the
+        structured dtype of `data` (numpy writes the padding the dtype declares), so the bytes that reach the buffer are `data.tobytes()`."""
+        arr = np.ascontiguousarray(data)
+        assert arr.size >= self.len(), (
+            "Incorrect number of elements provided for initializing Tensor."
+            f"Expected at least {self.len()}, found {arr.size}")
+        return self.build_bytes(device, arr.reshape(-1)[: self.len()].tobytes(), arr.dtype)
+
+
+class GpuBuffer:
+    """What `GpuTensor.into_inner` hands over (tensor.rs:277-279): the device allocation without a shape. Freed when dropped, like the reference's `wgpu::Buffer`."""
+
+    def __init__(self, ctx: _Ctx, handle, nbytes: int):
+        self._ctx, self._h, self.size = ctx, handle, int(nbytes)
+
+    def device_ptr(self) -> int:
+        return lib.wg_buf_device_ptr(self._h) or 0
+
+    def destroy(self):
+        h = getattr(self, "_h", None)
+        if h:
+            if self._ctx.handle:
+                lib.wg_buf_destroy(h)
+            self._h = None
+
+    __del__ = destroy
+
+
 class GpuTensor:
     """tensor.rs:192-400 (GpuScalar / GpuVector / GpuMatrix / GpuCube are DIM = 0..3 of the same type)."""
 
@@ -479,6 +513,14 @@ class GpuTensor:
 
     def device_ptr(self) -> int:
         return lib.wg_buf_device_ptr(self._h) or 0
+
+    def into_inner(self) -> "GpuBuffer":
+        """tensor.rs:277-279: gives up the tensor, keeps the allocation. The tensor is unusable afterwards (Rust moves it)."""
+        assert self._h, "into_inner: the tensor was already consumed"
+        inner = GpuBuffer(self._ctx, self._h, self.bytes_len())
+        inner._keepalive = self._keepalive
+        self._h = None
+        return inner
 
     # copies (tensor.rs:227-264)
     def copy_from(self, encoder: CommandEncoder, source: "GpuTensor") -> None:
