@@ -1672,3 +1672,36 @@ def test_encased_builders_and_into_inner(gpu):
     del t  # the consumed tensor no longer owns anything: dropping it must not free the allocation
     again = wg.GpuTensor.wrap(gpu.device(), inner.device_ptr(), (37 * 4,), np.uint32, keepalive=inner)
     assert again.read_bytes(gpu.device()) == host.tobytes()
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 160, 12288), (12288, 160, 64), (48, 256, 16384), (64, 132, 24576)])
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f32_few_rows_or_columns_one_tile_per_cu(gpu, oracle_c, M, K, N, tr):
+    """One 64-row (or 64-column) strip of 192 .. 512 tiles of 64 x 64: the launcher's own choice there is the mid family's 64 x 64 tile UNSPLIT (gemm_f32.hip,
+    few-row branch) -- against the oracle and f64, and bit for bit against the same tile forced through the knob (K % 32 != 0 in two of the cases: its remainder tile)."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M + 3 * K + 5 * N + int(tr))
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float32)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float32)
+    s1 = wo.Shape(K, M, 1) if tr else wo.Shape(M, K, 1)
+    s2, so = wo.Shape(K, N, 1), wo.Shape(M, N, 1)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    orc = np.zeros(M * N, np.float32)
+    oracle_c.gemm(int(variant), orc, so, a, s1, b, s2)
+    m1, m2 = upload(gpu, (K, M, 1) if tr else (M, K, 1), a), upload(gpu, (K, N, 1), b)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    A, B = wo.view(a, s1)[:, :, 0], wo.view(b, s2)[:, :, 0]
+    truth, sabs = wo.gemm_f64(A.T if tr else A, B)
+    got = {}
+    for knob in (-1, 64064):
+        old = gpu.set_tuning("f32_mid", knob)
+        try:
+            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float32))
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            got[knob] = out.read(gpu.device())
+        finally:
+            gpu.set_tuning("f32_mid", old)
+        g = wo.view(got[knob], so)[:, :, 0]
+        U.assert_close_f64(g, truth, K, sabs, f"few rows / columns, knob {knob}: gemm {M}x{K}x{N} tr={tr} vs f64")
+        U.assert_close_oracle(g, wo.view(orc, so)[:, :, 0], K, sabs, f"few rows / columns, knob {knob} vs oracle")
+    U.assert_bits_equal(got[-1], got[64064], "the launcher's choice is the unsplit 64 x 64 tile")

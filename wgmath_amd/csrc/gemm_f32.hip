@@ -530,7 +530,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         const uint64_t t64 = (uint64_t)((M + 63u) / 64u) * ((N + 63u) / 64u) * nmats;
         uint32_t best_ns = 1;
         est_out = 1e30;
-        if (K < 1024u || t64 * 2u > (uint64_t)cus0) return 1;
+        if (K < 1024u || t64 > (uint64_t)cus0) return 1; // (up to one 64 x 64 tile per CU: 64 x 11008 x 4096 -- 172 tiles -- 76 -> 57 us with 4 splits, vendor 61)
         const double ob = (double)M * N * nmats * 4.0;
         static const uint32_t opts[] = { 2, 3, 4, 6, 8, 12, 16, 24, 32 };
         for (uint32_t ns : opts) {
@@ -545,8 +545,17 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     };
     if (ctx->tuning[WG_TUNE_F32_MID] != 0 && !mid_forced && (M <= 64 || N <= 64) && M >= 48 && N >= 48 && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
         double est;
-        const uint32_t ns = mid_split_plan(est);
-        if (ns > 1) return wgk_gemm_f32_mid(ctx, trans, 64, 64, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, ns);
+        uint32_t ns = mid_split_plan(est);
+        // ... and the same tile UNSPLIT when the output is about one to two 64 x 64 tiles per CU (the few-row / few-column paths below stream the long operand
+        // through wave-private rings and leave the matrix cores at ~45 %): 64 x 16384 x 1024 31 -> 22 us (vendor 21.7), 64 x 16384 x 512 22 -> 13.5 (19),
+        // 64 x 14336 x 4096 73 -> 64 (62), 64 x 32768 x 1024 43 -> 38 (35); the same model, without slabs and reduce.
+        const uint64_t t64 = (uint64_t)((M + 63u) / 64u) * ((N + 63u) / 64u) * nmats;
+        if (t64 * 4u >= 3ull * (uint64_t)cus0 && t64 <= 2ull * (uint64_t)cus0 && K >= 128u) {
+            const double r = (double)((t64 + (uint64_t)cus0 - 1) / (uint64_t)cus0);
+            const double est1 = r * (2.0 * 64 * 64 * (double)K / 614400.0 * (r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r)) + 1.5) + 3.0;
+            if (est1 < est) { est = est1; ns = 1; }
+        }
+        if (est < 1e29) return wgk_gemm_f32_mid(ctx, trans, 64, 64, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, ns);
     }
     if (!mid_forced && M > 64 && M <= 128 && N > 4096 && K >= 128 && beta == 0.f) {
         const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
