@@ -9,11 +9,13 @@ namespace {
 template <typename OUT>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ part, uint32_t nsplit, uint32_t M, uint32_t N,
                                                             OUT *__restrict__ out, uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
-    const uint32_t m4 = blockIdx.x * 256u + threadIdx.x; // float4 index within a column (M % 4 == 0)
-    if (m4 * 4u >= M) return;
-    const uint32_t z = blockIdx.z;
+    // one float4 (4 consecutive rows, M % 4 == 0) of the dense slabs per thread and trip, numbered through the whole matrix: a 64-row output keeps every lane
+    // busy (one block per column left 240 of 256 threads idle: 64 x 4096 in four parts 4.8 us, the kernel's launch and one memory round trip now)
+    const uint32_t z = blockIdx.z, m4s = M / 4u;
     const uint64_t slab = (uint64_t)M * N;
-    for (uint32_t col = blockIdx.y; col < N; col += gridDim.y) { // grid.y is capped at 65535: wider outputs loop
+    const uint32_t total4 = (uint32_t)(slab / 4u); // (< 2^32: the launcher checks)
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total4; e += gridDim.x * 256u) {
+    const uint32_t col = e / m4s, m4 = e - col * m4s;
     const float4 *p = reinterpret_cast<const float4 *>(part + ((uint64_t)z * nsplit) * slab + (uint64_t)col * M) + m4;
     float4 s = p[0];
     for (uint32_t i = 1; i < nsplit; ++i) {
@@ -69,7 +71,9 @@ uint32_t wg_splitk_plan(uint64_t tiles, uint32_t slots, uint32_t k_units, uint32
 int wg_splitk_reduce(wg_ctx *ctx, const float *part, uint32_t nsplit, uint32_t M, uint32_t N, uint32_t nmats, wg_dtype dtype, void *out,
                      uint32_t ldc, uint64_t c_batch, float alpha, float beta) {
     if (nmats > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: more than 65535 matrices");
-    const dim3 grid((M / 4u + 255u) / 256u, N < 65535u ? N : 65535u, nmats), block(256);
+    if ((uint64_t)(M / 4u) * N >= (1ull << 32) - 65536ull * 256ull) return wg_set_error(WG_ERR_UNSUPPORTED, "split-K reduce: output of more than 2^34 elements");
+    const uint64_t blocks = ((uint64_t)(M / 4u) * N + 255u) / 256u;
+    const dim3 grid((uint32_t)(blocks < 65536u ? (blocks ? blocks : 1u) : 65536u), 1, nmats), block(256); // (larger outputs: grid-stride trips)
     if (dtype == WG_F32) hipLaunchKernelGGL(splitk_reduce_kernel<float>, grid, block, 0, ctx->stream, part, nsplit, M, N, (float *)out, ldc, c_batch, alpha, beta);
     else hipLaunchKernelGGL(splitk_reduce_kernel<_Float16>, grid, block, 0, ctx->stream, part, nsplit, M, N, (_Float16 *)out, ldc, c_batch, alpha, beta);
     WG_HIP_TRY(hipGetLastError());
