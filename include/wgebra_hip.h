@@ -171,7 +171,8 @@ int wg_debug_mfma_ceiling(wg_ctx *ctx, double min_seconds, double *tflops, doubl
  * reads the environment.
  */
 typedef enum wg_tuning {
-    WG_TUNE_F16_TILE = 0,    /* 0 = by shape (default), 128 / 256 = force the 128 x 128 / 256 x 256 f16 kernel family */
+    WG_TUNE_F16_TILE = 0,    /* 0 = by shape (default), 128 / 256 = force the 128 x 128 / 256 x 256 f16 kernel family, 256128 = the 256 x 128 tile (two
+                                workgroups per CU: short K) whenever its kernel takes the shape */
     WG_TUNE_F16_SCHED = 1,   /* -1 = by size (default), 0 / 1 = static tile map / tile queues with stealing across XCDs */
     WG_TUNE_F32_SKINNY = 2,  /* -1 = by shape, 0 / 1 = never / whenever applicable: the few-column f32 kernel */
     WG_TUNE_F32_PANELS = 3,  /* -1 = by estimate, 0 / 1: 64-column panels of the few-column kernel for small square f32 products */

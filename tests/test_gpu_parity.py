@@ -490,7 +490,7 @@ F16_SHAPES = [
 ]
 
 
-@pytest.fixture(params=["auto", "128", "256"])
+@pytest.fixture(params=["auto", "128", "256", "256128"])
 def f16_tile(request, gpu):
     """The f16 launcher picks between the 256 x 256 kernels and the 128 x 128 kernel (mid-size outputs) by shape; the context's
     WG_TUNE_F16_TILE knob (wg_ctx_set_tuning) forces one family, so that every shape below exercises both."""
@@ -972,7 +972,7 @@ def test_gemm_f16_k_remainder_small_tiles(gpu, M, K, N, tr):
     variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
     old = gpu.get_tuning("f16_tile")
     try:
-        for tile in (128, 0):
+        for tile in (128, 256128, 0):
             gpu.set_tuning("f16_tile", tile)
             out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
             run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, va, vb, variant))

@@ -1112,6 +1112,26 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // 128 x 128 0.00875 alone on a CU, 0.0108 each when several share it, + 6 us; f32 partial slabs written at ~3.5 TB/s + 3 us,
         // reduced at ~7 TB/s + 4 us). WG_F16_TILE=128|256 forces the choice (tests, experiments).
         // (K % 64 != 0: the 128 x 128 kernel multiplies the remainder first, like the big one; it needs >= 64 whole k behind it)
+        // 256 x 128 tiles, two workgroups per CU (gemm_f16_t128.hip, TM = 256): short K against the big kernel's per-tile costs. WG_F16_TILE=256128 forces it.
+        // Model from the sweep (profiles/r04_evidence.md section 9; us per round of the chip): the big kernel 12.3 + 0.0213 K per round of 256 tiles; a PAIR of
+        // co-resident 256 x 128 tiles per CU 6.1 + 0.0263 K (Gemm) / 5.7 + 0.0298 K (GemmTr: its k-contiguous A arrives as 64-byte row pieces, twice the L2
+        // requests), a last partial round of at most one tile per CU 0.6 of that. Crossover K ~ 1300 (Gemm) / ~ 650 (GemmTr): 8192 x 8192 x 256 71 -> 51 us
+        // (vendor 55), x 512 92 -> 78 (83), 6144 x 6144 x 512 76 -> 50 (52). Only from one round of 256 x 256 tiles on (fewer: the 128 x 128 logic below).
+        bool t256x128 = ctx->tuning[WG_TUNE_F16_TILE] == 256128;
+        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
+            const double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
+            const double r2 = (double)((uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats) / (2.0 * cus), fl = floor(r2), fr = r2 - fl;
+            const double pair = trans ? 5.7 + 0.0298 * K : 6.1 + 0.0263 * K;
+            t256x128 = fl * pair + (fr > 0.0 ? (fr <= 0.5 ? 0.6 : 1.0) * pair : 0.0) < 0.95 * t_big;
+        }
+        if ((krem == 0 || K - krem >= 64u) && !panels && t256x128) {
+            GemmArgs t = g;
+            t.tiles_m = (M + 255u) / 256u;
+            t.tiles_n = (N + 127u) / 128u;
+            t.nsplit = 1; t.k_per_split = K; t.part = nullptr;
+            const uint64_t tiles_t = (uint64_t)t.tiles_m * t.tiles_n;
+            if (tiles_t <= 0x7fffffffull && nmats <= 65535u) return t128_launch(ctx, trans, dim3((uint32_t)tiles_t, nmats), t, 256);
+        }
         if ((krem == 0 || K - krem >= 64u) && !panels) {
             const double out_bytes = (double)M * N * nmats * 4.0;
             auto slabs = [&](uint32_t ns) { return ns > 1 ? ns * out_bytes / 3.5e6 + 3.0 + 4.0 + ns * out_bytes / 7.0e6 : 0.0; };

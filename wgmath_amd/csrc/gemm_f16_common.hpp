@@ -186,7 +186,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
 
 // launch wrapper of gemm_f16_generic.hip (grid / arguments prepared by wgk_gemm_f16)
 int generic_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
-// gemm_f16_t128.hip: 128 x 128 tiles (g.tiles_m / g.tiles_n count those), grid = (tiles, nmats * nsplit); K per split % 64 == 0
-int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
+// gemm_f16_t128.hip: tm x 128 tiles, tm = 128 or 256 (g.tiles_m / g.tiles_n count those), grid = (tiles, nmats * nsplit); K per split % 64 == 0
+int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g, int tm = 128);
 
 } // namespace wgf16

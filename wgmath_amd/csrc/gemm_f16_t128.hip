@@ -1,4 +1,4 @@
-// f16 Gemm, mid-size variant: 128 x 128 block tile, two workgroups per CU.
+// f16 Gemm, mid-size variants: 128 x 128 and 256 x 128 block tiles, two workgroups per CU.
 //
 // The 256 x 256 kernel (gemm_f16.hip) owns a whole CU per workgroup; an output with fewer than ~one such tile per CU
 // (2048^3: 64 tiles on 256 CUs) can only fill the chip through split-K, whose f32 partial slabs then cost more than the
@@ -20,6 +20,13 @@
 // M0 is written by the inline asm without save/restore, as in gemm_f16.hip (tests/test_abi_and_host.py checks the ISA).
 // Bound: LDS bandwidth (per CU and half-step pair: 64 KiB of fragment reads + 32 KiB of DMA writes against 512 MFMA cycles per
 // SIMD) and L2 -> CU bandwidth; see DESIGN.md section 3.
+//
+// TM = 256 (round 4): the same kernel with 2 x 2 waves of 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers: still two workgroups per CU). What it is
+// for: products whose K is short against the big kernel's per-tile costs. gemm_f16.hip owns a CU per workgroup, so a tile's prologue (2.8 us), store
+// burst (6.3 us) and re-dispatch are serial with its main loop (21 us at K = 1024): a third of the time no MFMA runs. Two co-resident workgroups of half
+// the tile cover each other's prologue and epilogue. Per wave and half-step: 32 MFMAs between two barriers (128 x 128: 16), 12 KiB of fragment reads (8),
+// 6 DMA pieces (4); a half-stage is A 256 x 32 + B 32 x 128 = 24 KiB and the ring has 3 slots (72 KiB), i.e. ONE half-stage of lead beyond the one being read --
+// the other workgroup covers the rest.
 #include "gemm_f16_common.hpp"
 
 namespace wgf16 {
@@ -37,9 +44,12 @@ __device__ __forceinline__ void t_static_for(F &&f) { t_static_for_impl(f, std::
 #ifndef WG_T128_ABLATE
 #define WG_T128_ABLATE 0 // timing experiments only (results are garbage): 1 = no MFMA / fragment reads, 2 = no DMA, 4 = no barriers
 #endif
-constexpr int TM = 128, TN = 128;
-constexpr int T_RING = 5;
-constexpr int T_SLOT = 16 * 1024;   // one half-stage: per wave w a 4 KiB region [A piece 2w | A piece 2w+1 | B piece 2w | B piece 2w+1]
+constexpr int TN = 128;
+// per block height TM (128 / 256): APW A pieces per wave and half-stage, the wave's region of a slot [A pieces APW w .. | B pieces 2 w, 2 w + 1], the slot, the ring
+template <int TM> struct TCfg {
+    static constexpr int APW = TM / 64, PPW = APW + 2, RB = PPW * 1024, SLOT = 4 * RB, RING = TM == 128 ? 5 : 3, MT = TM / 32, MP = MT / 2;
+    static_assert(TM == 128 || TM == 256, "block heights built");
+};
 constexpr uint32_t T_BIAS = 3072;   // see M16_BIAS in gemm_f16.hip
 
 __device__ __forceinline__ void t_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0" ::"s"(lds_dst)); }
@@ -49,8 +59,18 @@ __device__ __forceinline__ void t_dma(uint32_t voff, const void *sbase) {
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
 
-template <bool TRANS_A>
+template <int N, int STEP>
+__device__ __forceinline__ void t_wait_keep_pieces(int n) { // s_waitcnt's count is an immediate: a run-time count (a multiple of STEP below STEP * N) picks its instruction
+    if constexpr (N > 0) {
+        if (n == STEP * (N - 1)) wait_dma_keep<STEP * (N - 1)>();
+        else t_wait_keep_pieces<N - 1, STEP>(n);
+    }
+}
+
+template <bool TRANS_A, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
+    using Cfg = TCfg<TM>;
+    constexpr int APW = Cfg::APW, PPW = Cfg::PPW, RB = Cfg::RB, T_SLOT = Cfg::SLOT, T_RING = Cfg::RING, MT = Cfg::MT, MP = Cfg::MP;
     __shared__ __attribute__((aligned(16))) char smem[T_RING * T_SLOT];
 
     const int lane = threadIdx.x & 63;
@@ -80,72 +100,93 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     // 16P + (lane>>2), position lane&3 holds the logical chunk (lane&3) ^ G(key(row)), key = (row>>2)&3 for B (rows read in natural
     // order) and (row>>3)&3 for op(A) (rows read permuted). Column-major A: piece P = k-quad kq = P, blocks [mblk = lane>>4] of
     // [4 k][32 m]: k row (lane>>2)&3, 16-byte unit lane&3. Rows past the end of a ragged tile are clamped (results never stored).
-    uint32_t a_voff[2], b_voff[2];
+    // (TM = 256: the wave stages A pieces 4 wave + q, q < 4; a column-major k-quad is 2 pieces -- m halves -- so P = 2 kq + half. Its two B pieces lie beyond the
+    // instruction offset's 4095 bytes from the region's start: a second M0 value, B_IMM0 = 0; TM = 128: one M0, B_IMM0 = 2048, as before)
+    constexpr int B_IMM0 = APW == 2 ? 2048 : 0;
+    uint32_t a_voff[APW], b_voff[2];
     const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const uint32_t P = 2u * wave + q;
-        const uint32_t row = 16u * P + (lane >> 2);
+    for (int q = 0; q < APW; ++q) {
+        const uint32_t P = (uint32_t)APW * wave + q;
         if constexpr (TRANS_A) {
+            const uint32_t row = 16u * P + (lane >> 2);
             const uint32_t ra = min(row, g.M - 1u - m0);
             a_voff[q] = (ra * g.lda + 8u * ((lane & 3u) ^ ((4u - ((row >> 3) & 3u)) & 3u))) * 2u + (T_BIAS - 1024u * q);
         } else {
-            const uint32_t k = 4u * P + ((lane >> 2) & 3u);
-            const uint32_t m = min(32u * (lane >> 4) + 8u * (lane & 3u), g.M - 8u - m0); // M % 8 == 0
+            const uint32_t kq = APW == 2 ? P : P >> 1, mh = APW == 2 ? 0u : (P & 1u);
+            const uint32_t k = 4u * kq + ((lane >> 2) & 3u);
+            const uint32_t m = min(128u * mh + 32u * (lane >> 4) + 8u * (lane & 3u), g.M - 8u - m0); // M % 8 == 0
             a_voff[q] = (k * g.lda + m) * 2u + (T_BIAS - 1024u * q);
         }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t row = 16u * (2u * wave + q) + (lane >> 2);
         const uint32_t rb = min(row, g.N - 1u - n0);
-        b_voff[q] = (rb * g.ldb + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u))) * 2u + (T_BIAS - 1024u * (2 + q));
+        b_voff[q] = (rb * g.ldb + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u))) * 2u + (T_BIAS - (uint32_t)B_IMM0 - 1024u * q);
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
-    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * 4096);
+    const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * RB);
     const uint64_t a_step = TRANS_A ? 64u : (uint64_t)64u * g.lda; // bytes per half-stage (32 k)
     const char *ga0 = (const char *)a_base - T_BIAS - (rem ? 2u * a_step : 0u), *gb0 = (const char *)b_base - T_BIAS - (rem ? 128u : 0u);
-    auto issue = [&](uint32_t H, uint32_t slot_off) { // the 4 pieces of half-stage H into the slot at byte offset slot_off
+    auto issue = [&](uint32_t H, uint32_t slot_off) { // this wave's PPW pieces of half-stage H into the slot at byte offset slot_off
         const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * 64u;
         t_set_m0(lds_wave + slot_off);
         asm volatile("s_nop 0");
-        t_dma<0>(a_voff[0], ga); t_dma<1024>(a_voff[1], ga); t_dma<2048>(b_voff[0], gb); t_dma<3072>(b_voff[1], gb);
+        t_dma<0>(a_voff[0], ga); t_dma<1024>(a_voff[1], ga);
+        if constexpr (APW == 4) {
+            t_dma<2048>(a_voff[2], ga); t_dma<3072>(a_voff[3], ga);
+            t_set_m0(lds_wave + slot_off + 4096u);
+            asm volatile("s_nop 0");
+        }
+        t_dma<B_IMM0>(b_voff[0], gb); t_dma<B_IMM0 + 1024>(b_voff[1], gb);
     };
 
     // ---- per-lane LDS read offsets within a slot ----
     // B tile u: row 64 wn + 16 u + i16 = piece 4 wn + u, row i16 of it -> (2 wn + (u>>1)) * 4096 + 2048 + (u&1) * 1024 + i16 * 64 + pos * 16
     const uint32_t pos = (uint32_t)(kg ^ gq);
-    const uint32_t b_off = 2u * wn * 4096u + 2048u + (uint32_t)i16 * 64u + pos * 16u;
+    const uint32_t b_off = 2u * wn * (uint32_t)RB + (uint32_t)APW * 1024u + (uint32_t)i16 * 64u + pos * 16u;
     // A, TN: MFMA tile t = 2 p + tb, MFMA row i16 <-> tile row 64 wm + 32 p + 8 aq + 4 tb + bb = piece 4 wm + 2 p + (aq>>1), row 8 (aq&1) + 4 tb + bb
     // A, NN: transpose read i = 2 h + ins of pair p: k-quad kq = 4 (kg>>1) + 2 ins + h (piece kq), block mblk = 2 wm + p, unit i16, half kg&1
+    // (TM = 256, TN: the wave's rows (TM / 2) wm + 32 p + ..: piece 8 wm + 2 p + (aq>>1) = region 2 wm + (p>>1), sub-piece 2 (p&1) + (aq>>1);
+    //  NN: k-quad kq = 2 pieces [m half 0 | m half 1], the wave's half is wm, block p of it: region kq >> 1, + ((kq & 1) * 2 + wm) KiB + p * 256)
     uint32_t a_off[2];
     if constexpr (TRANS_A) {
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
-            a_off[tb] = 2u * wm * 4096u + (uint32_t)(aq >> 1) * 1024u + (uint32_t)(8 * (aq & 1) + 4 * tb + bb) * 64u + pos * 16u;
+            a_off[tb] = 2u * wm * (uint32_t)RB + (uint32_t)(aq >> 1) * 1024u + (uint32_t)(8 * (aq & 1) + 4 * tb + bb) * 64u + pos * 16u;
     } else {
-        a_off[0] = (uint32_t)(2 * (kg >> 1)) * 4096u + (2u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        a_off[0] = (uint32_t)(2 * (kg >> 1)) * (uint32_t)RB + (APW == 2 ? (2u * wm) * 256u : (uint32_t)wm * 1024u) + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
         a_off[1] = 0;
     }
+    constexpr auto a_pair_off = [](int p) { return APW == 2 ? p * RB : (p >> 1) * RB + (p & 1) * 2048; }; // TN: where pair p's rows start
+    constexpr int NN_H = APW == 2 ? 1024 : 2048;                                                         // NN: the second k-quad of a region
 
-    floatx4 acc[4][4]; // [t][u]
+    floatx4 acc[MT][4]; // [t][u]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[t][u][e] = 0.f;
-    uintx4 a_r[2][4]; // [register set][M tile]
+    uintx4 a_r[2][MT]; // [register set][M tile]
     half8_t b_f[2][4];
 
-    // fragment-producing operations of one half-stage (slot pointer sl), into register set `set`
-    constexpr int kOps = TRANS_A ? 8 : 20;
+    // fragment-producing operations of one half-stage (slot pointer sl), into register set `set`.
+    // TN: MT reads of A, 4 of B. NN: per pair p 4 transposing reads and, behind them, 4 lane swaps; 4 reads of B -- numbered
+    // [pairs 0, 1: 8 reads | B: 4 | pairs 2, 3: 8 reads (TM = 256) | swaps: 4 per pair]
+    constexpr int kReads = TRANS_A ? MT + 4 : 4 * MP + 4;
+    constexpr int kOps = TRANS_A ? kReads : kReads + 4 * MP;
     auto frag_op = [&](const char *sl, int op, int set) {
-        auto rb = [&](int u) { b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * 4096 + (u & 1) * 1024); };
+        auto rb = [&](int u) { b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * RB + (u & 1) * 1024); };
         if constexpr (TRANS_A) {
-            if (op < 4) a_r[set][op] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[op & 1] + (op >> 1) * 4096));
-            else rb(op - 4);
+            if (op < MT) a_r[set][op] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[op & 1] + a_pair_off(op >> 1)));
+            else rb(op - MT);
         } else {
             auto tr = [&](int p, int i) { // lands in tile 2 p + ins, dwords 2 h, 2 h + 1
                 const int h = i >> 1, ins = i & 1;
-                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sl + a_off[0] + ins * 4096 + h * 1024 + p * 256));
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sl + a_off[0] + ins * RB + h * NN_H + p * 256));
                 a_r[set][2 * p + ins][2 * h] = v[0];
                 a_r[set][2 * p + ins][2 * h + 1] = v[1];
             };
@@ -154,11 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 a_r[set][2 * p][i] = r[0];
                 a_r[set][2 * p + 1][i] = r[1];
             };
-            if (op < 4) tr(0, op);
-            else if (op < 8) tr(1, op - 4);
+            if (op < 8) tr(op >> 2, op & 3);
             else if (op < 12) rb(op - 8);
-            else if (op < 16) sw(0, op - 12);
-            else sw(1, op - 16);
+            else if (op < kReads) tr(2 + ((op - 12) >> 2), (op - 12) & 3);
+            else sw((op - kReads) >> 2, (op - kReads) & 3);
         }
     };
 
@@ -175,15 +215,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const uint32_t P = 2u * wave + q, row = 16u * P + (lane >> 2);
+            for (int q = 0; q < APW; ++q) {
+                const uint32_t PA = (uint32_t)APW * wave + q, row_a = 16u * PA + (lane >> 2);
                 // k-contiguous rows: the lane's 8 k are logical chunk (lane & 3) ^ G(key(row)) of the half-stage's 32
-                const uint32_t kb = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u));
                 uint32_t ka;
-                if constexpr (TRANS_A) ka = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row >> 3) & 3u)) & 3u));
-                else ka = 32u * h + 4u * P + ((lane >> 2) & 3u); // column-major A: the piece's k row
+                if constexpr (TRANS_A) ka = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row_a >> 3) & 3u)) & 3u));
+                else ka = 32u * h + 4u * (APW == 2 ? PA : PA >> 1) + ((lane >> 2) & 3u); // column-major A: the piece's k row
                 put(lds_wave + (uint32_t)h * T_SLOT + 1024u * q, ra + (uint64_t)h * a_step + (a_voff[q] - (T_BIAS - 1024u * q)), ka < rem);
-                put(lds_wave + (uint32_t)h * T_SLOT + 2048u + 1024u * q, rb + (uint64_t)h * 64u + (b_voff[q] - (T_BIAS - 1024u * (2 + q))), kb < rem);
+                if (q < 2) {
+                    const uint32_t row_b = 16u * (2u * wave + q) + (lane >> 2);
+                    const uint32_t kb = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row_b >> 2) & 3u)) & 3u));
+                    put(lds_wave + (uint32_t)h * T_SLOT + (uint32_t)APW * 1024u + 1024u * q, rb + (uint64_t)h * 64u + (b_voff[q] - (T_BIAS - (uint32_t)B_IMM0 - 1024u * q)), kb < rem);
+                }
             }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0); // the loads above are the compiler's to wait for: keep them in front of the DMA pieces it cannot see
@@ -195,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 #pragma unroll
         for (int h = 0; h < T_RING; ++h)
             if ((uint32_t)h < NH) issue(h, h * T_SLOT);
-        if (NH >= 5) wait_dma_keep<12>(); else if (NH == 4) wait_dma_keep<8>(); else wait_dma_all();
+        t_wait_keep_pieces<T_RING, PPW>(PPW * ((int)min(NH, (uint32_t)T_RING) - 2)); // half-stages 0 and 1 have landed (NH >= 2)
     }
     __syncthreads();
 #pragma unroll
@@ -205,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
 
     uint32_t cur = 0; // byte offset of the slot of half-stage H
-    // half-step H on register set SET: 16 MFMAs; fragments of H+1 into the other set (NEXT); DMA of H+5 into the slot of H (DMA:
+    // half-step H on register set SET: 4 MT MFMAs; fragments of H+1 into the other set (NEXT); DMA of H+T_RING into the slot of H (DMA:
     // its fragments were read during H-1 and the barrier that ended H-1 has passed); then wait until at most KEEP of this
     // wave's pieces are in flight (half-stage H+2 has landed; KEEP < 0: nothing to wait for) and publish. The flags are
     // compile-time in the steady state and the peeled tail: as run-time conditions they put a branch around every fragment
@@ -214,8 +257,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         constexpr int SET = decltype(set_c)::value;
         const uint32_t nxt = cur + T_SLOT == T_RING * T_SLOT ? 0u : cur + T_SLOT;
         const char *sl = smem + nxt;
-        if (dma_f()) issue(H + 5u, cur);
-        t_static_for<16>([&](auto jc) {
+        if (dma_f()) issue(H + (uint32_t)T_RING, cur);
+        t_static_for<4 * MT>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int t = j >> 2, u = j & 3;
             if (!(WG_T128_ABLATE & 1))
@@ -224,15 +267,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 if constexpr (TRANS_A) {
                     if constexpr (j < kOps) frag_op(sl, j, SET ^ 1);
                 } else {
-                    if constexpr (j < 12) frag_op(sl, j, SET ^ 1);               // 8 transpose reads, 4 B reads
-                    if constexpr (j >= 8 && j < 16) frag_op(sl, j + 4, SET ^ 1);  // 8 lane swaps, behind their reads
+                    constexpr int SW0 = 4 + 2 * MP; // first swap's slot: pair p's swaps sit >= 4 slots behind its reads (TM = 128: 8; 256: 12)
+                    if constexpr (j < kReads) frag_op(sl, j, SET ^ 1);                                  // transpose reads and B reads
+                    if constexpr (j >= SW0 && j < SW0 + 4 * MP) frag_op(sl, kReads + (j - SW0), SET ^ 1); // lane swaps, behind their reads
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): fragments of H+1 are in registers
-        const int keep = keep_f();
-        if (keep == 12) wait_dma_keep<12>(); else if (keep == 8) wait_dma_keep<8>(); else if (keep == 4) wait_dma_keep<4>(); else if (keep == 0) wait_dma_all();
+        constexpr int keep = decltype(keep_f())::value; // pieces of this wave that may stay in flight (half-stage H+2 has landed); < 0: nothing to wait for
+        if constexpr (keep > 0) wait_dma_keep<keep>(); else if constexpr (keep == 0) wait_dma_all();
         if (next_f() && !(WG_T128_ABLATE & 4)) __builtin_amdgcn_s_barrier();
         cur = nxt;
     };
@@ -240,26 +284,28 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     using s1 = std::integral_constant<int, 1>;
     auto yes = [] { return true; };
     auto no = [] { return false; };
-    auto k12 = [] { return 12; };
-    auto k8 = [] { return 8; };
-    auto k4 = [] { return 4; };
-    auto k0 = [] { return 0; };
-    auto kn = [] { return -1; };
-    if (NH >= 6) {
+    constexpr int kSteady = PPW * (T_RING - 2); // in flight after the steady-state wait: half-stages H+3 .. H+T_RING
+    auto keep_c = [](auto n) { return [] { return std::integral_constant<int, decltype(n)::value>{}; }; };
+    auto k0 = keep_c(std::integral_constant<int, 0>{});
+    auto kn = keep_c(std::integral_constant<int, -1>{});
+    if (NH >= (uint32_t)T_RING + 1u) {
         uint32_t H = 0;
-        for (; H + 6u < NH; H += 2) {
-            half_step(s0{}, H, yes, yes, k12);
-            half_step(s1{}, H + 1u, yes, yes, k12);
+        for (; H + (uint32_t)T_RING + 1u < NH; H += 2) {
+            half_step(s0{}, H, yes, yes, keep_c(std::integral_constant<int, kSteady>{}));
+            half_step(s1{}, H + 1u, yes, yes, keep_c(std::integral_constant<int, kSteady>{}));
         }
-        // six half-steps left (NH is even): H+5 = NH-1 is the last half-stage to issue
-        half_step(s0{}, H, yes, yes, k12);      // in flight after the wait: H+3, H+4, H+5
-        half_step(s1{}, H + 1u, no, yes, k8);   // H+4, H+5
-        half_step(s0{}, H + 2u, no, yes, k4);   // H+5
-        half_step(s1{}, H + 3u, no, yes, k0);
-        half_step(s0{}, H + 4u, no, yes, kn);
-        half_step(s1{}, H + 5u, no, no, kn);
+        // T_RING + 1 half-steps left (NH is even): H + T_RING = NH - 1 is the last half-stage to issue; step i leaves H+i+3 .. H+T_RING in flight
+        t_static_for<T_RING + 1>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            constexpr int left = T_RING - 2 - i;
+            auto keep = keep_c(std::integral_constant<int, (left > 0 ? PPW * left : left == 0 ? 0 : -1)>{});
+            if constexpr (i == 0) half_step(s0{}, H, yes, yes, keep);
+            else if constexpr (i == T_RING) half_step(s1{}, H + (uint32_t)i, no, no, keep);
+            else if constexpr (i % 2 == 0) half_step(s0{}, H + (uint32_t)i, no, yes, keep);
+            else half_step(s1{}, H + (uint32_t)i, no, yes, keep);
+        });
     } else {
-        for (uint32_t H = 0; H < NH; H += 2) { // NH = 2 or 4: everything was issued by the prologue
+        for (uint32_t H = 0; H < NH; H += 2) { // NH = 2 .. T_RING - 1: everything was issued by the prologue
             half_step(s0{}, H, no, yes, k0);
             half_step(s1{}, H + 1u, no, [&] { return H + 2u < NH; }, kn);
         }
@@ -267,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 
     // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 of the wave tile ----
     const bool full_tile = (m0 + TM <= g.M) && (n0 + TN <= g.N);
-    const uint32_t row0 = m0 + 64u * wm + 8u * kg;
+    const uint32_t row0 = m0 + (uint32_t)(TM / 2) * wm + 8u * kg;
     if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M); wg_splitk_reduce finishes
         float *P = g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
 #pragma unroll
@@ -276,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
             if (!full_tile && col >= g.N) continue;
             float *pc = P + (uint64_t)col * g.M + row0;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < MP; ++p) {
                 if (!(full_tile || row0 + 32 * p < g.M)) continue;
                 float4 *d = reinterpret_cast<float4 *>(pc + 32 * p);
                 d[0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
@@ -293,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         if (!full_tile && col >= g.N) continue;
         _Float16 *cc = C + (uint64_t)col * g.ldc + row0;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < MP; ++p) {
             if (!(full_tile || row0 + 32 * p < g.M)) continue; // 8 consecutive rows, all in or all out (M % 8 == 0)
             float r[8];
 #pragma unroll
@@ -320,9 +366,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 
 } // namespace
 
-int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g) {
-    if (trans) hipLaunchKernelGGL((gemm_f16_t128_kernel<true>), grid, dim3(256), 0, ctx->stream, g);
-    else hipLaunchKernelGGL((gemm_f16_t128_kernel<false>), grid, dim3(256), 0, ctx->stream, g);
+int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g, int tm) {
+    if (tm == 256) {
+        if (trans) hipLaunchKernelGGL((gemm_f16_t128_kernel<true, 256>), grid, dim3(256), 0, ctx->stream, g);
+        else hipLaunchKernelGGL((gemm_f16_t128_kernel<false, 256>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (trans) hipLaunchKernelGGL((gemm_f16_t128_kernel<true, 128>), grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_f16_t128_kernel<false, 128>), grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

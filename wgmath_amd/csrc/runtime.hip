@@ -275,8 +275,8 @@ int wg_debug_spin(wg_ctx *ctx, uint32_t blocks, uint32_t usec, wg_buf *start_tic
 
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value) {
     if (!ctx || (int)key < 0 || (int)key >= (int)WG_TUNE_COUNT_) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: bad context or key %d", (int)key);
-    if (key == WG_TUNE_F16_TILE && value != 0 && value != 128 && value != 256)
-        return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F16_TILE takes 0, 128 or 256, not %d", value);
+    if (key == WG_TUNE_F16_TILE && value != 0 && value != 128 && value != 256 && value != 256128)
+        return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F16_TILE takes 0, 128, 256 or 256128, not %d", value);
     if (key == WG_TUNE_F32_MID && (value == 64064 || value == 64128 || value == 128064 || value == 128128 || value == 64032 || value == 32064 || value == 96096 || value == 96064 || value == 64096)) {
         ctx->tuning[key] = value;
         return WG_OK;
