@@ -704,6 +704,9 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             // (+5 % at 4 rounds) until the small tiles' traffic shows (+9 % at 16 rounds, +13 % at 64: 2048^3 / 4096^3 / 8192^3 on 64 x 64)
             double loop = c[2] ? (r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r)) + 0.01 * c[3] : 1.0 + 0.01 * c[3];
             if (c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) loop = 1.30;
+            // a 64 x 32 / 32 x 64 tile alone on its CU has 8 MFMAs per wave between two barriers: with a long K that shows (256 x 256 x 4096 x 8 matrices 44.7 us measured
+            // against 38.5 by the curve above; 128 x 128 x 4096 x 32 matrices 62 -- there the K cut on 64 x 64 tiles is the better plan, 42)
+            if (c[2] && r <= 1.0 && (c[0] == 32 || c[1] == 32) && K >= 2048u) loop += 0.25;
             if (c[2] && pow2_ldb) loop += 0.10; // 1024 x 1024 x 32768: 536 us on 64 x 32 tiles against 486 for this file's split-K plan
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
