@@ -741,7 +741,10 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
 static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
     if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
     const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= 128ull * cus && rows_out % 4u == 0 && k % 4u == 0;
+#ifndef WG_GEMVT_LDS_MIN_COLS
+#define WG_GEMVT_LDS_MIN_COLS 128 // outputs per CU from which staging the vectors into every workgroup's LDS pays
+#endif
+    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= (uint64_t)WG_GEMVT_LDS_MIN_COLS * cus && rows_out % 4u == 0 && k % 4u == 0;
 }
 
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
