@@ -1,6 +1,6 @@
 """Gemm / GemmTr over a sweep of shapes (squares, LLM-like projections, few rows / few columns, ragged), f16 and f32, against hipBLASLt / rocBLAS through
 torch.matmul on the SAME memory layout (column-major C = A B is row-major C^T = B^T A^T). GPU time per call from back-to-back launches.
-Usage (GPU box): python tools/gemm_sweep.py [f16|f32] [MxNxK ...]   (torch first: one HIP runtime per process)"""
+Usage (GPU box): python tools/gemm_sweep.py [f16|f32] [MxNxK[xB] ...]   (B: a batch of B matrices; torch first: one HIP runtime per process)"""
 import os
 import sys
 import time
@@ -28,6 +28,7 @@ if args and args[0] in ("f16", "f32"):
     args = args[1:]
 if args:
     SHAPES = [tuple(int(x) for x in a.split("x")) for a in args]
+SHAPES = [s if len(s) == 4 else tuple(s) + (1,) for s in SHAPES]
 
 
 def reps_for(M, N, K, dt):
@@ -35,10 +36,10 @@ def reps_for(M, N, K, dt):
     return max(10, min(300, int(0.15 / (2.0 * M * N * K / rate + 5e-6))))
 
 
-def ours(M, N, K, dt, tr):
-    a = device_random(wg, gpu, (K, M) if tr else (M, K), dt, 1)
-    b = device_random(wg, gpu, (K, N), dt, 2)
-    c = wg.TensorBuilder.matrix(M, N, S.STORAGE).build(dev, dt)
+def ours(M, N, K, dt, tr, B=1):
+    a = device_random(wg, gpu, (K, M, B) if tr else (M, K, B), dt, 1)
+    b = device_random(wg, gpu, (K, N, B), dt, 2)
+    c = wg.TensorBuilder.tensor((M, N, B), S.STORAGE).build(dev, dt)
     variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
 
     def run(n):
@@ -50,7 +51,7 @@ def ours(M, N, K, dt, tr):
         gpu.queue().submit([enc.finish()])
         gpu.sync()
     run(3)
-    n = reps_for(M, N, K, dt)
+    n = reps_for(M, N, K * B, dt)
     best = 1e9
     for _ in range(2):
         t0 = time.perf_counter()
@@ -59,15 +60,17 @@ def ours(M, N, K, dt, tr):
     return best
 
 
-def vendor(M, N, K, dt, tr):
+def vendor(M, N, K, dt, tr, B=1):
     td = torch.float16 if dt == np.float16 else torch.float32
-    bt = (torch.rand(N, K, device="cuda") * 2 - 1).to(td)                       # B^T row-major = B column-major (k-contiguous)
-    at = (torch.rand(M, K, device="cuda") * 2 - 1).to(td).t() if tr else (torch.rand(K, M, device="cuda") * 2 - 1).to(td)  # A^T as (K, M): tr -> k-contiguous storage
-    ct = torch.empty(N, M, device="cuda", dtype=td)
+    bt = (torch.rand(B, N, K, device="cuda") * 2 - 1).to(td)                    # B^T row-major = B column-major (k-contiguous)
+    at = (torch.rand(B, M, K, device="cuda") * 2 - 1).to(td).transpose(1, 2) if tr else (torch.rand(B, K, M, device="cuda") * 2 - 1).to(td)  # A^T as (K, M): tr -> k-contiguous storage
+    ct = torch.empty(B, N, M, device="cuda", dtype=td)
+    if B == 1:
+        bt, at, ct = bt[0], at[0], ct[0]
     for _ in range(3):
         torch.matmul(bt, at, out=ct)
     torch.cuda.synchronize()
-    n = reps_for(M, N, K, dt)
+    n = reps_for(M, N, K * B, dt)
     best = 1e9
     for _ in range(2):
         t0 = time.perf_counter()
@@ -80,8 +83,8 @@ def vendor(M, N, K, dt, tr):
 
 for dt in dts:
     for tr in (False, True):
-        for (M, N, K) in SHAPES:
-            f = 2.0 * M * N * K / 1e12
-            to, tv = ours(M, N, K, dt, tr), vendor(M, N, K, dt, tr)
+        for (M, N, K, B) in SHAPES:
+            f = 2.0 * M * N * K * B / 1e12
+            to, tv = ours(M, N, K, dt, tr, B), vendor(M, N, K, dt, tr, B)
             flag = "  <-- behind" if to > 1.10 * tv else ""
-            print(f"{np.dtype(dt).name} {'gemm_tr' if tr else 'gemm   '} {M}x{N}x{K}: ours {to*1e6:9.1f} us {f/to:7.1f} TF | vendor {tv*1e6:9.1f} us {f/tv:7.1f} TF | ours/vendor time {to/tv:5.2f}{flag}", flush=True)
+            print(f"{np.dtype(dt).name} {'gemm_tr' if tr else 'gemm   '} {M}x{N}x{K}{'' if B == 1 else 'x' + str(B)}: ours {to*1e6:9.1f} us {f/to:7.1f} TF | vendor {tv*1e6:9.1f} us {f/tv:7.1f} TF | ours/vendor time {to/tv:5.2f}{flag}", flush=True)
