@@ -1705,3 +1705,37 @@ def test_gemm_f32_few_rows_or_columns_one_tile_per_cu(gpu, oracle_c, M, K, N, tr
         U.assert_close_f64(g, truth, K, sabs, f"few rows / columns, knob {knob}: gemm {M}x{K}x{N} tr={tr} vs f64")
         U.assert_close_oracle(g, wo.view(orc, so)[:, :, 0], K, sabs, f"few rows / columns, knob {knob} vs oracle")
     U.assert_bits_equal(got[-1], got[64064], "the launcher's choice is the unsplit 64 x 64 tile")
+
+
+@pytest.mark.parametrize("M,K,N,mats", [(4096, 256, 4096, 1), (4104, 328, 4360, 1), (2048, 192, 2048, 4)])
+@pytest.mark.parametrize("tr", [False, True])
+def test_gemm_f16_short_k_on_a_large_output_is_the_256x128_tile(gpu, M, K, N, mats, tr):
+    """From one round of 256 x 256 tiles on and a short K the launcher's own choice is the 256 x 128 tile with two workgroups per CU (gemm_f16.hip: the model
+    of the two kernels' times per round): same bits as that tile forced, within the f16 gate of f64 -- whole, ragged (M, N not multiples of the tile, K % 64 != 0)
+    and batched outputs."""
+    wg, wo = _wg(), _wo()
+    rng = np.random.default_rng(M * 31 + K * 17 + N + mats + int(tr))
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    s1 = wo.Shape(K, M, mats) if tr else wo.Shape(M, K, mats)
+    s2, so = wo.Shape(K, N, mats), wo.Shape(M, N, mats)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a, np.float16)
+    m2 = upload(gpu, (K, N, mats), b, np.float16)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    got = {}
+    old = gpu.get_tuning("f16_tile")
+    try:
+        for tile in (0, 256128, 256):
+            gpu.set_tuning("f16_tile", tile)
+            out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float16), np.float16)
+            run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, out, m1, m2, variant))
+            got[tile] = out.read(gpu.device())
+    finally:
+        gpu.set_tuning("f16_tile", old)
+    U.assert_bits_equal(got[0], got[256128], f"f16 {M}x{K}x{N}x{mats} tr={tr}: the launcher's choice vs the 256 x 128 tile forced")
+    U.assert_bits_equal(got[0], got[256], f"f16 {M}x{K}x{N}x{mats} tr={tr}: the 256 x 128 tile vs the 256 x 256 kernel (same k order per element)")
+    A, B = wo.view(a, s1), wo.view(b, s2)
+    for t in range(mats):
+        amk = (A[:, :, t].T if tr else A[:, :, t]).astype(np.float64)
+        f16_check(wo.view(got[0], so)[:, :, t], amk, B[:, :, t].astype(np.float64), K, f"f16 gemm {M}x{K}x{N} mat {t} tr={tr}, launcher's choice")
