@@ -9,18 +9,20 @@
 //   * cholesky               (cholesky.wgsl)  : L in the lower triangle (diagonal included), the upper triangle keeps the input;
 //   * lu                     (lu.wgsl)        : partial pivoting; L (unit diagonal implicit) below, U on and above the diagonal,
 //                                               + the row swaps as (ia[i], ib[i]), i < len;
-//   * qr                     (qr2/3/4.wgsl)   : Householder; Q orthonormal, R upper triangular with a NON-NEGATIVE diagonal
-//                                               (nalgebra's convention, which makes the factorisation unique for full rank);
-//   * symmetric_eigen        (eig2/3/4.wgsl)  : M = V diag(lambda) V^T for symmetric M; eigenvalue order unspecified (the
-//                                               reference's tests check the reconstruction); here: cyclic Jacobi rotations;
-//   * svd (2, 3)             (svd2/3.wgsl)    : M = U diag(S) Vt, S >= 0 in descending order;
+//   * qr                     (qr2/3/4.wgsl)   : nalgebra's Householder QR as ported by the reference; diag(R) >= 0;
+//   * symmetric_eigen        (eig2/3/4.wgsl)  : M = V diag(lambda) V^T; N = 2 closed form with eigenvalues ((a+b+sigma)/2, (a+b-sigma)/2) in that
+//                                               order; N = 3, 4 tridiagonalisation + Wilkinson-shift implicit QR, eigenvalues unsorted as the
+//                                               deflation leaves them;
+//   * svd (2, 3)             (svd2/3.wgsl)    : M = U diag(S) Vt; N = 2 closed form through stable_atan2 (S sorted, >= 0); N = 3 the
+//                                               Givens-quaternion Jacobi + QR of McAdams et al. (S sorted by magnitude, the last may be < 0);
+//   * trig, min_max          (utils/*.wgsl)   : stable_tanh, stable_atan2 (0 on the axis x <= 0, y == 0 and for x == 0), max / amax of vectors and matrices;
 //   * Quat, Rot2, Sim2, Sim3 (quat/rot2/sim2/sim3.wgsl): unit quaternion (x, y, z, w), 2-D rotation (cos, sin), similarities
 //                                               x -> scale * R x + t, with the reference's function names.
-// Results agree with the reference within its own test tolerances (relative 1e-3 / 1e-4 against nalgebra). The CLOSED-FORM functions -- inv2/3/4,
-// cholesky, lu, Rot2, Quat, Sim2, Sim3 -- follow the reference's WGSL expression by expression, every product and sum rounded separately (no FMA
-// contraction: WGG_EXACT below), so that on the same inputs they give the bits the WGSL text gives when read that way (left to right, `dot` and
-// `cross` as their defining formulas: tests/golden/wgsl_exec_geometry.npz, made by running the reference's .wgsl files through the tests' WGSL executor).
-// QR, eigen and SVD are different but equivalent algorithms and are not bit-identical.
+// EVERY function follows the reference's WGSL statement by statement and expression by expression, every product and sum rounded separately (no FMA
+// contraction: WGG_EXACT below; `fma(..)` where the WGSL says fma), so that on the same inputs it gives the bits the WGSL text gives when read that
+// way (left to right, `dot` / `cross` / `length` / matrix products as their defining formulas, sqrt and division correctly rounded, sin / cos / atan /
+// exp correctly rounded): tests/golden/wgsl_exec_geometry.npz and wgsl_exec_decomp.npz, made by running the reference's .wgsl files through the tests'
+// WGSL executor, are matched at 0 ulp by the host build and by the HIP kernels (tests/test_geometry.py).
 #pragma once
 
 #include <math.h>
@@ -90,6 +92,95 @@ WGG_FN Vec<N> mul(const Mat<N> &a, const Vec<N> &x) {
     }
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// WGSL builtins as the functions pinned to the reference's text read them (oracle/wgsl_exec.py fixes the same reading)
+// ---------------------------------------------------------------------------------------------------------------
+// sin / cos / atan / exp: the correctly rounded f32 value (the float64 function rounded once) -- the one result every conformant WGSL implementation's
+// error bound contains, and the only one a fixture can pin. These are per-item building blocks, not throughput code: the f64 evaluation costs nothing
+// that matters and makes the host build, the HIP build and the executed-WGSL fixtures agree bit for bit.
+WGG_FN float w_sin(float x) { return (float)sin((double)x); }
+WGG_FN float w_cos(float x) { return (float)cos((double)x); }
+WGG_FN float w_atan(float x) { return (float)atan((double)x); }
+WGG_FN float w_exp(float x) { return (float)exp((double)x); }
+// sign(): 1, -1, and +0 for both zeros (WGSL leaves sign(-0) open; the fixtures use +0)
+WGG_FN float w_sign(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+WGG_FN float w_max(float a, float b) { return a < b ? b : a; }
+WGG_FN float w_length2(float x, float y) { WGG_EXACT return sqrtf(x * x + y * y); }
+// matN x matN as WGSL evaluates it here: element (row i, column j) = a[0][i] b[j][0] + a[1][i] b[j][1] + ..., left to right from the first product
+template <int N>
+WGG_FN Mat<N> mul_exact(const Mat<N> &a, const Mat<N> &b) {
+    WGG_EXACT
+    Mat<N> r;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) {
+            float s = a.c[0][i] * b.c[j][0];
+            for (int k = 1; k < N; ++k) s = s + a.c[k][i] * b.c[j][k];
+            r.c[j][i] = s;
+        }
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgebra::trig (utils/trig.wgsl:15-38)
+// ---------------------------------------------------------------------------------------------------------------
+namespace trig {
+constexpr float PI = 3.14159265358979323846264338327950288f; // trig.wgsl:4
+WGG_FN float stable_tanh(float x) { // trig.wgsl:12-18: both branches are evaluated, the sign of x selects
+    WGG_EXACT
+    const float exp_neg2x = w_exp(-2.f * x);
+    const float exp_pos2x = w_exp(2.f * x);
+    const float tanh_pos = (1.f - exp_neg2x) / (1.f + exp_neg2x);
+    const float tanh_neg = (exp_pos2x - 1.f) / (exp_pos2x + 1.f);
+    return x >= 0.f ? tanh_pos : tanh_neg;
+}
+WGG_FN float stable_atan2(float y, float x) { // trig.wgsl:25-38: 0 for x == 0 and for x < 0, y == 0 (NOT pi / +-pi/2: the reference's choice)
+    WGG_EXACT
+    const float ang = w_atan(y / x);
+    if (x > 0.f) return ang;
+    if (x < 0.f && y > 0.f) return ang + PI;
+    if (x < 0.f && y < 0.f) return ang - PI;
+    return 0.f;
+}
+} // namespace trig
+
+// ---------------------------------------------------------------------------------------------------------------
+// wgebra::min_max (utils/min_max.wgsl:4-51)
+// ---------------------------------------------------------------------------------------------------------------
+namespace min_max {
+template <int N>
+WGG_FN float maxv(const Vec<N> &v) { // max2 / max3 / max4: max(v.x, max(v.y, ..))
+    float r = v.v[N - 1];
+    for (int k = N - 2; k >= 0; --k) r = w_max(v.v[k], r);
+    return r;
+}
+template <int N>
+WGG_FN float maxm(const Mat<N> &m) { // max2x2 / max3x3 / max4x4: the component-wise max of the columns, then maxv
+    Vec<N> vm;
+    for (int i = 0; i < N; ++i) {
+        float r = m.c[N - 1][i];
+        for (int k = N - 2; k >= 0; --k) r = w_max(m.c[k][i], r);
+        vm.v[i] = r;
+    }
+    return maxv<N>(vm);
+}
+template <int N>
+WGG_FN float amaxm(const Mat<N> &m) { // amax2x2 / amax3x3 / amax4x4
+    Mat<N> a;
+    for (int j = 0; j < N; ++j)
+        for (int i = 0; i < N; ++i) a.c[j][i] = fabsf(m.c[j][i]);
+    return maxm<N>(a);
+}
+WGG_FN float max2(const Vec<2> &v) { return maxv<2>(v); }
+WGG_FN float max3(const Vec<3> &v) { return maxv<3>(v); }
+WGG_FN float max4(const Vec<4> &v) { return maxv<4>(v); }
+WGG_FN float max2x2(const Mat2 &m) { return maxm<2>(m); }
+WGG_FN float max3x3(const Mat3 &m) { return maxm<3>(m); }
+WGG_FN float max4x4(const Mat4 &m) { return maxm<4>(m); }
+WGG_FN float amax2x2(const Mat2 &m) { return amaxm<2>(m); }
+WGG_FN float amax3x3(const Mat3 &m) { return amaxm<3>(m); }
+WGG_FN float amax4x4(const Mat4 &m) { return amaxm<4>(m); }
+} // namespace min_max
 
 // ---------------------------------------------------------------------------------------------------------------
 // inverse (inv.wgsl:8-88): adjugate / determinant
@@ -236,7 +327,9 @@ WGG_FN LU<N> lu(const Mat<N> &x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// QR (qr2/3/4.wgsl): Householder reflections, then signs fixed so that diag(R) >= 0
+// QR (qr2.wgsl:15-107, qr3.wgsl:15-109, qr4.wgsl:15-111): nalgebra's Householder QR as the reference ported it, statement for statement --
+// the reflection axes are normalised twice (householder::reflection_axis_mut), each reflection is also applied to its own axis column
+// (the `c = i` trip of the loop), Q is assembled backwards from the stored axes, diag(R) = |diag| >= 0.
 // ---------------------------------------------------------------------------------------------------------------
 template <int N>
 struct QR {
@@ -244,182 +337,53 @@ struct QR {
 };
 template <int N>
 WGG_FN QR<N> qr(const Mat<N> &x) {
+    WGG_EXACT
+    Mat<N> m = x;
+    float diag[N];
+    for (int i = 0; i < N; ++i) diag[i] = 0.f;
+    for (int i = 0; i < N; ++i) {
+        float axis_sq_norm = 0.f; // the axis is m[i.., i]
+        for (int r = i; r < N; ++r) axis_sq_norm = axis_sq_norm + m.c[i][r] * m.c[i][r];
+        const float axis_norm = sqrtf(axis_sq_norm);
+        const float modulus = fabsf(m.c[i][i]);
+        const float signed_norm = w_sign(m.c[i][i]) * axis_norm;
+        const float factor = (axis_sq_norm + modulus * axis_norm) * 2.f;
+        m.c[i][i] = m.c[i][i] + signed_norm;
+        if (factor != 0.f) {
+            const float factor_sqrt = sqrtf(factor);
+            float norm = 0.f;
+            for (int r = i; r < N; ++r) {
+                m.c[i][r] = m.c[i][r] / factor_sqrt;
+                norm = norm + m.c[i][r] * m.c[i][r];
+            }
+            norm = sqrtf(norm);
+            for (int r = i; r < N; ++r) m.c[i][r] = m.c[i][r] / norm; // renormalisation
+            diag[i] = -signed_norm;
+            const float sgn = w_sign(diag[i]); // reflect_with_sign on the columns i.. (column i, the axis itself, included)
+            for (int c = i; c < N; ++c) {
+                const float m_two = -2.f * sgn;
+                float f = 0.f;
+                for (int r = i; r < N; ++r) f = f + m.c[i][r] * m.c[c][r];
+                for (int r = i; r < N; ++r) m.c[c][r] = m_two * f * m.c[i][r] + m.c[c][r] * sgn;
+            }
+        } else {
+            diag[i] = signed_norm;
+        }
+    }
     QR<N> o;
-    o.r = x;
-    o.q = identity<N>();
-    for (int i = 0; i < N; ++i) {
-        float n2 = 0.f;
-        for (int rr = i; rr < N; ++rr) n2 += o.r.c[i][rr] * o.r.c[i][rr];
-        const float nrm = sqrtf(n2);
-        if (nrm == 0.f) continue;
-        float v[N];
-        for (int rr = 0; rr < N; ++rr) v[rr] = rr >= i ? o.r.c[i][rr] : 0.f;
-        v[i] += (v[i] >= 0.f ? nrm : -nrm);
-        float vn2 = 0.f;
-        for (int rr = i; rr < N; ++rr) vn2 += v[rr] * v[rr];
-        if (vn2 == 0.f) continue;
-        const float beta = 2.f / vn2;
-        // R <- H R,  Q <- Q H   (H = I - beta v v^T)
-        for (int cc = 0; cc < N; ++cc) {
-            float d = 0.f;
-            for (int rr = i; rr < N; ++rr) d += v[rr] * o.r.c[cc][rr];
-            d *= beta;
-            for (int rr = i; rr < N; ++rr) o.r.c[cc][rr] -= d * v[rr];
-        }
-        for (int rr = 0; rr < N; ++rr) {
-            float d = 0.f;
-            for (int cc = i; cc < N; ++cc) d += o.q.c[cc][rr] * v[cc];
-            d *= beta;
-            for (int cc = i; cc < N; ++cc) o.q.c[cc][rr] -= d * v[cc];
+    o.q = identity<N>(); // QR::q() of nalgebra: the reflections applied to the identity, last one first
+    for (int i = N - 1; i >= 0; --i) {
+        const float sgn = w_sign(diag[i]);
+        for (int c = i; c < N; ++c) {
+            const float m_two = -2.f * sgn;
+            float f = 0.f;
+            for (int r = i; r < N; ++r) f = f + m.c[i][r] * o.q.c[c][r];
+            for (int r = i; r < N; ++r) o.q.c[c][r] = m_two * f * m.c[i][r] + o.q.c[c][r] * sgn;
         }
     }
-    for (int i = 0; i < N; ++i) {
-        for (int rr = i + 1; rr < N; ++rr) o.r.c[i][rr] = 0.f; // exact zeros below the diagonal
-        if (o.r.c[i][i] < 0.f) {
-            for (int cc = 0; cc < N; ++cc) o.r.c[cc][i] = -o.r.c[cc][i]; // row i of R
-            for (int rr = 0; rr < N; ++rr) o.q.c[i][rr] = -o.q.c[i][rr]; // column i of Q
-        }
-    }
+    for (int c = 0; c < N; ++c) // R: the strict upper triangle of m, |diag| on the diagonal, zeros below
+        for (int r = 0; r < N; ++r) o.r.c[c][r] = r < c ? m.c[c][r] : (r == c ? fabsf(diag[c]) : 0.f);
     return o;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// symmetric eigendecomposition (eig2/3/4.wgsl): cyclic Jacobi; M = V diag(lambda) V^T
-// ---------------------------------------------------------------------------------------------------------------
-template <int N>
-struct SymmetricEigen {
-    Mat<N> eigenvectors;
-    Vec<N> eigenvalues;
-};
-template <int N>
-WGG_FN SymmetricEigen<N> symmetric_eigen(const Mat<N> &x) {
-    Mat<N> a = x;
-    Mat<N> v = identity<N>();
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        float off = 0.f;
-        for (int p = 0; p < N; ++p)
-            for (int q = p + 1; q < N; ++q) off += a.c[q][p] * a.c[q][p];
-        if (off == 0.f) break;
-        for (int p = 0; p < N; ++p)
-            for (int q = p + 1; q < N; ++q) {
-                const float apq = a.c[q][p];
-                if (apq == 0.f) continue;
-                const float theta = (a.c[q][q] - a.c[p][p]) / (2.f * apq);
-                const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-                const float cs = 1.f / sqrtf(t * t + 1.f), sn = t * cs;
-                // A <- J^T A J on rows/columns p, q (A stays symmetric: update both triangles)
-                for (int k = 0; k < N; ++k) {
-                    const float akp = a.c[p][k], akq = a.c[q][k];
-                    a.c[p][k] = cs * akp - sn * akq;
-                    a.c[q][k] = sn * akp + cs * akq;
-                }
-                for (int k = 0; k < N; ++k) {
-                    const float apk = a.c[k][p], aqk = a.c[k][q];
-                    a.c[k][p] = cs * apk - sn * aqk;
-                    a.c[k][q] = sn * apk + cs * aqk;
-                }
-                for (int k = 0; k < N; ++k) {
-                    const float vkp = v.c[p][k], vkq = v.c[q][k];
-                    v.c[p][k] = cs * vkp - sn * vkq;
-                    v.c[q][k] = sn * vkp + cs * vkq;
-                }
-            }
-    }
-    SymmetricEigen<N> r;
-    r.eigenvectors = v;
-    for (int i = 0; i < N; ++i) r.eigenvalues.v[i] = a.c[i][i];
-    return r;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// SVD (svd2.wgsl, svd3.wgsl): M = U diag(S) Vt, S descending and non-negative. One-sided Jacobi (Hestenes) on the columns.
-// ---------------------------------------------------------------------------------------------------------------
-template <int N>
-struct Svd {
-    Mat<N> u;
-    Vec<N> s;
-    Mat<N> vt;
-};
-template <int N>
-WGG_FN Svd<N> svd(const Mat<N> &x) {
-    Mat<N> a = x;              // columns become U * S
-    Mat<N> v = identity<N>();  // accumulates V
-    for (int sweep = 0; sweep < 16; ++sweep) {
-        bool rotated = false;
-        for (int p = 0; p < N; ++p)
-            for (int q = p + 1; q < N; ++q) {
-                float app = 0.f, aqq = 0.f, apq = 0.f;
-                for (int k = 0; k < N; ++k) {
-                    app += a.c[p][k] * a.c[p][k];
-                    aqq += a.c[q][k] * a.c[q][k];
-                    apq += a.c[p][k] * a.c[q][k];
-                }
-                if (fabsf(apq) <= 1e-7f * sqrtf(app * aqq) || apq == 0.f) continue; // columns already orthogonal to f32 precision
-                rotated = true;
-                const float theta = (aqq - app) / (2.f * apq);
-                const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-                const float cs = 1.f / sqrtf(t * t + 1.f), sn = t * cs;
-                for (int k = 0; k < N; ++k) {
-                    const float ap = a.c[p][k], aq = a.c[q][k];
-                    a.c[p][k] = cs * ap - sn * aq;
-                    a.c[q][k] = sn * ap + cs * aq;
-                    const float vp = v.c[p][k], vq = v.c[q][k];
-                    v.c[p][k] = cs * vp - sn * vq;
-                    v.c[q][k] = sn * vp + cs * vq;
-                }
-            }
-        if (!rotated) break;
-    }
-    Svd<N> r;
-    float s[N];
-    for (int j = 0; j < N; ++j) {
-        float n2 = 0.f;
-        for (int k = 0; k < N; ++k) n2 += a.c[j][k] * a.c[j][k];
-        s[j] = sqrtf(n2);
-    }
-    int order[N];
-    for (int j = 0; j < N; ++j) order[j] = j;
-    for (int i = 0; i < N; ++i) // selection sort, descending
-        for (int j = i + 1; j < N; ++j)
-            if (s[order[j]] > s[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
-    for (int j = 0; j < N; ++j) {
-        const int src = order[j];
-        r.s.v[j] = s[src];
-        const float invs = s[src] > 0.f ? 1.f / s[src] : 0.f;
-        for (int k = 0; k < N; ++k) {
-            r.u.c[j][k] = a.c[src][k] * invs;
-            r.vt.c[k][j] = v.c[src][k]; // Vt(j, k) = V(k, j)
-        }
-    }
-    // rank-deficient input: complete the zero columns of U to an orthonormal basis (Gram-Schmidt against the canonical basis)
-    for (int j = 0; j < N; ++j) {
-        if (r.s.v[j] > 0.f) continue;
-        for (int e = 0; e < N; ++e) {
-            float w[N];
-            for (int k = 0; k < N; ++k) w[k] = k == e ? 1.f : 0.f;
-            for (int jj = 0; jj < N; ++jj) {
-                if (jj == j) continue;
-                float d = 0.f;
-                for (int k = 0; k < N; ++k) d += r.u.c[jj][k] * w[k];
-                for (int k = 0; k < N; ++k) w[k] -= d * r.u.c[jj][k];
-            }
-            float n2 = 0.f;
-            for (int k = 0; k < N; ++k) n2 += w[k] * w[k];
-            if (n2 > 1e-6f) {
-                const float in = 1.f / sqrtf(n2);
-                for (int k = 0; k < N; ++k) r.u.c[j][k] = w[k] * in;
-                break;
-            }
-        }
-    }
-    return r;
-}
-template <int N>
-WGG_FN Mat<N> recompose(const Svd<N> &d) { // svd2.wgsl:43-46, svd3.wgsl:309-312
-    Mat<N> us = d.u;
-    for (int j = 0; j < N; ++j)
-        for (int k = 0; k < N; ++k) us.c[j][k] *= d.s.v[j];
-    return mul(us, d.vt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -430,8 +394,17 @@ struct Rot2 {
 };
 namespace rot2 {
 WGG_FN Rot2 identity() { return Rot2{ 1.f, 0.f }; }
-WGG_FN Rot2 fromAngle(float angle) { return Rot2{ cosf(angle), sinf(angle) }; }
-WGG_FN float angle(Rot2 r) { return atan2f(r.sin, r.cos); }
+WGG_FN bool is_valid(Rot2 r) { return r.cos != 0.f || r.sin != 0.f; } // rot2.wgsl:15-17: the zero Rot2 means "no rotation found"
+WGG_FN Rot2 fromAngle(float angle) { return Rot2{ w_cos(angle), w_sin(angle) }; }
+WGG_FN float angle(Rot2 r) { return trig::stable_atan2(r.sin, r.cos); } // rot2.wgsl:51-53: 0 (not pi) for (cos, sin) = (-1, 0)
+WGG_FN Rot2 cancel_y(Vec<2> v) { // rot2.wgsl:28-36: R with (R v).y == 0; the zero Rot2 if v.y is 0 already
+    WGG_EXACT
+    if (v.v[1] != 0.f) {
+        const float r = w_sign(v.v[0]) / w_length2(v.v[0], v.v[1]);
+        return Rot2{ v.v[0] * r, -v.v[1] * r };
+    }
+    return Rot2{ 0.f, 0.f };
+}
 WGG_FN Rot2 inv(Rot2 r) { return Rot2{ r.cos, -r.sin }; }
 WGG_FN Rot2 mul(Rot2 a, Rot2 b) { // rot2.wgsl:61-65
     WGG_EXACT
@@ -451,7 +424,220 @@ WGG_FN Mat2 toMatrix(Rot2 r) {
     m.c[1][0] = -r.sin; m.c[1][1] = r.cos;
     return m;
 }
+// rotate_rows3 / rotate_rows4 (rot2.wgsl:78-95): (m[i][r], m[i + 1][r]) <- invMulVec(rot, .) for every r -- columns i and i + 1 of the column-major
+// matrix, i.e. two "rows" of the eigenvector matrix nalgebra keeps transposed
+template <int N>
+WGG_FN void rotate_rows(Rot2 rot, Mat<N> &m, uint32_t i) {
+    for (int r = 0; r < N; ++r) {
+        const Vec<2> rv = invMulVec(rot, Vec<2>{ { m.c[i][r], m.c[i + 1][r] } });
+        m.c[i][r] = rv.v[0];
+        m.c[i + 1][r] = rv.v[1];
+    }
+}
+WGG_FN void rotate_rows3(Rot2 rot, Mat3 &m, uint32_t i) { rotate_rows<3>(rot, m, i); }
+WGG_FN void rotate_rows4(Rot2 rot, Mat4 &m, uint32_t i) { rotate_rows<4>(rot, m, i); }
 } // namespace rot2
+
+// ---------------------------------------------------------------------------------------------------------------
+// symmetric eigendecomposition, M = V diag(lambda) V^T (eig2.wgsl:15-56, eig3.wgsl:24-282, eig4.wgsl:24-284)
+//   N = 2: closed form; eigenvalues ((a + b + sigma) / 2, (a + b - sigma) / 2) in THAT order, eigenvectors normalised with last component +;
+//          the identity basis and (a, b) as they come when the off-diagonal entry is exactly 0.
+//   N = 3, 4: nalgebra's SymmetricEigen as the reference ported it -- scale by the largest |entry|, Householder tridiagonalisation, implicit
+//          Wilkinson-shift QR steps on the unreduced block found by delimit_subproblem, the closed form for a 2 x 2 block; eigenvalues in the order
+//          the deflation leaves them (unsorted). The reference's loop has no iteration cap; ITERATION_CAP below only bounds inputs (NaN-free inputs
+//          never come near it: a 4 x 4 needs < 20 sweeps) on which the reference itself would not return.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+struct SymmetricEigen {
+    Mat<N> eigenvectors;
+    Vec<N> eigenvalues;
+};
+namespace eig2 {
+WGG_FN Vec<2> eigenvalues(const Mat2 &m) { // eig2.wgsl:44-56
+    WGG_EXACT
+    const float a = m.c[0][0], c = m.c[0][1], b = m.c[1][1];
+    if (c == 0.f) return Vec<2>{ { a, b } };
+    const float ab = a - b;
+    const float sigma = sqrtf(4.f * c * c + ab * ab);
+    return Vec<2>{ { (a + b + sigma) / 2.f, (a + b - sigma) / 2.f } };
+}
+WGG_FN SymmetricEigen<2> symmetric_eigen(const Mat2 &m) { // eig2.wgsl:15-42
+    WGG_EXACT
+    const float a = m.c[0][0], c = m.c[0][1], b = m.c[1][1];
+    SymmetricEigen<2> r;
+    if (c == 0.f) {
+        r.eigenvectors = identity<2>();
+        r.eigenvalues = Vec<2>{ { a, b } };
+        return r;
+    }
+    const float ab = a - b;
+    const float sigma = sqrtf(4.f * c * c + ab * ab);
+    r.eigenvalues = Vec<2>{ { (a + b + sigma) / 2.f, (a + b - sigma) / 2.f } };
+    const float e1 = (a - b + sigma) / (2.f * c), e2 = (a - b - sigma) / (2.f * c);
+    const float l1 = w_length2(e1, 1.f), l2 = w_length2(e2, 1.f);
+    r.eigenvectors.c[0][0] = e1 / l1; r.eigenvectors.c[0][1] = 1.f / l1;
+    r.eigenvectors.c[1][0] = e2 / l2; r.eigenvectors.c[1][1] = 1.f / l2;
+    return r;
+}
+} // namespace eig2
+
+namespace eig_detail {
+constexpr float EPS = 1.1920929e-7f; // eig3.wgsl:26
+constexpr uint32_t ITERATION_CAP = 100000u;
+template <int N>
+struct Tridiag {
+    Mat<N> m;
+    float off_diag[N - 1];
+};
+template <int N>
+WGG_FN Tridiag<N> tridiagonalize(const Mat<N> &x) { // eig3.wgsl:211-282: Householder axes stay in the lower triangle of m, one per column
+    WGG_EXACT
+    Tridiag<N> t;
+    t.m = x;
+    Mat<N> &m = t.m;
+    for (int i = 0; i < N - 1; ++i) t.off_diag[i] = 0.f;
+    for (int i = 0; i < N - 1; ++i) {
+        float axis_sq_norm = 0.f; // the axis is m[i + 1.., i]
+        for (int r = i + 1; r < N; ++r) axis_sq_norm = axis_sq_norm + m.c[i][r] * m.c[i][r];
+        const float axis_norm = sqrtf(axis_sq_norm);
+        const float modulus = fabsf(m.c[i][i + 1]);
+        const float signed_norm = w_sign(m.c[i][i + 1]) * axis_norm;
+        const float factor = (axis_sq_norm + modulus * axis_norm) * 2.f;
+        m.c[i][i + 1] = m.c[i][i + 1] + signed_norm;
+        if (factor != 0.f) {
+            const float factor_sqrt = sqrtf(factor);
+            float norm = 0.f;
+            for (int r = i + 1; r < N; ++r) {
+                m.c[i][r] = m.c[i][r] / factor_sqrt;
+                norm = norm + m.c[i][r] * m.c[i][r];
+            }
+            norm = sqrtf(norm);
+            for (int r = i + 1; r < N; ++r) m.c[i][r] = m.c[i][r] / norm;
+            t.off_diag[i] = -signed_norm;
+            float p[N]; // p = 2 M axis   (hegemv)
+            for (int r = 0; r < N; ++r) p[r] = 0.f;
+            for (int c = i + 1; c < N; ++c)
+                for (int r = i + 1; r < N; ++r) p[r] = p[r] + 2.f * m.c[c][r] * m.c[i][c];
+            float dot = 0.f;
+            for (int r = i + 1; r < N; ++r) dot = dot + m.c[i][r] * p[r];
+            for (int c = i + 1; c < N; ++c) // M <- M - p axis^T - axis p^T + 2 dot axis axis^T
+                for (int r = i + 1; r < N; ++r)
+                    m.c[c][r] = m.c[c][r] + (2.f * dot * m.c[i][r] * m.c[i][c] - p[r] * m.c[i][c] - m.c[i][r] * p[c]);
+        } else {
+            t.off_diag[i] = signed_norm;
+        }
+    }
+    return t;
+}
+template <int N>
+WGG_FN void delimit_subproblem(const float *diag, float *off_diag, uint32_t end, float eps, uint32_t &start_out, uint32_t &end_out) { // eig3.wgsl:162-198
+    WGG_EXACT
+    uint32_t n = end;
+    while (n > 0u) {
+        const uint32_t m = n - 1u;
+        if (fabsf(off_diag[m]) > eps * (fabsf(diag[n]) + fabsf(diag[m]))) break;
+        n -= 1u;
+    }
+    if (n == 0u) { start_out = 0u; end_out = 0u; return; }
+    uint32_t new_start = n - 1u;
+    while (new_start > 0u) {
+        const uint32_t m = new_start - 1u;
+        if (off_diag[m] == 0.f || fabsf(off_diag[m]) <= eps * (fabsf(diag[new_start]) + fabsf(diag[m]))) {
+            off_diag[m] = 0.f;
+            break;
+        }
+        new_start -= 1u;
+    }
+    start_out = new_start;
+    end_out = n;
+}
+WGG_FN float wilkinson_shift(float tmm, float tnn, float tmn) { // eig3.wgsl:200-209
+    WGG_EXACT
+    const float sq_tmn = tmn * tmn;
+    if (sq_tmn != 0.f) {
+        const float d = (tmm - tnn) * 0.5f;
+        return tnn - sq_tmn / (d + w_sign(d) * sqrtf(d * d + sq_tmn));
+    }
+    return tnn;
+}
+} // namespace eig_detail
+
+template <int N>
+WGG_FN SymmetricEigen<N> symmetric_eigen(const Mat<N> &x) { // eig3.wgsl:24-160 (N = 3), eig4.wgsl:24-162 (N = 4)
+    WGG_EXACT
+    using namespace eig_detail;
+    Mat<N> m = x;
+    const float m_amax = min_max::amaxm<N>(x);
+    if (m_amax != 0.f)
+        for (int c = 0; c < N; ++c)
+            for (int r = 0; r < N; ++r) m.c[c][r] = m.c[c][r] / m_amax;
+    const Tridiag<N> tri = tridiagonalize<N>(m);
+    float diag[N], off_diag[N - 1];
+    for (int k = 0; k < N; ++k) diag[k] = tri.m.c[k][k];
+    for (int k = 0; k < N - 1; ++k) off_diag[k] = fabsf(tri.off_diag[k]); // SymmetricTridiagonal::unpack takes the modulus
+    Mat<N> q = identity<N>(); // householder::assemble_q
+    for (int i = N - 2; i >= 0; --i) {
+        const float sgn = w_sign(tri.off_diag[i]);
+        for (int c = i; c < N; ++c) {
+            const float m_two = -2.f * sgn;
+            float f = 0.f;
+            for (int r = i + 1; r < N; ++r) f = f + tri.m.c[i][r] * q.c[c][r];
+            for (int r = i + 1; r < N; ++r) q.c[c][r] = m_two * f * tri.m.c[i][r] + q.c[c][r] * sgn;
+        }
+    }
+    uint32_t start, end;
+    delimit_subproblem<N>(diag, off_diag, (uint32_t)N - 1u, EPS, start, end);
+    uint32_t niter = 0;
+    while (end != start && niter < ITERATION_CAP) {
+        const uint32_t subdim = end - start + 1u;
+        if (subdim > 2u) {
+            const uint32_t mm = end - 1u, n = end;
+            const float shift = wilkinson_shift(diag[mm], diag[n], off_diag[mm]);
+            Vec<2> v{ { diag[start] - shift, off_diag[start] } };
+            for (uint32_t i = start; i < n; ++i) {
+                const uint32_t j = i + 1u;
+                const Rot2 rot = rot2::cancel_y(v);
+                if (!rot2::is_valid(rot)) break;
+                if (i > start) off_diag[i - 1] = w_sign(v.v[0]) * w_length2(v.v[0], v.v[1]);
+                const float mii = diag[i], mjj = diag[j], mij = off_diag[i];
+                const float cc = rot.cos * rot.cos, ss = rot.sin * rot.sin, cs = rot.cos * rot.sin;
+                const float b = cs * 2.f * mij;
+                diag[i] = (cc * mii + ss * mjj) - b;
+                diag[j] = (ss * mii + cc * mjj) + b;
+                off_diag[i] = cs * (mii - mjj) + mij * (cc - ss);
+                if (i != n - 1u) {
+                    v.v[0] = off_diag[i];
+                    v.v[1] = -rot.sin * off_diag[i + 1];
+                    off_diag[i + 1] = off_diag[i + 1] * rot.cos;
+                }
+                rot2::rotate_rows<N>(rot2::inv(rot), q, i);
+            }
+            if (fabsf(off_diag[mm]) <= EPS * (fabsf(diag[mm]) + fabsf(diag[n]))) end -= 1u;
+        } else if (subdim == 2u) {
+            Mat2 m2;
+            m2.c[0][0] = diag[start]; m2.c[0][1] = off_diag[start];
+            m2.c[1][0] = off_diag[start]; m2.c[1][1] = diag[start + 1];
+            const Vec<2> eigvals = eig2::eigenvalues(m2);
+            const float bx = eigvals.v[0] - diag[start + 1], by = off_diag[start];
+            diag[start] = eigvals.v[0];
+            diag[start + 1] = eigvals.v[1];
+            const float basis_len = w_length2(bx, by);
+            if (basis_len > EPS) {
+                const float s = w_sign(bx) / basis_len;
+                rot2::rotate_rows<N>(Rot2{ bx * s, by * s }, q, start);
+            }
+            end -= 1u;
+        }
+        delimit_subproblem<N>(diag, off_diag, end, EPS, start, end); // decoupling may have happened
+        ++niter;
+    }
+    SymmetricEigen<N> r;
+    r.eigenvectors = q;
+    for (int k = 0; k < N; ++k) r.eigenvalues.v[k] = diag[k] * m_amax;
+    return r;
+}
+template <>
+WGG_FN SymmetricEigen<2> symmetric_eigen<2>(const Mat2 &x) { return eig2::symmetric_eigen(x); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Quat (quat.wgsl): unit quaternion, coords = (x, y, z, w)
@@ -471,7 +657,7 @@ WGG_FN Quat fromScaledAxis(Vec<3> aa) { // quat.wgsl:16-28: rotation of |aa| rad
     WGG_EXACT
     const float angle = sqrtf(dot3(aa.v, aa.v));
     if (angle == 0.f) return identity();
-    const float hs = sinf(angle / 2.f), hc = cosf(angle / 2.f);
+    const float hs = w_sin(angle / 2.f), hc = w_cos(angle / 2.f);
     return Quat{ (aa.v[0] / angle) * hs, (aa.v[1] / angle) * hs, (aa.v[2] / angle) * hs, hc };
 }
 WGG_FN Vec<3> imag(Quat q) { return Vec<3>{ { q.x, q.y, q.z } }; }
@@ -518,6 +704,230 @@ WGG_FN Mat3 toMatrix(Quat q) { // quat.wgsl:31-54 -- ww + ii - jj - kk on the di
     return m;
 }
 } // namespace quat
+
+// ---------------------------------------------------------------------------------------------------------------
+// SVD, M = U diag(S) Vt (svd2.wgsl:12-46, svd3.wgsl:56-312; the reference has no svd4)
+//   N = 2: closed form through two stable_atan2 angles; S = (q + r, |q - r|), the sign of q - r moved into Vt's rows.
+//   N = 3: McAdams et al., "Computing the SVD of 3x3 matrices with minimal branching and elementary floating point operations", as the reference
+//          ported it from tbtSVD: JACOBI_STEPS fixed sweeps of approximate Givens conjugations on A^T A accumulated in a quaternion, columns of
+//          B = A V sorted by norm with sign-flipping swaps, then a Givens-quaternion QR of B: U = Q, S = diag(R) (the last one may be negative:
+//          the reference leaves it so). Only + - * / and fma occur, and the reciprocal square roots are the bit-trick + Newton steps of the
+//          reference ("allows for exact matching results on CPU and GPU", svd3.wgsl:55): every build of this header returns the same bits.
+// ---------------------------------------------------------------------------------------------------------------
+template <int N>
+struct Svd {
+    Mat<N> u;
+    Vec<N> s;
+    Mat<N> vt;
+};
+namespace svd2 {
+WGG_FN Svd<2> svd(const Mat2 &m) { // svd2.wgsl:12-40
+    WGG_EXACT
+    const float e = (m.c[0][0] + m.c[1][1]) * 0.5f;
+    const float f = (m.c[0][0] - m.c[1][1]) * 0.5f;
+    const float g = (m.c[0][1] + m.c[1][0]) * 0.5f;
+    const float h = (m.c[0][1] - m.c[1][0]) * 0.5f;
+    const float q = sqrtf(e * e + h * h);
+    const float r = sqrtf(f * f + g * g);
+    const float sx = q + r, sy = q - r;
+    const float sy_sign = sy < 0.f ? -1.f : 1.f;
+    const float a1 = trig::stable_atan2(g, f);
+    const float a2 = trig::stable_atan2(h, e);
+    const float theta = (a2 - a1) * 0.5f;
+    const float phi = (a2 + a1) * 0.5f;
+    const float st = w_sin(theta), ct = w_cos(theta), sp = w_sin(phi), cp = w_cos(phi);
+    Svd<2> o;
+    o.s = Vec<2>{ { sx, sy * sy_sign } };
+    o.u.c[0][0] = cp; o.u.c[0][1] = sp;
+    o.u.c[1][0] = -sp; o.u.c[1][1] = cp;
+    o.vt.c[0][0] = ct; o.vt.c[0][1] = st * sy_sign;
+    o.vt.c[1][0] = -st; o.vt.c[1][1] = ct * sy_sign;
+    return o;
+}
+} // namespace svd2
+
+namespace svd3 {
+constexpr float GAMMA = 5.828427124f;  // sqrt(8) + 3   (svd3.wgsl:19-27)
+constexpr float CSTAR = 0.923879532f;  // cos(pi / 8)
+constexpr float SSTAR = 0.3826834323f; // sin(pi / 8)
+constexpr float SVD_EPSILON = 1e-6f;
+constexpr uint32_t JACOBI_STEPS = 12, RSQRT_STEPS = 4, RSQRT1_STEPS = 6;
+struct Symmetric3x3 {
+    float mxx, myx, myy, mzx, mzy, mzz;
+};
+struct givens {
+    float ch, sh;
+};
+WGG_FN float rsqrt_steps(float val, uint32_t steps) { // svd3.wgsl:56-80: the 0x5f375a82 seed, then `steps` Newton iterations x <- x fma(x x, -val / 2, 1.5)
+    WGG_EXACT
+    float x = val;
+    const float xhalf = -0.5f * x;
+    int32_t i;
+    __builtin_memcpy(&i, &x, 4);
+    i = 0x5f375a82 - (i >> 1);
+    __builtin_memcpy(&x, &i, 4);
+    for (uint32_t k = 0; k < steps; ++k) x = x * __builtin_fmaf(x * x, xhalf, 1.5f);
+    return x;
+}
+WGG_FN float rsqrt(float val) { return rsqrt_steps(val, RSQRT_STEPS); }
+WGG_FN float rsqrt1(float val) { return rsqrt_steps(val, RSQRT1_STEPS); }
+WGG_FN float accurateSqrt(float x) { return 1.f / rsqrt1(x); } // svd3.wgsl:83-85
+WGG_FN void condSwap(bool c, float &x, float &y) { const float x0 = x; x = c ? y : x; y = c ? x0 : y; }        // svd3.wgsl:88-92
+WGG_FN void condNegSwap(bool c, float &x, float &y) { const float x0 = -x; x = c ? y : x; y = c ? x0 : y; }    // svd3.wgsl:95-99
+WGG_FN void condNegSwapVec(bool c, float *x, float *y) {                                                       // svd3.wgsl:107-111
+    for (int k = 0; k < 3; ++k) condNegSwap(c, x[k], y[k]);
+}
+WGG_FN givens approximateGivensQuaternion(const Symmetric3x3 &A) { // svd3.wgsl:116-129 (Algorithm 2)
+    WGG_EXACT
+    const givens g{ 2.f * (A.mxx - A.myy), A.myx };
+    bool b = GAMMA * g.sh * g.sh < g.ch * g.ch;
+    const float w = rsqrt(__builtin_fmaf(g.ch, g.ch, g.sh * g.sh));
+    if (w != w) b = false;
+    return b ? givens{ w * g.ch, w * g.sh } : givens{ CSTAR, SSTAR };
+}
+WGG_FN void jacobiConjugation(int x, int y, int z, Symmetric3x3 &S, float *q) { // svd3.wgsl:132-166; q = quaternion coords (x, y, z, w)
+    WGG_EXACT
+    givens g = approximateGivensQuaternion(S);
+    const float scale = 1.f / __builtin_fmaf(g.ch, g.ch, g.sh * g.sh);
+    const float a = __builtin_fmaf(g.ch, g.ch, -g.sh * g.sh) * scale;
+    const float b = 2.f * g.sh * g.ch * scale;
+    Symmetric3x3 _S = S;
+    // S = Q' S Q
+    S.mxx = __builtin_fmaf(a, __builtin_fmaf(a, _S.mxx, b * _S.myx), b * (__builtin_fmaf(a, _S.myx, b * _S.myy)));
+    S.myx = __builtin_fmaf(a, __builtin_fmaf(-b, _S.mxx, a * _S.myx), b * (__builtin_fmaf(-b, _S.myx, a * _S.myy)));
+    S.myy = __builtin_fmaf(-b, __builtin_fmaf(-b, _S.mxx, a * _S.myx), a * (__builtin_fmaf(-b, _S.myx, a * _S.myy)));
+    S.mzx = __builtin_fmaf(a, _S.mzx, b * _S.mzy);
+    S.mzy = __builtin_fmaf(-b, _S.mzx, a * _S.mzy);
+    S.mzz = _S.mzz;
+    // the cumulative rotation
+    const float tmp[3] = { q[0] * g.sh, q[1] * g.sh, q[2] * g.sh };
+    g.sh = g.sh * q[3];
+    // (x, y, z) is ((0, 1, 2), (1, 2, 0), (2, 0, 1)) for (p, q) = ((0, 1), (1, 2), (0, 2))
+    q[z] = __builtin_fmaf(q[z], g.ch, g.sh);
+    q[3] = __builtin_fmaf(q[3], g.ch, -tmp[z]);
+    q[x] = __builtin_fmaf(q[x], g.ch, tmp[y]);
+    q[y] = __builtin_fmaf(q[y], g.ch, -tmp[x]);
+    // re-arrange the matrix for the next pair
+    _S.mxx = S.myy;
+    _S.myx = S.mzy; _S.myy = S.mzz;
+    _S.mzx = S.myx; _S.mzy = S.mzx; _S.mzz = S.mxx;
+    S = _S;
+}
+WGG_FN Quat jacobiEigenanalysis(const Symmetric3x3 &S) { // svd3.wgsl:170-179
+    Symmetric3x3 mat = S;
+    float q[4] = { 0.f, 0.f, 0.f, 1.f };
+    for (uint32_t i = 0; i < JACOBI_STEPS; ++i) {
+        jacobiConjugation(0, 1, 2, mat, q);
+        jacobiConjugation(1, 2, 0, mat, q);
+        jacobiConjugation(2, 0, 1, mat, q);
+    }
+    return Quat{ q[0], q[1], q[2], q[3] };
+}
+WGG_FN void sortSingularValues(Mat3 &B, Mat3 &V) { // svd3.wgsl:190-214 (Algorithm 3): columns by decreasing norm, a swap negates one column
+    WGG_EXACT
+    float rho1 = quat::dot3(B.c[0], B.c[0]), rho2 = quat::dot3(B.c[1], B.c[1]), rho3 = quat::dot3(B.c[2], B.c[2]);
+    bool c = rho1 < rho2;
+    condNegSwapVec(c, B.c[0], B.c[1]);
+    condNegSwapVec(c, V.c[0], V.c[1]);
+    condSwap(c, rho1, rho2);
+    c = rho1 < rho3;
+    condNegSwapVec(c, B.c[0], B.c[2]);
+    condNegSwapVec(c, V.c[0], V.c[2]);
+    condSwap(c, rho1, rho3);
+    c = rho2 < rho3;
+    condNegSwapVec(c, B.c[1], B.c[2]);
+    condNegSwapVec(c, V.c[1], V.c[2]);
+}
+WGG_FN givens QRGivensQuaternion(float a1, float a2) { // svd3.wgsl:217-230 (Algorithm 4): a1 = the pivot, a2 = the entry to annihilate
+    WGG_EXACT
+    const float epsilon = SVD_EPSILON;
+    const float rho = accurateSqrt(__builtin_fmaf(a1, a1, a2 * a2));
+    float ch = fabsf(a1) + w_max(rho, epsilon);
+    float sh = rho > epsilon ? a2 : 0.f;
+    const bool b = a1 < 0.f;
+    condSwap(b, sh, ch);
+    const float w = rsqrt(__builtin_fmaf(ch, ch, sh * sh));
+    ch = ch * w;
+    sh = sh * w;
+    return givens{ ch, sh };
+}
+struct QR3 {
+    Mat3 Q, R;
+};
+WGG_FN QR3 QRDecomposition(const Mat3 &B) { // svd3.wgsl:233-293 (section 4.2): three Givens quaternions, Q = Q1 Q2 Q3 in closed form
+    WGG_EXACT
+    // first rotation (ch, 0, 0, sh)
+    const givens g1 = QRGivensQuaternion(B.c[0][0], B.c[0][1]);
+    float a = __builtin_fmaf(-2.f, g1.sh * g1.sh, 1.f);
+    float b = 2.f * g1.ch * g1.sh;
+    float r00 = __builtin_fmaf(a, B.c[0][0], b * B.c[0][1]), r01 = __builtin_fmaf(a, B.c[1][0], b * B.c[1][1]), r02 = __builtin_fmaf(a, B.c[2][0], b * B.c[2][1]);
+    float r10 = __builtin_fmaf(-b, B.c[0][0], a * B.c[0][1]), r11 = __builtin_fmaf(-b, B.c[1][0], a * B.c[1][1]), r12 = __builtin_fmaf(-b, B.c[2][0], a * B.c[2][1]);
+    float r20 = B.c[0][2], r21 = B.c[1][2], r22 = B.c[2][2];
+    // second rotation (ch, 0, -sh, 0)
+    const givens g2 = QRGivensQuaternion(r00, r20);
+    a = __builtin_fmaf(-2.f, g2.sh * g2.sh, 1.f);
+    b = 2.f * g2.ch * g2.sh;
+    const float b00 = __builtin_fmaf(a, r00, b * r20), b01 = __builtin_fmaf(a, r01, b * r21), b02 = __builtin_fmaf(a, r02, b * r22);
+    const float b10 = r10, b11 = r11, b12 = r12;
+    const float b20 = __builtin_fmaf(-b, r00, a * r20), b21 = __builtin_fmaf(-b, r01, a * r21), b22 = __builtin_fmaf(-b, r02, a * r22);
+    // third rotation (ch, sh, 0, 0)
+    const givens g3 = QRGivensQuaternion(b11, b21);
+    a = __builtin_fmaf(-2.f, g3.sh * g3.sh, 1.f);
+    b = 2.f * g3.ch * g3.sh;
+    r00 = b00; r01 = b01; r02 = b02;
+    r10 = __builtin_fmaf(a, b10, b * b20); r11 = __builtin_fmaf(a, b11, b * b21); r12 = __builtin_fmaf(a, b12, b * b22);
+    r20 = __builtin_fmaf(-b, b10, a * b20); r21 = __builtin_fmaf(-b, b11, a * b21); r22 = __builtin_fmaf(-b, b12, a * b22);
+    // Q = Q1 Q2 Q3
+    const float sh12 = 2.f * __builtin_fmaf(g1.sh, g1.sh, -0.5f);
+    const float sh22 = 2.f * __builtin_fmaf(g2.sh, g2.sh, -0.5f);
+    const float sh32 = 2.f * __builtin_fmaf(g3.sh, g3.sh, -0.5f);
+    const float q00 = sh12 * sh22;
+    const float q01 = __builtin_fmaf(4.f * g2.ch * g3.ch, sh12 * g2.sh * g3.sh, 2.f * g1.ch * g1.sh * sh32);
+    const float q02 = __builtin_fmaf(4.f * g1.ch * g3.ch, g1.sh * g3.sh, -2.f * g2.ch * sh12 * g2.sh * sh32);
+    const float q10 = -2.f * g1.ch * g1.sh * sh22;
+    const float q11 = __builtin_fmaf(-8.f * g1.ch * g2.ch * g3.ch, g1.sh * g2.sh * g3.sh, sh12 * sh32);
+    const float q12 = __builtin_fmaf(-2.f * g3.ch, g3.sh, 4.f * g1.sh * __builtin_fmaf(g3.ch * g1.sh, g3.sh, g1.ch * g2.ch * g2.sh * sh32));
+    const float q20 = 2.f * g2.ch * g2.sh;
+    const float q21 = -2.f * g3.ch * sh22 * g3.sh;
+    const float q22 = sh22 * sh32;
+    QR3 o;
+    o.Q.c[0][0] = q00; o.Q.c[0][1] = q10; o.Q.c[0][2] = q20;
+    o.Q.c[1][0] = q01; o.Q.c[1][1] = q11; o.Q.c[1][2] = q21;
+    o.Q.c[2][0] = q02; o.Q.c[2][1] = q12; o.Q.c[2][2] = q22;
+    o.R.c[0][0] = r00; o.R.c[0][1] = r10; o.R.c[0][2] = r20;
+    o.R.c[1][0] = r01; o.R.c[1][1] = r11; o.R.c[1][2] = r21;
+    o.R.c[2][0] = r02; o.R.c[2][1] = r12; o.R.c[2][2] = r22;
+    return o;
+}
+WGG_FN Svd<3> svd(const Mat3 &A) { // svd3.wgsl:296-307
+    const Mat3 ata = mul_exact<3>(transpose<3>(A), A);
+    const Symmetric3x3 ata_sym{ ata.c[0][0], ata.c[0][1], ata.c[1][1], ata.c[0][2], ata.c[1][2], ata.c[2][2] };
+    Mat3 V = quat::toMatrix(jacobiEigenanalysis(ata_sym));
+    Mat3 B = mul_exact<3>(A, V);
+    sortSingularValues(B, V);
+    const QR3 qr = QRDecomposition(B);
+    Svd<3> o;
+    o.u = qr.Q;
+    o.s = Vec<3>{ { qr.R.c[0][0], qr.R.c[1][1], qr.R.c[2][2] } };
+    o.vt = transpose<3>(V);
+    return o;
+}
+} // namespace svd3
+
+template <int N>
+WGG_FN Svd<N> svd(const Mat<N> &x);
+template <>
+WGG_FN Svd<2> svd<2>(const Mat2 &x) { return svd2::svd(x); }
+template <>
+WGG_FN Svd<3> svd<3>(const Mat3 &x) { return svd3::svd(x); }
+template <int N>
+WGG_FN Mat<N> recompose(const Svd<N> &d) { // svd2.wgsl:43-46, svd3.wgsl:309-312: (U with column j scaled by S[j]) Vt
+    WGG_EXACT
+    Mat<N> us = d.u;
+    for (int j = 0; j < N; ++j)
+        for (int k = 0; k < N; ++k) us.c[j][k] = us.c[j][k] * d.s.v[j];
+    return mul_exact<N>(us, d.vt);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Sim2 / Sim3 (sim2.wgsl, sim3.wgsl): x -> scale * R x + translation

@@ -141,7 +141,11 @@ typedef enum wg_geom_op {
     WG_GEOM_ROT2 = 6, WG_GEOM_QUAT = 7, WG_GEOM_SIM2 = 8, WG_GEOM_SIM3 = 9,
     /* the transform functions one by one on raw coordinates (a non-unit quaternion, a (cos, sin) pair that is no rotation): the items the
        fixtures executed from the reference's WGSL text hold (tests/golden/wgsl_exec_geometry.npz); FROM = quat::fromScaledAxis + rot2::fromAngle */
-    WG_GEOM_QUAT_RAW = 10, WG_GEOM_ROT2_RAW = 11, WG_GEOM_SIM2_RAW = 12, WG_GEOM_SIM3_RAW = 13, WG_GEOM_FROM = 14
+    WG_GEOM_QUAT_RAW = 10, WG_GEOM_ROT2_RAW = 11, WG_GEOM_SIM2_RAW = 12, WG_GEOM_SIM3_RAW = 13, WG_GEOM_FROM = 14,
+    /* UTILS = wgebra::trig (utils/trig.wgsl:12-38: stable_atan2, stable_tanh) + wgebra::min_max (utils/min_max.wgsl:4-51); ROT2_EXT = rot2.wgsl's
+       angle / cancel_y / is_valid / rotate_rows3 / rotate_rows4 (:15-36, :51-53, :78-95); EIGVALS2 = eig2.wgsl:44-56 `eigenvalues`;
+       SVD_RECOMPOSE (dim 2, 3) = svd2.wgsl:43-46 / svd3.wgsl:309-312 `recompose` on items in the layout WG_GEOM_SVD writes */
+    WG_GEOM_UTILS = 15, WG_GEOM_ROT2_EXT = 16, WG_GEOM_EIGVALS2 = 17, WG_GEOM_SVD_RECOMPOSE = 18
 } wg_geom_op;
 int wg_geometry_apply(wg_ctx *ctx, wg_geom_op op, uint32_t dim, const wg_buf *in, wg_buf *out, uint32_t count);
 

@@ -27,6 +27,14 @@ swizzles, `dot` / `cross` / `length` as their defining formulas (left to right, 
 `sin` / `cos` rounded from float64, zero-value constructors (`Rot2()`), `var x: T;`, element writes `m[i][j] = ..`, `ptr<function, T>`
 parameters (`&m`, `(*m)`), `continue`, struct member writes, and the textual macro substitution (DIM, MAT, NROWS, ...) the Rust side does
 through naga_oil shader defs (cholesky.rs, lu.rs). tests/golden/make_wgsl_geometry_golden.py writes the fixtures.
+
+Round 5: the rest of the geometry library and the two utils modules (qr2/3/4, eig2/3/4, svd2/3, utils/trig.wgsl, utils/min_max.wgsl): `while`,
+`break` (and `continue`) in both loop forms, function-scope `const`, block-scoped shadowing (`let m = ..` inside a loop whose function already has an
+`m`), `ptr<function, T>` as real references (`&x` = a cell that is written back to the local after the statement, `*p` reads / writes the cell: what
+`condSwap(c, &rho1, &rho2)` on two f32 locals needs), `select` (scalar and vector conditions), `fma` (ONE rounding: the exact product plus the addend
+rounded once, computed through a round-to-odd float64 sum), `bitcast<i32>` / `bitcast<f32>`, `>>` on i32, hexadecimal literals, `array<f32, N>(..)`,
+integer vectors (`vec2<u32>`), matN x matN / matN x vecN products for N = 2, 3, 4 (left to right, every product and sum rounded), `atan` / `exp` as the
+float64 value rounded to f32 (like `sin` / `cos`), `sign(+-0) = +0`, module-scope constants of imported modules (`Trig::PI` inside `stable_atan2`).
 """
 from __future__ import annotations
 
@@ -51,13 +59,13 @@ def _num(x):
 
 
 def _matmul(a, b):
-    """a: mat4x4 as a (4, 4) array of COLUMNS (a[k] = column k); b: mat4x4 (columns) or vec4."""
+    """a: matNxN as an (N, N) array of COLUMNS (a[k] = column k); b: matNxN (columns) or vecN."""
     if b.ndim == 1:
         r = a[0] * b[0]
-        for k in (1, 2, 3):
+        for k in range(1, a.shape[0]):
             r = r + a[k] * b[k]
         return r
-    return np.stack([_matmul(a, b[j]) for j in range(4)])
+    return np.stack([_matmul(a, b[j]) for j in range(b.shape[0])])
 
 
 def op_add(a, b):
@@ -137,8 +145,12 @@ def fn_vec(n, *args):
     if not flat:
         return np.zeros(n, f32)
     if len(flat) == 1:
-        return np.full(n, _num(flat[0]), f32)
+        flat = flat * n
     assert len(flat) == n, (n, args)
+    if all(isinstance(x, (bool, np.bool_)) for x in flat):  # vec3(c) with a bool: the condition of a component-wise select
+        return np.array(flat, bool)
+    if all(_is_int(x) for x in flat):                        # vec2(0u, 0u), vec2(new_start, n): a vecN<u32>
+        return IVec(flat)
     return np.array([_num(x) for x in flat], f32)
 
 
@@ -155,7 +167,21 @@ def fn_mat(n, *cols):
 _SW = {"x": 0, "y": 1, "z": 2, "w": 3}
 
 
+class IVec(list):
+    """vecN<u32> / vecN<i32>: Python ints (u32 arithmetic stays exact integer arithmetic), indexable and swizzle-readable."""
+
+
+class Ref:
+    """A `ptr<function, T>`: `&x` makes one around the local's value, `*p` is `.v`; the caller copies `.v` back into the local after the statement."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+
 def member(obj, name):
+    if isinstance(obj, IVec):
+        return obj[_SW[name]]
     if isinstance(obj, np.ndarray):
         idx = [_SW[ch] for ch in name]
         return obj[idx[0]] if len(idx) == 1 else obj[idx].copy()
@@ -175,6 +201,8 @@ def copyval(v):
         return v.copy()
     if isinstance(v, Struct):
         return Struct(v._fields, [copyval(getattr(v, f)) for f in v._fields])
+    if isinstance(v, IVec):
+        return IVec(v)
     if isinstance(v, list):
         return list(v)
     return v
@@ -207,12 +235,72 @@ def fn_cos(x):
     return f32(np.cos(np.float64(_num(x))))
 
 
+def fn_atan(x):
+    return f32(np.arctan(np.float64(_num(x))))
+
+
+def fn_exp(x):
+    with np.errstate(over="ignore"):
+        return f32(np.exp(np.float64(_num(x))))
+
+
 def fn_abs(x):
     return abs(x) if _is_int(x) else np.abs(_num(x))
 
 
 def fn_sign(x):
-    return np.sign(_num(x))
+    """1 for x > 0, -1 for x < 0, +0 otherwise (WGSL leaves the sign of sign(-0) open; the header fixes it the same way)."""
+    x = _num(x)
+    one = f32(1)
+    if isinstance(x, np.ndarray):
+        return np.where(x > 0, one, np.where(x < 0, -one, f32(0))).astype(f32)
+    return one if x > 0 else (-one if x < 0 else f32(0))
+
+
+def fn_select(f, t, cond):
+    """select(f, t, cond): t where cond, else f; component-wise for a vector condition."""
+    if isinstance(cond, np.ndarray):
+        return np.where(cond, t, f).astype(np.asarray(t).dtype)
+    return copyval(t) if cond else copyval(f)
+
+
+def fn_fma(a, b, c):
+    """fma(a, b, c) with ONE rounding. The f32 x f32 product is exact in float64; the float64 sum p + c is rounded to odd (its TwoSum error says on
+    which side of the float64 sum the exact value lies), and a round-to-odd float64 rounds to f32 exactly as the exact value does (53 >= 24 + 2)."""
+    a, b, c = np.float64(_num(a)), np.float64(_num(b)), np.float64(_num(c))
+    p = a * b
+    s = p + c
+    if not np.isfinite(s):
+        return f32(s)
+    bb = s - p
+    err = (p - (s - bb)) + (c - bb)
+    if err != 0.0 and (int(np.float64(s).view(np.int64)) & 1) == 0:
+        s = np.nextafter(s, np.float64(np.inf) if err > 0 else np.float64(-np.inf))
+    return f32(s)
+
+
+def fn_bitcast_i32(x):
+    v = int(np.float32(x).view(np.int32)) if not _is_int(x) else x & M32
+    return v - (1 << 32) if v >= (1 << 31) else v  # signed: `i >> 1` on it is Python's arithmetic shift
+
+
+def fn_bitcast_u32(x):
+    return int(np.float32(x).view(np.uint32)) if not _is_int(x) else x & M32
+
+
+def fn_bitcast_f32(i):
+    return np.uint32(int(i) & M32).view(np.float32) if _is_int(i) else f32(i)
+
+
+def fn_array(*args):
+    """array<T, N>(a, b, ..): a fixed-size array of scalars (f32 here) or of whatever the elements are."""
+    if args and all(not isinstance(a, (np.ndarray, Struct)) and not _is_int(a) for a in args):
+        return np.array([_num(a) for a in args], f32)
+    return [copyval(a) for a in args]
+
+
+def op_shr(a, b):
+    return a >> b
 
 
 def fn_f32(x):
@@ -241,7 +329,7 @@ class Struct:
 # ------------------------------------------------------------------------------------------------------------------
 # lexer / parser  ->  Python source
 # ------------------------------------------------------------------------------------------------------------------
-TOKEN = re.compile(r"\s*(?:(//[^\n]*)|(\d+\.\d*(?:[eE][+-]?\d+)?f?|\d+[eE][+-]?\d+f?|\d+u?)|([A-Za-z_][A-Za-z_0-9]*)|(::|\+\+|--|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||->|[-+*/%<>=!(){}\[\];:,.@&|]))")
+TOKEN = re.compile(r"\s*(?:(//[^\n]*)|(0x[0-9a-fA-F]+u?|\d+\.\d*(?:[eE][+-]?\d+)?f?|\d+[eE][+-]?\d+f?|\d+[uif]?)|([A-Za-z_][A-Za-z_0-9]*)|(::|\+\+|--|\+=|-=|\*=|/=|==|!=|<=|>=|&&|\|\||->|>>|[-+*/%<>=!(){}\[\];:,.@&|]))")
 
 
 def preprocess(src: str, defs: set) -> str:
@@ -296,16 +384,20 @@ class Module:
         self.toks = tokenize("\n".join(lines))
         self.i = 0
         self.py = []
+        self.pre, self.post, self.loops, self.nflag, self.nref = [], [], [], 0, 0
         self._parse_module()
         self.ns = {"op_add": op_add, "op_sub": op_sub, "op_mul": op_mul, "op_div": op_div, "load": load, "Struct": Struct,
                    "fn_transpose": fn_transpose, "fn_min": fn_min, "fn_max": fn_max, "fn_vec4": fn_vec4, "fn_mat4x4": fn_mat4x4,
                    "f32": f32, "M32": M32, "MOD": self, "op_neg": op_neg, "fn_vec": fn_vec, "fn_mat": fn_mat, "member": member,
                    "setmember": setmember, "copyval": copyval, "fn_dot": fn_dot, "fn_cross": fn_cross, "fn_sqrt": fn_sqrt,
                    "fn_length": fn_length, "fn_sin": fn_sin, "fn_cos": fn_cos, "fn_abs": fn_abs, "fn_sign": fn_sign, "fn_f32": fn_f32,
-                   "fn_u32": fn_u32, "zero_of": self.zero_of}
+                   "fn_u32": fn_u32, "zero_of": self.zero_of, "fn_atan": fn_atan, "fn_exp": fn_exp, "fn_select": fn_select, "fn_fma": fn_fma,
+                   "fn_bitcast_i32": fn_bitcast_i32, "fn_bitcast_u32": fn_bitcast_u32, "fn_bitcast_f32": fn_bitcast_f32, "fn_array": fn_array,
+                   "op_shr": op_shr, "Ref": Ref, "IVec": IVec}
         for alias, mod in self.imports.items():
             self.ns["IMP_" + alias] = mod
         exec("\n".join(self.py), self.ns)
+        self._constG = None
 
     def zero_of(self, ty: str):
         """The zero value of a WGSL type (`var x: T;`, `T()`)."""
@@ -330,9 +422,22 @@ class Module:
             return Struct(self.structs[ty], [self.zero_of(t) for t in self.struct_types[ty]])
         raise TypeError(f"no zero value for type {ty!r}")
 
+    @property
+    def G(self):
+        """Module-scope constants as the `G` object of functions run outside an entry point (call_fn, and calls from an importing module)."""
+        if self._constG is None:
+            class G:
+                pass
+            g = G()
+            for k, v in self.consts.items():
+                setattr(g, k, eval(v, self.ns, {"G": g}))
+            self._constG = g
+        return self._constG
+
     def call_fn(self, name: str, *args):
-        """Runs function `name` (not an entry point) to completion and returns its value. Arguments are copied (value semantics)."""
-        gen = self.ns["F_" + name](None, *[copyval(a) for a in args])
+        """Runs function `name` (not an entry point) to completion and returns its value. Arguments are copied (value semantics); an argument of a
+        `ptr<function, T>` parameter is passed as a wgsl_exec.Ref (read `.v` afterwards)."""
+        gen = self.ns["F_" + name](self.G, *[a if isinstance(a, Ref) else copyval(a) for a in args])
         try:
             while True:
                 next(gen)
@@ -381,7 +486,7 @@ class Module:
             depth = 1
             while depth:
                 x = self.next()
-                depth += (x == "<") - (x == ">")
+                depth += (x == "<") - (x == ">") - 2 * (x == ">>")
                 t += x
         return t
 
@@ -470,7 +575,7 @@ class Module:
     def parse_simple(self, scope):
         """let / var / assignment / call / ++ without the trailing ';' -> list of python statements (no indentation)."""
         t = self.peek()
-        if t in ("let", "var"):
+        if t in ("let", "var", "const"):
             self.next()
             name = self.next()
             ty = self.parse_type() if self.accept(":") else None
@@ -481,7 +586,8 @@ class Module:
             rhs = self.parse_expr(scope)
             scope.declare(name)  # after the right-hand side: `let shape = f(shape)` reads the outer `shape`
             return [f"{scope.local(name)} = copyval({rhs})"]
-        lhs = self.parse_postfix(scope, lvalue=True)
+        through_ptr = self.accept("*")  # `*x = ..`: a store through a ptr<function, T>
+        lhs = LV(self.parse_postfix(scope).read() + ".v") if through_ptr else self.parse_postfix(scope, lvalue=True)
         t = self.peek()
         if t in ("=", "+=", "-=", "*=", "/="):
             self.next()
@@ -489,7 +595,7 @@ class Module:
             if t != "=":
                 cur = lhs.read()
                 rhs = {"+=": "op_add", "-=": "op_sub", "*=": "op_mul", "/=": "op_div"}[t] + f"({cur}, {rhs})"
-            return [lhs.write(rhs)]
+            return [lhs.write(f"copyval({rhs})" if through_ptr else rhs)]
         if t in ("++", "--"):
             self.next()
             return [lhs.write(("op_add" if t == "++" else "op_sub") + f"({lhs.read()}, 1)")]
@@ -500,9 +606,23 @@ class Module:
         t = self.peek()
         if t == "{":
             return self.parse_block(scope, ind)
+        self.pre, self.post = [], []   # `&x` in the statement: cells made before it, written back to the locals after it
+        if t == "while":
+            self.next()
+            cond = self.parse_expr(scope)
+            assert not self.pre, "`&x` in a loop condition is not supported"
+            self.loops.append(None)
+            body = self.parse_block(scope, ind + 1)
+            self.loops.pop()
+            return [f"{pad}while {cond}:"] + (body or [f"{pad}    pass"])
+        if t == "break":
+            self.next(); self.expect(";")
+            flag = self.loops[-1]
+            return [f"{pad}break"] if flag is None else [f"{pad}{flag} = True", f"{pad}break"]
         if t == "if":
             self.next()
             cond = self.parse_expr(scope)
+            assert not self.pre, "`&x` in an if condition is not supported"
             out = [f"{pad}if {cond}:"] + (self.parse_block(scope, ind + 1) or [f"{pad}    pass"])
             if self.accept("else"):
                 if self.peek() == "if":
@@ -520,24 +640,32 @@ class Module:
             self.expect(";")
             upd = self.parse_simple(inner) if self.peek() != ")" else []
             self.expect(")")
+            assert not self.pre, "`&x` in a for header is not supported"
+            self.nflag += 1
+            flag = f"_brk{self.nflag}"
+            self.loops.append(flag)
             body = self.parse_block(inner, ind + 2)
-            # `continue` must still run the update: the body sits in a one-trip loop and `continue` leaves that one
-            return ([pad + s for s in init] + [f"{pad}while {cond}:", f"{pad}    for _once in (0,):"] + (body or [f"{pad}        pass"]) +
-                    [f"{pad}    {s}" for s in upd])
+            self.loops.pop()
+            # `continue` must still run the update: the body sits in a one-trip loop and `continue` leaves that one; `break` leaves it with the
+            # loop's flag set, and the flag leaves the `while`
+            return ([pad + s for s in init] + [f"{pad}{flag} = False", f"{pad}while {cond}:", f"{pad}    for _once in (0,):"] +
+                    (body or [f"{pad}        pass"]) + [f"{pad}    if {flag}: break"] + [f"{pad}    {s}" for s in upd])
         if t == "return":
             self.next()
             if self.accept(";"):
                 return [f"{pad}return"]
             e = self.parse_expr(scope)
             self.expect(";")
-            return [f"{pad}return {e}"]
+            return [pad + x for x in self.pre] + [f"{pad}return {e}"]
         if t == "continue":
             self.next(); self.expect(";")
-            return [f"{pad}break"]
+            return [f"{pad}break"] if self.loops[-1] is not None else [f"{pad}continue"]
         if t == "workgroupBarrier":
             self.next(); self.expect("("); self.expect(")"); self.expect(";")
             return [f"{pad}yield"]
-        out = [pad + s for s in self.parse_simple(scope)]
+        body = self.parse_simple(scope)
+        out = [pad + s for s in self.pre + body + self.post]
+        self.pre, self.post = [], []
         self.expect(";")
         return out
 
@@ -545,7 +673,7 @@ class Module:
     def parse_expr(self, scope):
         return self.parse_bin(scope, 0)
 
-    LEVELS = [["||"], ["&&"], ["==", "!=", "<", ">", "<=", ">="], ["+", "-"], ["*", "/", "%"]]
+    LEVELS = [["||"], ["&&"], ["==", "!=", "<", ">", "<=", ">="], [">>"], ["+", "-"], ["*", "/", "%"]]
 
     def parse_bin(self, scope, lvl):
         if lvl == len(self.LEVELS):
@@ -562,6 +690,8 @@ class Module:
                 lhs = f"({lhs} and {rhs})"
             elif op == "%":
                 lhs = f"({lhs} % {rhs})"
+            elif op == ">>":
+                lhs = f"op_shr({lhs}, {rhs})"
             else:
                 lhs = f"({lhs} {op} {rhs})"
         return lhs
@@ -569,8 +699,17 @@ class Module:
     def parse_unary(self, scope):
         if self.accept("-"):
             return f"op_neg({self.parse_unary(scope)})"
-        if self.accept("&") or self.accept("*"):  # ptr<function, T>: arrays and structs are references here already
-            return self.parse_postfix(scope).ref()
+        if self.accept("&"):  # `&x`: a cell around the local's value, copied back into the local after the statement
+            node = self.parse_postfix(scope)
+            if node.base is None and node.obj is None and node.expr.startswith("L_"):
+                self.nref += 1
+                cell = f"_ref{self.nref}"
+                self.pre.append(f"{cell} = Ref({node.expr})")
+                self.post.append(f"{node.expr} = {cell}.v")
+                return cell
+            return f"Ref({node.ref()})"  # a component of an array / struct: the object itself is the reference
+        if self.accept("*"):
+            return self.parse_postfix(scope).read() + ".v"
         if self.accept("!"):
             return f"(not {self.parse_unary(scope)})"
         return self.parse_postfix(scope).read()
@@ -581,7 +720,9 @@ class Module:
             e = self.parse_expr(scope)
             self.expect(")")
             node = LV(f"({e})")
-        elif re.fullmatch(r"\d+u", t):
+        elif re.fullmatch(r"0x[0-9a-fA-F]+u?", t):
+            node = LV(str(int(t.rstrip("u"), 16)))
+        elif re.fullmatch(r"\d+[ui]", t):
             node = LV(t[:-1])
         elif re.fullmatch(r"\d+", t):
             node = LV(t)
@@ -593,8 +734,10 @@ class Module:
             if self.peek() == "::":
                 self.next()
                 alias, t = t, self.next()
-            if self.peek() == "<" and re.fullmatch(r"vec\d|mat\dx\d|array", t):  # explicit template arguments: vec4<f32>(...)
-                self.parse_type_args()
+            if self.peek() == "<" and re.fullmatch(r"vec\d|mat\dx\d|array|bitcast", t):  # explicit template arguments: vec4<f32>(...)
+                targs = self.parse_type_args()
+                if t == "bitcast":
+                    t = "bitcast_" + targs[0]
             if self.peek() == "(":
                 self.next()
                 args = []
@@ -616,10 +759,12 @@ class Module:
 
     def parse_type_args(self):
         self.expect("<")
-        depth = 1
+        depth, toks = 1, []
         while depth:
             x = self.next()
-            depth += (x == "<") - (x == ">")
+            depth += (x == "<") - (x == ">") - 2 * (x == ">>")
+            toks.append(x)
+        return toks[:-1]
 
     def call(self, scope, alias, name, args):
         a = ", ".join(args)
@@ -634,7 +779,8 @@ class Module:
             m = re.fullmatch(r"mat(\d)x\1f?", name)
             if m:
                 return f"fn_mat({m.group(1)}{', ' if a else ''}{a})"
-            if name in ("transpose", "min", "max", "dot", "cross", "sqrt", "length", "sin", "cos", "abs", "sign", "f32", "u32"):
+            if name in ("transpose", "min", "max", "dot", "cross", "sqrt", "length", "sin", "cos", "abs", "sign", "f32", "u32", "atan", "exp", "select",
+                        "fma", "bitcast_i32", "bitcast_u32", "bitcast_f32", "array"):
                 return f"fn_{name}({a})"
             if name in self.structs:
                 if not args:
@@ -647,7 +793,7 @@ class Module:
             if not args:
                 return f"IMP_{alias}.zero_of({name!r})"
             return f"Struct({mod.structs[name]!r}, [{a}])"
-        return f"(yield from IMP_{alias}.ns['F_{name}'](None{', ' if a else ''}{a}))"
+        return f"(yield from IMP_{alias}.ns['F_{name}'](IMP_{alias}.G{', ' if a else ''}{a}))"
 
     # -- execution
     def run(self, entry: str, grid, bindings: dict):
@@ -749,14 +895,28 @@ class LV:
 
 
 class Scope:
+    """Block scope. A name declared again in an inner block (or again in the same one) gets a Python local of its own, so that leaving the block
+    gives the outer variable back: `let m = end - 1u;` inside a loop of a function whose matrix is called `m` (eig3.wgsl:82)."""
+
     def __init__(self, mod, parent):
-        self.mod, self.parent, self.names = mod, parent, set()
+        self.mod, self.parent, self.names = mod, parent, {}
+        self.used = parent.used if parent is not None else set()   # python names taken in this function
 
     def declare(self, name):
-        self.names.add(name)
+        py, k = "L_" + name, 0
+        while py in self.used:
+            k += 1
+            py = f"L_{name}__{k}"
+        self.used.add(py)
+        self.names[name] = py
 
     def local(self, name):
-        return "L_" + name
+        sc = self
+        while sc is not None:
+            if name in sc.names:
+                return sc.names[name]
+            sc = sc.parent
+        raise NameError(name)
 
     def has(self, name):
         return name in self.names or (self.parent is not None and self.parent.has(name))

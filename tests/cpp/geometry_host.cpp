@@ -9,8 +9,8 @@ extern "C" int geom_apply_host(int op, unsigned dim, const float *in, float *out
     for (unsigned i = 0; i < count; ++i) {
         const float *p = in + (size_t)i * nin;
         float *o = out + (size_t)i * nout;
-        if (op >= OP_QUAT_RAW) raw_item(op, p, o);
-        else if (op >= OP_ROT2) transform_item(op, p, o);
+        if (!is_mat_op(op) && op >= OP_QUAT_RAW) raw_item(op, p, o);
+        else if (!is_mat_op(op)) transform_item(op, p, o);
         else if (dim == 2) mat_item<2>(op, p, o);
         else if (dim == 3) mat_item<3>(op, p, o);
         else if (dim == 4) mat_item<4>(op, p, o);

@@ -13,11 +13,17 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 LEN = 345
-OPS = dict(INV=0, CHOLESKY=1, LU=2, QR=3, SYM_EIGEN=4, SVD=5, ROT2=6, QUAT=7, SIM2=8, SIM3=9, QUAT_RAW=10, ROT2_RAW=11, SIM2_RAW=12, SIM3_RAW=13, FROM=14)
+OPS = dict(INV=0, CHOLESKY=1, LU=2, QR=3, SYM_EIGEN=4, SVD=5, ROT2=6, QUAT=7, SIM2=8, SIM3=9, QUAT_RAW=10, ROT2_RAW=11, SIM2_RAW=12, SIM3_RAW=13, FROM=14,
+           UTILS=15, ROT2_EXT=16, EIGVALS2=17, SVD_RECOMPOSE=18)
 
 
 def out_floats(op, n):
-    return {0: n * n, 1: n * n, 2: n * n + 2 * n + 1, 3: 2 * n * n, 4: n * n + n, 5: 2 * n * n + n, 6: 11, 7: 19, 8: 14, 9: 25, 10: 27, 11: 12, 12: 18, 13: 28, 14: 6}[op]
+    return {0: n * n, 1: n * n, 2: n * n + 2 * n + 1, 3: 2 * n * n, 4: n * n + n, 5: 2 * n * n + n, 6: 11, 7: 19, 8: 14, 9: 25, 10: 27, 11: 12, 12: 18, 13: 28, 14: 6,
+            15: 11, 16: 29, 17: 2, 18: n * n}[op]
+
+
+def in_floats(op, n):
+    return {6: 4, 7: 9, 8: 10, 9: 17, 10: 11, 11: 6, 12: 12, 13: 19, 14: 4, 15: 19, 16: 31, 17: 4, 18: 2 * n * n + n}.get(op, n * n)
 
 
 @pytest.fixture(scope="module")
@@ -48,7 +54,8 @@ def gpu_apply_factory(gpu):
         count = inp.shape[0]
         tin = wg.TensorBuilder.vector(inp.size, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(gpu.device(), inp.reshape(-1))
         tout = wg.TensorBuilder.vector(count * out_floats(op, dim), S.STORAGE | S.COPY_SRC).build(gpu.device(), np.float32)
-        assert wg.geometry.in_floats(op, dim) * count == inp.size and wg.geometry.out_floats(op, dim) == out_floats(op, dim)
+        assert wg.geometry.in_floats(op, dim) == in_floats(op, dim) and in_floats(op, dim) * count == inp.size
+        assert wg.geometry.out_floats(op, dim) == out_floats(op, dim)
         wg.geometry.apply(gpu, wg.GeomOp(op), dim, tin, tout, count)
         return tout.read(gpu.device()).reshape(count, -1)
     return apply
@@ -112,13 +119,16 @@ def run_checks(apply):
         allow(rel_close(rec, sym, 1e-4), 2, f"symmetric_eigen{n}")
         allow(rel_close(np.einsum("bki,bkj->bij", V, V), np.broadcast_to(np.eye(n), (LEN, n, n)), 1e-4), 2, f"eigenvectors{n} orthonormal")
         assert np.allclose(np.sort(lam, axis=1), np.linalg.eigvalsh(sym.astype(np.float64)), atol=1e-4)
-        # SVD (svd3.rs:100-110): U diag(S) Vt == M, eps 1e-4; S descending, non-negative (2 and 3 only, like the reference)
+        # SVD (svd2.rs:96-106, svd3.rs:100-110): U diag(S) Vt == M at eps 1e-4 for EVERY item (the reference's SVD tests allow no misses); 2 and 3 only,
+        # like the reference. |S| descending; svd3's last singular value may come out negative (the sign stays in S: svd3.wgsl:303), svd2's never does.
         if n < 4:
             o = apply(OPS["SVD"], n, items)
             U_, S_, Vt = cm(o[:, :n * n], n).astype(np.float64), o[:, n * n:n * n + n].astype(np.float64), cm(o[:, n * n + n:], n).astype(np.float64)
-            allow(rel_close(np.einsum("bik,bk,bkj->bij", U_, S_, Vt), M64, 1e-4), 2, f"svd{n}")
-            assert (S_ >= 0).all() and (np.diff(S_, axis=1) <= 1e-6).all()
-            assert np.allclose(S_, np.linalg.svd(M64, compute_uv=False), atol=1e-4)
+            assert rel_close(np.einsum("bik,bk,bkj->bij", U_, S_, Vt), M64, 1e-4).all(), f"svd{n}"
+            assert (S_[:, :n - 1] >= 0).all() and (np.diff(np.abs(S_), axis=1) <= 1e-6).all() and (n == 3 or (S_ >= 0).all())
+            assert np.allclose(np.abs(S_), np.linalg.svd(M64, compute_uv=False), atol=1e-4)
+            rec = cm(apply(OPS["SVD_RECOMPOSE"], n, o), n)
+            assert rel_close(rec, M64, 1e-4).all(), f"svd{n}::recompose"
     # Rot2 / Quat / Sim2 / Sim3 against NumPy rotation matrices
     ang = (rng.random((LEN, 2)) * 2 - 1).astype(np.float32) * 3
     vec = (rng.random((LEN, 2)) * 2 - 1).astype(np.float32)
@@ -194,30 +204,44 @@ def test_geometry_gpu_matches_reference_procedure(gpu):
     run_checks(gpu_apply_factory(gpu))
 
 
+def same_bits(got, exp):
+    """Bit-for-bit, NaN where NaN (payloads aside). Returns (ok, description of the first difference)."""
+    got, exp = np.asarray(got, np.float32), np.asarray(exp, np.float32)
+    nan_g, nan_e = np.isnan(got), np.isnan(exp)
+    bad = (nan_g != nan_e) | (~nan_g & ~nan_e & (got.view(np.uint32) != exp.view(np.uint32)))
+    if not bad.any():
+        return True, ""
+    at = tuple(np.argwhere(bad)[0])
+    return False, f"{int(bad.sum())} values differ, first at item/field {at}: {got[at]!r} vs {exp[at]!r}"
+
+
 @pytest.mark.gpu
 def test_geometry_gpu_vs_host(gpu, host_apply):
-    """The HIP build and the host build of the same header agree (FMA contraction aside) on every item kind."""
+    """The HIP build and the host build of the same header return the same bits on every item kind: contraction is off in both, division and sqrt are
+    correctly rounded in both, sin / cos / atan / exp are the float64 functions rounded once in both."""
     gapply = gpu_apply_factory(gpu)
     rng = np.random.default_rng(7)
-    for op, dims in ((0, (2, 3, 4)), (1, (2, 3, 4)), (2, (2, 3, 4)), (3, (2, 3, 4)), (4, (2, 3, 4)), (5, (2, 3)), (6, (0,)), (7, (0,)), (8, (0,)), (9, (0,))):
+    for op, dims in ((0, (2, 3, 4)), (1, (2, 3, 4)), (2, (2, 3, 4)), (3, (2, 3, 4)), (4, (2, 3, 4)), (5, (2, 3)), (6, (0,)), (7, (0,)), (8, (0,)), (9, (0,)),
+                     (10, (0,)), (11, (0,)), (12, (0,)), (13, (0,)), (14, (0,)), (15, (0,)), (17, (0,)), (18, (2, 3))):
         for n in dims:
-            nin = {6: 4, 7: 9, 8: 10, 9: 17}.get(op, n * n)
-            x = rng.random((64, nin)).astype(np.float32) + (0.5 if op >= 8 else 0)
-            if n:  # well-conditioned, well-separated spectra: the two builds differ by FMA contraction only, which ill-conditioning would amplify
-                m = x.reshape(64, n, n) + 2 * np.diag(np.arange(1, n + 1)).astype(np.float32)
-                if op in (1, 4):  # SPD / symmetric inputs
-                    m = np.einsum("bki,bkj->bij", m, m) if op == 1 else (m + m.transpose(0, 2, 1)) / 2
-                x = m.reshape(64, n * n).astype(np.float32)
-            a, b = gapply(op, n, x), host_apply(op, n, x)
-            assert np.allclose(a, b, rtol=2e-4, atol=2e-5), f"op {op} dim {n}: GPU and host builds differ by {np.abs(a - b).max()}"
+            nin = in_floats(op, n)
+            x = (rng.random((512, nin)) * 2 - 1).astype(np.float32) + (1.5 if op in (8, 9, 12, 13) else 0)
+            if op in (1, 4) and n:  # SPD / symmetric inputs
+                m = x.reshape(-1, n, n)
+                m = np.einsum("bki,bkj->bij", m, m) + np.eye(n, dtype=np.float32) if op == 1 else (m + m.transpose(0, 2, 1)) / 2
+                x = m.reshape(-1, n * n).astype(np.float32)
+            ok, why = same_bits(gapply(op, n, x), host_apply(op, n, x))
+            assert ok, f"op {op} dim {n}: GPU and host builds differ: {why}"
 
 
 # --------------------------------------------------------------------------------------------------------
-# Pinned to the reference's WGSL TEXT: tests/golden/wgsl_exec_geometry.npz holds seeded inputs and what crates/wgebra/src/geometry/
-# {inv,cholesky,lu,quat,rot2,sim2,sim3}.wgsl return when executed by oracle/wgsl_exec.py (left to right, every product and sum rounded,
-# dot / cross as their defining formulas; generator: tests/golden/make_wgsl_geometry_golden.py). The header's closed-form functions follow the
-# same expressions with contraction off: 0 ulp for everything built from + - * / sqrt -- non-unit quaternions and (cos, sin) pairs that are no
-# rotations included --, <= 2 ulp where sin / cos enter (fromScaledAxis, fromAngle: the fixture rounds them from float64).
+# Pinned to the reference's WGSL TEXT: tests/golden/wgsl_exec_geometry.npz and wgsl_exec_decomp.npz hold seeded inputs and what the reference's
+# crates/wgebra/src/geometry/*.wgsl and utils/{trig,min_max}.wgsl return when executed by oracle/wgsl_exec.py (left to right, every product and sum
+# rounded, dot / cross / length / matrix products as their defining formulas, `fma` one rounding, sin / cos / atan / exp correctly rounded; generators:
+# tests/golden/make_wgsl_geometry_golden.py, make_wgsl_decomp_golden.py). The header follows the same statements with contraction off: 0 ulp on EVERY
+# function, no allowance -- non-unit quaternions, (cos, sin) pairs that are no rotations, and the inputs on which the reference itself returns NaN
+# included (svd3 of a matrix whose sorted first column starts with two exact zeros: rsqrt1(0) overflows to inf * -0 (svd3.wgsl:69-80); eig4 when the
+# Wilkinson shift divides by d + sign(d) * .. with d == 0, sign(0) = 0 (eig3.wgsl:205) -- the fixtures hold them and the header returns NaN there too).
 # --------------------------------------------------------------------------------------------------------
 def max_ulp(a, b):
     a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
@@ -233,21 +257,56 @@ def run_wgsl_pinned(apply):
             key = f"{op.lower()}{n}"
             got = apply(OPS[op], n, g[key + "_in"])
             assert got.tobytes() == g[key + "_out"].tobytes(), f"{key}: {max_ulp(got, g[key + '_out'])} ulp from the executed WGSL (must be 0)"
-    for op, key in (("QUAT_RAW", "quat_raw"), ("ROT2_RAW", "rot2_raw"), ("SIM2_RAW", "sim2_raw"), ("SIM3_RAW", "sim3_raw")):
-        got = apply(OPS[op], 0, g[key + "_in"])
-        exp = g[key + "_out"]
-        bad = np.argwhere(got.view(np.uint32) != exp.view(np.uint32))
-        assert bad.size == 0, f"{key}: {len(bad)} values differ from the executed WGSL, first at item/field {bad[0]}: {got[tuple(bad[0])]!r} vs {exp[tuple(bad[0])]!r}"
-    got, exp = apply(OPS["FROM"], 0, g["from_in"]), g["from_out"]
-    assert np.array_equal(got[0, :4], np.array([0, 0, 0, 1], np.float32))  # the zero axis is the identity (quat.wgsl:20-22)
-    # sin / cos: within 2 ulp of the correctly rounded value at the SCALE of the result's vector (|sin| near 0 has tiny ulps of its own)
-    assert np.abs(got.astype(np.float64) - exp.astype(np.float64)).max() <= 2 * 2.0 ** -24, np.abs(got - exp).max()
+    for op, key in (("QUAT_RAW", "quat_raw"), ("ROT2_RAW", "rot2_raw"), ("SIM2_RAW", "sim2_raw"), ("SIM3_RAW", "sim3_raw"), ("FROM", "from")):
+        ok, why = same_bits(apply(OPS[op], 0, g[key + "_in"]), g[key + "_out"])
+        assert ok, f"{key} vs the executed WGSL: {why}"
+    assert np.array_equal(apply(OPS["FROM"], 0, g["from_in"])[0, :4], np.array([0, 0, 0, 1], np.float32))  # the zero axis is the identity (quat.wgsl:20-22)
+
+
+def run_wgsl_pinned_decompositions(apply):
+    """QR, symmetric eigen, SVD (+ recompose), eig2::eigenvalues, trig, min_max and the Rot2 helpers against the executed reference text: 0 ulp."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wgsl_exec_decomp.npz"))
+    seen = 0
+    for n in (2, 3, 4):
+        for op, key in (("QR", f"qr{n}"), ("SYM_EIGEN", f"sym_eigen{n}"), ("SVD", f"svd{n}"), ("SVD_RECOMPOSE", f"svd_recompose{n}")):
+            if key + "_in" not in g.files:
+                assert n == 4 and op.startswith("SVD")
+                continue
+            ok, why = same_bits(apply(OPS[op], n, g[key + "_in"]), g[key + "_out"])
+            assert ok, f"{key} vs the executed WGSL: {why}"
+            seen += 1
+    for op, key in (("EIGVALS2", "eigvals2"), ("UTILS", "utils"), ("ROT2_EXT", "rot2_ext")):
+        ok, why = same_bits(apply(OPS[op], 0, g[key + "_in"]), g[key + "_out"])
+        assert ok, f"{key} vs the executed WGSL: {why}"
+    assert seen == 10
+    # the conventions the reference's text fixes, read off the fixture itself (so a regenerated fixture cannot silently drop them)
+    e2_in, e2 = g["sym_eigen2_in"], g["sym_eigen2_out"]
+    off = e2_in[:, 1] != 0
+    assert (e2[off, 4] >= e2[off, 5]).all(), "eig2: ((a + b + sigma) / 2, (a + b - sigma) / 2) in that order (eig2.wgsl:28-31)"
+    assert (e2[off][:, [1, 3]] > 0).all(), "eig2: eigenvectors normalised with last component + (eig2.wgsl:32-35)"
+    assert np.array_equal(e2[~off, :4], np.tile(np.array([1, 0, 0, 1], np.float32), ((~off).sum(), 1))), "eig2: c == 0 returns the identity basis"
+    ut_in, ut = g["utils_in"], g["utils_out"]
+    axis = (ut_in[:, 1] == 0) | ((ut_in[:, 1] < 0) & (ut_in[:, 0] == 0))
+    assert axis.sum() >= 6 and (ut[axis, 0] == 0).all(), "stable_atan2 is 0 for x == 0 and for x < 0, y == 0 (trig.wgsl:25-38)"
+    for n in (2, 3, 4):
+        r = g[f"qr{n}_out"][:, n * n:].reshape(-1, n, n)     # columns: r[:, c, r]
+        assert (np.diagonal(r, axis1=1, axis2=2) >= 0).all() and (np.triu(r.transpose(0, 2, 1), 0) == r.transpose(0, 2, 1)).all()
+    assert np.isnan(g["svd3_out"]).any() and np.isnan(g["sym_eigen4_out"]).any()  # the reference's own NaN cases are in the fixture
 
 
 def test_closed_form_functions_match_the_executed_wgsl_host(host_apply):
     run_wgsl_pinned(host_apply)
 
 
+def test_decompositions_and_utils_match_the_executed_wgsl_host(host_apply):
+    run_wgsl_pinned_decompositions(host_apply)
+
+
 @pytest.mark.gpu
 def test_closed_form_functions_match_the_executed_wgsl_gpu(gpu):
     run_wgsl_pinned(gpu_apply_factory(gpu))
+
+
+@pytest.mark.gpu
+def test_decompositions_and_utils_match_the_executed_wgsl_gpu(gpu):
+    run_wgsl_pinned_decompositions(gpu_apply_factory(gpu))

@@ -8,7 +8,10 @@ using namespace wgebra::geometry;
 enum { OP_INV = 0, OP_CHOLESKY = 1, OP_LU = 2, OP_QR = 3, OP_SYM_EIGEN = 4, OP_SVD = 5, OP_ROT2 = 6, OP_QUAT = 7, OP_SIM2 = 8, OP_SIM3 = 9,
        // the transform functions one by one on RAW coordinates (a quaternion that is not unit, a (cos, sin) pair that is no rotation): what the
        // fixtures executed from the reference's WGSL text hold (tests/golden/wgsl_exec_geometry.npz)
-       OP_QUAT_RAW = 10, OP_ROT2_RAW = 11, OP_SIM2_RAW = 12, OP_SIM3_RAW = 13, OP_FROM = 14 };
+       OP_QUAT_RAW = 10, OP_ROT2_RAW = 11, OP_SIM2_RAW = 12, OP_SIM3_RAW = 13, OP_FROM = 14,
+       // utils/trig.wgsl + utils/min_max.wgsl; the Rot2 functions the eigen-solvers use; eig2::eigenvalues; svd2/svd3::recompose (a matrix op: dim = 2, 3)
+       OP_UTILS = 15, OP_ROT2_EXT = 16, OP_EIGVALS2 = 17, OP_SVD_RECOMPOSE = 18, OP_LAST = 18 };
+WGG_FN bool is_mat_op(int op) { return op <= OP_SVD || op == OP_SVD_RECOMPOSE; }
 
 template <int N>
 WGG_FN Mat<N> load_mat(const float *p) {
@@ -24,7 +27,26 @@ WGG_FN void store_mat(float *p, const Mat<N> &m) {
 }
 
 template <int N>
+WGG_FN void svd_item(int op, const float *in, float *o) { // the reference has svd2 and svd3 only
+    if (op == OP_SVD) {
+        const Svd<N> r = svd<N>(load_mat<N>(in));
+        store_mat<N>(o, r.u);
+        for (int k = 0; k < N; ++k) o[N * N + k] = r.s.v[k];
+        store_mat<N>(o + N * N + N, r.vt);
+    } else { // OP_SVD_RECOMPOSE: in = u, s, vt in the layout OP_SVD writes
+        Svd<N> d;
+        d.u = load_mat<N>(in);
+        for (int k = 0; k < N; ++k) d.s.v[k] = in[N * N + k];
+        d.vt = load_mat<N>(in + N * N + N);
+        store_mat<N>(o, recompose<N>(d));
+    }
+}
+template <>
+WGG_FN void svd_item<4>(int, const float *, float *) {}
+
+template <int N>
 WGG_FN void mat_item(int op, const float *in, float *o) {
+    if (op == OP_SVD || op == OP_SVD_RECOMPOSE) { svd_item<N>(op, in, o); return; }
     const Mat<N> m = load_mat<N>(in);
     switch (op) {
     case OP_INV: store_mat<N>(o, inv<N>(m)); break;
@@ -44,12 +66,6 @@ WGG_FN void mat_item(int op, const float *in, float *o) {
         const SymmetricEigen<N> r = symmetric_eigen<N>(m);
         store_mat<N>(o, r.eigenvectors);
         for (int k = 0; k < N; ++k) o[N * N + k] = r.eigenvalues.v[k];
-    } break;
-    case OP_SVD: {
-        const Svd<N> r = svd<N>(m);
-        store_mat<N>(o, r.u);
-        for (int k = 0; k < N; ++k) o[N * N + k] = r.s.v[k];
-        store_mat<N>(o + N * N + N, r.vt);
     } break;
     }
 }
@@ -142,6 +158,34 @@ WGG_FN void raw_item(int op, const float *p, float *o) {
         const Quat q = quat::fromScaledAxis(Vec<3>{ { p[0], p[1], p[2] } });
         const Rot2 r = rot2::fromAngle(p[3]);
         o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; o[4] = r.cos; o[5] = r.sin;
+    } else if (op == OP_UTILS) { // in: y, x, t, m[16];  out: stable_atan2(y, x), stable_tanh(t), then max / amax / max of the leading 2-, 3-, 4-sized prefix
+        o[0] = trig::stable_atan2(p[0], p[1]);
+        o[1] = trig::stable_tanh(p[2]);
+        const float *m = p + 3;
+        o[2] = min_max::max2(Vec<2>{ { m[0], m[1] } });
+        o[3] = min_max::amax2x2(load_mat<2>(m));
+        o[4] = min_max::max2x2(load_mat<2>(m));
+        o[5] = min_max::max3(Vec<3>{ { m[0], m[1], m[2] } });
+        o[6] = min_max::amax3x3(load_mat<3>(m));
+        o[7] = min_max::max3x3(load_mat<3>(m));
+        o[8] = min_max::max4(Vec<4>{ { m[0], m[1], m[2], m[3] } });
+        o[9] = min_max::amax4x4(load_mat<4>(m));
+        o[10] = min_max::max4x4(load_mat<4>(m));
+    } else if (op == OP_ROT2_EXT) { // in: rot (cos, sin), v, m3[9], m4[16], i3, i4;  out: angle(rot), cancel_y(v), is_valid(cancel_y(v)), rotate_rows3, rotate_rows4
+        const Rot2 r{ p[0], p[1] };
+        const Rot2 cy = rot2::cancel_y(Vec<2>{ { p[2], p[3] } });
+        o[0] = rot2::angle(r);
+        o[1] = cy.cos; o[2] = cy.sin;
+        o[3] = rot2::is_valid(cy) ? 1.f : 0.f;
+        Mat3 m3 = load_mat<3>(p + 4);
+        Mat4 m4 = load_mat<4>(p + 13);
+        rot2::rotate_rows3(r, m3, (uint32_t)p[29]);
+        rot2::rotate_rows4(r, m4, (uint32_t)p[30]);
+        store_mat<3>(o + 4, m3);
+        store_mat<4>(o + 13, m4);
+    } else if (op == OP_EIGVALS2) { // in: a 2 x 2 symmetric matrix;  out: eig2::eigenvalues
+        const Vec<2> e = eig2::eigenvalues(load_mat<2>(p));
+        o[0] = e.v[0]; o[1] = e.v[1];
     }
 }
 
@@ -161,6 +205,10 @@ WGG_FN unsigned out_floats(int op, unsigned n) {
     case OP_SIM2_RAW: return 18;
     case OP_SIM3_RAW: return 28;
     case OP_FROM: return 6;
+    case OP_UTILS: return 11;
+    case OP_ROT2_EXT: return 29;
+    case OP_EIGVALS2: return 2;
+    case OP_SVD_RECOMPOSE: return n * n;
     }
     return 0;
 }
@@ -175,6 +223,10 @@ WGG_FN unsigned in_floats(int op, unsigned n) {
     case OP_SIM2_RAW: return 12;
     case OP_SIM3_RAW: return 19;
     case OP_FROM: return 4;
+    case OP_UTILS: return 19;
+    case OP_ROT2_EXT: return 31;
+    case OP_EIGVALS2: return 4;
+    case OP_SVD_RECOMPOSE: return 2 * n * n + n;
     default: return n * n;
     }
 }

@@ -24,15 +24,21 @@ class GeomOp(enum.IntEnum):
     SIM2_RAW = 12
     SIM3_RAW = 13
     FROM = 14      # quat::fromScaledAxis + rot2::fromAngle
+    UTILS = 15     # wgebra::trig (stable_atan2, stable_tanh) + wgebra::min_max
+    ROT2_EXT = 16  # rot2: angle, cancel_y, is_valid, rotate_rows3, rotate_rows4
+    EIGVALS2 = 17  # eig2::eigenvalues
+    SVD_RECOMPOSE = 18  # svd2 / svd3 ::recompose (dim 2, 3)
 
 
 _FIXED_IN = {GeomOp.ROT2: 4, GeomOp.QUAT: 9, GeomOp.SIM2: 10, GeomOp.SIM3: 17, GeomOp.QUAT_RAW: 11, GeomOp.ROT2_RAW: 6, GeomOp.SIM2_RAW: 12,
-             GeomOp.SIM3_RAW: 19, GeomOp.FROM: 4}
+             GeomOp.SIM3_RAW: 19, GeomOp.FROM: 4, GeomOp.UTILS: 19, GeomOp.ROT2_EXT: 31, GeomOp.EIGVALS2: 4}
 _FIXED_OUT = {GeomOp.ROT2: 11, GeomOp.QUAT: 19, GeomOp.SIM2: 14, GeomOp.SIM3: 25, GeomOp.QUAT_RAW: 27, GeomOp.ROT2_RAW: 12, GeomOp.SIM2_RAW: 18,
-              GeomOp.SIM3_RAW: 28, GeomOp.FROM: 6}
+              GeomOp.SIM3_RAW: 28, GeomOp.FROM: 6, GeomOp.UTILS: 11, GeomOp.ROT2_EXT: 29, GeomOp.EIGVALS2: 2}
 
 
 def in_floats(op: GeomOp, dim: int = 0) -> int:
+    if GeomOp(op) == GeomOp.SVD_RECOMPOSE:
+        return 2 * dim * dim + dim
     return _FIXED_IN.get(GeomOp(op), dim * dim)
 
 
@@ -42,7 +48,7 @@ def out_floats(op: GeomOp, dim: int = 0) -> int:
         return _FIXED_OUT[op]
     n = dim
     return {GeomOp.INV: n * n, GeomOp.CHOLESKY: n * n, GeomOp.LU: n * n + 2 * n + 1, GeomOp.QR: 2 * n * n,
-            GeomOp.SYM_EIGEN: n * n + n, GeomOp.SVD: 2 * n * n + n}[op]
+            GeomOp.SYM_EIGEN: n * n + n, GeomOp.SVD: 2 * n * n + n, GeomOp.SVD_RECOMPOSE: n * n}[op]
 
 
 def apply(gpu: GpuInstance, op: GeomOp, dim: int, items: GpuTensor, out: GpuTensor, count: int) -> None:
