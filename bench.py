@@ -682,10 +682,12 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     if hasattr(w, "finish"):
         w.finish()  # (pipelined multi-rank steps: the last step's deferred panel; no-op otherwise)
     ts.write(gpu.device())
+    # the closing stamp goes in right behind the last step, in stream order, BEFORE the stream drains and before the inter-rank barrier: the interval
+    # must not include idle time at the idle clock (a few microseconds of stamp kernel inside the timed region against a biased clock otherwise)
+    clock_ghz = clock.end()  # {"mean", "min", "max"} over the XCDs: the shader clock the timed steps actually ran at (None if unavailable); synchronises
     gpu.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    clock_ghz = clock.end()  # {"mean", "min", "max"} over the XCDs: the shader clock the timed steps actually ran at (None if unavailable)
     ev = ts.wait_for_results_ms()
     launches = getattr(w, "launches_per_step", lambda: 1)()
     kernel_ms = (ev[1] - ev[0]) / (steps * launches)  # HIP events on the stream the kernels run on

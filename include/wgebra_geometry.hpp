@@ -94,7 +94,7 @@ WGG_FN Vec<N> mul(const Mat<N> &a, const Vec<N> &x) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// WGSL builtins as the functions pinned to the reference's text read them (oracle/wgsl_exec.py fixes the same reading)
+// WGSL builtins as the functions pinned to the reference's text read them (the fixtures under tests/golden/ fix the same reading)
 // ---------------------------------------------------------------------------------------------------------------
 // sin / cos / atan / exp: the correctly rounded f32 value (the float64 function rounded once) -- the one result every conformant WGSL implementation's
 // error bound contains, and the only one a fixture can pin. These are per-item building blocks, not throughput code: the f64 evaluation costs nothing

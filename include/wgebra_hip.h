@@ -130,6 +130,9 @@ int wg_ctx_device(const wg_ctx *ctx);
 void *wg_ctx_stream(const wg_ctx *ctx); /* the hipStream_t, for interop */
 /* Device facts the bench prints next to every roofline: name (<=255 chars), CU count, clock MHz, HBM bytes. */
 int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int *clock_mhz, uint64_t *hbm_bytes);
+/* Free and total device memory in bytes right now (hipMemGetInfo on the context's device): what `wgpu::Device::limits` cannot say; the sharded
+   GEMM sizes its panels from it and the tests check that dropped buffers really come back. */
+int wg_ctx_mem_info(const wg_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes);
 /*
  * Geometry: the reference's `wgebra::geometry` WGSL modules (the .wgsl files under crates/wgebra/src/geometry) are device
  * functions used inside other shaders; their HIP counterpart is the header include/wgebra_geometry.hpp (`__host__ __device__`).
@@ -183,7 +186,9 @@ typedef enum wg_tuning {
     WG_TUNE_F16_BALANCE = 4, /* calibrated per-XCD shares (K-prefix units) for f16 products of few rounds: 0 = off (default: measured not to pay on
                                 MI355X, gemm_f16.hip), -1 = measure slot rates and let the planner decide, 1 = the tests' fixed pattern */
     WG_TUNE_F32_MID = 5,     /* the mid-size f32 tile family (gemm_f32_mid.hip: 128 x 128, 128 x 64, 64 x 128 tiles on 2 x 2 waves; 96 x 96, 96 x 64, 64 x 96, 64 x 64, 64 x 32,
-                                32 x 64 with K split over the workgroup's waves; no slabs, no second launch): -1 = by estimate (default), 0 = never, 1 = whenever
+                                32 x 64 with K split over the workgroup's waves; the whole K in one workgroup unless WG_TUNE_F32_MID_SPLIT / its estimate cuts K across workgroups
+                                (few tiles, long K: slabs + a reduce launch); for outputs of <= 64 rows or columns it is tried BEFORE the few-column kernels unless
+                                WG_TUNE_F32_SKINNY or _PANELS is forced to 1): -1 = by estimate (default), 0 = never, 1 = whenever
                                 applicable with the estimate's tile, 128128 / 128064 / 64128 / 96096 / 96064 / 64096 / 64064 / 64032 / 32064 = that tile (tests) */
     WG_TUNE_F32_MID_SPLIT = 6, /* K cut of the mid family's k-split tiles across workgroups (few tiles, long K: 64 x 4096 x 4096): 0 = by estimate (default), n >= 2 = n
                                  splits whenever that family runs (tests) */

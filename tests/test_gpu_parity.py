@@ -467,6 +467,41 @@ def test_objects_dropped_during_a_recording_are_freed_after_it(gpu):
     gpu.sync()
 
 
+@pytest.mark.gpu
+def test_a_tensor_the_recording_used_and_the_host_dropped_outlives_every_replay(gpu):
+    """The operand of a recorded dispatch loses its last host reference DURING the recording. Its destroy is queued on the command buffer (not run at
+    wg_encoder_finish): every later submit still reads valid memory -- wgpu keeps a dropped buffer alive until the submission using it retires -- and
+    the memory is returned when the command buffer is destroyed. Checked by value (the replays keep adding the operand's 3s; fresh allocations made
+    after finish() would be handed the freed block and overwrite it) and by the allocator's own accounting."""
+    import gc
+    wg = _wg()
+    dev, shapes = gpu.device(), wg.ViewShapeBuffers()
+    n = 1 << 22                                                   # 16 MiB: a block of its own in the HIP allocator
+    a = upload(gpu, (n,), np.zeros(n, np.float32))
+    b = upload(gpu, (n,), np.full(n, 3, np.float32))
+    gpu.sync()
+    add = wg.OpAssign.new(dev, wg.OpAssignVariant.Add)
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p:
+        add.dispatch(dev, shapes, p, a, b)
+        del b
+        gc.collect()                                              # wg_buf_destroy(b) arrives inside the recording
+    cb = enc.finish()
+    free_with_b = gpu.mem_info()[0]
+    squatters = [upload(gpu, (n,), np.full(n, -1000, np.float32)) for _ in range(4)]  # would land on b's block had finish() freed it
+    for _ in range(3):
+        gpu.queue().submit([cb])
+    assert np.array_equal(a.read(dev), np.full(n, 9, np.float32))
+    del squatters
+    gc.collect()
+    gpu.sync()
+    assert abs(gpu.mem_info()[0] - free_with_b) < (4 << 20)
+    del cb
+    gc.collect()                                                  # wg_cmdbuf_destroy: the queued wg_buf_destroy(b) runs now
+    gpu.sync()
+    assert gpu.mem_info()[0] >= free_with_b + n * 4 - (4 << 20), "b's 16 MiB must come back when the command buffer goes"
+
+
 # --------------------------------------------------------------------------------------------------------
 # f16 Gemm (extension: no reference kernel -- contract defined in DESIGN.md: f16 in, f32 accumulate, one RNE rounding)
 # --------------------------------------------------------------------------------------------------------

@@ -84,6 +84,7 @@ def _load() -> ctypes.CDLL:
         "wg_ctx_device": (ci, [vp]),
         "wg_ctx_stream": (vp, [vp]),
         "wg_ctx_device_info": (ci, [vp, cp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(u64)]),
+        "wg_ctx_mem_info": (ci, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64)]),
         "wg_ctx_reserve_workspace": (ci, [vp, sz]),
         "wg_debug_f16_balance_plan": (ci, [ctypes.POINTER(ctypes.c_double), u32, u32, ci, ctypes.POINTER(u32), u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]),
         "wg_ctx_f16_balance_info": (ci, [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ci), ctypes.POINTER(u32), ctypes.POINTER(u32)]),

@@ -543,7 +543,10 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         }
         return best_ns;
     };
-    if (ctx->tuning[WG_TUNE_F32_MID] != 0 && !mid_forced && (M <= 64 || N <= 64) && M >= 48 && N >= 48 && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
+    // (a forced few-column kernel -- WG_TUNE_F32_SKINNY / _PANELS = 1, "whenever applicable" -- goes past this early path to the kernel it names)
+    const bool other_forced = ctx->tuning[WG_TUNE_F32_SKINNY] == 1 || ctx->tuning[WG_TUNE_F32_PANELS] == 1;
+    if (ctx->tuning[WG_TUNE_F32_MID] != 0 && !mid_forced && !other_forced && (M <= 64 || N <= 64) && M >= 48 && N >= 48 &&
+        wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
         double est;
         uint32_t ns = mid_split_plan(est);
         // ... and the same tile UNSPLIT when the output is about one to two 64 x 64 tiles per CU (the few-row / few-column paths below stream the long operand

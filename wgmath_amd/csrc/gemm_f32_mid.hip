@@ -214,6 +214,7 @@ __global__ __launch_bounds__(kThreads, (WT_M * WT_N == 4 ? 2 : 3)) void gemm_f32
         // substep 1: multiply set 1; tile t + 1 has landed (sent a whole tile ago) -- publish it and read its first fragments
         mfma_step(1, 0);
         wait_dma_keep<PPW>();
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's fragment ds_reads have returned before another wave's DMA may overwrite the slot
         __builtin_amdgcn_s_barrier();
         read_frags(nxt, 0, 0);
 #pragma unroll
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
         mfma_step(set, 0);
         mfma_step(set, 1);
         wait_dma_keep<PPW>(); // tile t + 1 (sent two barriers ago) has landed; tile t + 2's pieces may stay in flight
+        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): "all fragments are in registers" made true before the slot is handed to the DMA
         __builtin_amdgcn_s_barrier();
         read_frags(next_slot(cur), set ^ 1);
         __builtin_amdgcn_sched_barrier(0);

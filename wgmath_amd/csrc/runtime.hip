@@ -82,19 +82,25 @@ int wg_ctx_bal_workspace(wg_ctx *ctx, size_t bytes, void **out) {
 }
 
 namespace {
-thread_local int t_capturing = 0;                         // recordings open on this thread
-thread_local std::vector<std::function<void()>> t_deferred; // destroy calls that arrived meanwhile
-void capture_ended() {
-    if (t_capturing > 0 && --t_capturing == 0) {
-        std::vector<std::function<void()>> run;
-        run.swap(t_deferred);
-        for (auto &f : run) f();
-    }
+thread_local int t_capturing = 0;                          // recordings open on this thread
+thread_local std::shared_ptr<wg_deferred_batch> t_batch;   // destroy calls that arrived meanwhile (shared with those recordings)
+void capture_began(wg_ctx *ctx) {
+    if (t_capturing++ == 0 || !t_batch) t_batch = std::make_shared<wg_deferred_batch>();
+    ctx->capture_batch = t_batch;
+    ctx->recording_thread = std::this_thread::get_id();
+}
+// The recording of `ctx` is over (on the thread that began it). Returns the batch for the command buffer to hold; dropping the returned pointer
+// without storing it (an abandoned recording) runs the queued destroys as soon as no other recording of this thread shares them.
+std::shared_ptr<wg_deferred_batch> capture_ended(wg_ctx *ctx) {
+    std::shared_ptr<wg_deferred_batch> batch = std::move(ctx->capture_batch);
+    ctx->capture_batch.reset();
+    if (t_capturing > 0 && --t_capturing == 0) t_batch.reset();
+    return batch;
 }
 } // namespace
-bool wg_defer_if_capturing(std::function<void()> fn) {
-    if (t_capturing == 0) return false;
-    t_deferred.push_back(std::move(fn));
+bool wg_defer_if_capturing(std::function<void()> fn, bool is_ctx) {
+    if (t_capturing == 0 || !t_batch) return false;
+    (is_ctx ? t_batch->ctx_items : t_batch->items).push_back(std::move(fn));
     return true;
 }
 
@@ -204,13 +210,18 @@ int wg_ctx_create_with_cu_count_one_xcd(int device, uint32_t cu_count, wg_ctx **
 
 int wg_ctx_destroy(wg_ctx *ctx) {
     if (!ctx) return WG_OK;
-    if (!ctx->recording && wg_defer_if_capturing([ctx] { (void)wg_ctx_destroy(ctx); })) return WG_OK; // (another context of this thread is recording)
+    if (!ctx->recording && wg_defer_if_capturing([ctx] { (void)wg_ctx_destroy(ctx); }, true)) return WG_OK; // (another context of this thread is recording)
     if (ctx->recording) { // destroyed in the middle of its own recording: end the capture first
+        if (ctx->recording_thread != std::this_thread::get_id()) // (thread-local capture: only the recording thread can end it, and its counters are its own)
+            return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_destroy: the context is recording on another thread; finish or destroy it there");
         hipGraph_t g = nullptr;
         (void)hipStreamEndCapture(ctx->stream, &g);
         if (g) (void)hipGraphDestroy(g);
         ctx->recording = false;
-        capture_ended();
+        // the recording is abandoned: what was queued during it runs now -- unless another recording is still open on this thread, which then shares
+        // the batch (t_batch holds it) and passes it on to its own command buffer
+        std::shared_ptr<wg_deferred_batch> abandoned = capture_ended(ctx);
+        abandoned.reset();
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -249,6 +260,16 @@ int wg_ctx_device_info(const wg_ctx *ctx, char *name256, int *compute_units, int
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
     if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return WG_OK;
+}
+
+int wg_ctx_mem_info(const wg_ctx *ctx, uint64_t *free_bytes, uint64_t *total_bytes) {
+    if (!ctx) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_mem_info: ctx is NULL");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    WG_HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
     return WG_OK;
 }
 
@@ -440,7 +461,7 @@ int wg_encoder_begin(wg_ctx *ctx) {
     WG_HIP_TRY(hipSetDevice(ctx->device));
     WG_HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
     ctx->recording = true;
-    ++t_capturing;
+    capture_began(ctx);
     return WG_OK;
 }
 
@@ -448,10 +469,14 @@ int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out) {
     if (!ctx || !out) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: NULL argument");
     *out = nullptr;
     if (!ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: not recording");
+    if (ctx->recording_thread != std::this_thread::get_id())
+        return wg_set_error(WG_ERR_INVALID_ARG, "wg_encoder_finish: called from another thread than wg_encoder_begin (thread-local capture)");
     ctx->recording = false;
     hipGraph_t graph = nullptr;
     const hipError_t ec = hipStreamEndCapture(ctx->stream, &graph);
-    capture_ended(); // destroy calls that arrived while this thread was recording run now
+    // Destroy calls that arrived while this thread was recording: the command buffer holds them until it is destroyed itself (a dropped buffer the
+    // recording used must outlive every replay); on any failure below `deferred` goes out of scope and they run at once.
+    std::shared_ptr<wg_deferred_batch> deferred = capture_ended(ctx);
     WG_HIP_TRY(ec);
     hipGraphExec_t exec = nullptr;
     hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -464,6 +489,7 @@ int wg_encoder_finish(wg_ctx *ctx, wg_cmdbuf **out) {
     cb->ctx = ctx;
     cb->graph = graph;
     cb->exec = exec;
+    cb->deferred = std::move(deferred);
     ctx->live_cmdbufs++;
     *out = cb;
     return WG_OK;
@@ -490,7 +516,9 @@ int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf) {
         for (void *p : ctx->retired_scratch) (void)hipFree(p);
         ctx->retired_scratch.clear();
     }
+    std::shared_ptr<wg_deferred_batch> deferred = std::move(cmdbuf->deferred);
     delete cmdbuf;
+    deferred.reset(); // the last command buffer of the recording(s) it was queued under: the buffers dropped meanwhile are freed now
     return WG_OK;
 }
 

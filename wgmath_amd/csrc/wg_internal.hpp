@@ -9,15 +9,31 @@
 #include <cstdint>
 #include <cstdio>
 #include <functional>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/wgebra_hip.h"
+
+// Destroy calls that arrived while a thread was recording (see wg_defer_if_capturing). The batch belongs to every recording that was open on that
+// thread meanwhile and, after wg_encoder_finish, to their command buffers: the calls run when the LAST of those is destroyed (or at once if a
+// recording is abandoned) -- a buffer a recorded dispatch used and the host dropped during the recording stays allocated for as long as something can
+// still replay into it. Context destroys run last (the buffer destroys before them dereference buf->ctx).
+struct wg_deferred_batch {
+    std::vector<std::function<void()>> items, ctx_items;
+    ~wg_deferred_batch() {
+        for (auto &f : items) f();
+        for (auto &f : ctx_items) f();
+    }
+};
 
 struct wg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;
     bool recording = false;
+    std::thread::id recording_thread;                 // the thread that called wg_encoder_begin (thread-local capture mode)
+    std::shared_ptr<wg_deferred_batch> capture_batch; // while recording: the deferred-destroy batch of the recording thread
     void *workspace = nullptr; // scratch for split reductions (GEMV partials)
     size_t workspace_bytes = 0;
     void *tr_workspace = nullptr; // second scratch: transposed operand of the row-major GemmTr (lives across the GEMM that may use `workspace`)
@@ -58,9 +74,9 @@ struct wg_ctx {
 // A destroy call that arrives while THIS THREAD records a command buffer (hipStreamBeginCapture, thread-local mode) must not run now: hipFree /
 // hipStreamSynchronize from the capturing thread are prohibited and invalidate the capture. It happens -- a garbage-collected host object
 // (Python's cyclic GC, a Rust drop at scope end) owns a buffer or a command buffer -- and it is legal in the reference (wgpu keeps a dropped
-// buffer alive until the submission using it retires). Returns true if `fn` was queued: it then runs right after the recording ends
-// (wg_encoder_finish), otherwise the caller runs it itself.
-bool wg_defer_if_capturing(std::function<void()> fn);
+// buffer alive until the submission using it retires). Returns true if `fn` was queued into the thread's wg_deferred_batch (it runs when the last
+// command buffer recorded meanwhile is destroyed), otherwise the caller runs it itself. `is_ctx`: a context destroy (ordered after the others).
+bool wg_defer_if_capturing(std::function<void()> fn, bool is_ctx = false);
 void wg_ctx_register_async_error(wg_ctx *ctx, uint32_t *word, const char *what, uint32_t *dev_word = nullptr); // dev_word: a device-side twin cleared with it
 void wg_ctx_unregister_async_error(wg_ctx *ctx, uint32_t *word);
 int wg_ctx_check_async(wg_ctx *ctx); // WG_ERR_HIP + message "<what> <word - 1>" if a registered word is set (and clears it)
@@ -80,6 +96,7 @@ struct wg_cmdbuf {
     wg_ctx *ctx = nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    std::shared_ptr<wg_deferred_batch> deferred; // destroys that arrived during the recording: released (and, by the last holder, run) in wg_cmdbuf_destroy
 };
 
 struct wg_timestamps {
@@ -145,7 +162,8 @@ int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, fl
 
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f);
-// gemm_f32_mid.hip: bm x bn tiles (128 x 128, 128 x 64, 64 x 128 on 2 x 2 waves; 64 x 64, 64 x 32, 32 x 64 with K split over the waves), whole K per workgroup;
+// gemm_f32_mid.hip: bm x bn tiles (128 x 128, 128 x 64, 64 x 128 on 2 x 2 waves; 64 x 64, 64 x 32, 32 x 64 with K split over the waves), whole K per workgroup
+// for nsplit = 1; nsplit >= 2 cuts K across workgroups too (f32 slabs in the context's workspace + a reduce launch: few tiles, long K);
 // _ok: the shapes / strides it takes
 bool wgk_gemm_f32_mid_ok(uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, wgk_mat m1, wgk_mat m2);
 int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,

@@ -297,6 +297,12 @@ class GpuInstance:
             info["stream_compute_units"] = int(self._stream_compute_units)
         return info
 
+    def mem_info(self) -> tuple:
+        """(free, total) bytes of device memory right now."""
+        free, total = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib.wg_ctx_mem_info(self._ctx.handle, ctypes.byref(free), ctypes.byref(total)))
+        return free.value, total.value
+
     def device(self) -> Device:
         return self._device
 
