@@ -92,12 +92,33 @@ def time_port(C, run, work_items: int, budget_s: float):
 # ------------------------------------------------------------------------------------------------------------
 # synthetic data: seeded, U[-1,1) (full-range random operands: zero/constant fills flatter the clocks)
 # ------------------------------------------------------------------------------------------------------------
+# Operand distribution (SURVEY 8(d) "inputs"): "pm1" = U[-1, 1) (the headline: sign bits toggle, the harder case for a power-capped part);
+# "u01" = U[0, 1), the reference's own (`GpuTensor::new_random`, gemm.rs:152 / nalgebra `new_random`) -- reported next to it as *_u01 workloads and
+# `c3_*_u01` / `c5_*_u01` targets; "zero" = experiments only (zero operands take the chip off its power cap: kernel time then measures cycles).
+VALUES = os.environ.get("WG_BENCH_VALUES", "pm1")
+
+
+class values_as:
+    """`with values_as("u01"):` -- the distribution rand_block draws from inside the block."""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        global VALUES
+        self.saved, VALUES = VALUES, (self.v or VALUES)
+
+    def __exit__(self, *exc):
+        global VALUES
+        VALUES = self.saved
+
+
 def rand_block(seed: int, n: int, dtype) -> np.ndarray:
     rng = np.random.default_rng(seed)
-    if os.environ.get("WG_BENCH_VALUES") == "u01":  # the reference tests' distribution (`new_random`: U[0,1)); experiments only
+    if VALUES == "u01":
         return rng.random(n, dtype=np.float32).astype(dtype)
-    if os.environ.get("WG_BENCH_VALUES") == "zero":  # experiments only: zero operands take the chip off its power cap, so the clock pins at
-        return np.zeros(n, dtype)                     # its maximum and kernel time measures CYCLES (schedule quality), not energy per flop
+    if VALUES == "zero":
+        return np.zeros(n, dtype)
     return (rng.random(n, dtype=np.float32) * np.float32(2) - np.float32(1)).astype(dtype)
 
 
@@ -172,8 +193,9 @@ class GemmWorkload(Workload):
     metric = "gemm_tflops"
     unit = "TFLOP/s"
 
-    def __init__(self, name, M, N, K, dtype, trans=False):
+    def __init__(self, name, M, N, K, dtype, trans=False, values=None):
         self.name, self.M, self.N, self.K = name, M, N, K
+        self.values = values  # operand distribution of THIS workload (None: the run's, --dist)
         self.dtype = dtype
         self.trans = trans  # GemmTr: m1 is stored K x M (op(A) = m1^T)
         self.np_dtype = np.float32 if dtype == "f32" else np.float16
@@ -192,8 +214,9 @@ class GemmWorkload(Workload):
         if self.M % (4 * world):
             raise ValueError(f"M={self.M} does not split into {world} vec4-aligned row blocks")
         self.Mg = self.M // world
-        self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
-        self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
+        with values_as(self.values):
+            self.A = device_random(wg, gpu, (self.K, self.Mg) if self.trans else (self.Mg, self.K), self.np_dtype, 0xA000 + rank)
+            self.B = device_random(wg, gpu, (self.K, self.N), self.np_dtype, 0xB000)  # replicated
         S = wg.BufferUsages
         self.C = wg.TensorBuilder.matrix(self.M, self.N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(gpu.device(), self.np_dtype)
         self.gemm = wg.Gemm.from_device(gpu.device())
@@ -217,6 +240,16 @@ class GemmWorkload(Workload):
             cus = int(self.gpu.adapter()["compute_units"])  # ONE scheduler-driven launch per step: panels need not be whole rounds of the masked stream
         self.panel_cols = plan_panel_cols(self.Mg, self.N, cus, tile=256 if self.dtype == "f16" else 128)
         self.npanels = -(-self.N // self.panel_cols)
+        self.panel_widths = None
+        # Tapered tail (wg_gemm_sharded_panels) for the engine that runs a step as ONE kernel: equal panels, then narrower and narrower ones, each at
+        # least `taper` times the one before it (taper = exchange time / Gemm time of a panel, ~0.7 at 60 GB/s per link and 1.4 PFLOP/s whatever the
+        # rank count: both scale with the rows per rank) -- every exchange still hides under the next panel's Gemm and the one exchange nothing
+        # hides is that of a single tile column (1/8 of a panel). WG_BENCH_TAPER=0 switches it off, another value sets the ratio.
+        taper = float(os.environ.get("WG_BENCH_TAPER", "0.72"))
+        if rccl and self.dtype == "f16" and taper > 0 and self.panel_cols % 256 == 0 and self.npanels > 2:
+            from wgmath_amd.sharded import tapered_panels
+            self.panel_widths = tapered_panels(self.N, self.panel_cols, taper)
+            self.npanels = len(self.panel_widths)
         self.gather_mode = GatherMode.PEER_STAGED if mode == "staged" else GatherMode.RCCL
         if rccl and self.dtype == "f16":  # the one-launch form defers its last panel too (two cubes by step parity inside the library)
             comm.set_pipelined(os.environ.get("WG_BENCH_PIPELINED", "1") != "0")
@@ -232,7 +265,7 @@ class GemmWorkload(Workload):
         if self.dist is None:
             self.gemm.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.C, self.A, self.B, self.variant)
             return
-        self.dist["comm"].sharded_gemm(self.C, self.A, self.B, int(self.variant), self.gather_mode, self.panel_cols)
+        self.dist["comm"].sharded_gemm(self.C, self.A, self.B, int(self.variant), self.gather_mode, self.panel_widths or self.panel_cols)
 
     def finish(self):
         """End of a run of steps (inside the timed region): complete what pipelined steps deferred."""
@@ -278,7 +311,8 @@ class GemmWorkload(Workload):
                 A = self.A.read(gpu.device())
             else:  # the peer's row block, regenerated the way device_random filled it (one seeded block, tiled)
                 n = self.Mg * self.K
-                blk = rand_block(0xA000 + g, min(n, 1 << 24), self.np_dtype)
+                with values_as(self.values):
+                    blk = rand_block(0xA000 + g, min(n, 1 << 24), self.np_dtype)
                 A = np.resize(blk, n)
             A = (A.reshape(self.K, self.Mg, order="F").T if self.trans else A.reshape(self.Mg, self.K, order="F"))[rows].astype(np.float64)
             got = np.empty((rows.size, cols.size))
@@ -572,6 +606,11 @@ WORKLOADS = {
     "gemm_f32_ts_65536x512x4096": lambda: GemmWorkload("gemm_f32_ts_65536x512x4096", 65536, 512, 4096, "f32"),
     "gemmtr_f16_8192": lambda: GemmWorkload("gemmtr_f16_8192", 8192, 8192, 8192, "f16", trans=True),
     "gemmtr_f16_32768": lambda: GemmWorkload("gemmtr_f16_32768", 32768, 32768, 32768, "f16", trans=True),
+    # the same products on the reference's own operand distribution, U[0, 1) (gemm.rs:152 `new_random`); the clock of a power-capped part depends on it
+    "gemm_f16_8192_u01": lambda: GemmWorkload("gemm_f16_8192_u01", 8192, 8192, 8192, "f16", values="u01"),
+    "gemmtr_f16_8192_u01": lambda: GemmWorkload("gemmtr_f16_8192_u01", 8192, 8192, 8192, "f16", trans=True, values="u01"),
+    "gemm_f16_32768_u01": lambda: GemmWorkload("gemm_f16_32768_u01", 32768, 32768, 32768, "f16", values="u01"),
+    "gemm_f32_4096_u01": lambda: GemmWorkload("gemm_f32_4096_u01", 4096, 4096, 4096, "f32", values="u01"),
     # short K on many tiles: the per-tile prologue / pipeline drain / epilogue weigh most here (A/B shapes of tools/ab2.sh)
     "gemm_f16_8192x8192x512": lambda: GemmWorkload("gemm_f16_8192x8192x512", 8192, 8192, 512, "f16"),
     "gemm_f16_8192x8192x2048": lambda: GemmWorkload("gemm_f16_8192x8192x2048", 8192, 8192, 2048, "f16"),
@@ -592,7 +631,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f32_4096", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
@@ -968,6 +1007,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--dist", default=VALUES, choices=["pm1", "u01", "zero"],
+                    help="operand distribution of the run: pm1 = U[-1,1) (default, the headline), u01 = U[0,1) (the reference's new_random); the *_u01 "
+                         "secondary workloads always use u01")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")
     ap.add_argument("--skip", default="", help="comma-separated secondary workloads to skip (e.g. under rocprofv3)")
@@ -978,6 +1020,9 @@ def main():
                          "staged contiguous peer copies (+ relayout), or auto = a short trial of each as a fresh child group, the timed steps on the fastest")
     ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing test without a GPU (gloo, host arithmetic)")
     args = ap.parse_args()
+    global VALUES
+    VALUES = args.dist
+    os.environ["WG_BENCH_VALUES"] = args.dist  # (self-launched ranks inherit it)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))  # before anything touches the GPU
@@ -1182,7 +1227,7 @@ def main():
         engine = {"rccl": "RCCL all-gather", "rccl_cus4": "RCCL all-gather",
                   "staged": "staged peer-copy gather (one SDMA engine per link + relayout)"}[DIST["mode"]]
         par = f"m-shard x{world} + {engine}"
-        cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels,
+        cfg_extra = {"ranks": dist.get_world_size(), "gather_engine": DIST["mode"], "panel_cols": w.panel_cols, "panels": w.npanels, "panel_tail": ",".join(str(x) for x in (w.panel_widths or [])[-8:]),
                      "all_gather_bytes_per_step": int(w.gather_bytes_per_step()), "stream_compute_units": info.get("stream_compute_units", info["compute_units"]),
                      "comm_compute_units": int(info["compute_units"]) - int(info.get("stream_compute_units", info["compute_units"])),
                      "rccl_reported_ranks": DIST["comm"].reported_size if DIST["comm"].has_collectives else 0,  # ncclCommCount: what RCCL itself says
@@ -1249,28 +1294,34 @@ def main():
         by = {o["workload"]: o for o in others if "roofline" in o}
         targets = {}
 
-        def put(prefix, o, unit_key):
+        def put(prefix, o, unit_key, brief=False):  # brief: value + clock only (the tail the driver keeps is 2000 characters)
             if o is None:
                 return
             rf = o["roofline"]
             targets[f"{prefix}_{unit_key}"] = round(o["value"], 1)
-            targets[f"{prefix}_frac"] = rf["frac"]
+            if not brief:
+                targets[f"{prefix}_frac"] = rf["frac"]
             if "clock_ghz_measured" in rf:
                 targets[f"{prefix}_ghz"] = rf["clock_ghz_measured"]
-            if "frac_of_ceiling" in rf:
+            if "frac_of_ceiling" in rf and not brief:
                 targets[f"{prefix}_frac_of_ceiling"] = rf["frac_of_ceiling"]
 
         head = {"workload": w_name, "value": value, "roofline": roof}
         put("c5_gemm_f16_32768", head if w_name == "gemm_f16_32768" else by.get("gemm_f16_32768"), "tflops")
         put("c3_gemm_f16_8192", head if w_name == "gemm_f16_8192" else by.get("gemm_f16_8192"), "tflops")
         put("c3_gemmtr_f16_8192", by.get("gemmtr_f16_8192"), "tflops")
+        # the reference's own distribution, U[0, 1) (gemm.rs:152), beside the U[-1, 1) headline figures
+        put("c5_gemm_f16_32768_u01", by.get("gemm_f16_32768_u01"), "tflops", brief=True)
+        put("c3_gemm_f16_8192_u01", by.get("gemm_f16_8192_u01"), "tflops", brief=True)
+        put("c3_gemmtr_f16_8192_u01", by.get("gemmtr_f16_8192_u01"), "tflops", brief=True)
+        put("c2_gemm_f32_4096_u01", by.get("gemm_f32_4096_u01"), "tflops", brief=True)
         put("c2_gemm_f32_4096", head if w_name == "gemm_f32_4096" else by.get("gemm_f32_4096"), "tflops")
         put("c4_gemv", by.get("gemv_f32_4096x65536"), "gbs")
         put("c4_gemvtr", by.get("gemvtr_f32_65536x4096"), "gbs")
         put("c4_reduce", by.get("reduce_f32_4096x65536"), "gbs")
-        put("op_assign", by.get("op_assign_f32_256M"), "gbs")
-        put("gemm_f16_2048", by.get("gemm_f16_2048"), "tflops")
-        put("gemm_f32_2048", by.get("gemm_f32_2048"), "tflops")
+        put("op_assign", by.get("op_assign_f32_256M"), "gbs", brief=True)
+        put("gemm_f16_2048", by.get("gemm_f16_2048"), "tflops", brief=True)
+        put("gemm_f32_2048", by.get("gemm_f32_2048"), "tflops", brief=True)
         for key, name in (("c1_gemv_1024_us", "gemv_f32_1024"), ("c1_gemv_1024_graph_us", "gemv_f32_1024_graph")):
             if name in by:
                 targets[key] = by[name]["roofline"].get("dispatch_us")
@@ -1295,7 +1346,8 @@ def main():
             "metric": w_metric, "value": round(value, 3), "unit": w_unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "strong" if w_is_gemm else "weak", "vs_baseline": None, "dtype": w_dtype,
-            "data": "synthetic (seeded U[-1,1): one 16 Mi-element random block tiled over each operand, resident in HBM before the timed region)",
+            "data": f"synthetic (seeded {'U[0,1)' if VALUES == 'u01' else 'zeros' if VALUES == 'zero' else 'U[-1,1)'}: one 16 Mi-element random block tiled over each operand, resident in HBM "
+                    "before the timed region; *_u01 workloads: U[0,1), the reference's new_random)",
             "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra),
             "roofline": roof, "cpu_baseline": main_cpu, "checks": checks, "others": others,
             "targets": targets,  # LAST key, scalars only: BASELINE configs 1-5 at a glance (value, fraction of the 8 TB/s / 2.5 PF / 157.3 TF peak, measured clock)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WGEBRA_HIP_ABI_VERSION 3 /* 3: the SDMA rect-copy exchange engine (gather mode 1, wg_comm_copy_engine, wg_gemm_sharded's peer_out) is gone;
+#define WGEBRA_HIP_ABI_VERSION 4 /* 4: wg_gemm_sharded_panels (ragged N-panels), wg_ctx_mem_info, geometry ops 15-18; 3: the SDMA rect-copy exchange engine (gather mode 1, wg_comm_copy_engine, wg_gemm_sharded's peer_out) is gone;
                                     wg_comm_reported_size, wg_debug_*; non-vec4 views compute staged; async time-outs surface in wg_ctx_sync */
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -400,6 +400,13 @@ int wg_comm_join(wg_comm *comm);    /* the context's stream waits for the collec
  * launches, on < 0 (default) decides by engine: RCCL on -- the scheduler-driven launch does not care how many CUs its stream has, so
  * RCCL's copy kernels need only 8 of them instead of 32 --, staged off (measured 1-2 % slower than 16 synchronised one-round launches). */
 int wg_comm_set_one_launch(wg_comm *comm, int on);
+/* Diagnostics: with on != 0 every later wg_gemm_sharded call stamps the context's stream right before and right after each "wait for panel p's
+ * exchange" (a pair of timing events; a few microseconds of host time per panel -- leave it off in timed regions). wg_comm_wait_times synchronises
+ * the context, returns (panel, milliseconds the compute stream stood still) for up to `capacity` waits since the last call, oldest first, and
+ * starts over. An exchange that hid under the Gemms reads ~0; a slow link shows up as the waits of a step's FIRST relayouts, a slow rank as waits
+ * on every panel of its peers, the un-hidden tail as the last panel's wait. */
+int wg_comm_set_wait_timing(wg_comm *comm, int on);
+int wg_comm_wait_times(wg_comm *comm, uint32_t *panels, float *ms, uint32_t capacity, uint32_t *count);
 int wg_comm_set_pipelined(wg_comm *comm, int on); /* (a step with ONE panel always completes in its call: deferring it would let a rank run two steps ahead of a peer) */
 int wg_comm_flush(wg_comm *comm);   /* host-blocking: every peer copy this rank issued has landed */
 int wg_comm_barrier(wg_comm *comm); /* flush + a one-element all-reduce joined into the context: all ranks' earlier exchanges are complete */
@@ -430,6 +437,14 @@ int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_s
 int wg_gemm_sharded(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols,
                     wg_buf *out, wg_view_shape out_shape,
                     const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
+/* The same with the N-panels' widths given one by one (`npanels` column counts, multiples of 4 summing to N): a TAPERED TAIL -- equal panels, then a
+ * few narrower and narrower ones -- leaves only a narrow last panel's exchange exposed at the end of a step, and every panel's exchange still hides
+ * under the next panel's Gemm as long as a panel is at least (exchange time / Gemm time) of the one before it. The one-launch forms
+ * (wg_comm_set_one_launch) take lists of the shape "n equal panels of whole 256-column tiles, then 1 .. 8 other panels of whole tiles, the last one
+ * whatever is left"; any other list runs panel by panel. Results are bit for bit those of wg_gemm_sharded. */
+int wg_gemm_sharded_panels(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, const uint32_t *panel_widths, uint32_t npanels,
+                           wg_buf *out, wg_view_shape out_shape,
+                           const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);
 
 /* ------------------------------------------------------------------------------------------------ */
 /* record / replay: CommandEncoder -> finish() -> CommandBuffer -> Queue::submit, as a hipGraph      */

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(_lib.lib._wg_signatures), "the ctypes binding and the header disagree on the entry points"
     # 3: the SDMA rect-copy exchange engine is gone (gather mode 1, wg_comm_copy_engine, peer_out), + wg_comm_reported_size, wg_debug_clock_*, wg_debug_mfma_ceiling
     hdr = open(_lib.HEADER_PATH).read()
-    assert _lib.lib.wg_abi_version() == _lib.ABI_VERSION == 3 and f"#define WGEBRA_HIP_ABI_VERSION {_lib.ABI_VERSION} " in hdr
+    assert _lib.lib.wg_abi_version() == _lib.ABI_VERSION == 4 and f"#define WGEBRA_HIP_ABI_VERSION {_lib.ABI_VERSION} " in hdr
 
 
 def test_exported_symbols_are_plain_c():

@@ -147,3 +147,41 @@ def test_ragged_panel_plan():
         assert pl.element_index(row, col) == o.offset + i + j * o.stride
     with pytest.raises(ValueError):
         MShardPlan(64, 40, 8, 2, panel_cols=(16, 16, 4, 2))
+
+
+def _tail_timeline(widths, ratio):
+    """Exposed exchange time at the end of a step, in units of "Gemm time of one tile column": panel p's Gemm takes widths[p], its exchange
+    ratio * widths[p]; the exchanges run one after the other on their own stream, each after its panel's Gemm."""
+    t_gemm, t_exch = 0.0, 0.0
+    for w in widths:
+        t_gemm += w
+        t_exch = max(t_exch, t_gemm) + ratio * w
+    return t_exch - t_gemm
+
+
+@pytest.mark.parametrize("N,main,ratio", [(32768, 2048, 0.72), (32768, 2048, 0.5), (8192, 2048, 0.72), (8448, 2048, 0.7), (32768 + 128, 2048, 0.72),
+                                          (32768, 4096, 0.72), (16384, 1024, 0.72), (32768, 2304, 0.72), (4096, 2048, 0.72), (2048, 2048, 0.7), (256, 256, 0.7)])
+def test_tapered_panel_plan(N, main, ratio):
+    """The bench's N-panels with a tapered tail (wgmath_amd.sharded.tapered_panels): what the one-launch kernels take (equal panels of whole
+    tiles, then <= 8 others, the last one the rest), widths never growing, and -- the point of it -- the exchange left exposed at the end of a
+    step no longer that of a full panel."""
+    from wgmath_amd.sharded import MShardPlan, tapered_panels
+    w = tapered_panels(N, main, ratio)
+    assert sum(w) == N and all(x > 0 for x in w)
+    assert all(x % 256 == 0 for x in w[:-1]) and w[-1] % 4 == 0
+    n_main = 0
+    while n_main < len(w) and w[n_main] == main:
+        n_main += 1
+    tail = w[n_main:]
+    assert len(tail) <= 8 and (n_main >= 1 or len(w) == 1)
+    assert all(a >= b for a, b in zip(w[:-1], w[1:-1] + [w[-1] - N % 256])), f"widths must not grow: {w}"
+    MShardPlan(8192, N, 64, 4, panel_cols=tuple(w))  # a valid ragged plan of the host-side planner too
+    if N >= 4 * main:
+        tiles = [x / 256 for x in w]
+        uniform = [main / 256] * (N // main)
+        assert tiles[-1] < 2.0, "the last panel is one tile column (plus the fraction of a ragged N)"
+        assert _tail_timeline(tiles, ratio) <= 0.5 * _tail_timeline(uniform, ratio), (w, _tail_timeline(tiles, ratio), _tail_timeline(uniform, ratio))
+    with pytest.raises(ValueError):
+        tapered_panels(N, main + 4, ratio)
+    with pytest.raises(ValueError):
+        tapered_panels(N, main, 1.0)

@@ -281,16 +281,20 @@ def _staged_one_launch_worker(rank, world, port, q):
         dist.barrier()
         comm.set_pipelined(True)
         results = {}
-        for one in (False, True):
-            comm.set_one_launch(one)
+        # "taper": the one-launch form on a tapered tail (wg_gemm_sharded_panels): two equal panels, then 6, 4, 3, 2, 1, 1 tile columns -- the same
+        # tiles and chains as any other split, so the same bits; the slot layout (and so the peers' copies) is another one
+        taper = [2048, 2048, 1536, 1024, 768, 512, 256, 256]
+        assert sum(taper) == N
+        for one in (False, True, "taper"):
+            comm.set_one_launch(bool(one))
             tcs = [wg.TensorBuilder.matrix(M, N, U).build_init(dev, np.full(M * N, np.nan, np.float16)) for _ in range(nsteps)]
             for tb, tc in zip(tbs, tcs):
-                comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, panel)
+                comm.sharded_gemm(tc, ta, tb, wg.GemmVariant.Gemm, GatherMode.PEER_STAGED, taper if one == "taper" else panel)
             comm.join()
             results[one] = [tc.read(dev).view(np.uint16).copy() for tc in tcs]
             comm.flush()
             dist.barrier()
-        same = all(np.array_equal(x, y) for x, y in zip(results[False], results[True]))
+        same = all(np.array_equal(x, y) for x, y in zip(results[False], results[True])) and all(np.array_equal(x, y) for x, y in zip(results["taper"], results[True]))
         A64 = A.astype(np.float64)
         rows = np.unique(rng.integers(0, M, 64))
         ok = True

@@ -251,6 +251,59 @@ def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus,
 
 
 @pytest.mark.parametrize("engine", ["rccl", "staged"])
+@pytest.mark.parametrize("M,K,N,widths,one_launch_shape", [
+    (8192, 512, 8192, (2048, 2048, 1536, 1024, 768, 512, 256), True),            # two equal panels, then 6, 4, 3, 2, 1 tile columns
+    (4096, 512 + 32, 8192 + 128, (2048, 2048, 2048, 1024, 512, 256, 384), True),  # K remainder; N not a multiple of the tile: the ragged rest in the last panel
+    (8192, 512, 8192, (4096, 2048, 1024, 512, 256, 256), True),                   # ONE main panel and a tail of five
+    (4096, 512, 8192, (1024, 2048, 2048, 3072), False),                           # not "equal panels, then a tail": runs panel by panel
+])
+def test_sharded_gemm_tapered_tail_is_bit_identical_to_uniform_panels(engine, M, K, N, widths, one_launch_shape):
+    """wg_gemm_sharded_panels: the N-panels' widths given one by one. A tapered tail changes WHEN a tile's columns are exchanged, never how a
+    tile is computed: in the one-launch form the result must equal, bit for bit, the one-launch result of a uniform split (same tiles, same
+    accumulation chains) -- slot layout of the staging cube, per-panel counters and relayouts all follow the ragged plan. A list that is not of
+    the one-launch shape runs panel by panel and is held to the f64 bound."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    wg = _wg()
+    from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
+    inst = wg.GpuInstance.new(0)
+    dev = inst.device()
+    comm = Comm(inst, 1, 0, new_unique_id() if engine == "rccl" else None)
+    rng = np.random.default_rng(M + K + N + len(widths))
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
+    A = wg.TensorBuilder.matrix(M, K, S_ALL).build_init(dev, a)
+    B = wg.TensorBuilder.matrix(K, N, S_ALL).build_init(dev, b)
+    mode = GatherMode.RCCL if engine == "rccl" else GatherMode.PEER_STAGED
+    if engine == "staged":
+        comm.stage_reserve(2 * M * N * 2)
+    comm.set_one_launch(True)
+    res = []
+    for pc in (2048, list(widths), list(widths)):
+        C = wg.TensorBuilder.matrix(M, N, S_ALL).build_init(dev, np.full(M * N, np.nan, np.float16))
+        comm.sharded_gemm(C, A, B, 0, mode, pc)
+        comm.join()
+        inst.sync()
+        res.append(C.read(dev).view(np.uint16).copy())
+    assert not np.isnan(res[1].view(np.float16)).any(), "unwritten elements"
+    assert np.array_equal(res[1], res[2])
+    if one_launch_shape:
+        assert np.array_equal(res[0], res[1]), "the tapered one-launch result differs from the uniform one-launch result"
+    A64, B64 = a.reshape(K, M).T.astype(np.float64), b.reshape(N, K).T.astype(np.float64)
+    rows = np.unique(rng.integers(0, M, 96))
+    truth, sabs = A64[rows] @ B64, np.abs(A64[rows]) @ np.abs(B64)
+    tol = U.f32_gate(K, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+    got = res[1].view(np.float16).reshape(N, M).T.astype(np.float64)
+    assert (np.abs(got[rows] - truth) <= tol).all()
+    # bad lists are refused with the reference-style precondition error, not run
+    for bad in ([2048, 2048], [N - 2, 2], [0, N]):
+        with pytest.raises(wg.WgError):
+            comm.sharded_gemm(C, A, B, 0, mode, bad)
+    comm.close()
+    inst.close()
+
+
+@pytest.mark.parametrize("engine", ["rccl", "staged"])
 def test_sharded_gemm_pipelined_steps_one_launch(engine):
     """Pipelined steps of the one-launch form (each call's last panel completes behind the NEXT call's kernel; two staging cubes by step
     parity), RCCL engine (1 rank) and staged engine: five back-to-back steps on different B and different outputs with no synchronisation

@@ -50,14 +50,15 @@ for P in Ps:
     # (WG_STAGED_NO_COPY) and the flags pre-set so that the wait kernels pass: what the contiguous per-link copies run BESIDE.
     # Panel by panel (round 2's form) and as ONE launch per step (round 3), on all 256 CUs; and on a 248-CU masked stream = the compute
     # side of the RCCL engine (the same kernel + the same relayouts; RCCL's own copy kernels run on the 8 CUs left over).
-    def staged_side(inst, cm, a_t, b_t, c_t, one_launch):
+    def staged_side(inst, cm, a_t, b_t, c_t, one_launch, panels=None):
+        panels = panels or panel
         cm.set_one_launch(one_launch)
         for _ in range(2):
-            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panel)
+            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panels)
         inst.sync()
         t0 = time.perf_counter()
         for _ in range(STEPS):
-            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panel)
+            cm.sharded_gemm(c_t, a_t, b_t, 0, GatherMode.PEER_STAGED, panels)
         inst.sync()
         return (time.perf_counter() - t0) / STEPS
 
@@ -85,6 +86,12 @@ for P in Ps:
         prepare_staged(gpu2, comm2)
         dt = staged_side(gpu2, comm2, A, B, C, True)
         res["rccl_compute_side_248_cus"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "stream_compute_units": 248}
+        # round 5: the same with the tapered tail bench.py now gives that engine (wg_gemm_sharded_panels): more, narrower panels at the end of a step
+        from wgmath_amd.sharded import tapered_panels
+        widths = tapered_panels(N, panel, float(os.environ.get("WG_BENCH_TAPER", "0.72")))
+        dt = staged_side(gpu2, comm2, A, B, C, True, widths)
+        res["rccl_compute_side_248_cus_tapered"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1),
+                                                    "stream_compute_units": 248, "panel_widths": widths}
         comm2.close()
         gpu2.close()
     del A, B, C
@@ -108,9 +115,21 @@ t1 = (time.perf_counter() - t0) / STEPS * 1e3
 out["single_gpu_best"] = {"ms_per_step": round(t1, 3), "tflops": round(2.0 * M * N * K / t1 / 1e9, 1), "what": "wg_gemm 32768^3, one launch, tile scheduler"}
 del A, B, C
 gpu.close()
-# measured beside busy SDMA engines (tools/cpp/sdma_probe2.cpp): Gemm slowdown with 1 / 3 / 7 engines at 60.7 GB/s each
 SLOW = {2: 1.006, 4: 1.023, 8: 1.048}
 ENGINE_GBS = 60.7
+
+
+def exposed_tail_ms(widths, step_ms, rows, slow):
+    """Timeline of one step: panel p's Gemm takes its share of the step's compute time, its exchange (one link at the engine rate) starts when the Gemm
+    and the previous panel's exchange are done; what is left of the exchanges when the last Gemm ends is exposed."""
+    t_gemm = t_exch = 0.0
+    for w in widths:
+        t_gemm += step_ms * slow * w / N
+        t_exch = max(t_exch, t_gemm) + rows * w * 2 / (ENGINE_GBS * 1e6)
+    return t_exch - t_gemm
+
+
+# measured beside busy SDMA engines (tools/cpp/sdma_probe2.cpp): Gemm slowdown with 1 / 3 / 7 engines at 60.7 GB/s each
 if t1:
     for P, r in out["ranks"].items():
         if "staged_compute_and_relayout" in r:
@@ -133,4 +152,14 @@ if t1:
                                                 "note": "wg_comm_set_pipelined: the last panel's gather + relayout run behind the next step's kernel"}
             r["expected_rccl_248"] = {"ms_per_step": round(t, 3), "speedup_vs_1_gpu": round(t1 / t, 3),
                                       "assumes": "RCCL's gather of a panel keeps up with the per-link rate measured for the copy engines (60.7 GB/s) on its 8 CUs; the last panel's gather is exposed"}
+            if "rccl_compute_side_248_cus_tapered" in r:
+                rt = r["rccl_compute_side_248_cus_tapered"]
+                sl = SLOW.get(int(P), 1.05)
+                uniform = [r["panel_cols"]] * (N // r["panel_cols"])
+                tail_u = exposed_tail_ms(uniform, rc["ms_per_step"], r["rows_per_rank"], sl)
+                tail_t = exposed_tail_ms(rt["panel_widths"], rt["ms_per_step"], r["rows_per_rank"], sl)
+                tt = max(rt["ms_per_step"] * sl, steady) + tail_t
+                r["expected_rccl_248_tapered"] = {"ms_per_step": round(tt, 3), "speedup_vs_1_gpu": round(t1 / tt, 3), "exposed_tail_ms": round(tail_t, 3),
+                                                  "exposed_tail_ms_uniform_panels_same_timeline": round(tail_u, 3),
+                                                  "assumes": "as expected_rccl_248 (plain, not pipelined); the tail from a per-panel timeline: panel p's gather starts when its Gemm and panel p-1's gather are done"}
 print(json.dumps(out, indent=1))

@@ -16,7 +16,7 @@ WG_OK, WG_ERR_DIM_MISMATCH, WG_ERR_PRECONDITION, WG_ERR_INVALID_ARG, WG_ERR_OUT_
     WG_ERR_UNSUPPORTED, WG_ERR_NO_DEVICE, WG_ERR_WORKSPACE = range(9)
 WG_GATHER_RCCL, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 2, 3  # (1 was the SDMA rect-copy engine: removed in ABI 3)
 WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
-ABI_VERSION = 3  # == WGEBRA_HIP_ABI_VERSION (checked when the library is loaded, and against the header by tests/test_abi_and_host.py)
+ABI_VERSION = 4  # == WGEBRA_HIP_ABI_VERSION (checked when the library is loaded, and against the header by tests/test_abi_and_host.py)
 WG_F32, WG_F16 = 0, 1
 WG_TUNE_F16_TILE, WG_TUNE_F16_SCHED, WG_TUNE_F32_SKINNY, WG_TUNE_F32_PANELS, WG_TUNE_F16_BALANCE, WG_TUNE_F32_MID, WG_TUNE_F32_MID_SPLIT = range(7)
 
@@ -136,6 +136,9 @@ def _load() -> ctypes.CDLL:
         "wg_comm_set_peer_stages": (ci, [vp, pvp, pvp]),
         "wg_cube_to_matrix": (ci, [vp, ci, vp, S, vp, S]),
         "wg_gemm_sharded": (ci, [vp, ci, ci, ci, u32, vp, S, vp, S, vp, S]),
+        "wg_comm_set_wait_timing": (ci, [vp, ci]),
+        "wg_comm_wait_times": (ci, [vp, ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]),
+        "wg_gemm_sharded_panels": (ci, [vp, ci, ci, ci, ctypes.POINTER(u32), u32, vp, S, vp, S, vp, S]),
         "wg_encoder_begin": (ci, [vp]),
         "wg_encoder_finish": (ci, [vp, pvp]),
         "wg_queue_submit": (ci, [vp, vp]),

@@ -105,7 +105,7 @@ struct wg_comm {
     uint32_t *wait_err = nullptr;    // pinned: set by the wait kernel when a peer's slot did not arrive within the timeout (registered with the context)
     uint64_t timeout_ticks = 3000000000ull; // wait kernel's patience in 100 MHz ticks (WG_COMM_TIMEOUT_MS at creation, default 30 s)
     uint32_t step = 0;
-    uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, panel_cols, element size of the previous staged call: the slot layout its events refer to
+    uint64_t staged_geom[4] = { 0, 0, 0, 0 }; // M, N, a hash of the panel widths, element size of the previous staged call: the slot layout its events refer to
     // one launch per step (f16): the rank's whole product is ONE kernel over all N-panels whose waves count themselves into panel_sync[p] as
     // their stores reach memory; the exchange of panel p waits for the full count (hipStreamWaitValue32) while the kernel works on
     bool can_wait_value = false;              // hipDeviceAttributeCanUseStreamWaitValue: without it every product launches panel by panel
@@ -117,6 +117,12 @@ struct wg_comm {
     // pipelined steps (wg_comm_set_pipelined): the wait + relayout of a call's LAST panel is deferred until the next call has enqueued its
     // first Gemm (or wg_comm_join / flush / barrier), so that the one exchange nothing of its own step can hide runs under the next step
     bool pipelined = false;
+    // diagnostics (wg_comm_set_wait_timing): a pair of timing events on the context's stream around every "wait for panel p's exchange" -- how long
+    // the compute stream actually stood still for each panel (0 when the exchange hid under the Gemms; a slow link shows up as the first panels' waits)
+    bool time_waits = false;
+    struct WaitStamp { hipEvent_t before = nullptr, after = nullptr; uint32_t panel = 0; };
+    std::vector<WaitStamp> wait_stamps;
+    size_t wait_used = 0;
     struct Pending {
         bool on = false;
         hipEvent_t after = nullptr; // RCCL engine: the panel's gather (an event of the communicator's stream) instead of the peers' flags
@@ -216,12 +222,34 @@ int comm_flush(wg_comm *c) { // host-blocking: every peer copy enqueued so far h
     return WG_OK;
 }
 
+// wait timing (diagnostics): stamp the context's stream right before / right after the wait for `panel`'s exchange
+int wait_begin(wg_comm *c, uint32_t panel) {
+    if (!c->time_waits) return WG_OK;
+    if (c->wait_used == c->wait_stamps.size()) {
+        wg_comm::WaitStamp w;
+        WG_HIP_TRY(hipEventCreate(&w.before));
+        WG_HIP_TRY(hipEventCreate(&w.after));
+        c->wait_stamps.push_back(w);
+    }
+    c->wait_stamps[c->wait_used].panel = panel;
+    WG_HIP_TRY(hipEventRecord(c->wait_stamps[c->wait_used].before, c->ctx->stream));
+    return WG_OK;
+}
+int wait_end(wg_comm *c) {
+    if (!c->time_waits) return WG_OK;
+    WG_HIP_TRY(hipEventRecord(c->wait_stamps[c->wait_used].after, c->ctx->stream));
+    ++c->wait_used;
+    return WG_OK;
+}
+
 int run_pending(wg_comm *c) { // the deferred last panel of the previous staged call: wait for its slots, relayout it
     if (!c->pending.on) return WG_OK;
     c->pending.on = false;
     const wg_comm::Pending &q = c->pending;
+    if (int rc = wait_begin(c, q.panel)) return rc;
     if (q.after) { // RCCL engine
         WG_HIP_TRY(hipStreamWaitEvent(c->ctx->stream, q.after, 0));
+        if (int rc = wait_end(c)) return rc;
         return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es);
     }
     if (c->nranks > 1) {
@@ -229,6 +257,7 @@ int run_pending(wg_comm *c) { // the deferred last panel of the previous staged 
                            c->seq_src + 64, c->timeout_ticks);
         WG_HIP_TRY(hipGetLastError());
     }
+    if (int rc = wait_end(c)) return rc;
     return launch_cube_to_matrix(c->ctx, q.src, q.dst, q.mg, q.np, (uint32_t)c->nranks, q.ld, q.es, c->nranks > 1 ? c->seq_src + 64 : nullptr);
 }
 
@@ -314,6 +343,11 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
 
 int wg_comm_destroy(wg_comm *c) {
     if (!c) return WG_OK;
+    for (auto &w : c->wait_stamps) {
+        if (w.before) (void)hipEventDestroy(w.before);
+        if (w.after) (void)hipEventDestroy(w.after);
+    }
+    c->wait_stamps.clear();
     (void)hipSetDevice(c->ctx->device);
     for (hipStream_t st : c->peer_stream)
         if (st) (void)hipStreamSynchronize(st);
@@ -360,6 +394,29 @@ uint64_t wg_comm_bytes_sent(const wg_comm *c) { return c ? c->bytes_sent : 0; }
 int wg_comm_set_one_launch(wg_comm *c, int on) {
     if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_one_launch: comm is NULL");
     c->one_launch = on < 0 ? -1 : (on != 0 ? 1 : 0);
+    return WG_OK;
+}
+
+int wg_comm_set_wait_timing(wg_comm *c, int on) {
+    if (!c) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_set_wait_timing: comm is NULL");
+    c->time_waits = on != 0;
+    c->wait_used = 0;
+    return WG_OK;
+}
+
+int wg_comm_wait_times(wg_comm *c, uint32_t *panels, float *ms, uint32_t capacity, uint32_t *count) {
+    if (!c || !count) return wg_set_error(WG_ERR_INVALID_ARG, "wg_comm_wait_times: NULL argument");
+    WG_HIP_TRY(hipSetDevice(c->ctx->device));
+    WG_HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    uint32_t n = 0;
+    for (size_t i = 0; i < c->wait_used && n < capacity; ++i, ++n) {
+        float t = 0.f;
+        WG_HIP_TRY(hipEventElapsedTime(&t, c->wait_stamps[i].before, c->wait_stamps[i].after));
+        if (panels) panels[n] = c->wait_stamps[i].panel;
+        if (ms) ms[n] = t;
+    }
+    *count = n;
+    c->wait_used = 0;
     return WG_OK;
 }
 
@@ -567,8 +624,11 @@ int wg_cube_to_matrix(wg_ctx *ctx, wg_dtype dtype, const wg_buf *cube, wg_view_s
 // ---------------------------------------------------------------------------------------------------------------
 // the M-sharded Gemm
 // ---------------------------------------------------------------------------------------------------------------
-int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols, wg_buf *out, wg_view_shape out_shape,
-                    const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
+// `widths` = the N-panels' column counts, left to right (multiples of 4 summing to N). The one-launch forms take lists of the shape "n equal panels
+// of whole 256-column tiles, then 1 .. 8 other panels of whole tiles (the last one: whatever is left)" -- a uniform split and a tapered tail are
+// both of that shape; any other list runs panel by panel.
+static int gemm_sharded_impl(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, const uint32_t *widths, uint32_t nwidths, wg_buf *out,
+                             wg_view_shape out_shape, const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
     if (!c || !out || !a_rows || !b) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): NULL argument");
     if (dtype != WG_F32 && dtype != WG_F16) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): unknown dtype %d", (int)dtype);
     if ((int)variant < 0 || (int)variant > 3) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm: unknown variant %d", (int)variant);
@@ -586,18 +646,45 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     if (M == 0 || N == 0) return WG_OK;
     if (mg % 4 || N % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): the row block (%u rows) and N=%u must be multiples of 4 (vec4 views, shape.wgsl:64-66)", mg, N);
     if (mode == WG_GATHER_RCCL && P > 1 && !c->nccl) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): WG_GATHER_RCCL needs a communicator created with a unique id");
-    if (panel_cols == 0) { // default: ~8 panels of whole 256-column tiles, so that all but the last exchange hides under a Gemm
-        panel_cols = N >= 2048 ? ((N / 8 + 255u) / 256u) * 256u : N;
+    // ---- the panel plan: first column and width of every panel ----
+    std::vector<uint32_t> pc0, pnp;
+    {
+        uint64_t at = 0;
+        for (uint32_t i = 0; i < nwidths; ++i) {
+            if (widths[i] == 0 || widths[i] % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): panel %u is %u columns wide; widths must be positive multiples of 4", i, widths[i]);
+            pc0.push_back((uint32_t)at);
+            pnp.push_back(widths[i]);
+            at += widths[i];
+        }
+        if (at != N) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): the panel widths sum to %llu, N is %u", (unsigned long long)at, N);
     }
-    if (panel_cols % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): panel_cols=%u must be a multiple of 4", panel_cols);
-    if (panel_cols > N) panel_cols = N;
-    const uint32_t npanels = (N + panel_cols - 1) / panel_cols;
+    const uint32_t npanels = (uint32_t)pnp.size();
+    uint32_t panel_cols = 0; // the widest panel (sizes the panel-by-panel staging)
+    for (uint32_t w : pnp) panel_cols = w > panel_cols ? w : panel_cols;
+    // "n_main equal panels of whole tiles + 1 .. 8 tail panels of whole tiles (the last: the rest)": what the one-launch kernels take (wgk_panels)
+    wgk_panels shape;
+    bool one_launch_shape = false;
+    if (npanels > 1 && pnp[0] % 256u == 0) {
+        uint32_t n_main = 1;
+        while (n_main < npanels - 1u && pnp[n_main] == pnp[0]) ++n_main;
+        // (a uniform split whose last panel is as wide as the others: that one is the tail)
+        const uint32_t n_tail = npanels - n_main;
+        bool ok = n_tail >= 1 && n_tail <= 8;
+        for (uint32_t q = 0; ok && q + 1u < n_tail; ++q) ok = pnp[n_main + q] % 256u == 0 && pnp[n_main + q] / 256u <= 255u;
+        ok = ok && (pnp[npanels - 1u] + 255u) / 256u <= 255u;
+        if (ok) {
+            shape.cols = pnp[0]; shape.n_main = n_main; shape.n_tail = n_tail;
+            for (uint32_t q = 0; q < n_tail; ++q) shape.tail_cols[q] = pnp[n_main + q];
+            shape.col_stride = M; shape.slot_rows = (uint64_t)g * mg;
+            one_launch_shape = true;
+        }
+    }
     const size_t es = wg_dtype_size(dtype);
     WG_HIP_TRY(hipSetDevice(ctx->device));
 
     // (the RCCL engine's one-launch form completes a deferred last panel itself, behind its kernel)
-    const bool rccl_one = mode == WG_GATHER_RCCL && c->nccl != nullptr && c->one_launch != 0 && c->can_wait_value && dtype == WG_F16 && (N + panel_cols - 1) / panel_cols > 1 &&
-                          panel_cols % 256u == 0 && 2ull * M * N < (1ull << 32);
+    const bool rccl_one = mode == WG_GATHER_RCCL && c->nccl != nullptr && c->one_launch != 0 && c->can_wait_value && dtype == WG_F16 && one_launch_shape &&
+                          2ull * M * N < (1ull << 32);
     if (mode != WG_GATHER_PEER_STAGED && !rccl_one)
         if (int rc = run_pending(c)) return rc;
     if (mode == WG_GATHER_PEER_STAGED) {
@@ -616,7 +703,9 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         const uint64_t half_elems = ((c->pstage_bytes / 2) & ~(size_t)15) / es;
         if (half_elems + (uint64_t)M * N >= (1ull << 32)) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm (sharded): the two staging cubes exceed u32 element indexing");
         if (int rc = wg_ctx_check_async(ctx)) return rc; // a wait of an earlier step gave up: reported here (both words cleared: the next call is a clean retry)
-        const uint64_t geom[4] = { M, N, panel_cols, es };
+        uint64_t plan_hash = 1469598103934665603ull; // FNV-1a over the widths: another split of the same M x N is another slot layout
+        for (uint32_t w : pnp) plan_hash = (plan_hash ^ w) * 1099511628211ull;
+        const uint64_t geom[4] = { M, N, plan_hash, es };
         if (memcmp(geom, c->staged_geom, sizeof geom) != 0) {
             // another slot layout than the previous call's: its per-slot "sent" events no longer name these slots -- let everything of
             // THIS rank that is still leaving the old layout finish before any Gemm writes the cubes (host-blocking on this rank's own
@@ -639,11 +728,13 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         sbuf.ctx = ctx; sbuf.ptr = c->pstage; sbuf.bytes = c->pstage_bytes; sbuf.usage = 0; sbuf.owned = false; sbuf.host_pinned = false;
         auto slot_elem = [&](uint32_t c0, uint32_t np, uint32_t r) { return (uint64_t)parity * half_elems + (uint64_t)c0 * M + (uint64_t)r * mg * np; };
         auto finish_panel = [&](uint32_t p) -> int { // wait for the peers' slots of panel p, then relayout it into columns of `out`
-            const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            const uint32_t c0 = pc0[p], np = pnp[p];
+            if (int rc = wait_begin(c, p)) return rc;
             if (P > 1) {
                 hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, ctx->stream, c->pflags, P, g, p, seq, c->wait_err, c->seq_src + 64, c->timeout_ticks);
                 WG_HIP_TRY(hipGetLastError());
             }
+            if (int rc = wait_end(c)) return rc;
             const char *src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
             char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
             return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es, P > 1 ? c->seq_src + 64 : nullptr);
@@ -653,12 +744,9 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // walks the panels left to right, its waves count themselves into a word per panel as their write-through stores reach memory; every
         // peer stream waits for panel p's full count (hipStreamWaitValue32) and pushes the slot; the relayouts follow the kernel on the
         // context's stream. The tile scheduler sees the rank's whole product.
-        if (c->one_launch == 1 && c->can_wait_value && dtype == WG_F16 && npanels > 1 && panel_cols % 256u == 0) {
+        if (c->one_launch == 1 && c->can_wait_value && dtype == WG_F16 && one_launch_shape) {
             if (int rc = ensure_panel_sync(c)) return rc;
-            const uint32_t np_last = N - (npanels - 1u) * panel_cols;
-            wgk_panels pa;
-            pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
-            pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols; // (wraps: pointer arithmetic modulo 2^64)
+            wgk_panels pa = shape;
             pa.counters = c->panel_sync;
             // every slot of this parity is rewritten by the one kernel: the copies that left them two steps ago must be done
             for (uint32_t p = 0; p < npanels; ++p)
@@ -666,13 +754,13 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                     hipEvent_t e = c->sent_ev[((size_t)parity * npanels + p) * P + r];
                     if (r != g && e) WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, e, 0));
                 }
-            const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->pstage + slot_elem(0, panel_cols, g) * es, mg, a_rows, a_shape, b, b_shape, pa);
+            const int rc1 = wg_gemm_f16_panels(ctx, tr, (char *)c->pstage + slot_elem(0, pa.cols, g) * es, mg, a_rows, a_shape, b, b_shape, pa);
             if (rc1 == WG_OK) {
                 for (uint32_t p = 0; p < npanels; ++p) // this launch's arrivals, on top of every earlier launch's
-                    c->panel_total[p] += wgk_panel_goal(mg, (N - p * panel_cols < panel_cols) ? N - p * panel_cols : panel_cols);
+                    c->panel_total[p] += wgk_panel_goal(mg, pnp[p]);
                 if (P > 1 && !no_copy) {
                     for (uint32_t p = 0; p < npanels; ++p) {
-                        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                        const uint32_t c0 = pc0[p], np = pnp[p];
                         const size_t off = slot_elem(c0, np, g) * es, bytes = (size_t)mg * np * es;
                         for (uint32_t i = 1; i < P; ++i) {
                             const uint32_t r = (g + i) % P;
@@ -693,7 +781,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
                 for (uint32_t p = 0; p < upto; ++p)
                     if (int rc = finish_panel(p)) return rc;
                 if (c->pipelined) {
-                    const uint32_t p = npanels - 1, c0 = p * panel_cols, np = N - c0;
+                    const uint32_t p = npanels - 1, c0 = pc0[p], np = pnp[p];
                     c->pending.on = true; c->pending.after = nullptr;
                     c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
                     c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
@@ -705,7 +793,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             if (rc1 != WG_ERR_UNSUPPORTED) return rc1; // (unsupported: not that kind of product -- panel by panel below)
         }
         for (uint32_t p = 0; p < npanels; ++p) {
-            const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            const uint32_t c0 = pc0[p], np = pnp[p];
             wg_view_shape bs = b_shape;
             bs.size[1] = np;
             const uint64_t b_off = (uint64_t)b_shape.offset + (uint64_t)c0 * b_shape.stride; // 64-bit: K * N may reach 2^32 elements
@@ -745,7 +833,7 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
         // anything of this step -- the "at most one step ahead of a peer" rule the parity halves rely on would not hold (the peer could
         // still be reading that half) -- so a one-panel step completes in the call.
         if (c->pipelined && npanels > 1) {
-            const uint32_t p = npanels - 1, c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+            const uint32_t p = npanels - 1, c0 = pc0[p], np = pnp[p];
             c->pending.on = true; c->pending.after = nullptr;
             c->pending.seq = seq; c->pending.panel = p; c->pending.mg = mg; c->pending.np = np;
             c->pending.src = (const char *)c->pstage + slot_elem(c0, np, 0) * es;
@@ -788,21 +876,18 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             hipEvent_t &e = c->ev_panel[(size_t)kMaxPanels * (1u + parity) + p];
             if (!e) WG_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
-        const uint32_t np_last = N - (npanels - 1u) * panel_cols;
         char *cube = (char *)c->stage + (size_t)parity * half; // this step's cube; the other one may still be gathering its last panel
-        wgk_panels pa;
-        pa.cols = panel_cols; pa.c_stride = (uint64_t)panel_cols * M;
-        pa.c_last_adjust = (uint64_t)g * mg * np_last - (uint64_t)g * mg * panel_cols;
+        wgk_panels pa = shape;
         pa.counters = c->panel_sync;
         // (this parity's cube is free: its last user's relayouts -- two steps ago, the deferred one included, see below -- precede this
         // kernel on the context's stream, and this step's gathers only start on counts this kernel produces)
         if (c->pending.on && c->pending.after && (c->pending.seq & 1u) == parity)
             if (int rc = run_pending(c)) return rc; // (cannot happen with alternating parities; kept as a guard)
-        const int rc1 = wg_gemm_f16_panels(ctx, tr, cube + (size_t)g * mg * panel_cols * es, mg, a_rows, a_shape, b, b_shape, pa);
+        const int rc1 = wg_gemm_f16_panels(ctx, tr, cube + (size_t)g * mg * pa.cols * es, mg, a_rows, a_shape, b, b_shape, pa);
         if (rc1 == WG_OK) {
             hipEvent_t *ev = c->ev_panel.data() + (size_t)kMaxPanels * (1u + parity);
             for (uint32_t p = 0; p < npanels; ++p) {
-                const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                const uint32_t c0 = pc0[p], np = pnp[p];
                 char *base = cube + (size_t)c0 * M * es;
                 c->panel_total[p] += wgk_panel_goal(mg, np);
                 WG_HIP_TRY(hipStreamWaitValue32(c->stream, pa.counters + p, c->panel_total[p], hipStreamWaitValueGte, 0xffffffffu));
@@ -814,11 +899,13 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
             if (int rc = run_pending(c)) return rc; // the previous call's deferred last panel: behind this call's kernel
             const uint32_t upto = c->pipelined ? npanels - 1u : npanels;
             for (uint32_t p = 0; p < npanels; ++p) {
-                const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+                const uint32_t c0 = pc0[p], np = pnp[p];
                 const char *src = cube + (size_t)c0 * M * es;
                 char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
                 if (p < upto) {
+                    if (int rc = wait_begin(c, p)) return rc;
                     WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, ev[p], 0));
+                    if (int rc = wait_end(c)) return rc;
                     if (int rc = launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es)) return rc;
                 } else {
                     c->pending.on = true; c->pending.after = ev[p];
@@ -851,15 +938,17 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     }
 
     auto relayout = [&](uint32_t p) -> int { // panel p's cube -> columns of `out`, once its all-gather is done
-        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+        const uint32_t c0 = pc0[p], np = pnp[p];
+        if (int rc = wait_begin(c, p)) return rc;
         WG_HIP_TRY(hipStreamWaitEvent(ctx->stream, c->ev_panel[p], 0));
+        if (int rc = wait_end(c)) return rc;
         const char *src = (const char *)c->stage + (size_t)(p & 1u) * M * panel_cols * es;
         char *dst = (char *)out->ptr + ((size_t)out_shape.offset + (size_t)c0 * out_shape.stride) * es;
         return launch_cube_to_matrix(ctx, src, dst, mg, np, P, out_shape.stride, es);
     };
 
     for (uint32_t p = 0; p < npanels; ++p) {
-        const uint32_t c0 = p * panel_cols, np = (N - c0 < panel_cols) ? N - c0 : panel_cols;
+        const uint32_t c0 = pc0[p], np = pnp[p];
         wg_view_shape bs = b_shape;
         bs.size[1] = np;
         const uint64_t b_off = (uint64_t)b_shape.offset + (uint64_t)c0 * b_shape.stride; // 64-bit: K * N may reach 2^32 elements
@@ -891,6 +980,24 @@ int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gath
     }
     if (staged) return relayout(npanels - 1); // the only exposed exchange
     return WG_OK;
+}
+
+int wg_gemm_sharded(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, uint32_t panel_cols, wg_buf *out, wg_view_shape out_shape,
+                    const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
+    const uint32_t N = out_shape.size[1];
+    if (panel_cols == 0) // default: ~8 panels of whole 256-column tiles, so that all but the last exchange hides under a Gemm
+        panel_cols = N >= 2048 ? ((N / 8 + 255u) / 256u) * 256u : N;
+    if (panel_cols % 4) return wg_set_error(WG_ERR_PRECONDITION, "Gemm (sharded): panel_cols=%u must be a multiple of 4", panel_cols);
+    if (panel_cols > N) panel_cols = N;
+    std::vector<uint32_t> widths;
+    for (uint32_t c0 = 0; c0 < N; c0 += panel_cols) widths.push_back(N - c0 < panel_cols ? N - c0 : panel_cols);
+    return gemm_sharded_impl(c, variant, dtype, mode, widths.data(), (uint32_t)widths.size(), out, out_shape, a_rows, a_shape, b, b_shape);
+}
+
+int wg_gemm_sharded_panels(wg_comm *c, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, const uint32_t *panel_widths, uint32_t npanels, wg_buf *out,
+                           wg_view_shape out_shape, const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape) {
+    if (!panel_widths || npanels == 0) return wg_set_error(WG_ERR_INVALID_ARG, "Gemm (sharded): no panel widths");
+    return gemm_sharded_impl(c, variant, dtype, mode, panel_widths, npanels, out, out_shape, a_rows, a_shape, b, b_shape);
 }
 
 } // extern "C"

@@ -134,14 +134,31 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     uint32_t q_a = 0, q_b = 0, q_c = 0, q_d = 0, s_vm = 0, s_bar = 0, s_probe = 0, m_vm = 0, m_bar = 0, n_adv = 0, loop_t0 = 0, loop_t1 = 0;
 #endif
     uint32_t tm, tn, panel = 0;
+    uint32_t panel_c0 = 0, panel_np = 0; // first column / columns of this tile's panel (paneled launches)
     if (g.panel.cols) { // tiles are numbered panel by panel (PanelArgs); within a panel the usual XCD-aware order on the panel's own grid
         const uint32_t id = bid + g.tile_base;
-        panel = __builtin_amdgcn_readfirstlane(min(id / g.panel.tiles, g.panel.npanels - 1u)); // (the division runs on the vector unit)
-        const uint32_t ptn = panel + 1u == g.panel.npanels ? g.panel.last_tn : g.panel.cols / 256u;
-        tile_of(id - panel * g.panel.tiles, g.tiles_m, ptn, tm, tn);
-        tn += panel * (g.panel.cols / 256u);
+        const uint32_t mtn = g.panel.cols / 256u, main_tiles = g.panel.n_main * g.panel.tiles;
+        uint32_t loc, ptn, tn0;
+        if (id < main_tiles) {
+            panel = __builtin_amdgcn_readfirstlane(id / g.panel.tiles); // (the division runs on the vector unit)
+            loc = id - panel * g.panel.tiles; ptn = mtn; tn0 = panel * mtn;
+        } else { // the tail: at most kPanelTail narrower panels, widths in tile columns
+            loc = __builtin_amdgcn_readfirstlane(id - main_tiles);
+            tn0 = g.panel.n_main * mtn;
+            const uint32_t n_tail = g.panel.npanels - g.panel.n_main;
+            uint32_t q = 0;
+            uint64_t tail = g.panel.tail_tn;
+            ptn = (uint32_t)tail & 0xffu;
+            while (q + 1u < n_tail && loc >= g.tiles_m * ptn) { loc -= g.tiles_m * ptn; tn0 += ptn; ++q; tail >>= 8; ptn = (uint32_t)tail & 0xffu; }
+            panel = g.panel.n_main + q;
+        }
+        tile_of(loc, g.tiles_m, ptn, tm, tn);
+        tn += tn0;
+        panel_c0 = tn0 * 256u;
+        panel_np = panel + 1u == g.panel.npanels ? g.N - panel_c0 : ptn * 256u;
     } else tile_of(bid + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
-    panel = __builtin_amdgcn_readfirstlane(panel); // (all three are workgroup-uniform; said explicitly: they end up in scalar operands of the DMA asm)
+    panel = __builtin_amdgcn_readfirstlane(panel); // (all of these are workgroup-uniform; said explicitly: they end up in scalar operands of the DMA asm)
+    panel_c0 = __builtin_amdgcn_readfirstlane(panel_c0); panel_np = __builtin_amdgcn_readfirstlane(panel_np);
     tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
     const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
@@ -180,9 +197,10 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     const _Float16 *B = g.b + z * g.b_batch + k_begin;
     _Float16 *C = g.c + z * g.c_batch;
     const bool paneled = g.panel.cols != 0; // workgroup-uniform
-    if (paneled) { // the epilogue indexes columns globally: C + col * ldc; panel p's columns start at its own base
+    if (paneled) { // the epilogue indexes columns globally: C + col * ldc; panel p's columns start at its own base: the cube's columns are col_stride
+        // apart, this rank's slot of panel p starts slot_rows * np(p) elements into it (C already points slot_rows * cols into panel 0)
         // (64-bit products run on the vector unit even when uniform: back to scalar registers by hand, C is pinned in SGPRs below)
-        const uint64_t off = (uint64_t)panel * g.panel.c_stride + (panel + 1u == g.panel.npanels ? g.panel.c_last_adjust : 0ull) - (uint64_t)panel * g.panel.cols * g.ldc;
+        const uint64_t off = (uint64_t)panel_c0 * (g.panel.col_stride - g.ldc) + g.panel.slot_rows * (uint64_t)panel_np - g.panel.slot_rows * (uint64_t)g.panel.cols;
         C += ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
     }
     uint32_t *panel_counter = g.panel.counters + panel;
@@ -1091,7 +1109,16 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const bool a_step_fits = trans || (uint64_t)m1.ld * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
     const bool fast = (M % 8 == 0) && (k_big || k_small) && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) && a_step_fits &&
                       (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
-    if (panels && !(fast && k_big && nmats == 1 && alpha == 1.f && beta == 0.f && panels->cols && panels->cols % 256u == 0 && panels->cols < N &&
+    auto panels_ok = [&]() -> bool { // n_main panels of `cols`, then 1 .. 8 tail panels (<= 255 tile columns each) that end exactly at N
+        if (!panels->cols || panels->cols % 256u || panels->n_tail < 1 || panels->n_tail > (uint32_t)kPanelTail || panels->n_main + panels->n_tail < 2) return false;
+        uint64_t c0 = (uint64_t)panels->n_main * panels->cols;
+        for (uint32_t q = 0; q + 1u < panels->n_tail; ++q) {
+            if (panels->tail_cols[q] == 0 || panels->tail_cols[q] % 256u || panels->tail_cols[q] / 256u > 255u) return false;
+            c0 += panels->tail_cols[q];
+        }
+        return c0 < N && N - c0 == panels->tail_cols[panels->n_tail - 1u] && (N - c0 + 255u) / 256u <= 255u;
+    };
+    if (panels && !(fast && k_big && nmats == 1 && alpha == 1.f && beta == 0.f && panels_ok() &&
                     (uint64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) >= (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256)))
         return WG_ERR_UNSUPPORTED; // (no message: the caller falls back to one launch per panel)
     if (fast) {
@@ -1101,9 +1128,15 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (tiles > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many tiles");
         const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
         if (panels) {
-            const uint32_t ptn = panels->cols / 256u, np_ = (g.tiles_n + ptn - 1u) / ptn;
-            g.panel.cols = panels->cols; g.panel.npanels = np_; g.panel.tiles = g.tiles_m * ptn; g.panel.last_tn = g.tiles_n - (np_ - 1u) * ptn;
-            g.panel.c_stride = panels->c_stride; g.panel.c_last_adjust = panels->c_last_adjust;
+            const uint32_t ptn = panels->cols / 256u;
+            g.panel.cols = panels->cols; g.panel.n_main = panels->n_main; g.panel.npanels = panels->n_main + panels->n_tail; g.panel.tiles = g.tiles_m * ptn;
+            uint32_t tn_left = g.tiles_n - panels->n_main * ptn;
+            for (uint32_t q = 0; q < panels->n_tail; ++q) { // (validated above: multiples of 256 that, with the main panels, cover N exactly; the last may be ragged)
+                const uint32_t t = q + 1u == panels->n_tail ? tn_left : panels->tail_cols[q] / 256u;
+                g.panel.tail_tn |= (uint64_t)t << (8u * q);
+                tn_left -= t;
+            }
+            g.panel.col_stride = panels->col_stride; g.panel.slot_rows = panels->slot_rows;
             g.panel.counters = panels->counters; // (never reset here: they only ever grow, the caller waits for its own running totals)
         }
         // Outputs with fewer 256 x 256 tiles than CUs: the 128 x 128 kernel (gemm_f16_t128.hip) fills the chip with four times as many

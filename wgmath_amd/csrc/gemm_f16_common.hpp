@@ -70,16 +70,22 @@ __host__ __device__ inline bool bal_decode(const BalancePlan &bp, uint32_t b, ui
     return true;
 }
 
-// N-panels with arrival counters (the M-sharded Gemm of comm.hip as ONE launch per step): the output is written panel by panel -- panel p's
-// columns live at c + p * c_stride (+ c_last_adjust for the narrower last panel) with leading dimension ldc, i.e. the slots of a staging
-// cube or simply the columns of one matrix -- the tiles are numbered panel by panel, the epilogue stores write through to memory, and every
-// WAVE that has its stores acknowledged adds one to counters[p] (system scope, fire and forget): panel p is complete in memory when the
-// word has grown by 4 x its tile count. A copy engine's stream waits on exactly that (hipStreamWaitValue32) while the kernel is still working on
-// the next panels.
+// N-panels with arrival counters (the M-sharded Gemm of comm.hip as ONE launch per step): the output is written panel by panel into the slots of a
+// staging cube [panel][rank][np x ldc] (col_stride = all ranks' rows of a column; slot_rows = the rows of the ranks in front of this one) -- or, with
+// col_stride == ldc and slot_rows == 0, simply into the columns of one matrix. The tiles are numbered panel by panel, the epilogue stores write through
+// to memory, and every WAVE that has its stores acknowledged adds one to counters[p] (system scope, fire and forget): panel p is complete in memory
+// when the word has grown by 4 x its tile count. A copy engine's stream waits on exactly that (hipStreamWaitValue32) while the kernel is still working
+// on the next panels.
+// Widths: n_main panels of `cols` columns, then a TAIL of 1 .. 8 panels given in tile columns (tail_tn) -- the narrower panels that let the last
+// exchanges of a step hide under less and less compute (the only exposed exchange is the last panel's); the very last panel takes whatever is left of N.
+constexpr int kPanelTail = 8;
 struct PanelArgs {
-    uint32_t cols;       // columns per panel (a multiple of 256); 0: off
-    uint32_t npanels, tiles, last_tn; // tiles of a full panel (tiles_m * cols / 256); tile columns of the last panel
-    uint64_t c_stride, c_last_adjust; // elements
+    uint32_t cols;       // columns per main panel (a multiple of 256); 0: off
+    uint32_t npanels, tiles; // n_main + tail panels; tiles of a main panel (tiles_m * cols / 256)
+    uint32_t n_main;     // panels of full width
+    uint64_t tail_tn;    // tile columns of the tail panels, 8 bits each, panel n_main + q in bits [8 q, 8 q + 8) (the last one: ceil of what is left);
+                         // packed, not an array: a dynamically indexed member would move the by-value kernel argument into scratch
+    uint64_t col_stride, slot_rows; // elements
     uint32_t *counters;  // [npanels] waves finished, running totals over every launch (never reset between launches: a waiter of an earlier
                          // launch may not have looked yet)
 };

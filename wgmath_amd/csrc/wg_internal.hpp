@@ -170,16 +170,19 @@ int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32
                      wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t nsplit = 1);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
-// N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is panel 0's base,
-// panel p's columns live at out + p * c_stride (+ c_last_adjust for the narrower last panel), leading dimension out_ld; counters[p]
+// N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is where the product's column 0
+// would sit if every panel were `cols` wide and the cube had one rank (i.e. panel 0's slot of this rank), leading dimension out_ld; panel p (first
+// column c0, np columns) lives at out + c0 * col_stride + slot_rows * (np - cols) ... see m16_tile. n_main panels of `cols` columns, then n_tail
+// (1 .. 8) panels of tail_cols[] columns (multiples of 256; the last one = whatever is left of N, may be ragged). counters[p]
 // grows by wgk_panel_goal(...) per launch, complete once every tile of panel p is in memory (running totals, never reset by the kernel
 // or its launcher: the caller keeps the totals and waits for them). wgk_gemm_f16 returns
 // WG_ERR_UNSUPPORTED -- silently -- when the product does not take that path (shapes off the MFMA fast path, fewer tiles than CUs, ...):
 // the caller then launches panel by panel.
 struct wgk_panels {
-    uint32_t cols;
-    uint64_t c_stride, c_last_adjust;
-    uint32_t *counters;
+    uint32_t cols = 0, n_main = 0, n_tail = 0;
+    uint32_t tail_cols[8] = { 0 };
+    uint64_t col_stride = 0, slot_rows = 0;
+    uint32_t *counters = nullptr;
 };
 // what counters[p] reads when panel p (np columns of an M-row product) is complete: one arrival per wave, 4 waves per 256 x 256 tile
 static inline uint32_t wgk_panel_goal(uint32_t M, uint32_t np) { return 4u * ((M + 255u) / 256u) * ((np + 255u) / 256u); }

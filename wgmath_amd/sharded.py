@@ -161,6 +161,39 @@ class ShardedGemm:
             self._wait(h)
 
 
+def tapered_panels(N: int, main_cols: int, ratio: float, tile: int = 256, max_tail: int = 8) -> List[int]:
+    """Widths of the N-panels with a tapered tail: equal panels of `main_cols`, then panels that shrink by `ratio` (the time of a panel's exchange
+    over the time of its Gemm, < 1; rounded UP to whole tiles so that every exchange still hides under the next panel's Gemm) down to one tile
+    column -- the only exposed exchange of a step is then that of a one-tile-wide panel instead of a full one. At most `max_tail` panels follow
+    the equal ones (what the one-launch kernels take, wg_gemm_sharded_panels); the last panel takes whatever is left of N.
+    Pure host arithmetic (tests/test_dist_gloo.py)."""
+    if N <= 0 or main_cols <= 0 or main_cols % tile or not 0.0 < ratio < 1.0:
+        raise ValueError("tapered_panels: N, main_cols (a multiple of the tile) > 0 and 0 < ratio < 1")
+    taper, w = [], main_cols // tile
+    while w > 1 and len(taper) < max_tail - 1:
+        w = max(1, min(w - 1, -(-int(w * ratio * 1000) // 1000)))  # ceil(w * ratio), but strictly narrower
+        taper.append(w * tile)
+    if not taper or taper[-1] != tile:  # a last panel of one tile column closes the taper
+        taper.append(tile)
+    tail_total = sum(taper)
+    if N <= tail_total + main_cols:  # not enough columns for equal panels in front of a taper: a plain split
+        n = max(1, -(-N // main_cols))
+        return [main_cols] * (n - 1) + [N - (n - 1) * main_cols]
+    n_main = (N - tail_total) // main_cols
+    left = N - n_main * main_cols - tail_total  # < main_cols: one more panel, placed where the widths stay in descending order
+    frag, whole = left % tile, left - left % tile
+    tail = list(taper)
+    if whole:
+        at = 0
+        while at < len(tail) and tail[at] > whole:
+            at += 1
+        tail.insert(at, whole)
+    while len(tail) > max_tail:  # too many for the one-launch kernels: join the two narrowest panels in front of the last one
+        tail[-3:-1] = [tail[-3] + tail[-2]]
+    tail[-1] += frag  # a ragged N: the fraction of a tile goes to the very last panel
+    return [main_cols] * n_main + tail
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # product path: the C ABI's communicator and M-sharded Gemm
 # ---------------------------------------------------------------------------------------------------------------------
@@ -233,6 +266,16 @@ class Comm:
         panel-by-panel launches, None = by engine (the default: RCCL on, staged off)."""
         self._lib.check(self._lib.lib.wg_comm_set_one_launch(self._h, -1 if on is None else (1 if on else 0)))
 
+    def set_wait_timing(self, on: bool) -> None:
+        """Diagnostics: stamp the compute stream around every wait for a panel's exchange (wg_comm_set_wait_timing); read with wait_times()."""
+        self._lib.check(self._lib.lib.wg_comm_set_wait_timing(self._h, 1 if on else 0))
+
+    def wait_times(self, capacity: int = 4096):
+        """[(panel, ms the compute stream waited for that panel's exchange), ...] since the last call, oldest first (synchronises the context)."""
+        pan, ms, n = (ctypes.c_uint32 * capacity)(), (ctypes.c_float * capacity)(), ctypes.c_uint32(0)
+        self._lib.check(self._lib.lib.wg_comm_wait_times(self._h, pan, ms, capacity, ctypes.byref(n)))
+        return [(int(pan[i]), float(ms[i])) for i in range(n.value)]
+
     def join(self) -> None:
         self._lib.check(self._lib.lib.wg_comm_join(self._h))
 
@@ -293,11 +336,17 @@ class Comm:
         self._lib.check(self._lib.lib.wg_comm_set_peer_stages(self._h, sa, fa))
         self._peers["__stages__"] = ((sa, fa), [])
 
-    def sharded_gemm(self, out, a_rows, b, variant=0, mode: int = GatherMode.RCCL, panel_cols: int = 0) -> None:
+    def sharded_gemm(self, out, a_rows, b, variant=0, mode: int = GatherMode.RCCL, panel_cols=0) -> None:
         """out (M x N GpuMatrix, on every rank) = op(A) * B with A sharded on M: `a_rows` is this rank's row block (M/P x K, or
         K x M/P for the GemmTr variants), `b` (K x N) replicated. Views or tensors; enqueues and returns (see wg_gemm_sharded for
-        when `out` is complete)."""
+        when `out` is complete). `panel_cols`: one width for every N-panel (0 = default), or the list of the panels' widths
+        (wg_gemm_sharded_panels: a tapered tail, see `tapered_panels`)."""
         from .wgcore import as_view, wg_dtype
         ov, av, bv = as_view(out), as_view(a_rows), as_view(b)
+        if not isinstance(panel_cols, int):
+            widths = (ctypes.c_uint32 * len(panel_cols))(*[int(w) for w in panel_cols])
+            self._lib.check(self._lib.lib.wg_gemm_sharded_panels(self._h, int(variant), wg_dtype(ov.dtype), int(mode), widths, len(panel_cols), ov.buffer()._h,
+                                                                 ov.shape().to_c(), av.buffer()._h, av.shape().to_c(), bv.buffer()._h, bv.shape().to_c()))
+            return
         self._lib.check(self._lib.lib.wg_gemm_sharded(self._h, int(variant), wg_dtype(ov.dtype), int(mode), int(panel_cols), ov.buffer()._h, ov.shape().to_c(),
                                                       av.buffer()._h, av.shape().to_c(), bv.buffer()._h, bv.shape().to_c()))
