@@ -725,6 +725,7 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
     # must not include idle time at the idle clock (a few microseconds of stamp kernel inside the timed region against a biased clock otherwise)
     clock_ghz = clock.end()  # {"mean", "min", "max"} over the XCDs: the shader clock the timed steps actually ran at (None if unavailable); synchronises
     gpu.sync()
+    own_elapsed = time.perf_counter() - t0  # this rank's own steps, drained, before it waits for the others
     barrier()
     elapsed = time.perf_counter() - t0
     ev = ts.wait_for_results_ms()
@@ -737,7 +738,7 @@ def run_workload(wg, gpu, name, steps, warmup, rank, world, barrier, with_cpu, c
         if hasattr(w, "close") and not keep:
             w.close()
         barrier()  # ... and nobody frees a buffer a peer still has mapped for copying
-    res = {"workload": w if keep else None, "elapsed": elapsed, "kernel_ms": kernel_ms, "steps": steps, "clock": clock_ghz,
+    res = {"workload": w if keep else None, "elapsed": elapsed, "own_elapsed": own_elapsed, "kernel_ms": kernel_ms, "steps": steps, "clock": clock_ghz,
            "max_ulp_vs_f64": getattr(w, "max_ulp_vs_f64", None)}
     res["cpu"] = w.cpu_baseline(cpu_budget) if (with_cpu and rank == 0 and world == 1) else None
     return res
@@ -952,13 +953,22 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
         outs = [gathered[start + g * count:start + (g + 1) * count] for g in range(world)]
         return dist.all_gather(outs, gathered[start + rk * count:start + (rk + 1) * count].clone(), async_op=True)
 
-    drv = ShardedGemm(pl, rank, local_gemm, all_gather, wait=lambda w: w.wait())
+    waits = []  # (panel, ms) of every wait for a panel's all-gather, the dry run's stand-in for wg_comm_wait_times
+
+    def timed_wait(w):
+        t = time.perf_counter()
+        w.wait()
+        waits.append((len(waits) % pl.npanels, (time.perf_counter() - t) * 1e3))
+
+    drv = ShardedGemm(pl, rank, local_gemm, all_gather, wait=timed_wait)
     for _ in range(args.warmup):
         drv.step()
+    del waits[:]
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         drv.step()
+    own = time.perf_counter() - t0
     dist.barrier()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -970,9 +980,13 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
         print(json.dumps({"trial": trial_mode, "ms_per_step": round(float(el.item()) / args.steps * 1e3, 5)}), flush=True)
         dist.destroy_process_group()
         return
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"ms_per_step": own / max(args.steps, 1) * 1e3, "clock_ghz": None, "waits": waits})
     if rank == 0:
         elapsed = float(el.item())
         extra = {} if report is None else dict(report, gather_engine=chosen)
+        detail, flat = ranks_detail(per_rank, pl.npanels)
+        extra.update(flat)
         print(json.dumps({"metric": "dry_run_gemm_tflops", "value": round(2.0 * M * N * K * args.steps / elapsed / 1e12, 9), "unit": "TFLOP/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -980,8 +994,39 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
                           "config": {"workload": f"dry_run_{M}x{N}x{K}", "ranks": dist.get_world_size(),
                                      "parallelism": f"m-shard x{world} + gloo all-gather (dry run)",
                                      "all_gather_bytes_per_step": (world - 1) * pl.Mg * N * 4,
-                                     "comm_compute_units": ENGINE_COMM_CUS.get(chosen or args.gather, 0), "rccl_reported_ranks": 0, **extra}}), flush=True)
+                                     "comm_compute_units": ENGINE_COMM_CUS.get(chosen or args.gather, 0), "rccl_reported_ranks": 0, **extra},
+                          "ranks_detail": detail}), flush=True)
     dist.destroy_process_group()
+
+
+def ranks_detail(per_rank, npanels):
+    """What tells a slow link from a slow rank from a slow clock in ONE multi-rank run. `per_rank`: one dict per rank -- {"ms_per_step": its own
+    timed region / steps, "clock_ghz": its measured shader clock (None if unavailable), "waits": [(panel, ms the compute stream stood still for that
+    panel's exchange), ...] from a few extra steps after the timed region (wg_comm_set_wait_timing)}. Returns (detail object, flat scalars for `config`).
+    Reading it: one rank's ms_per_step above the others with a lower clock = a slow chip; every rank waiting on the same early panels = the links
+    (or RCCL's share of CUs) do not keep up with the Gemm; waits on the LAST panel only = the un-hidden tail, what a taper / pipelined steps shrink."""
+    ms = [float(r["ms_per_step"]) for r in per_rank]
+    clk = [r.get("clock_ghz") for r in per_rank]
+    wait = np.zeros((len(per_rank), max(1, npanels)))
+    cnt = np.zeros_like(wait)
+    for i, r in enumerate(per_rank):
+        for p, t in r.get("waits") or []:
+            if 0 <= int(p) < wait.shape[1]:
+                wait[i, int(p)] += float(t)
+                cnt[i, int(p)] += 1
+    mean = np.where(cnt > 0, wait / np.maximum(cnt, 1), 0.0)          # per rank, per panel: mean wait of a step
+    per_step_total = mean.sum(axis=1)
+    detail = {"ms_per_step": [round(x, 4) for x in ms], "clock_ghz": clk,
+              "panel_wait_ms_max_over_ranks": [round(float(x), 4) for x in mean.max(axis=0)],
+              "panel_wait_rank_of_max": [int(x) for x in mean.argmax(axis=0)],
+              "wait_ms_per_step": [round(float(x), 4) for x in per_step_total]}
+    known = [c for c in clk if c is not None]
+    flat = {"rank_ms_per_step_min": round(min(ms), 4), "rank_ms_per_step_max": round(max(ms), 4), "rank_slowest": int(np.argmax(ms)),
+            "rank_clock_ghz_min": round(min(known), 3) if known else None, "rank_clock_ghz_max": round(max(known), 3) if known else None,
+            "exchange_wait_ms_per_step_max": round(float(per_step_total.max()), 4),
+            "exchange_wait_ms_last_panel_max": round(float(mean[:, -1].max()), 4),
+            "exchange_wait_ms_before_last_panel_max": round(float(mean[:, :-1].sum(axis=1).max()) if mean.shape[1] > 1 else 0.0, 4)}
+    return detail, flat
 
 
 def agree_on_engine(trials, all_reduce_max, device):
@@ -1002,6 +1047,7 @@ def agree_on_engine(trials, all_reduce_max, device):
 
 
 def main():
+    global VALUES
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -1020,7 +1066,6 @@ def main():
                          "staged contiguous peer copies (+ relayout), or auto = a short trial of each as a fresh child group, the timed steps on the fastest")
     ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing test without a GPU (gloo, host arithmetic)")
     args = ap.parse_args()
-    global VALUES
     VALUES = args.dist
     os.environ["WG_BENCH_VALUES"] = args.dist  # (self-launched ranks inherit it)
 
@@ -1202,12 +1247,33 @@ def main():
     main_res = run_workload(wg, gpu, args.workload, args.steps, args.warmup, rank, world, barrier,
                             not args.no_cpu_baseline, args.cpu_budget, agree=agree if dist_mode else None)
     elapsed = main_res["elapsed"]
+    rank_detail, rank_flat = None, {}
     if dist_mode:
         import torch
         import torch.distributed as dist
+        own_ms = main_res["own_elapsed"] / args.steps * 1e3  # this rank's own clock around its own steps (before the closing barrier)
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if oversub else f"cuda:{dev_index}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # a few steps more, outside the timed region, with the compute stream stamped around every wait for a panel's exchange
+        waits, wl = [], main_res["workload"]
+        if isinstance(wl, GemmWorkload) and wl.dist is not None:
+            try:
+                cm = wl.dist["comm"]
+                barrier()
+                cm.set_wait_timing(True)
+                for _ in range(3):
+                    wl.step()
+                wl.finish()
+                waits = cm.wait_times()
+                cm.set_wait_timing(False)
+                barrier()
+            except Exception as e:  # noqa: BLE001 -- a diagnostic must not take the line down
+                log(f"[bench] rank {rank}: wait timing failed: {e}")
+        ck = main_res["clock"]
+        per_rank = DIST["all_gather_object"]({"ms_per_step": own_ms, "clock_ghz": (ck or {}).get("mean") if isinstance(ck, dict) else ck, "waits": waits})
+        if rank == 0:
+            rank_detail, rank_flat = ranks_detail(per_rank, getattr(wl, "npanels", 1))
     w = main_res["workload"]
     global MFMA_CEILING
     if world == 1 and not dist_mode and w.dtype == "f16" and w.bound == "mfma" and os.environ.get("WG_BENCH_NO_CEILING") != "1":
@@ -1234,6 +1300,7 @@ def main():
                      "pipelined_steps": bool(os.environ.get("WG_BENCH_PIPELINED", "1") != "0")}
         if dist_report:
             cfg_extra.update(dist_report)
+        cfg_extra.update(rank_flat)
         if oversub:
             cfg_extra["oversubscribed"] = f"{world} ranks on {ndev} GPU(s): plumbing test, not a scaling number"
     if dist_mode and hasattr(w, "close"):
@@ -1349,7 +1416,7 @@ def main():
             "data": f"synthetic (seeded {'U[0,1)' if VALUES == 'u01' else 'zeros' if VALUES == 'zero' else 'U[-1,1)'}: one 16 Mi-element random block tiled over each operand, resident in HBM "
                     "before the timed region; *_u01 workloads: U[0,1), the reference's new_random)",
             "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra),
-            "roofline": roof, "cpu_baseline": main_cpu, "checks": checks, "others": others,
+            "roofline": roof, "cpu_baseline": main_cpu, "checks": checks, "ranks_detail": rank_detail, "others": others,
             "targets": targets,  # LAST key, scalars only: BASELINE configs 1-5 at a glance (value, fraction of the 8 TB/s / 2.5 PF / 157.3 TF peak, measured clock)
         }
         sys.stdout.flush()

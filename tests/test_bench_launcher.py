@@ -31,6 +31,37 @@ def test_self_launch_two_ranks_dry_run():
     assert "dry-run" in line["data"]
     # what a multi-rank line says about its CU split and about the rank count the collective library itself reports (none in a dry run)
     assert line["config"]["comm_compute_units"] in (0, 4, 8) and line["config"]["rccl_reported_ranks"] == 0
+    # the self-diagnosing part of a multi-rank line: every rank's own ms per step and clock, every panel's exchange-wait time
+    _check_ranks_detail(line, world=2, npanels=3)
+
+
+def _check_ranks_detail(line, world, npanels):
+    d, c = line["ranks_detail"], line["config"]
+    assert len(d["ms_per_step"]) == world and all(x > 0 for x in d["ms_per_step"])
+    assert len(d["clock_ghz"]) == world
+    assert len(d["panel_wait_ms_max_over_ranks"]) == npanels and len(d["panel_wait_rank_of_max"]) == npanels and len(d["wait_ms_per_step"]) == world
+    assert all(x >= 0 for x in d["panel_wait_ms_max_over_ranks"]) and all(0 <= r < world for r in d["panel_wait_rank_of_max"])
+    assert c["rank_ms_per_step_min"] == min(d["ms_per_step"]) and c["rank_ms_per_step_max"] == max(d["ms_per_step"])
+    assert c["rank_ms_per_step_max"] <= line["ms_per_step"] * 1.001 + 1e-3, "a rank's own time cannot exceed the max-over-ranks time of the line"
+    assert 0 <= c["rank_slowest"] < world
+    for k in ("rank_clock_ghz_min", "rank_clock_ghz_max", "exchange_wait_ms_per_step_max", "exchange_wait_ms_last_panel_max", "exchange_wait_ms_before_last_panel_max"):
+        assert k in c
+    assert abs(c["exchange_wait_ms_per_step_max"] - max(d["wait_ms_per_step"])) < 1e-3
+
+
+def test_ranks_detail_tells_a_slow_link_from_a_slow_rank():
+    """bench.ranks_detail on made-up inputs: per-panel means over the stamped steps, max over ranks with the rank that holds it, the last panel's
+    wait apart from the others'."""
+    import bench
+    per_rank = [{"ms_per_step": 13.1, "clock_ghz": 1.52, "waits": [(0, 0.0), (1, 0.0), (2, 0.4), (0, 0.0), (1, 0.0), (2, 0.6)]},
+                {"ms_per_step": 14.9, "clock_ghz": 1.31, "waits": [(0, 0.2), (1, 0.0), (2, 0.1), (0, 0.4), (1, 0.0), (2, 0.1)]}]
+    d, c = bench.ranks_detail(per_rank, 3)
+    assert d["panel_wait_ms_max_over_ranks"] == [0.3, 0.0, 0.5] and d["panel_wait_rank_of_max"][0] == 1 and d["panel_wait_rank_of_max"][2] == 0
+    assert d["wait_ms_per_step"] == [0.5, 0.4]
+    assert c["rank_slowest"] == 1 and c["rank_clock_ghz_min"] == 1.31 and c["rank_ms_per_step_max"] == 14.9
+    assert c["exchange_wait_ms_last_panel_max"] == 0.5 and c["exchange_wait_ms_before_last_panel_max"] == 0.3 and c["exchange_wait_ms_per_step_max"] == 0.5
+    d, c = bench.ranks_detail([{"ms_per_step": 1.0, "clock_ghz": None, "waits": []}], 1)
+    assert c["rank_clock_ghz_min"] is None and d["panel_wait_ms_max_over_ranks"] == [0.0]
 
 
 def test_rccl_engine_variants_leave_4_and_8_compute_units():
