@@ -339,64 +339,105 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// T with 2 .. 8 right-hand sides and a SHORT contraction (k x nrhs floats fit the LDS): the small-batch product x^T W of a weight matrix stored
-// k x outputs. The vectors are staged once per workgroup into the LDS (as f32), then every half-wave streams ONE column of the matrix exactly
-// like gemv_t_cols_kernel and multiplies each 16-byte piece with the NRHS pieces of the vectors read from the LDS: no split of k, no combine
-// pass, the matrix read once. 1024 threads = 32 columns per workgroup (one workgroup per CU when the vectors take > 80 KiB).
-// grid = (column groups of 32, 1, nmats); dynamic LDS = k * NRHS * 4 bytes.
+// T with 2 .. 8 right-hand sides: the small-batch product x^T W of a weight matrix stored k x outputs. The vectors are staged into the LDS (as f32) in
+// chunks of KC contracted rows -- the whole of k when it fits, which is the common case: then once per workgroup --, and every half-wave streams its
+// columns of the matrix exactly like gemv_t_cols_kernel (whole 128-byte lines, U loads in flight) and multiplies each 16-byte piece with the NRHS pieces
+// of the vectors read from the LDS: no split of k across workgroups, no combine pass, the matrix read once, and the work is FMAs on the vector unit (the
+// few-column Gemm kernels run the same products on the matrix cores at 1/4 .. 1/8 utilisation and pay for it in clock).
+// Shape of a workgroup (round 5; before: always 1024 threads x 4 columns per half-wave = 128 columns per trip, which left 2/3 of the chip idle at 11008 outputs):
+// THREADS / 32 half-waves x COLS adjacent columns per trip; the launcher picks the pair that gives every CU a workgroup and, when it can, all of them ONE trip
+// (gemv_t_lds_plan). COLS > 1 shares each LDS piece of the vectors between COLS matrix pieces (8 right-hand sides with COLS = 1 read 8 x the matrix's bytes
+// out of the LDS: 104 of the LDS's 128 bytes per clock at HBM speed).
+// grid = (workgroups, 1, nmats), persistent over the column groups g, g + gridDim.x, ...; dynamic LDS = KC * NRHS * 4 bytes.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kLdsThreads = 1024;
-template <int NRHS, typename T>
-__global__ __launch_bounds__(kLdsThreads) void gemv_t_lds_kernel(GemvArgsT<T> a) {
-    extern __shared__ __attribute__((aligned(16))) float vs[]; // [y][k]
+template <int NRHS, typename T, int COLS, int THREADS>
+__global__ __launch_bounds__(THREADS) void gemv_t_lds_kernel(GemvArgsT<T> a, uint32_t kc) {
+    extern __shared__ __attribute__((aligned(16))) float vs[]; // [y][kc]
     const uint32_t z = blockIdx.z;
     const uint32_t kk = a.k; // % 4 == 0
     const T *vp = a.v + z * a.v_batch;
-    for (uint32_t idx = threadIdx.x * 4u; idx < kk * (uint32_t)NRHS; idx += kLdsThreads * 4u) {
-        const uint32_t y = idx / kk, r = idx - y * kk; // (kk % 4 == 0: a thread's 4 entries belong to one vector)
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (y < a.nrhs) x = load4(vp + (uint64_t)y * a.ldv + r);
-        *reinterpret_cast<float4 *>(vs + idx) = x;
-    }
-    __syncthreads();
     const uint32_t p = threadIdx.x & 31u, hw = threadIdx.x >> 5;
-    // persistent: the vectors are staged once, then the workgroup walks its column groups (group g, g + gridDim.x, ...). A half-wave takes FOUR
-    // adjacent columns: a piece of the vectors read from the LDS serves four pieces of the matrix (one column per half-wave made the kernel
-    // LDS-bound: 8 right-hand sides = 8 x the matrix's bytes out of the LDS, 4096 x 65536 x 8 320 us; this form: 2 x).
-    constexpr uint32_t kGroup = (kLdsThreads / 32) * 4; // 128 columns per workgroup and trip
-    for (uint32_t c0 = blockIdx.x * kGroup + hw * 4u; c0 < a.rows_out; c0 += gridDim.x * kGroup) { // rows_out % 4 == 0: a half-wave's 4 columns are all in or all out
-        const T *mp = a.m + z * a.m_batch + (uint64_t)c0 * a.ldm;
-        float acc[4][NRHS];
+    constexpr uint32_t kGroup = (THREADS / 32) * COLS; // columns per workgroup and trip
+    const uint32_t nchunks = (kk + kc - 1u) / kc;
+    auto stage = [&](uint32_t k0, uint32_t len) { // vectors' rows [k0, k0 + len) -> vs[y][0 .. len), len % 4 == 0
+        for (uint32_t idx = threadIdx.x * 4u; idx < len * (uint32_t)NRHS; idx += THREADS * 4u) {
+            const uint32_t y = idx / len, r = idx - y * len; // (len % 4 == 0: a thread's 4 entries belong to one vector)
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (y < a.nrhs) x = load4(vp + (uint64_t)y * a.ldv + k0 + r);
+            *reinterpret_cast<float4 *>(vs + (uint32_t)y * kc + r) = x;
+        }
+    };
+    if (nchunks == 1u) { // staged once, every trip reads it
+        stage(0u, kk);
+        __syncthreads();
+    }
+    // rows_out % 4 == 0 and COLS | 4: a half-wave's columns are all in or all out
+    for (uint32_t g0 = blockIdx.x * kGroup; g0 < a.rows_out; g0 += gridDim.x * kGroup) {
+        const uint32_t c0 = g0 + hw * (uint32_t)COLS;
+        const bool live = c0 < a.rows_out;
+        const T *mp = a.m + z * a.m_batch + (uint64_t)(live ? c0 : 0u) * a.ldm;
+        float acc[COLS][NRHS];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < COLS; ++c)
 #pragma unroll
             for (int y = 0; y < NRHS; ++y) acc[c][y] = 0.f;
-        for (uint32_t r = 4u * p; r < kk; r += 128u) {
-            float4 mv[4];
+        for (uint32_t ch = 0; ch < nchunks; ++ch) {
+            const uint32_t k0 = ch * kc, len = min(kc, kk - k0);
+            if (nchunks > 1u) {
+                __syncthreads(); // everyone is done with the previous chunk
+                stage(k0, len);
+                __syncthreads();
+            }
+            if (!live) continue; // (after the barriers: a workgroup's half-waves past the last column still take part in them)
+            constexpr int U = COLS >= 4 ? 1 : (COLS == 2 ? 2 : 4); // row-steps in flight per lane: COLS * U = 4 loads of 16 bytes
+            uint32_t r = 4u * p;
+            for (; r + 128u * (U - 1) < len; r += 128u * U) {
+                float4 mv[U][COLS];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mv[c] = load4s(mp + (uint64_t)c * a.ldm + r);
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int y = 0; y < NRHS; ++y) {
-                const float4 x = *reinterpret_cast<const float4 *>(vs + (uint32_t)y * kk + r);
+                    for (int c = 0; c < COLS; ++c) mv[u][c] = load4s(mp + (uint64_t)c * a.ldm + k0 + r + 128u * u);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]); acc[c][y] = fmaf(mv[c].y, x.y, acc[c][y]);
-                    acc[c][y] = fmaf(mv[c].z, x.z, acc[c][y]); acc[c][y] = fmaf(mv[c].w, x.w, acc[c][y]);
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int y = 0; y < NRHS; ++y) {
+                        const float4 x = *reinterpret_cast<const float4 *>(vs + (uint32_t)y * kc + r + 128u * u);
+#pragma unroll
+                        for (int c = 0; c < COLS; ++c) {
+                            acc[c][y] = fmaf(mv[u][c].x, x.x, acc[c][y]); acc[c][y] = fmaf(mv[u][c].y, x.y, acc[c][y]);
+                            acc[c][y] = fmaf(mv[u][c].z, x.z, acc[c][y]); acc[c][y] = fmaf(mv[u][c].w, x.w, acc[c][y]);
+                        }
+                    }
+            }
+            for (; r < len; r += 128u) { // what is left of the chunk (< U row-steps)
+                float4 mv[COLS];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) mv[c] = load4s(mp + (uint64_t)c * a.ldm + k0 + r);
+#pragma unroll
+                for (int y = 0; y < NRHS; ++y) {
+                    const float4 x = *reinterpret_cast<const float4 *>(vs + (uint32_t)y * kc + r);
+#pragma unroll
+                    for (int c = 0; c < COLS; ++c) {
+                        acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]); acc[c][y] = fmaf(mv[c].y, x.y, acc[c][y]);
+                        acc[c][y] = fmaf(mv[c].z, x.z, acc[c][y]); acc[c][y] = fmaf(mv[c].w, x.w, acc[c][y]);
+                    }
                 }
             }
         }
+        if (!live) continue;
 #pragma unroll
         for (int y = 0; y < NRHS; ++y) {
-            float s[4];
+            float s[COLS];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < COLS; ++c) {
                 s[c] = acc[c][y];
 #pragma unroll
                 for (int sh = 16; sh >= 1; sh >>= 1) s[c] += __shfl_xor(s[c], sh, 64);
             }
             if (p == 0 && (uint32_t)y < a.nrhs) {
                 T *o = a.out + z * a.dst_batch + (uint64_t)y * a.ld_dst + c0;
-                o[0] = (T)s[0]; o[1] = (T)s[1]; o[2] = (T)s[2]; o[3] = (T)s[3];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) o[c] = (T)s[c];
             }
         }
     }
@@ -495,7 +536,11 @@ __device__ __forceinline__ float4 gemv_small_rows(const T *mp, uint32_t ldm, con
     return s;
 }
 // rows per workgroup = 4 RL: as few as gives the chip >= 128 workgroups
-static inline int gemv_small_rl(uint32_t rows_out) { return rows_out >= 4096u ? 8 : (rows_out >= 2048u ? 4 : 2); }
+static inline int gemv_small_rl(uint32_t rows_out) {
+    static const int forced = [] { const char *e = getenv("WG_GEMV_SMALL_RL"); return e ? atoi(e) : 0; }(); // experiments: 2 / 4 / 8 lanes x float4 of rows per workgroup
+    if (forced == 2 || forced == 4 || forced == 8) return forced;
+    return rows_out >= 4096u ? 8 : (rows_out >= 2048u ? 4 : 2);
+}
 
 template <int RL, typename T>
 __global__ __launch_bounds__(kThreads) void gemv_n_small_kernel(GemvArgsT<T> a) {
@@ -708,7 +753,39 @@ static bool few_rhs_as_gemm(bool trans, bool f16, uint32_t rows_out, uint32_t k,
 #ifndef WG_GEMVT_LDS
 #define WG_GEMVT_LDS 1
 #endif
-// GemvTr with 2 .. 8 right-hand sides whose vectors fit the LDS (see gemv_t_lds_kernel): very many outputs (a vocabulary-sized projection of a small batch).
+// GemvTr with 2 .. 8 right-hand sides on gemv_t_lds_kernel: shape of the workgroups, chunk of k in the LDS, grid.
+struct TLdsPlan {
+    int cols, threads;   // columns per half-wave, threads per workgroup
+    uint32_t kc, grid;   // contracted rows per LDS chunk (== k: one chunk), workgroups
+    size_t lds;
+};
+static TLdsPlan gemv_t_lds_plan(uint32_t cus, uint32_t rows_out, uint32_t k, uint32_t tile) {
+    TLdsPlan pl;
+    // the vectors whole when k x tile floats fit 128 KiB (then they are staged once per workgroup), else chunks of 64 KiB (two workgroups per CU)
+    const uint32_t whole = (128u << 10) / (tile * 4u), chunk = (64u << 10) / (tile * 4u);
+    pl.kc = k <= whole ? k : chunk;
+    pl.lds = (size_t)pl.kc * tile * sizeof(float);
+    static const int shapes[5][2] = { { 4, 1024 }, { 2, 1024 }, { 1, 1024 }, { 1, 512 }, { 1, 256 } }; // 128, 64, 32, 16, 8 columns per trip
+    double best = 1e30;
+    pl.cols = 1; pl.threads = 256; pl.grid = 1;
+    for (const auto &sh : shapes) {
+        const uint32_t per_wg = (uint32_t)sh[0] * (uint32_t)sh[1] / 32u;
+        const uint32_t groups = ceil_div(rows_out, per_wg);
+        uint32_t per_cu = (uint32_t)((160u << 10) / (pl.lds ? pl.lds : 1));
+        if (per_cu > 2048u / (uint32_t)sh[1]) per_cu = 2048u / (uint32_t)sh[1];
+        if (per_cu < 1u) per_cu = 1u;
+        const uint32_t slots = cus * per_cu, grid = groups < slots ? groups : slots;
+        const uint32_t trips = ceil_div(groups, grid);
+        // relative time: work per workgroup slot in column-trips, against an even share; a grid that leaves CUs without a workgroup pays for them;
+        // narrower shapes pay a little for re-reading the vectors from the LDS per column (COLS = 1) and for staging them per workgroup
+        double f = (double)trips * grid / (double)groups;
+        if (groups < cus) f *= (double)cus / groups;
+        // (staging: tile floats of the vectors per contracted row against per_wg floats of the matrix, from the L2; once per workgroup when k is one chunk)
+        f *= 1.0 + 0.02 * (4 - sh[0]) + 0.5 * (double)tile / per_wg * (k > pl.kc ? 1.0 : 1.0 / trips);
+        if (f < best) { best = f; pl.cols = sh[0]; pl.threads = sh[1]; pl.grid = grid; }
+    }
+    return pl;
+}
 template <typename T>
 static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, T *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     GemvArgsT<T> a;
@@ -717,41 +794,50 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
     a.rows_out = rows_out; a.k = k; a.nrhs = nrhs; a.k_per_split = k;
     a.out = out; a.part = nullptr; a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
     const int tile = nrhs > 4 ? 8 : (nrhs > 2 ? 4 : 2);
-    const size_t lds = (size_t)k * tile * sizeof(float);
-    const uint32_t groups = ceil_div(rows_out, (kLdsThreads / 32) * 4), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    const dim3 grid(groups < cus ? groups : cus, 1, nmats), block(kLdsThreads);
-#define WG_T_LDS(NR)                                                                                                                   \
-    do {                                                                                                                               \
-        /* per context (= per device and stream), per instantiation: a process may hold contexts on several devices */                \
-        const uint32_t bit = 1u << ((NR == 8 ? 0 : NR == 4 ? 1 : 2) + (sizeof(T) == 2 ? 3 : 0));                                       \
-        if (!(ctx->func_attr_bits & bit)) {                                                                                            \
-            WG_HIP_TRY(hipFuncSetAttribute((const void *)gemv_t_lds_kernel<NR, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
-            ctx->func_attr_bits |= bit;                                                                                                \
-        }                                                                                                                              \
-        hipLaunchKernelGGL((gemv_t_lds_kernel<NR, T>), grid, block, lds, ctx->stream, a);                                              \
+    const uint32_t cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const TLdsPlan pl = gemv_t_lds_plan(cus, rows_out, k, (uint32_t)tile);
+    const dim3 grid(pl.grid, 1, nmats);
+    // hipFuncAttributeMaxDynamicSharedMemorySize once per context (= per device and stream) and instantiation: bit = 5 * tile index + shape index
+#define WG_T_LDS(NR, COLS, THREADS, SHAPE)                                                                                                     \
+    do {                                                                                                                                       \
+        const uint32_t bit = 1u << (5 * (NR == 8 ? 0 : NR == 4 ? 1 : 2) + SHAPE);                                                              \
+        if (!(ctx->lds_attr_bits & bit)) {                                                                                                     \
+            WG_HIP_TRY(hipFuncSetAttribute((const void *)gemv_t_lds_kernel<NR, T, COLS, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); \
+            ctx->lds_attr_bits |= bit;                                                                                                         \
+        }                                                                                                                                      \
+        hipLaunchKernelGGL((gemv_t_lds_kernel<NR, T, COLS, THREADS>), grid, dim3(THREADS), pl.lds, ctx->stream, a, pl.kc);                     \
     } while (0)
-    if (tile == 8) WG_T_LDS(8); else if (tile == 4) WG_T_LDS(4); else WG_T_LDS(2);
+#define WG_T_LDS_SHAPES(NR)                                                            \
+    do {                                                                               \
+        if (pl.cols == 4) WG_T_LDS(NR, 4, 1024, 0);                                    \
+        else if (pl.cols == 2) WG_T_LDS(NR, 2, 1024, 1);                               \
+        else if (pl.threads == 1024) WG_T_LDS(NR, 1, 1024, 2);                         \
+        else if (pl.threads == 512) WG_T_LDS(NR, 1, 512, 3);                           \
+        else WG_T_LDS(NR, 1, 256, 4);                                                  \
+    } while (0)
+    if (tile == 8) WG_T_LDS_SHAPES(8); else if (tile == 4) WG_T_LDS_SHAPES(4); else WG_T_LDS_SHAPES(2);
+#undef WG_T_LDS_SHAPES
 #undef WG_T_LDS
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
-// Measured (tools/misc_sweep.py): it pays where every CU gets at least one group of 128 columns -- f32 4096 x 65536 x 8: 212 us on the
-// 4-columns-per-wave kernel, 279 on the few-column Gemm kernel, 184 here (vendor 178) -- and loses below that (4096 x 11008 x 4: 86 groups for 256 CUs:
-// 46 vs 36 us); f16 gains nothing over the f16 Gemm kernels (120 vs 111 us). So: f32, outputs >= 128 x CUs.
+// Where it runs (f32 only: f16 gains nothing over the f16 Gemm kernels, 120 vs 111 us at 4096 x 65536 x 8): from WG_GEMVT_LDS_MIN_COLS outputs per CU on
+// (environment, read once; default 8 = every CU gets a workgroup of the narrowest shape). Round 4's kernel had one shape (128 columns per workgroup) and ran
+// from 128 outputs per CU on -- 4096 x 65536 x 8: 184 us against 212 on the 4-columns-per-wave kernel and 279 on the few-column Gemm kernel (vendor 178).
 static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
     if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
-    const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u), cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-#ifndef WG_GEMVT_LDS_MIN_COLS
-#define WG_GEMVT_LDS_MIN_COLS 128 // outputs per CU from which staging the vectors into every workgroup's LDS pays
-#endif
-    return (uint64_t)k * tile * 4u <= (128u << 10) && (uint64_t)rows_out >= (uint64_t)WG_GEMVT_LDS_MIN_COLS * cus && rows_out % 4u == 0 && k % 4u == 0;
+    static const uint32_t min_cols = [] { const char *e = getenv("WG_GEMVT_LDS_MIN_COLS"); return e ? (uint32_t)atoi(e) : 8u; }();
+    const uint32_t cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u);
+    // at most 4 chunks of the vectors (two barriers per chunk and trip): longer contractions with few outputs stay on the split-k kernels
+    const bool k_ok = (uint64_t)k * tile * 4u <= (128u << 10) || (uint64_t)k * tile * 4u <= 4ull * (64u << 10);
+    return (uint64_t)rows_out >= (uint64_t)min_cols * cus && rows_out % 4u == 0 && k % 4u == 0 && k >= 128u && k_ok;
 }
 
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
     if (uses_t_lds(ctx, trans, rows_out, k, nrhs, nmats, dtype == WG_F16 ? 2u : 4u)) {
-        if (dtype == WG_F16) return gemv_t_lds_launch<_Float16>(ctx, rows_out, k, nrhs, nmats, (_Float16 *)out, out_ld, out_batch, m, v);
         return gemv_t_lds_launch<float>(ctx, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
     }
     if (dtype == WG_F16) {

@@ -63,6 +63,7 @@ struct wg_ctx {
     int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
     bool debug_clock_open = false;
+    uint32_t lds_attr_bits = 0;          // likewise for gemv_t_lds_kernel's instantiations (3 right-hand-side tiles x 5 workgroup shapes)
     uint32_t func_attr_bits = 0;         // hipFuncSetAttribute calls already made for this context's device (gemv.hip: GemvTr's 128 KiB dynamic LDS)
     int live_cmdbufs = 0;                // recorded command buffers not yet destroyed: their graphs hold scratch pointers
     std::vector<void *> retired_scratch; // outgrown scratch regions a live command buffer may still replay into
