@@ -21,7 +21,12 @@ N = K = M = 32768
 Ps = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 STEPS = int(os.environ.get("STEPS", "6"))
 out = {"problem": "f16 32768^3, M-sharded; one rank emulated on one GPU", "steps": STEPS, "ranks": {}}
+def note(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
 for P in Ps:
+    note(f"[rank_emulation] P = {P}")
     gpu = wg.GpuInstance.new(0)
     dev, S = gpu.device(), wg.BufferUsages
     Mg = M // P
@@ -75,6 +80,7 @@ for P in Ps:
         prepare_staged(gpu, comm)
         last = Mg * min(panel, N) * 2
         for one, key in ((False, "staged_compute_and_relayout_panel_launches"), (True, "staged_compute_and_relayout")):
+            note("  staged side, one launch:", one)
             dt = staged_side(gpu, comm, A, B, C, one)
             res[key] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "last_panel_bytes_per_peer": last,
                         "one_launch_per_step": one}
@@ -84,11 +90,13 @@ for P in Ps:
         gpu2 = wg.GpuInstance.new(0, cu_count=248, one_xcd=os.environ.get("WG_BENCH_CU_MASK_SPREAD") != "1")  # as bench.py does for the RCCL engine
         comm2 = Comm(gpu2, P, 0, None)
         prepare_staged(gpu2, comm2)
+        note("  248-CU stream, uniform panels")
         dt = staged_side(gpu2, comm2, A, B, C, True)
         res["rccl_compute_side_248_cus"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "stream_compute_units": 248}
         # round 5: the same with the tapered tail bench.py now gives that engine (wg_gemm_sharded_panels): more, narrower panels at the end of a step
         from wgmath_amd.sharded import tapered_panels
         widths = tapered_panels(N, panel, float(os.environ.get("WG_BENCH_TAPER", "0.72")))
+        note("  248-CU stream, tapered panels", widths)
         dt = staged_side(gpu2, comm2, A, B, C, True, widths)
         res["rccl_compute_side_248_cus_tapered"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1),
                                                     "stream_compute_units": 248, "panel_widths": widths}
