@@ -192,7 +192,10 @@ typedef enum wg_tuning {
                                 applicable with the estimate's tile, 128128 / 128064 / 64128 / 96096 / 96064 / 64096 / 64064 / 64032 / 32064 = that tile (tests) */
     WG_TUNE_F32_MID_SPLIT = 6, /* K cut of the mid family's k-split tiles across workgroups (few tiles, long K: 64 x 4096 x 4096): 0 = by estimate (default), n >= 2 = n
                                  splits whenever that family runs (tests) */
-    WG_TUNE_COUNT_ = 7
+    WG_TUNE_GEMVT_LDS = 7,   /* GemvTr with 2 .. 8 right-hand sides on the vectors-in-LDS kernel (gemv.hip gemv_t_lds_kernel): 0 = where it measured ahead (default: from
+                                128 outputs per CU on; two right-hand sides from 8), n >= 1 = from n outputs per CU on whatever the count of right-hand sides,
+                                vectors longer than the LDS in up to 4 chunks (tests: every workgroup shape of the kernel) */
+    WG_TUNE_COUNT_ = 8
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);
 /* Diagnostics / tests (no device needed): the f16 Gemm's calibrated-shares plan for `tiles` whole 256 x 256 tiles of `stages` stages (64 k

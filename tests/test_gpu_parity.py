@@ -318,10 +318,24 @@ GEMV_SHAPES = [
     (4096, 4096, 4, 1), (4096, 3072, 8, 1), (2048, 2304, 7, 1),
     # GemvTr, 2 .. 8 right-hand sides, >= 128 x CUs outputs, vectors in the LDS (gemv_t_lds_kernel); the transposed shape is the plain multi-vector Gemv
     (64, 32768, 3, 1), (132, 33000, 8, 1), (260, 32772, 2, 2),
-    # ... round 5: from 8 outputs per CU on, every workgroup shape of the kernel (8 / 16 / 32 / 64 / 128 columns per trip: gemv_t_lds_plan), vectors longer than
-    # the LDS in 2 - 4 chunks (8 right-hand sides x 8192 rows = 256 KiB; a ragged last chunk; a batch), a last column group that is not full
-    (512, 2048, 3, 1), (1024, 4096, 4, 1), (4096, 11008, 4, 1), (256, 16384, 5, 1), (8192, 2048, 8, 1), (12288, 2056, 4, 1), (9000, 2052, 3, 2), (2048, 6004, 2, 1),
+    # ... two right-hand sides from 8 outputs per CU on (round 5: the kernel's narrow workgroup shapes)
+    (2048, 6004, 2, 1), (1024, 4096, 2, 2),
 ]
+# gemv_t_lds_kernel forced (WG_TUNE_GEMVT_LDS = 8 outputs per CU) onto shapes the launcher keeps on other kernels: every workgroup shape (8 / 16 / 32 / 64 / 128
+# columns per trip: gemv_t_lds_plan), vectors longer than the LDS in 2 - 4 chunks (8 right-hand sides x 8192 rows = 256 KiB; a ragged last chunk; a batch), a
+# last column group that is not full
+GEMVT_LDS_SHAPES = [(512, 2048, 3, 1), (1024, 4096, 4, 1), (4096, 11008, 4, 1), (256, 16384, 5, 1), (8192, 2048, 8, 1), (12288, 2056, 4, 1), (9000, 2052, 3, 2),
+                    (2048, 6004, 2, 1), (128, 40000, 7, 1)]
+
+
+@pytest.mark.parametrize("R,C,nrhs,mats", GEMVT_LDS_SHAPES)
+def test_gemv_tr_lds_kernel_every_shape(gpu, oracle_c, R, C, nrhs, mats):
+    old = gpu.set_tuning("gemvt_lds", 8)
+    try:
+        test_gemv_shapes(gpu, oracle_c, R, C, nrhs, mats, True)
+    finally:
+        gpu.set_tuning("gemvt_lds", old)
+
 
 
 @pytest.mark.parametrize("R,C,nrhs,mats", GEMV_SHAPES)

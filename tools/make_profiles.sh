@@ -6,7 +6,7 @@
 #   3. the plain bench line                                                   -> ${R}_bench.json
 # Outputs go to gpurun_out/profiles_new/ (merged back by gpurun); copy them into profiles/ afterwards.
 set -u
-R=${R:-r04}
+R=${R:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/profiles_new
 rm -rf $OUT; mkdir -p $OUT

@@ -4,7 +4,7 @@
 # other trace domain next to the counters). Usage (GPU box, repo root): bash tools/pmc.sh [workload ...]
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-R=${R:-r04}
+R=${R:-r05}
 OUT=$ROOT/gpurun_out/pmc_$R
 mkdir -p $OUT
 WLS=${@:-gemm_f16_8192 gemmtr_f16_8192 gemm_f16_32768 gemm_f32_4096 gemm_f16_2048 gemm_f32_2048 gemm_f16_ts_131072x1024x8192 gemv_f32_4096x65536 gemvtr_f32_65536x4096 gemv_f16_4096x65536 gemvtr_f16_65536x4096 reduce_f32_4096x65536 op_assign_f32_256M}

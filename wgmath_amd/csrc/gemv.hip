@@ -389,7 +389,7 @@ __global__ __launch_bounds__(THREADS) void gemv_t_lds_kernel(GemvArgsT<T> a, uin
                 __syncthreads();
             }
             if (!live) continue; // (after the barriers: a workgroup's half-waves past the last column still take part in them)
-            constexpr int U = COLS >= 4 ? 1 : (COLS == 2 ? 2 : 4); // row-steps in flight per lane: COLS * U = 4 loads of 16 bytes
+            constexpr int U = 4 / COLS; // row-steps in flight per lane: COLS * U = 4 loads of 16 bytes (8 measured: 4096 x 11008 x 4 55 -> 86 us, 4096 x 65536 x 8 178 -> 196)
             uint32_t r = 4u * p;
             for (; r + 128u * (U - 1) < len; r += 128u * U) {
                 float4 mv[U][COLS];
@@ -821,17 +821,24 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
-// Where it runs (f32 only: f16 gains nothing over the f16 Gemm kernels, 120 vs 111 us at 4096 x 65536 x 8): from WG_GEMVT_LDS_MIN_COLS outputs per CU on
-// (environment, read once; default 8 = every CU gets a workgroup of the narrowest shape). Round 4's kernel had one shape (128 columns per workgroup) and ran
-// from 128 outputs per CU on -- 4096 x 65536 x 8: 184 us against 212 on the 4-columns-per-wave kernel and 279 on the few-column Gemm kernel (vendor 178).
+// Where it runs (f32 only: f16 gains nothing over the f16 Gemm kernels, 120 vs 111 us at 4096 x 65536 x 8), measured with tools/misc_sweep.py
+// (profiles/r05_evidence.md section 5):
+//   * from 128 outputs per CU on, the vectors whole in the LDS: 4096 x 65536 x 8 178 us against 212 on the
+//     4-columns-per-wave kernel and 279 on the few-column Gemm kernel (vendor 178);
+//   * TWO right-hand sides from 8 outputs per CU on (the narrow workgroup shapes of round 5): 4096^2 x 2 18.2 -> 12.8 us (vendor 18.9);
+//   * NOT 3 .. 8 right-hand sides on fewer outputs: every workgroup shape loses to the matrix-core path there (4096 x 11008 x 4: 55 us on 344 workgroups
+//     of 32 columns, 86 with twice the loads in flight, against 40 on the few-column Gemm kernel; 4096^2 x 8 26.5 against 18.1) -- a column is 16 KiB,
+//     each half-wave's whole life is a few dependent round trips behind the staging of the vectors.
 static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
     if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
-    static const uint32_t min_cols = [] { const char *e = getenv("WG_GEMVT_LDS_MIN_COLS"); return e ? (uint32_t)atoi(e) : 8u; }();
+    const uint32_t forced = (uint32_t)ctx->tuning[WG_TUNE_GEMVT_LDS], min_cols = forced ? forced : 128u; // (forced: tests, experiments -- wg_ctx_set_tuning)
     const uint32_t cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u);
-    // at most 4 chunks of the vectors (two barriers per chunk and trip): longer contractions with few outputs stay on the split-k kernels
-    const bool k_ok = (uint64_t)k * tile * 4u <= (128u << 10) || (uint64_t)k * tile * 4u <= 4ull * (64u << 10);
-    return (uint64_t)rows_out >= (uint64_t)min_cols * cus && rows_out % 4u == 0 && k % 4u == 0 && k >= 128u && k_ok;
+    if (rows_out % 4u || k % 4u || k < 128u) return false;
+    const bool whole = (uint64_t)k * tile * 4u <= (128u << 10);                       // one chunk: staged once per workgroup
+    const bool chunks_ok = whole || (uint64_t)k * tile * 4u <= 4ull * (64u << 10);     // at most 4 chunks (two barriers per chunk and trip)
+    if ((uint64_t)rows_out >= (uint64_t)min_cols * cus) return forced ? chunks_ok : whole;
+    return nrhs == 2u && whole && (uint64_t)rows_out >= 8ull * cus;
 }
 
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,

@@ -148,7 +148,8 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
     // kernel-selection knobs: the environment is consulted here and nowhere on the dispatch path
     static const struct { const char *env; wg_tuning key; } knobs[] = {
         { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
-        { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID }, { "WG_F32_MID_SPLIT", WG_TUNE_F32_MID_SPLIT } };
+        { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID }, { "WG_F32_MID_SPLIT", WG_TUNE_F32_MID_SPLIT },
+        { "WG_GEMVT_LDS", WG_TUNE_GEMVT_LDS } };
     for (const auto &k : knobs)
         if (const char *v = getenv(k.env)) {
             // the same validation as wg_ctx_set_tuning: a value the knob does not take is ignored (with a note), never silently reinterpreted
@@ -299,6 +300,11 @@ int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value) {
     if (key == WG_TUNE_F16_TILE && value != 0 && value != 128 && value != 256 && value != 256128)
         return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_F16_TILE takes 0, 128, 256 or 256128, not %d", value);
     if (key == WG_TUNE_F32_MID && (value == 64064 || value == 64128 || value == 128064 || value == 128128 || value == 64032 || value == 32064 || value == 96096 || value == 96064 || value == 64096)) {
+        ctx->tuning[key] = value;
+        return WG_OK;
+    }
+    if (key == WG_TUNE_GEMVT_LDS) {
+        if (value < 0 || value > 65536) return wg_set_error(WG_ERR_INVALID_ARG, "wg_ctx_set_tuning: WG_TUNE_GEMVT_LDS takes 0 or an output count per CU, not %d", value);
         ctx->tuning[key] = value;
         return WG_OK;
     }
