@@ -25,6 +25,10 @@ def note(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+import signal  # noqa: E402
+signal.alarm(int(os.environ.get("EMU_TIMEOUT", "600")))  # a stuck run ends by itself with SIGALRM (round 5: one 3-rank-count run never returned; see r05_evidence.md section 4)
+
+
 for P in Ps:
     note(f"[rank_emulation] P = {P}")
     gpu = wg.GpuInstance.new(0)
