@@ -88,6 +88,40 @@ template <typename T> static void rccl_one_rank(wg_ctx *ctx, wg_comm *comm, bool
     wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
 }
 
+// wg_gemm_sharded_panels through the plain C ABI: a tapered tail (equal panels, then narrower ones, the last one the rest) in the one-launch form and a list that
+// is not of that shape (panel by panel), against f64; bad lists are refused; the wait-timing diagnostics return one entry per panel of the stamped call
+static void rccl_one_rank_tapered(wg_ctx *ctx, wg_comm *comm) {
+    using T = _Float16;
+    const uint32_t M = 4096, N = 4096 + 128, K = 512;
+    auto A = rnd<T>((size_t)M * K, 71), B = rnd<T>((size_t)K * N, 72);
+    wg_buf *a = nullptr, *b = nullptr, *c = nullptr;
+    CK(wg_buf_create_init(ctx, A.data(), A.size() * sizeof(T), USAGE, &a));
+    CK(wg_buf_create_init(ctx, B.data(), B.size() * sizeof(T), USAGE, &b));
+    CK(wg_buf_create(ctx, (size_t)M * N * sizeof(T), USAGE, &c));
+    const uint32_t taper[] = { 1024, 1024, 768, 512, 512, 256, 128 }, other[] = { 512, 1024, 2048, 640 }, short_[] = { 1024, 1024 }, odd[] = { 4222, 2 };
+    for (int which = 0; which < 2; ++which) {
+        CK(wg_buf_fill_zero(ctx, c));
+        CK(wg_comm_set_wait_timing(comm, 1));
+        CK(wg_gemm_sharded_panels(comm, WG_GEMM, WG_F16, WG_GATHER_RCCL, which ? other : taper, which ? 4u : 7u, c, mat(M, N), a, mat(M, K), b, mat(K, N)));
+        CK(wg_comm_join(comm));
+        uint32_t panels[64], n = 0;
+        float ms[64];
+        CK(wg_comm_wait_times(comm, panels, ms, 64, &n));
+        CK(wg_comm_set_wait_timing(comm, 0));
+        EXPECT(n == (which ? 4u : 7u), "wait-timing entries: %u", n);
+        for (uint32_t i = 0; i < n; ++i) EXPECT(panels[i] == i && ms[i] >= 0.f && ms[i] < 1000.f, "wait %u: panel %u, %.3f ms", i, panels[i], ms[i]);
+        std::vector<T> got((size_t)M * N);
+        CK(wg_buf_read(ctx, c, 0, got.data(), got.size() * sizeof(T)));
+        check_product(which ? "rccl 1-rank f16, panels 512 1024 2048 640" : "rccl 1-rank f16, tapered panels", got, A, false, B, M, N, K);
+    }
+    EXPECT(wg_gemm_sharded_panels(comm, WG_GEMM, WG_F16, WG_GATHER_RCCL, short_, 2, c, mat(M, N), a, mat(M, K), b, mat(K, N)) == WG_ERR_PRECONDITION, "widths that do not sum to N");
+    EXPECT(wg_gemm_sharded_panels(comm, WG_GEMM, WG_F16, WG_GATHER_RCCL, odd, 2, c, mat(M, N), a, mat(M, K), b, mat(K, N)) == WG_ERR_PRECONDITION, "a width that is not a multiple of 4");
+    EXPECT(wg_gemm_sharded_panels(comm, WG_GEMM, WG_F16, WG_GATHER_RCCL, nullptr, 0, c, mat(M, N), a, mat(M, K), b, mat(K, N)) == WG_ERR_INVALID_ARG, "no widths");
+    uint64_t fr = 0, tot = 0;
+    EXPECT(wg_ctx_mem_info(ctx, &fr, &tot) == WG_OK && fr > 0 && fr <= tot, "wg_ctx_mem_info: %llu of %llu", (unsigned long long)fr, (unsigned long long)tot);
+    wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
+}
+
 // two ranks in one process, WG_GATHER_PEER_STAGED: staging cubes + contiguous per-peer copies + flags + wait kernel + relayout, three steps
 // back to back WITHOUT any host synchronisation or barrier in between (the engine is stream-ordered and double-buffered by step parity)
 template <typename T> static void staged_two_ranks(bool tr, uint32_t M, uint32_t N, uint32_t K, uint32_t panel, bool pipelined = false) {
@@ -318,6 +352,7 @@ int main() {
         EXPECT(wg_comm_reported_size(comm, &reported) == WG_OK && reported == 1, "ncclCommCount: %d (%s)", reported, wg_last_error_string());
     }
     rccl_pipelined_alternating_shapes(ctx, comm);
+    rccl_one_rank_tapered(ctx, comm);
     wg_comm_destroy(comm);
 
     staged_two_ranks<float>(false, 512, 768, 256, 256);
