@@ -1401,7 +1401,9 @@ def main():
             if u is None:
                 continue
             if o["metric"] == "gemm_tflops":
-                ulps["f16_gemm" if o["dtype"] == "f16" else "f32_gemm"].append(u)
+                # U[0,1) operands: every partial sum is positive and grows, rounding errors do not cancel the way they do for U[-1,1): its own figure
+                key = ("f16_gemm" if o["dtype"] == "f16" else "f32_gemm") + ("_u01" if o["workload"].endswith("_u01") else "")
+                ulps.setdefault(key, []).append(u)
             elif o["metric"] == "gemv_gbs" and o["dtype"] == "f32":
                 ulps["f32_gemv"].append(u)
         # sampled entries of every result checked after timing, |gpu - f64| in ulps of the result's format (bounds asserted in tests/test_gpu_ulp.py)
