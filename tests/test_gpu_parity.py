@@ -320,8 +320,7 @@ GEMV_SHAPES = [
     (64, 32768, 3, 1), (132, 33000, 8, 1), (260, 32772, 2, 2),
     # ... two right-hand sides from 8 outputs per CU on (round 5: the kernel's narrow workgroup shapes)
     (2048, 6004, 2, 1), (1024, 4096, 2, 2),
-    # GemvTr f32, 2 .. 8 right-hand sides, four columns per half-wave (gemv_t_cols_multi_kernel, round 5): few outputs with k split across workgroups + combine,
-    # a ragged last group of columns with a batch, k that is not a multiple of a trip, 3 / 5 / 8 right-hand sides on the 4- and 8-wide register tiles
+    # 2 .. 8 right-hand sides on more shapes (round 5): few outputs with a long contraction, a ragged column count with a batch, k off every tile size
     (65536, 128, 3, 1), (8192, 1028, 5, 2), (4100, 2048, 4, 1), (16384, 512, 8, 1), (6000, 3000, 2, 1),
 ]
 # gemv_t_lds_kernel forced (WG_TUNE_GEMVT_LDS = 8 outputs per CU) onto shapes the launcher keeps on other kernels: every workgroup shape (8 / 16 / 32 / 64 / 128

@@ -339,80 +339,6 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// T with 2 .. 8 right-hand sides, the half-wave-per-column shape of gemv_t_cols_kernel carried over (round 5): a half-wave streams COLS ADJACENT columns of
-// the matrix (whole 128-byte lines, COLS x U loads of 16 bytes in flight per lane) and multiplies every piece with the NR pieces of the vectors at the
-// same rows, read through the L1 like the single vector of gemv_t_cols_kernel. With COLS = 4 a piece of the vectors serves four pieces of the matrix: for
-// 4 right-hand sides the L1 delivers one byte of vectors per byte of matrix -- the ratio of the single-vector kernel, which streams at 6.5 TB/s -- and for 8
-// two. No LDS, no barrier, any k; a split of k across workgroups (blockIdx.y) writes f32 partials for gemv_combine_kernel like every GEMV kernel here.
-// grid = (ceil(outputs / (8 COLS)), splits, nmats); 256 threads = 8 half-waves.
-// ------------------------------------------------------------------------------------------------------
-template <int NR, int COLS>
-__global__ __launch_bounds__(kThreads) void gemv_t_cols_multi_kernel(GemvArgsT<float> a) {
-    const uint32_t c0 = (blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5)) * (uint32_t)COLS;
-    const uint32_t p = threadIdx.x & 31u;
-    const uint32_t z = blockIdx.z;
-    if (c0 >= a.rows_out) return; // whole half-waves leave together (rows_out % 4 == 0 and COLS | 4: a half-wave's columns are all in or all out)
-    const uint32_t r_begin = blockIdx.y * a.k_per_split;
-    const uint32_t r_end = min(a.k, r_begin + a.k_per_split);
-    const float *mp = a.m + z * a.m_batch + (uint64_t)c0 * a.ldm;
-    const float *vp = a.v + z * a.v_batch;
-    constexpr int U = 8 / COLS;           // row-steps in flight: COLS x U = 8 loads of 16 bytes per lane
-    constexpr uint32_t kChunk = 128u;     // rows a half-wave covers per load (32 lanes x float4)
-    constexpr uint32_t kBlock = kChunk * U;
-    float acc[COLS][NR];
-#pragma unroll
-    for (int c = 0; c < COLS; ++c)
-#pragma unroll
-        for (int y = 0; y < NR; ++y) acc[c][y] = 0.f;
-    auto step = [&](const float4 (&mv)[COLS], uint32_t r) {
-#pragma unroll
-        for (int y = 0; y < NR; ++y) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((uint32_t)y < a.nrhs) x = load4(vp + (uint64_t)y * a.ldv + r);
-#pragma unroll
-            for (int c = 0; c < COLS; ++c) {
-                acc[c][y] = fmaf(mv[c].x, x.x, acc[c][y]); acc[c][y] = fmaf(mv[c].y, x.y, acc[c][y]);
-                acc[c][y] = fmaf(mv[c].z, x.z, acc[c][y]); acc[c][y] = fmaf(mv[c].w, x.w, acc[c][y]);
-            }
-        }
-    };
-    const uint32_t nblocks = (r_end - r_begin) / kBlock;
-    for (uint32_t i = 0; i < nblocks; ++i) {
-        const uint32_t r = r_begin + i * kBlock + 4u * p;
-        float4 mv[U][COLS];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int c = 0; c < COLS; ++c) mv[u][c] = load4s(mp + (uint64_t)c * a.ldm + r + kChunk * u);
-#pragma unroll
-        for (int u = 0; u < U; ++u) step(mv[u], r + kChunk * u);
-    }
-    for (uint32_t r = r_begin + nblocks * kBlock + 4u * p; r < r_end; r += kChunk) { // < one trip left (k % 4 == 0: a lane's 4 rows are all in or all out)
-        float4 mv[COLS];
-#pragma unroll
-        for (int c = 0; c < COLS; ++c) mv[c] = load4s(mp + (uint64_t)c * a.ldm + r);
-        step(mv, r);
-    }
-#pragma unroll
-    for (int y = 0; y < NR; ++y) {
-        float s[COLS];
-#pragma unroll
-        for (int c = 0; c < COLS; ++c) {
-            s[c] = acc[c][y];
-#pragma unroll
-            for (int sh = 16; sh >= 1; sh >>= 1) s[c] += __shfl_xor(s[c], sh, 64);
-        }
-        if (p == 0 && (uint32_t)y < a.nrhs) {
-            const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)y * a.ld_dst + c0;
-#pragma unroll
-            for (int c = 0; c < COLS; ++c) {
-                if (a.part) a.part[off + c] = s[c]; else a.out[off + c] = s[c];
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // T with 2 .. 8 right-hand sides: the small-batch product x^T W of a weight matrix stored k x outputs. The vectors are staged into the LDS (as f32) in
 // chunks of KC contracted rows -- the whole of k when it fits, which is the common case: then once per workgroup --, and every half-wave streams its
 // columns of the matrix exactly like gemv_t_cols_kernel (whole 128-byte lines, U loads in flight) and multiplies each 16-byte piece with the NRHS pieces
@@ -915,59 +841,15 @@ static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_
     return nrhs == 2u && whole && (uint64_t)rows_out >= 8ull * cus;
 }
 
-// GemvTr f32 with 2 .. 8 right-hand sides on gemv_t_cols_multi_kernel: 4 columns per half-wave, k split like the single-vector kernel's (2 workgroups per CU).
-static int gemv_t_cols_multi_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m,
-                                    wgk_mat v) {
-    const uint32_t cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-    constexpr uint32_t COLS = 4;
-    const uint32_t gx = ceil_div(rows_out, 8u * COLS);
-    if (nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: more than 65535 matrices");
-    // ~2 workgroups per CU; a split takes >= 2048 contracted rows (8 trips per lane)
-    uint32_t want = (uint64_t)gx * nmats >= 2ull * cus ? 1u : ceil_div(2u * cus, gx * nmats);
-    const uint32_t max_split = k == 0 ? 1u : ceil_div(k, 2048u);
-    uint32_t nsplit = want > max_split ? max_split : want;
-    if (nsplit < 1u) nsplit = 1u;
-    uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u;
-    nsplit = k == 0 ? 1u : ceil_div(k, k_per_split);
-    GemvArgsT<float> a;
-    a.m = (const float *)m.ptr; a.ldm = m.ld; a.m_batch = m.batch;
-    a.v = (const float *)v.ptr; a.ldv = v.ld; a.v_batch = v.batch;
-    a.rows_out = rows_out; a.k = k; a.nrhs = nrhs; a.k_per_split = k_per_split;
-    a.out = out; a.part = nullptr;
-    if (nsplit > 1) {
-        void *ws = nullptr;
-        if (int rc = wg_ctx_workspace(ctx, (size_t)nmats * nsplit * nrhs * rows_out * sizeof(float), &ws)) return rc;
-        a.part = (float *)ws;
-        a.ld_dst = rows_out; a.dst_split = (uint64_t)nrhs * rows_out; a.dst_batch = (uint64_t)nsplit * nrhs * rows_out;
-    } else {
-        a.ld_dst = out_ld; a.dst_split = 0; a.dst_batch = out_batch;
-    }
-    const dim3 grid(gx, nsplit, nmats), block(kThreads);
-    if (nrhs <= 2u) hipLaunchKernelGGL((gemv_t_cols_multi_kernel<2, 4>), grid, block, 0, ctx->stream, a);
-    else if (nrhs <= 4u) hipLaunchKernelGGL((gemv_t_cols_multi_kernel<4, 4>), grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL((gemv_t_cols_multi_kernel<8, 4>), grid, block, 0, ctx->stream, a);
-    WG_HIP_TRY(hipGetLastError());
-    if (nsplit > 1) {
-        hipLaunchKernelGGL(gemv_combine_kernel<float>, dim3(ceil_div(rows_out / 4u, 4u), nrhs, nmats), block, 0, ctx->stream, a.part, nsplit, rows_out, nrhs, out, out_ld, out_batch);
-        WG_HIP_TRY(hipGetLastError());
-    }
-    return WG_OK;
-}
-#ifndef WG_GEMVT_MULTI
-#define WG_GEMVT_MULTI 1 // 0: GemvTr f32 with 2 .. 8 right-hand sides never runs on gemv_t_cols_multi_kernel (A/B builds)
-#endif
-static bool uses_t_cols_multi(bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t es) {
-    return WG_GEMVT_MULTI && trans && es == 4u && nrhs >= 2u && nrhs <= 8u && rows_out % 4u == 0 && k % 4u == 0 && k >= 512u && (uint64_t)rows_out * k >= (1ull << 22);
-}
-
+// (Round 5 also carried the half-wave-per-column shape of gemv_t_cols_kernel over to 2 .. 8 right-hand sides -- four adjacent columns per half-wave, the
+// vectors re-read through the L1 -- and measured it slower than every path above on all eight sweep cases (4096^2 x 4: 35.8 us against 18.3 on the few-column
+// Gemm kernel; 4096 x 11008 x 4: 47 against 39): the re-reads cost the L1 as much as the matrix itself. Removed; profiles/r05_evidence.md section 5.)
 int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats,
              void *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m, wgk_mat v) {
     if (rows_out == 0 || nrhs == 0 || nmats == 0) return WG_OK;
     if (uses_t_lds(ctx, trans, rows_out, k, nrhs, nmats, dtype == WG_F16 ? 2u : 4u)) {
         return gemv_t_lds_launch<float>(ctx, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
     }
-    if (uses_t_cols_multi(trans, rows_out, k, nrhs, dtype == WG_F16 ? 2u : 4u))
-        return gemv_t_cols_multi_launch(ctx, rows_out, k, nrhs, nmats, (float *)out, out_ld, out_batch, m, v);
     if (dtype == WG_F16) {
         // f16 (extension; the reference kernel is f32, gemv.wgsl:9-14): the same HBM-bound kernels on f16 elements (8-byte loads of 4 rows,
         // f32 accumulation in the same order, one rounding at the store; split partials stay f32). More than 8 right-hand sides are a
