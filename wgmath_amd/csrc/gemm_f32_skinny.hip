@@ -9,7 +9,8 @@
 // with a single chunk the kernel writes the output itself.
 // History (profiles/r01_evidence.md section 14): a first kernel streamed A straight from global memory into MFMA operands (register ring,
 // 4 waves splitting K, LDS sum) -- 20-40 % slower than this one once its loads overlapped the MFMAs; a shared B stage with one barrier per
-// stage was 50-70 % slower (the waves drift with memory latency); a 16-wide MFMA variant for N <= 16 changed nothing (stream-bound).
+// stage was 50-70 % slower (the waves drift with memory latency); a 16-wide MFMA variant for N <= 16 changed nothing THEN (round 1, a slower stream) and is
+// the shipped form for N <= 16 since round 5 (W16 below): with the stream at 5.3 TB/s the 32-wide MFMAs kept the matrix pipe busy 58 % of the time and the clock at 1.9 GHz.
 #include "wg_internal.hpp"
 #include <cstdlib>
 #include <type_traits>
@@ -17,6 +18,10 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+#ifndef WG_SKINNY_W16
+#define WG_SKINNY_W16 1 // N <= 16 on v_mfma_f32_16x16x4_f32 (two 16-row sub-tiles per wave) instead of 32x32x2 with half of its columns padding (0: A/B builds)
+#endif
 
 struct SkinnyArgs {
     const float *a; uint32_t lda; uint64_t a_batch;
@@ -57,11 +62,19 @@ __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mo
 
 // B_KMAJ: m2 is given with its COLUMNS contiguous (element (k, n) at b[n + k * ldb]) -- the untransposed m1 of a few-row Gemm computed
 // transposed; its stage image is [32 k][32 n] per column tile, read like the column-major A image.
-template <bool TRANS_A, int NT, bool B_KMAJ = false>
+// W16 (round 5, N <= 16): the same stages, rings and LDS images, multiplied by v_mfma_f32_16x16x4_f32 -- lane (i16 = lane & 15, kq = lane >> 4) feeds row / column i16
+// with k = 4 (kq + 4 j) + s of the stage (j = 0, 1; s = the component of its float4): two 16-row sub-tiles x 8 MFMAs of 32 cycles per stage instead of 16 of 64 (the
+// 32-wide tile spends half of its MFMA cycles -- 7/8 for 4 columns -- on columns that do not exist, and the counters show the MFMA pipe busy 58 % of this HBM-bound
+// kernel's time at N = 16: profiles/r05_evidence.md section 5). C/D: lane (i16, kq) holds column i16, rows 4 kq .. 4 kq + 3 of each sub-tile.
+template <bool TRANS_A, int NT, bool B_KMAJ = false, bool W16 = false>
 __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
-    constexpr int RING = NT == 1 ? 4 : 3;           // 128 / 144 KiB of LDS: one workgroup per CU
-    constexpr int STAGE_BYTES = 4096 * (1 + NT);      // per wave: A 32 rows x 128 B, then B 32 NT columns x 128 B
-    constexpr int PIECES = 4 * (1 + NT);              // DMA pieces per wave and stage
+    static_assert(!W16 || NT == 1, "the 16-wide form has one column tile");
+    // (W16 stages the same 32 columns of B and keeps the 4-stage ring: staging only the 16 it uses and giving the room to a 6-stage ring -- 20 KiB of A in flight per
+    // wave instead of 12 -- measured slower: 32000 x 16 x 4096 5.75 -> 5.57 TB/s, GemvTr 8192^2 x 3 43.1 -> 46.5 us; profiles/r05_evidence.md section 5)
+    constexpr int BP = 4 * NT;                        // DMA pieces of B per wave and stage
+    constexpr int RING = NT == 1 ? 4 : 3;             // 128 / 144 KiB of LDS: one workgroup per CU
+    constexpr int STAGE_BYTES = 4096 + 1024 * BP;     // per wave: A 32 rows x 128 B, then B 32 NT (16) columns x 128 B
+    constexpr int PIECES = 4 + BP;                    // DMA pieces per wave and stage
     __shared__ __attribute__((aligned(16))) char smem[4 * RING * STAGE_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -77,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     // ---- DMA addressing: piece q = rows 8 q .. 8 q + 7 of the wave's 32 (lane -> row 8 q + (lane >> 3), position lane & 7) ----
     const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda);
     const float *B = g.b + z * g.b_batch + (B_KMAJ ? (uint64_t)kb * g.ldb : (uint64_t)kb);
-    uint32_t a_voff[4], b_voff[4 * NT], a_tail[4], b_tail[4 * NT]; // byte offsets; *_tail: the last stage, k clamped into the matrix
+    uint32_t a_voff[4], b_voff[BP], a_tail[4], b_tail[BP]; // byte offsets; *_tail: the last stage, k clamped into the matrix
     const uint32_t kmax = g.K - 4u - kb - 32u * (nst - 1u);        // largest valid k offset (in floats) of a chunk in the last stage
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4 * NT; ++q) {
+    for (int q = 0; q < BP; ++q) {
         if constexpr (B_KMAJ) { // piece q & 3 = k rows 8 (q & 3) .. + 7 of column tile q >> 2; 4 columns per lane (N % 4 == 0)
             const uint32_t kr = 8u * (q & 3) + (lane >> 3);
             const uint32_t col = min(col0 + 32u * (q >> 2) + 4u * (lane & 7u), g.N - 4u);
@@ -147,6 +160,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     for (int u = 0; u < NT; ++u)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+    floatx4v acc16[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }; // W16: sub-tile t = rows 16 t .. 16 t + 15 of the wave's 32
+    const int i16 = lane & 15, kq = lane >> 4;
 
     const uint32_t rd = (uint32_t)i * 128u, sw = (uint32_t)((i >> 1) & 7);
     const char *wbase = smem + wave * (RING * STAGE_BYTES);
@@ -156,6 +171,41 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     // branches, which costs the overlap of the next substep's reads with this substep's MFMAs.
     auto compute = [&](const char *sl, auto tail_c, uint32_t valid) {
         constexpr bool TAIL = decltype(tail_c)::value;
+        if constexpr (W16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t c = (uint32_t)kq + 4u * j; // this lane's 16-byte chunk of the stage: k = 4 c .. 4 c + 3
+                float4 af[2], bf;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t row = 16u * t + (uint32_t)i16;
+                    if constexpr (TRANS_A) af[t] = *reinterpret_cast<const float4 *>(sl + row * 128u + ((c ^ ((row >> 1) & 7u)) * 16u));
+                    else {
+                        const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + row;
+                        af[t] = make_float4(ak[0], ak[32], ak[64], ak[96]);
+                    }
+                }
+                if constexpr (B_KMAJ) {
+                    const float *bk = reinterpret_cast<const float *>(sl + 4096u + (4u * c) * 128u) + i16;
+                    bf = make_float4(bk[0], bk[32], bk[64], bk[96]);
+                } else bf = *reinterpret_cast<const float4 *>(sl + 4096u + (uint32_t)i16 * 128u + ((c ^ (((uint32_t)i16 >> 1) & 7u)) * 16u));
+                if constexpr (TAIL) {
+                    const bool live = c < valid;
+                    asm volatile("" : "+v"(af[0].x), "+v"(af[0].y), "+v"(af[0].z), "+v"(af[0].w), "+v"(af[1].x), "+v"(af[1].y), "+v"(af[1].z), "+v"(af[1].w));
+                    asm volatile("" : "+v"(bf.x), "+v"(bf.y), "+v"(bf.z), "+v"(bf.w));
+                    af[0] = live ? af[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    af[1] = live ? af[1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bf = live ? bf : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc16[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(comp4(af[t], sidx), comp4(bf, sidx), acc16[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint32_t c = 2u * ks + h;
@@ -207,6 +257,33 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     const bool direct = g.nsplit == 1;
     float *P = direct ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
     const uint32_t ldp = direct ? g.ldc : g.M;
+    auto put4 = [&](uint32_t col, uint32_t row, float4 v) { // rows row .. row + 3 of column col (M % 4 == 0: all in or all out)
+        float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
+        if (direct) {
+            if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+            if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
+                float *t = P + (uint64_t)col * ldp + (uint64_t)row * g.crs;
+                t[0] = v.x; t[g.crs] = v.y; t[2u * g.crs] = v.z; t[3u * g.crs] = v.w;
+                return;
+            }
+            if (g.beta != 0.f) {
+                const float4 o = *dst;
+                v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
+            }
+        }
+        *dst = v;
+    };
+    if constexpr (W16) {
+        const uint32_t col = col0 + (uint32_t)i16;
+        if (col < g.N) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t row = r0 + 16u * t + 4u * (uint32_t)kq;
+                if (row < g.M) put4(col, row, make_float4(acc16[t][0], acc16[t][1], acc16[t][2], acc16[t][3]));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const uint32_t col = col0 + 32u * u + i;
@@ -272,13 +349,17 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = npanels;
     g.rot = (uint64_t)(ns > 1 ? kps : K) * (N < 32u * (N <= 32 ? 1u : 2u) ? N : 32u * (N <= 32 ? 1u : 2u)) * 4u <= (256u << 10) ? 1u : 0u;
     const dim3 grid(row_blocks, ns, nmats * npanels);
+    const bool w16 = WG_SKINNY_W16 && N <= 16u && npanels == 1u;
     if (m2_kmajor) { // GemmTr only (the few-row route)
-        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
+        if (w16) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true, true>), grid, dim3(256), 0, ctx->stream, g);
+        else if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, true>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2, true>), grid, dim3(256), 0, ctx->stream, g);
     } else if (trans) {
-        if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
+        if (w16) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, false, true>), grid, dim3(256), 0, ctx->stream, g);
+        else if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1>), grid, dim3(256), 0, ctx->stream, g);
         else hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 2>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 1>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (w16) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 1, false, true>), grid, dim3(256), 0, ctx->stream, g);
+    else if (N <= 32) hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 1>), grid, dim3(256), 0, ctx->stream, g);
     else hipLaunchKernelGGL((gemm_f32_skinny_kernel<false, 2>), grid, dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (ns == 1) return WG_OK;

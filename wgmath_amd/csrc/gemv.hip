@@ -747,7 +747,9 @@ static bool few_rhs_as_gemm(bool trans, bool f16, uint32_t rows_out, uint32_t k,
     const uint64_t bytes = (uint64_t)rows_out * k * es;
     if (nrhs < 3u || bytes < ((nrhs >= 7u ? 16ull : 48ull) << 20)) return false; // (7-8 right-hand sides pay from 16 MiB: 4096^2 f16 x 8 26 -> 19 us)
     if (trans) return f16 || (uint64_t)rows_out < 8ull * k;
-    return f16 || (nrhs >= 7u && bytes < (256ull << 20)); // f32 Gemv: only 7-8 right-hand sides on mid-size matrices (4096^2 x 8: 22.5 -> 19 us)
+    // f32 Gemv: since the few-column Gemm kernel multiplies N <= 16 on 16-wide MFMAs (round 5) it is ahead of the 8-accumulator N kernel on everything but a few
+    // rows with a long contraction (11008 x 4096 x 4: 36.4 -> 33.2 us, 65536 x 4096 x 8: 187 -> 176, 8192^2 x 3: 47.7 -> 42.9; 4096 x 65536 x 8: 173 stays, Gemm 180)
+    return f16 || (uint64_t)k < 8ull * rows_out;
 }
 
 #ifndef WG_GEMVT_LDS
