@@ -1098,6 +1098,15 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.calib = nullptr; g.bal = BalancePlan{}; g.panel = PanelArgs{};
 
     auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+#ifndef WG_F16_SKINNY
+#define WG_F16_SKINNY 1 // 0: f16 GemmTr with few columns never takes the streaming kernel (A/B builds)
+#endif
+    // GemmTr with N <= 16 on a matrix that is not launch-bound (an f16 GemvTr with a few right-hand sides; a weight matrix applied to a small batch): HBM-bound on m1,
+    // the tiled kernels below spend 15/16 of a 128-column tile on nothing. The few-column streaming kernel (gemm_f32_skinny.hip, T = _Float16) reads m1 once.
+    if (WG_F16_SKINNY && trans && !panels && N <= 16u && M >= 512u && M % 4u == 0 && K >= 256u && K % 8u == 0 && m1.ld % 8u == 0 && m2.ld % 8u == 0 &&
+        out_ld % 4u == 0 && al16(m1.ptr) && al16(m2.ptr) && ((uintptr_t)out & 7) == 0 && (nmats == 1 || (m1.batch % 8u == 0 && m2.batch % 8u == 0 && out_batch % 4u == 0)) &&
+        (uint64_t)M * K * 2u >= (16ull << 20) && (uint64_t)m1.ld * 32u * 2u < (1ull << 31) && (uint64_t)m2.ld * 32u * 2u < (1ull << 31))
+        return wgk_gemm_f16_skinny(ctx, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
     const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
     // 32-bit DMA offsets within a tile: rows * ld * 2 bytes must stay below 2^31
     const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);

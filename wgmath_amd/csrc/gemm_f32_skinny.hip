@@ -66,9 +66,18 @@ __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mo
 // with k = 4 (kq + 4 j) + s of the stage (j = 0, 1; s = the component of its float4): two 16-row sub-tiles x 8 MFMAs of 32 cycles per stage instead of 16 of 64 (the
 // 32-wide tile spends half of its MFMA cycles -- 7/8 for 4 columns -- on columns that do not exist, and the counters show the MFMA pipe busy 58 % of this HBM-bound
 // kernel's time at N = 16: profiles/r05_evidence.md section 5). C/D: lane (i16, kq) holds column i16, rows 4 kq .. 4 kq + 3 of each sub-tile.
-template <bool TRANS_A, int NT, bool B_KMAJ = false, bool W16 = false>
+// T = _Float16 (round 5; GemmTr with N <= 16 only, i.e. TRANS_A + W16 with k-contiguous m2): the same stages, rings and images at 64 k per 128-byte line; a lane's
+// 16-byte chunk is the 8 halves v_mfma_f32_16x16x32_f16 takes from it (k = 8 kq .. 8 kq + 7 of a 32-k block: chunk kq + 4 j is block j), f32 accumulation, one
+// rounding at the store (split partials stay f32). What it is for: f16 GemvTr with 3 .. 16 right-hand sides / f16 GemmTr with few columns, which the tiled
+// f16 kernels ran at 3.9 TB/s (65536 x 4096 x 8: 138 us, vendor 115).
+typedef _Float16 sk_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sk_h4 __attribute__((ext_vector_type(4)));
+template <bool TRANS_A, int NT, bool B_KMAJ = false, bool W16 = false, typename T = float>
 __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     static_assert(!W16 || NT == 1, "the 16-wide form has one column tile");
+    constexpr bool F16 = sizeof(T) == 2;
+    static_assert(!F16 || (TRANS_A && W16 && !B_KMAJ), "f16: GemmTr, N <= 16, k-contiguous m2");
+    constexpr uint32_t ES = sizeof(T), KS = 128u / ES, CK = 16u / ES; // element size; k per stage (one 128-byte line per row); k per 16-byte chunk
     // (W16 stages the same 32 columns of B and keeps the 4-stage ring: staging only the 16 it uses and giving the room to a 6-stage ring -- 20 KiB of A in flight per
     // wave instead of 12 -- measured slower: 32000 x 16 x 4096 5.75 -> 5.57 TB/s, GemvTr 8192^2 x 3 43.1 -> 46.5 us; profiles/r05_evidence.md section 5)
     constexpr int BP = 4 * NT;                        // DMA pieces of B per wave and stage
@@ -81,17 +90,17 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     const int i = lane & 31, h = lane >> 5;
     const uint32_t r0 = blockIdx.x * 128u + 32u * wave;
     const uint32_t z = blockIdx.z / g.npanels, col0 = (blockIdx.z % g.npanels) * (32u * NT), split = blockIdx.y;
-    const uint32_t kb = split * g.k_per_split;             // multiple of 32
+    const uint32_t kb = split * g.k_per_split;             // multiple of KS
     const uint32_t ke = min(kb + g.k_per_split, g.K);
     if (kb >= ke) return;                                   // (the launcher leaves no empty split)
-    const uint32_t nst = (ke - kb + 31u) / 32u;
-    const uint32_t last_chunks = (ke - kb - 32u * (nst - 1u)) / 4u; // valid 16-byte chunks of the last stage: 1 .. 8
+    const uint32_t nst = (ke - kb + KS - 1u) / KS;
+    const uint32_t last_chunks = (ke - kb - KS * (nst - 1u)) / CK; // valid 16-byte chunks of the last stage: 1 .. 8
 
     // ---- DMA addressing: piece q = rows 8 q .. 8 q + 7 of the wave's 32 (lane -> row 8 q + (lane >> 3), position lane & 7) ----
-    const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda);
-    const float *B = g.b + z * g.b_batch + (B_KMAJ ? (uint64_t)kb * g.ldb : (uint64_t)kb);
+    const T *A = reinterpret_cast<const T *>(g.a) + z * g.a_batch + (TRANS_A ? (uint64_t)kb : (uint64_t)kb * g.lda);
+    const T *B = reinterpret_cast<const T *>(g.b) + z * g.b_batch + (B_KMAJ ? (uint64_t)kb * g.ldb : (uint64_t)kb);
     uint32_t a_voff[4], b_voff[BP], a_tail[4], b_tail[BP]; // byte offsets; *_tail: the last stage, k clamped into the matrix
-    const uint32_t kmax = g.K - 4u - kb - 32u * (nst - 1u);        // largest valid k offset (in floats) of a chunk in the last stage
+    const uint32_t kmax = g.K - CK - kb - KS * (nst - 1u);         // largest valid k offset (in elements) of a chunk in the last stage
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const uint32_t rl = 8u * q + (lane >> 3);
@@ -99,9 +108,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             const uint32_t chunk = (lane & 7u) ^ ((rl >> 1) & 7u);
             const uint64_t row = min(r0 + rl, g.M - 1u);
             // 32-bit offsets relative to the wave's first row keep the per-lane address in one VGPR (the launcher checks the range)
-            const uint32_t rel = (uint32_t)((row - min(r0, g.M - 1u)) * g.lda) * 4u;
+            const uint32_t rel = (uint32_t)((row - min(r0, g.M - 1u)) * g.lda) * ES;
             a_voff[q] = rel + 16u * chunk + (TR_BIAS - 1024u * q);
-            a_tail[q] = rel + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * q);
+            a_tail[q] = rel + ES * min(CK * chunk, kmax) + (TR_BIAS - 1024u * q);
         } else { // column-major A: piece q = k rows 8 q .. 8 q + 7 of the stage, the wave's 32 rows = one 128-byte line each: image [32 k][32 m]
             const uint32_t m = min(r0 + 4u * (lane & 7u), g.M - 4u) - min(r0, g.M - 4u); // M % 4 == 0
             a_voff[q] = (rl * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
@@ -120,8 +129,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
         const uint32_t cl = 8u * q + (lane >> 3);
         const uint32_t chunk = (lane & 7u) ^ ((cl >> 1) & 7u);
         const uint32_t col = min(cl, g.N - 1u - col0); // relative to the panel's first column (gb0 below)
-        b_voff[q] = col * g.ldb * 4u + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
-        b_tail[q] = col * g.ldb * 4u + 4u * min(4u * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
+        b_voff[q] = col * g.ldb * ES + 16u * chunk + (TR_BIAS - 1024u * (q & 3));
+        b_tail[q] = col * g.ldb * ES + ES * min(CK * chunk, kmax) + (TR_BIAS - 1024u * (q & 3));
     }
     const uint64_t b_step = B_KMAJ ? (uint64_t)128u * g.ldb : 128u; // bytes per stage (32 k)
     const char *ga0 = (const char *)(TRANS_A ? A + (uint64_t)min(r0, g.M - 1u) * g.lda : A + min(r0, g.M - 4u)) - TR_BIAS;
@@ -171,7 +180,29 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     // branches, which costs the overlap of the next substep's reads with this substep's MFMAs.
     auto compute = [&](const char *sl, auto tail_c, uint32_t valid) {
         constexpr bool TAIL = decltype(tail_c)::value;
-        if constexpr (W16) {
+        if constexpr (W16 && F16) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t c = (uint32_t)kq + 4u * j; // this lane's 16-byte chunk of the stage: k = 8 c .. 8 c + 7 = the lane's share of 32-k block j
+                sk_h8 ah[2], bh;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t row = 16u * t + (uint32_t)i16;
+                    ah[t] = *reinterpret_cast<const sk_h8 *>(sl + row * 128u + ((c ^ ((row >> 1) & 7u)) * 16u));
+                }
+                bh = *reinterpret_cast<const sk_h8 *>(sl + 4096u + (uint32_t)i16 * 128u + ((c ^ (((uint32_t)i16 >> 1) & 7u)) * 16u));
+                if constexpr (TAIL) {
+                    if (c >= valid) { // (registers already loaded; the zeroing is a select per dword)
+                        const sk_h8 zero = { 0, 0, 0, 0, 0, 0, 0, 0 };
+                        ah[0] = zero; ah[1] = zero; bh = zero;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc16[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc16[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            return;
+        } else if constexpr (W16) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const uint32_t c = (uint32_t)kq + 4u * j; // this lane's 16-byte chunk of the stage: k = 4 c .. 4 c + 3
@@ -255,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
 
     // C/D map: lane (i, h), register e -> row (e&3) + 8 (e>>2) + 4 h of the wave's 32, column i: registers 4 gq .. 4 gq + 3 = 4 consecutive rows
     const bool direct = g.nsplit == 1;
-    float *P = direct ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
+    float *P = (direct && !F16) ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
     const uint32_t ldp = direct ? g.ldc : g.M;
     auto put4 = [&](uint32_t col, uint32_t row, float4 v) { // rows row .. row + 3 of column col (M % 4 == 0: all in or all out)
         float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
@@ -279,7 +310,19 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const uint32_t row = r0 + 16u * t + 4u * (uint32_t)kq;
-                if (row < g.M) put4(col, row, make_float4(acc16[t][0], acc16[t][1], acc16[t][2], acc16[t][3]));
+                if (row >= g.M) continue;
+                float4 v = make_float4(acc16[t][0], acc16[t][1], acc16[t][2], acc16[t][3]);
+                if constexpr (F16) {
+                    if (!direct) { put4(col, row, v); continue; } // f32 partial slab
+                    _Float16 *dst = reinterpret_cast<_Float16 *>(g.c) + z * g.c_batch + (uint64_t)col * g.ldc + row;
+                    if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
+                    if (g.beta != 0.f) {
+                        const sk_h4 o = *reinterpret_cast<const sk_h4 *>(dst);
+                        v.x = fmaf(g.beta, (float)o[0], v.x); v.y = fmaf(g.beta, (float)o[1], v.y); v.z = fmaf(g.beta, (float)o[2], v.z); v.w = fmaf(g.beta, (float)o[3], v.w);
+                    }
+                    const sk_h4 hv = { (_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w };
+                    *reinterpret_cast<sk_h4 *>(dst) = hv;
+                } else put4(col, row, v);
             }
         }
         return;
@@ -365,4 +408,38 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     if (ns == 1) return WG_OK;
     if (out_row_stride != 1u) return wg_splitk_reduce_strided(ctx, g.part, ns, M, N, nmats, out, out_row_stride, out_ld, out_batch, alpha);
     return wg_splitk_reduce(ctx, g.part, ns, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
+}
+
+// f16 GemmTr with N <= 16 (f16 GemvTr with a few right-hand sides arrives here through wgk_gemm_f16): out = alpha * m1^T * m2 + beta * out, m1 stored K x M and m2
+// K x N, both k-contiguous. The caller (wgk_gemm_f16) has checked: K % 8 == 0, leading dimensions % 8 == 0, 16-byte aligned bases, 32-bit offsets in range.
+int wgk_gemm_f16_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2,
+                        float alpha, float beta) {
+    const int cus = ctx->compute_units > 0 ? ctx->compute_units : 256;
+    const uint32_t row_blocks = (M + 127u) / 128u;
+    const uint32_t max_split = (K + 255u) / 256u; // >= 256 k (4 stages) per workgroup
+    const uint64_t blocks = (uint64_t)row_blocks * nmats;
+    uint32_t ns = 1;
+    uint64_t best = ~0ull;
+    for (uint32_t c = 1; c <= max_split && (uint64_t)c * blocks <= 4ull * cus + blocks; ++c) { // the f32 launcher's plan at 64 k per stage
+        if ((uint64_t)c * M * N * nmats * 4u > (512ull << 20)) break;
+        const uint64_t rounds = (blocks * c + cus - 1) / cus;
+        const uint64_t cost = rounds * ((K + c - 1) / c + 256u);
+        if (cost < best) { best = cost; ns = c; }
+    }
+    uint32_t kps = (((K + ns - 1) / ns) + 63u) & ~63u;
+    ns = (K + kps - 1) / kps;
+    if (ns > 65535u || nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: too many splits or matrices for the skinny path");
+    void *ws = nullptr;
+    if (ns > 1)
+        if (int rc = wg_ctx_workspace(ctx, (size_t)ns * M * N * nmats * sizeof(float), &ws)) return rc;
+    SkinnyArgs g;
+    g.c = (float *)out; g.ldc = out_ld; g.c_batch = out_batch; g.alpha = alpha; g.beta = beta; g.crs = 1;
+    g.a = (const float *)m1.ptr; g.lda = m1.ld; g.a_batch = m1.batch;
+    g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
+    g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = 1;
+    g.rot = (uint64_t)(ns > 1 ? kps : K) * N * 2u <= (256u << 10) ? 1u : 0u;
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, false, true, _Float16>), dim3(row_blocks, ns, nmats), dim3(256), 0, ctx->stream, g);
+    WG_HIP_TRY(hipGetLastError());
+    if (ns == 1) return WG_OK;
+    return wg_splitk_reduce(ctx, g.part, ns, M, N, nmats, WG_F16, out, out_ld, out_batch, alpha, beta);
 }

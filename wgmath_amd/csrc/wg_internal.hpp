@@ -171,6 +171,9 @@ int wgk_gemm_f32_mid(wg_ctx *ctx, bool trans, int bm, int bn, uint32_t M, uint32
                      wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t nsplit = 1);
 int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch,
                         wgk_mat m1, wgk_mat m2, float alpha, float beta, uint32_t out_row_stride = 1, bool m2_kmajor = false, uint32_t ns_force = 0);
+// f16 GemmTr with N <= 16 on the few-column streaming kernel (gemm_f32_skinny.hip, T = _Float16): HBM-bound, m1 read once
+int wgk_gemm_f16_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2,
+                        float alpha, float beta);
 // N-panels with arrival counters (comm.hip's one-launch-per-step sharded Gemm; gemm_f16_common.hpp PanelArgs): `out` is where the product's column 0
 // would sit if every panel were `cols` wide and the cube had one rank (i.e. panel 0's slot of this rank), leading dimension out_ld; panel p (first
 // column c0, np columns) lives at out + c0 * col_stride + slot_rows * (np - cols) ... see m16_tile. n_main panels of `cols` columns, then n_tail
