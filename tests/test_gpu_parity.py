@@ -540,8 +540,8 @@ F16_SHAPES = [
     # N a multiple of 4 only (columns are independent: no staging), on every MFMA kernel family
     (512, 256, 260, 1), (256, 192, 1004, 2), (1024, 64, 4100, 1),
     # GemmTr with N <= 16 on matrices of >= 16 MiB: the few-column streaming kernel in f16 (gemm_f32_skinny.hip, T = _Float16; round 5) -- a K that ends in a partial
-    # stage, a batch, rows that are not a multiple of a wave's 32, 3 columns (an f16 GemvTr with three right-hand sides), k split across workgroups + reduce
-    (4096, 2048, 8, 1), (8192, 1096, 16, 1), (2048, 4104, 4, 2), (4100, 2048, 12, 1), (4096, 2048, 3, 1), (1024, 16384, 8, 1),
+    # stage, a batch, rows that are not a multiple of a wave's 32, k split across workgroups + reduce (3 / 5 / 8 columns: test_gemv_f16's GemvTr cases)
+    (4096, 2048, 8, 1), (8192, 1096, 16, 1), (2048, 4104, 4, 2), (4100, 2048, 12, 1), (1024, 16384, 8, 1),
     # tail split: 17 x 17 = 289 tiles on 256 CUs -> 256 tiles as they are + 33 tiles cut along K (full and ragged tiles)
     (4352, 1024, 4352, 1), (4104, 512, 4104, 1),
 ]
