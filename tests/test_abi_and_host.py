@@ -161,7 +161,7 @@ def test_reduce_eval_cpu_matches_reference_helper():
 
 
 @pytest.mark.parametrize("source,kernel,min_dma,instances", [("gemm_f16.hip", "gemm_f16_m16_kernel", 16, 2), ("gemm_f16_t128.hip", "gemm_f16_t128_kernel", 8, 4),
-                                                             ("gemm_f32_skinny.hip", "gemm_f32_skinny_kernel", 8, 6),
+                                                             ("gemm_f32_skinny.hip", "gemm_f32_skinny_kernel", 8, 10),  # 6 + the 16-wide forms (3 f32, 1 f16)
                                                              ("gemm_f32_mid.hip", "gemm_f32_mid_kernel", 6, 6), ("gemm_f32_mid.hip", "gemm_f32_mid_kw_kernel", 6, 12)])
 def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):
     """The 16x16x32 f16 kernels issue their LDS-DMA as `s_mov_b32 m0, sN` + `global_load_lds_dwordx4` from inline asm WITHOUT
