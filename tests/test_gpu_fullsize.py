@@ -250,14 +250,14 @@ def test_sharded_gemm_one_launch_is_bit_identical_to_panel_launches(engine, cus,
     inst.close()
 
 
-@pytest.mark.parametrize("engine", ["rccl", "staged"])
+@pytest.mark.parametrize("engine,cus", [("rccl", None), ("staged", None), ("rccl", -248)])  # -248: the RCCL engine's own stream in bench.py (8 CUs of one XCD left out)
 @pytest.mark.parametrize("M,K,N,widths,one_launch_shape", [
     (8192, 512, 8192, (2048, 2048, 1536, 1024, 768, 512, 256), True),            # two equal panels, then 6, 4, 3, 2, 1 tile columns
     (4096, 512 + 32, 8192 + 128, (2048, 2048, 2048, 1024, 512, 256, 384), True),  # K remainder; N not a multiple of the tile: the ragged rest in the last panel
     (8192, 512, 8192, (4096, 2048, 1024, 512, 256, 256), True),                   # ONE main panel and a tail of five
     (4096, 512, 8192, (1024, 2048, 2048, 3072), False),                           # not "equal panels, then a tail": runs panel by panel
 ])
-def test_sharded_gemm_tapered_tail_is_bit_identical_to_uniform_panels(engine, M, K, N, widths, one_launch_shape):
+def test_sharded_gemm_tapered_tail_is_bit_identical_to_uniform_panels(engine, cus, M, K, N, widths, one_launch_shape):
     """wg_gemm_sharded_panels: the N-panels' widths given one by one. A tapered tail changes WHEN a tile's columns are exchanged, never how a
     tile is computed: in the one-launch form the result must equal, bit for bit, the one-launch result of a uniform split (same tiles, same
     accumulation chains) -- slot layout of the staging cube, per-panel counters and relayouts all follow the ragged plan. A list that is not of
@@ -266,7 +266,7 @@ def test_sharded_gemm_tapered_tail_is_bit_identical_to_uniform_panels(engine, M,
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     wg = _wg()
     from wgmath_amd.sharded import Comm, GatherMode, new_unique_id
-    inst = wg.GpuInstance.new(0)
+    inst = wg.GpuInstance.new(0, cu_count=abs(cus), one_xcd=cus < 0) if cus else wg.GpuInstance.new(0)
     dev = inst.device()
     comm = Comm(inst, 1, 0, new_unique_id() if engine == "rccl" else None)
     rng = np.random.default_rng(M + K + N + len(widths))

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     static_assert(!F16 || (TRANS_A && W16 && !B_KMAJ), "f16: GemmTr, N <= 16, k-contiguous m2");
     constexpr uint32_t ES = sizeof(T), KS = 128u / ES, CK = 16u / ES; // element size; k per stage (one 128-byte line per row); k per 16-byte chunk
     // (W16 stages the same 32 columns of B and keeps the 4-stage ring: staging only the 16 it uses and giving the room to a 6-stage ring -- 20 KiB of A in flight per
-    // wave instead of 12 -- measured slower: 32000 x 16 x 4096 5.75 -> 5.57 TB/s, GemvTr 8192^2 x 3 43.1 -> 46.5 us; profiles/r05_evidence.md section 5)
+    // wave instead of 12 -- measured slower: 32000 x 16 x 4096 5.75 -> 5.57 TB/s, GemvTr 8192^2 x 3 43.1 -> 46.5 us; and so did a 3-stage ring of 6 KiB stages with TWO
+    // workgroups per CU (72 KiB each): 5.73 -> 5.29 TB/s; profiles/r05_evidence.md section 5)
     constexpr int BP = 4 * NT;                        // DMA pieces of B per wave and stage
     constexpr int RING = NT == 1 ? 4 : 3;             // 128 / 144 KiB of LDS: one workgroup per CU
     constexpr int STAGE_BYTES = 4096 + 1024 * BP;     // per wave: A 32 rows x 128 B, then B 32 NT (16) columns x 128 B
