@@ -521,6 +521,43 @@ def test_a_tensor_the_recording_used_and_the_host_dropped_outlives_every_replay(
     assert gpu.mem_info()[0] >= free_with_b + n * 4 - (4 << 20), "b's 16 MiB must come back when the command buffer goes"
 
 
+@pytest.mark.gpu
+def test_a_recording_context_is_finished_or_destroyed_on_its_own_thread(gpu):
+    """Thread-local capture: only the thread that began a recording can end it, and the deferred-destroy bookkeeping is that thread's. wg_encoder_finish and
+    wg_ctx_destroy from another thread are refused (an error, not a silent no-op or a leaked counter); the recording thread then finishes normally and the result replays."""
+    import threading
+    wg = _wg()
+    from wgmath_amd._lib import lib
+    other = wg.GpuInstance.new(0)
+    dev, shapes = other.device(), wg.ViewShapeBuffers()
+    n = 4096
+    S = wg.BufferUsages
+    a = wg.TensorBuilder.vector(n, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.zeros(n, np.float32))
+    b = wg.TensorBuilder.vector(n, S.STORAGE | S.COPY_SRC | S.COPY_DST).build_init(dev, np.ones(n, np.float32))
+    add = wg.OpAssign.new(dev, wg.OpAssignVariant.Add)
+    enc = dev.create_command_encoder(record=True)
+    with enc.compute_pass("recorded", None) as p:
+        add.dispatch(dev, shapes, p, a, b)
+        rcs = {}
+
+        def elsewhere():
+            import ctypes
+            out = ctypes.c_void_p()
+            rcs["finish"] = lib.wg_encoder_finish(other._ctx.handle, ctypes.byref(out))
+            rcs["destroy"] = lib.wg_ctx_destroy(other._ctx.handle)
+        t = threading.Thread(target=elsewhere)
+        t.start()
+        t.join()
+        assert rcs["finish"] != 0 and rcs["destroy"] != 0, rcs
+        add.dispatch(dev, shapes, p, a, b)
+    cb = enc.finish()
+    other.queue().submit([cb])
+    other.queue().submit([cb])
+    assert np.array_equal(a.read(dev), np.full(n, 4, np.float32))
+    del cb
+    other.sync()
+
+
 # --------------------------------------------------------------------------------------------------------
 # f16 Gemm (extension: no reference kernel -- contract defined in DESIGN.md: f16 in, f32 accumulate, one RNE rounding)
 # --------------------------------------------------------------------------------------------------------
