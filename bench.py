@@ -1258,18 +1258,18 @@ def main():
         # a few steps more, outside the timed region, with the compute stream stamped around every wait for a panel's exchange
         waits, wl = [], main_res["workload"]
         if isinstance(wl, GemmWorkload) and wl.dist is not None:
+            cm = wl.dist["comm"]
+            barrier()
             try:
-                cm = wl.dist["comm"]
-                barrier()
                 cm.set_wait_timing(True)
                 for _ in range(3):
                     wl.step()
                 wl.finish()
                 waits = cm.wait_times()
                 cm.set_wait_timing(False)
-                barrier()
             except Exception as e:  # noqa: BLE001 -- a diagnostic must not take the line down
                 log(f"[bench] rank {rank}: wait timing failed: {e}")
+            barrier()  # (outside the try: every rank passes the same barriers whatever happened to its own diagnostic)
         ck = main_res["clock"]
         per_rank = DIST["all_gather_object"]({"ms_per_step": own_ms, "clock_ghz": (ck or {}).get("mean") if isinstance(ck, dict) else ck, "waits": waits})
         if rank == 0:
