@@ -196,6 +196,46 @@ def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):
             assert "scratch_" not in loop[:loop.index("s_cbranch_scc1")], f"{name}: register spills inside the main loop"
 
 
+def test_f16_continuous_kernel_accumulators_are_the_named_agprs():
+    """gemm_f16.hip's continuous Gemm / GemmTr kernel keeps its 64 accumulator quads in a[0:255] by NAME (inline asm: multiply, zeroing, read-out), because the compiler,
+    left to it, copies accumulators that live across an epilogue inside the tile loop to VGPRs wholesale and spills. That is only sound while the compiler keeps
+    nothing of its own in an AGPR there and inserts nothing between them: in the compiled kernel every AGPR instruction must be one of ours (128 MFMAs, 256 zeroing
+    writes, 256 reads, no moves), inside the asm markers, with no scratch at all, all 256 AGPRs accounted for in the kernel descriptor, and M0 only ours."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "wgmath_amd", "csrc", "gemm_f16.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k.s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-ffp-contract=on",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
+        text = open(out).read()
+    kernels = re.findall(r"^(_Z\S*gemm_f16_m16c_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
+    assert len(kernels) == 4, [k for k, _ in kernels]  # Gemm / GemmTr x plain / streaming stores
+    for name, whole in kernels:
+        body, desc = whole.split(".amdhsa_kernel")  # (the kernel descriptor sits between the code and .Lfunc_end)
+        assert "scratch_" not in body, f"{name}: register spills"
+        inside, ours, theirs = False, [], []
+        for l in (x.strip() for x in body.splitlines()):
+            if l.startswith(";;#ASMSTART"):
+                inside = True
+            elif l.startswith(";;#ASMEND"):
+                inside = False
+            elif re.match(r"v_mfma|v_accvgpr", l) or re.search(r"\ba\[?\d", l):
+                (ours if inside else theirs).append(l)
+        assert not theirs, f"{name}: the compiler touches AGPRs: {theirs[:4]}"
+        count = lambda pat: sum(1 for l in ours if l.startswith(pat))
+        assert (count("v_mfma_f32_16x16x32_f16"), count("v_accvgpr_write_b32"), count("v_accvgpr_read_b32"), count("v_accvgpr_mov")) == (128, 256, 256, 0)
+        m0 = [l.strip() for l in body.splitlines() if re.search(r"\bm0\b", l) and not l.strip().startswith(";")]
+        assert m0 and all(re.fullmatch(r"s_mov_b32 m0, s\d+", l) for l in m0), f"{name}: M0 used outside the LDS-DMA asm"
+        nv, off = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1)), int(re.search(r"\.amdhsa_accum_offset (\d+)", desc).group(1))
+        assert nv - off == 256 and nv <= 512, (nv, off)
+
+
 @pytest.mark.parametrize("which", ["ILb0", "ILb1"])  # NN, TN
 def test_f16_gemm_main_loop_issue_budget(which):
     """The shipped f16 Gemm kernel is scheduled against a measured issue model (profiles/r02_evidence.md 3d): one wave per SIMD hides

@@ -758,20 +758,23 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
         return v;
     };
+    // (every hand-written store carries its own `s_nop 1`: a store of more than 64 bits reads its data registers AFTER it issues, the compiler's hazard
+    // recognizer does not look inside an asm statement, and a read-out of the next pack into the same registers right behind the store changed the first
+    // dword for lanes 12 .. 15 of every row -- seen in the continuous kernel, round 5)
     auto store8 = [&](_Float16 *dst, half8_t v) {
         if (paneled) { // write-through to memory: when the store is acknowledged a copy engine may read it
             if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v; // (timing experiments only: NOT visible to a copy engine in time)
-            else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+            else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         } else if (!(WG_ABLATE & 32)) {
             if constexpr (WG_EPI_STORE == -1) {
-                if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+                if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
                 else *reinterpret_cast<half8_t *>(dst) = v;
             } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v;
             else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_t *>(dst));
-            else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
-            else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+            else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         }
     };
     // (A store instruction covers 16 columns x 64 bytes -- half lines -- and an idle CU gets a tile out four times faster when 16 consecutive lanes
@@ -861,6 +864,370 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
         if (!bal_decode(g.bal, blockIdx.x, g.K / 64u, bid, mode, kb, ns, pair)) return;
     }
     m16_tile<TRANS_A>(g, bid, smem, mode, kb, ns, pair); // (ONE call site: the tile body must exist once in the kernel)
+}
+
+
+// The continuous form's 64 accumulator quads live in a[0:255] BY NAME: left to the compiler, accumulators that are live across a tile's epilogue inside
+// an outer loop get copied to VGPRs wholesale at the inner loop's exit (on top of the fragments that must stay live there), spilled to scratch and shuffled
+// inside the multiply loop (three cuts, ISA read each time: profiles/r05_evidence.md section 3). So the multiply, the zeroing and the read-out are inline
+// asm on fixed registers, each naming what it overwrites; the compiler keeps no value of its own in an AGPR in that kernel (checked in the ISA test).
+#define WG_ACC_QUADS(X) \
+    X(0, 0, 1, 2, 3) X(1, 4, 5, 6, 7) X(2, 8, 9, 10, 11) X(3, 12, 13, 14, 15) \
+    X(4, 16, 17, 18, 19) X(5, 20, 21, 22, 23) X(6, 24, 25, 26, 27) X(7, 28, 29, 30, 31) \
+    X(8, 32, 33, 34, 35) X(9, 36, 37, 38, 39) X(10, 40, 41, 42, 43) X(11, 44, 45, 46, 47) \
+    X(12, 48, 49, 50, 51) X(13, 52, 53, 54, 55) X(14, 56, 57, 58, 59) X(15, 60, 61, 62, 63) \
+    X(16, 64, 65, 66, 67) X(17, 68, 69, 70, 71) X(18, 72, 73, 74, 75) X(19, 76, 77, 78, 79) \
+    X(20, 80, 81, 82, 83) X(21, 84, 85, 86, 87) X(22, 88, 89, 90, 91) X(23, 92, 93, 94, 95) \
+    X(24, 96, 97, 98, 99) X(25, 100, 101, 102, 103) X(26, 104, 105, 106, 107) X(27, 108, 109, 110, 111) \
+    X(28, 112, 113, 114, 115) X(29, 116, 117, 118, 119) X(30, 120, 121, 122, 123) X(31, 124, 125, 126, 127) \
+    X(32, 128, 129, 130, 131) X(33, 132, 133, 134, 135) X(34, 136, 137, 138, 139) X(35, 140, 141, 142, 143) \
+    X(36, 144, 145, 146, 147) X(37, 148, 149, 150, 151) X(38, 152, 153, 154, 155) X(39, 156, 157, 158, 159) \
+    X(40, 160, 161, 162, 163) X(41, 164, 165, 166, 167) X(42, 168, 169, 170, 171) X(43, 172, 173, 174, 175) \
+    X(44, 176, 177, 178, 179) X(45, 180, 181, 182, 183) X(46, 184, 185, 186, 187) X(47, 188, 189, 190, 191) \
+    X(48, 192, 193, 194, 195) X(49, 196, 197, 198, 199) X(50, 200, 201, 202, 203) X(51, 204, 205, 206, 207) \
+    X(52, 208, 209, 210, 211) X(53, 212, 213, 214, 215) X(54, 216, 217, 218, 219) X(55, 220, 221, 222, 223) \
+    X(56, 224, 225, 226, 227) X(57, 228, 229, 230, 231) X(58, 232, 233, 234, 235) X(59, 236, 237, 238, 239) \
+    X(60, 240, 241, 242, 243) X(61, 244, 245, 246, 247) X(62, 248, 249, 250, 251) X(63, 252, 253, 254, 255)
+template <int I> struct AccQuad;
+#define WG_ACC_QUAD_DEF(I, R0, R1, R2, R3)                                                                                                              \
+    template <> struct AccQuad<I> {                                                                                                                     \
+        static __device__ __forceinline__ void mfma(half8_t a, half8_t b) {                                                                             \
+            asm volatile("v_mfma_f32_16x16x32_f16 a[" #R0 ":" #R3 "], %0, %1, a[" #R0 ":" #R3 "]" ::"v"(a), "v"(b) : "a" #R0, "a" #R1, "a" #R2, "a" #R3);  \
+        }                                                                                                                                               \
+        static __device__ __forceinline__ void zero() {                                                                                                 \
+            asm volatile("v_accvgpr_write_b32 a" #R0 ", 0\n\tv_accvgpr_write_b32 a" #R1 ", 0\n\tv_accvgpr_write_b32 a" #R2 ", 0\n\tv_accvgpr_write_b32 a" #R3 ", 0" :: \
+                             : "a" #R0, "a" #R1, "a" #R2, "a" #R3);                                                                                     \
+        }                                                                                                                                               \
+        static __device__ __forceinline__ void read(float &x0, float &x1, float &x2, float &x3) {                                                       \
+            asm volatile("v_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2 "\n\tv_accvgpr_read_b32 %3, a" #R3 \
+                         : "=v"(x0), "=v"(x1), "=v"(x2), "=v"(x3));                                                                                      \
+        }                                                                                                                                               \
+    };
+WG_ACC_QUADS(WG_ACC_QUAD_DEF)
+#undef WG_ACC_QUAD_DEF
+
+// ===============================================================================================================
+// Gemm / GemmTr, continuous form (round 5): ONE workgroup per CU walks its tiles (id, id + grid, ...: the tiles the hardware's round-robin deal
+// would have given that CU) and the LDS-DMA stream never stops -- where m16_tile parks its cursors for a tile's last three stages, these jump to
+// the next tile, so when a tile's loop ends the next tile's first stages are in the LDS, its first fragments in registers, and the loop simply
+// goes on: no prologue (2.8 us), no re-dispatch (0.7 us), and the stores of the finished tile drain under the next tile's first stage (stores and
+// DMA pieces retire in order in vmcnt: the counted waits of the first stage after an epilogue allow the 32 stores on top of their pieces; the next
+// one is the first that needs anything issued behind them). What it is for: short K on many tiles, where those 5 us are a fifth of a tile
+// (8192^2 x 1024: profiles/r05_evidence.md section 3). Same tiles, same k order, same accumulation chains as m16_tile: bit-identical results.
+// The half-steps are m16_tile's (half_step_nn / half_step_s, slot for slot: see there for the plan); what differs is marked.
+// Restrictions (launcher): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, beta == 0, one matrix, no split, no panels.
+// ===============================================================================================================
+template <bool TRANS_A, bool STREAM>
+__device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int aq = i16 >> 2, bb = i16 & 3;
+    const int gq = (4 - aq) & 3; // G(aq)
+    const uint32_t ntiles = g.sched_tiles;                           // tile ids 0 .. ntiles - 1 (the full rounds when a cut-up tail follows: the launcher)
+    const uint32_t S = g.K / 64u;                                   // stages per tile (>= 4)
+    uint32_t tile = blockIdx.x;                                      // this workgroup's current tile
+    uint32_t rem_g = ((ntiles - 1u - tile) / gridDim.x + 1u) * S;    // stages this workgroup still has to multiply (all of its tiles)
+    float alpha = g.alpha;
+    uint32_t ldc = g.ldc;
+    asm volatile("" : "+s"(alpha), "+s"(ldc));
+
+    // ---- per-lane DMA offsets: the same for every (full) tile ----
+    uint32_t a_voff[TRANS_A ? 8 : 4], b_voff[8];
+    if constexpr (TRANS_A) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+            const uint32_t fa = ((4u - ((row >> 3) & 3u)) & 3u) | (((row >> 1) & 1u) << 2); // A's rows are permuted: G index (row >> 3) & 3
+            a_voff[q] = (row * g.lda + 8u * ((lane & 7u) ^ fa)) * 2u + (M16_BIAS - 1024u * (q & 3));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { // blocks 4P..4P+3: kq = P>>1, mblk = 4 (P&1) + (lane>>4), k row (lane>>2)&3, 16-byte unit lane&3
+            const uint32_t P = 4u * wave + q;
+            const uint32_t mpiece = 128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3);
+            a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u + (M16_BIAS - 1024u * q);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+        const uint32_t fb = ((4u - ((row >> 2) & 3u)) & 3u) | (((row >> 1) & 1u) << 2);
+        b_voff[q] = (row * g.ldb + 8u * ((lane & 7u) ^ fb)) * 2u + (M16_BIAS - 1024u * (q & 3));
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
+    const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * (TRANS_A ? 8192 : 4096));
+    const uint32_t lds_b_wave = __builtin_amdgcn_readfirstlane(lds_base + M16_B_BASE + wave * 8192);
+    uint32_t vbaseA[2], vbaseB[2];
+#pragma unroll
+    for (int hs = 0; hs < 2; ++hs) {
+        const uint32_t chunk = (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
+        vbaseB[hs] = lds_base + M16_B_BASE + ((uint32_t)128 * wn + i16) * 128u + chunk;
+        if constexpr (TRANS_A) vbaseA[hs] = lds_base + (128u * wm + 8u * aq + bb) * 128u + chunk;
+    }
+    if constexpr (!TRANS_A) {
+        vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        vbaseA[1] = vbaseA[0];
+    }
+    // one stage of A in global memory: 128 bytes along its k-contiguous rows (GemmTr), 64 columns (Gemm; the half-stage a_half = 32 columns is its unit there)
+    const uint64_t a_half = TRANS_A ? 64u : (uint64_t)BKH * g.lda * 2u;
+    const uint64_t a_full = TRANS_A ? 128u : a_half;            // what a cursor step of A covers: a stage (GemmTr) / a half-stage (Gemm)
+    // ---- tile -> global bases (scalar) ----
+    auto bases = [&](uint32_t t, const char *&a0, const char *&b0, uint32_t &m0, uint32_t &n0) {
+        uint32_t tm, tn;
+        tile_of(t, g.tiles_m, g.tiles_n, tm, tn);
+        tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+        m0 = tm * BM; n0 = tn * BN;
+        const uint64_t ao = TRANS_A ? (uint64_t)m0 * g.lda * 2u : (uint64_t)m0 * 2u, bo = (uint64_t)n0 * g.ldb * 2u; // (64-bit products run on the vector unit: back to scalars by hand)
+        a0 = (const char *)g.a + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ao >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ao)) - M16_BIAS;
+        b0 = (const char *)g.b + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo)) - M16_BIAS;
+    };
+    const char *a0, *b0; // stage 0 of the current tile's operands (less M16_BIAS)
+    uint32_t m0, n0;
+    bases(tile, a0, b0, m0, n0);
+
+    uintx4 a_r[2][8]; // (the accumulators: AccQuad<8 t + u>, a[0:255])
+    half8_t b_f[2][8];
+    using c0 = std::integral_constant<int, 0>;
+    using c1 = std::integral_constant<int, 1>;
+    uint32_t st = 0;
+    uint32_t va, vb;
+    const char *ga, *gb;
+    uint32_t oR = 0, oD = 2u * M16_BS_BYTES, oA = 0, oAD = 0, la = 0, lb = 0; // B ring (3 stages); GemmTr: A's two full-stage slots
+    uint32_t rR = 1u << 14, rD = 0;                                           // Gemm: A's four half-stage slots
+    // Cursor steps after a stage's pieces. m16_tile: 0 once the next piece would lie past the tile's last stage; here: 0 once this WORKGROUP has nothing left to
+    // fetch (rem_g), and at the step that leaves a tile -- behind the pieces of its stage S - 3 -- the distance to the next tile's first stage instead.
+    uint32_t a_step0 = 0;                   // Gemm: after the even half-step's A pieces (on to half-stage 2 st + 5)
+    uint64_t a_step1 = 0, b_step = 0;       // after the odd half-step's A pieces (on to A of stage st + 3) / the even half-step's B pieces (B(st + 3))
+    uint32_t a_plain = 0, b_plain = 0;      // ... inside a tile, for the stage that starts next (a stage of A is less than 4 GiB: launcher)
+    uint64_t a_cross = 0, b_cross = 0;      // ... out of the current tile: its own step + (first stage of the next tile - "stage S" of this one); set when a tile starts
+    uint32_t cross_st = ~0u;                // the stage whose steps leave the tile: S - 3, if this workgroup has a next tile
+    uint32_t after_store = 0;               // counted waits that still have to allow for the finished tile's 32 stores (in flight behind this tile's first pieces)
+    auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
+    constexpr int kOps = TRANS_A ? 16 : 40;
+    auto frag = [&](int op, int set) {
+        auto rb = [&](int u) { b_f[set][u] = lds_h8_at(vb + u * 2048); };
+        if constexpr (TRANS_A) {
+            auto ra = [&](int t) { a_r[set][t] = __builtin_bit_cast(uintx4, lds_h8_at(va + (t & 1) * 512 + (t >> 1) * 4096)); };
+            if (op == 0) ra(0);
+            else if (op <= 8) rb(op - 1);
+            else ra(op - 8);
+        } else {
+            auto tr = [&](int p, int i) {
+                const int h = i >> 1, ins = i & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at(va + (2 * ins + h) * 2048 + p * 256));
+                a_r[set][2 * p + ins][2 * h] = v[0];
+                a_r[set][2 * p + ins][2 * h + 1] = v[1];
+            };
+            auto sw = [&](int p, int i) {
+                const uintx2 r = __builtin_amdgcn_permlane16_swap(a_r[set][2 * p][i], a_r[set][2 * p + 1][i], false, false);
+                a_r[set][2 * p][i] = r[0];
+                a_r[set][2 * p + 1][i] = r[1];
+            };
+            if (op < 4) tr(0, op);
+            else if (op < 8) rb(op - 4);
+            else if (op < 12) tr(1, op - 8);
+            else if (op < 16) sw(0, op - 12);
+            else if (op < 20) rb(op - 12);
+            else if (op < 24) tr(2, op - 20);
+            else if (op < 28) sw(1, op - 24);
+            else if (op < 32) tr(3, op - 28);
+            else if (op < 36) sw(2, op - 32);
+            else sw(3, op - 36);
+        }
+    };
+    auto frag_slot = [&](auto jc, int set) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (TRANS_A) { if constexpr ((j % 3) == 0 && (j / 3) < kOps) frag(j / 3, set); }
+        else { if constexpr ((j & 3) != 3 && 3 * (j >> 2) + (j & 3) < kOps) frag(3 * (j >> 2) + (j & 3), set); }
+    };
+    // the end of a stage (odd half-step; four slots, at most three scalar instructions each): count, then the steps of the stage that starts next
+    auto stage_end = [&](int k) {
+        if (k == 0) { ++st; --rem_g; asm volatile("" : "+s"(st), "+s"(rem_g)); }
+        if (k == 1) {
+            const bool more = rem_g >= 4u;
+            a_plain = more ? (uint32_t)a_full : 0u; b_plain = more ? 128u : 0u;
+            asm volatile("" : "+s"(a_plain), "+s"(b_plain));
+        }
+        if (k == 2) { a_step1 = st == cross_st ? a_cross : (uint64_t)a_plain; asm volatile("" : "+s"(a_step1)); }
+        if (k == 3) { b_step = st == cross_st ? b_cross : (uint64_t)b_plain; asm volatile("" : "+s"(b_step)); }
+    };
+    // lgkmcnt(0), the counted wait (KEEP pieces may fly; behind an epilogue: and the 32 stores issued in front of them), barrier
+    auto sync = [&](auto keep_c) {
+        constexpr int KEEP = decltype(keep_c)::value;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (after_store) { wait_dma_keep<KEEP + 32>(); --after_store; }
+        else wait_dma_keep<KEEP>();
+        __builtin_amdgcn_s_barrier();
+    };
+    // m16_tile's half_step_s (GemmTr): A in two full-stage slots, ONE counted wait + barrier per stage, in the even half-step
+    auto half_step_tn = [&](auto hs_c) {
+        constexpr int HS = decltype(hs_c)::value;
+        constexpr bool ADMA = HS == 1;
+        constexpr int nA = ADMA ? 8 : 0, nB = 4;
+        constexpr int DS = 4, DO = 2, LASTB = 24;
+        static_for<64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 3, u = j & 7;
+            AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            frag_slot(jc, HS ^ 1);
+            if constexpr (ADMA && j == DO - 2) { la = lds_a_wave + oAD; asm volatile("" : "+s"(la)); }
+            if constexpr (ADMA && j == DO + 4 * DS - 2) { la += 4096u; asm volatile("" : "+s"(la)); }
+            if constexpr (j == DO + DS * nA - 2) { lb = lds_b_wave + oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(lb)); }
+            if constexpr (j + 1 >= DO && ((j + 1 - DO) % DS) == 0 && ((j + 1 - DO) / DS) < nA + nB && (((j + 1 - DO) / DS) & 3) == 0) {
+                constexpr int n = (j + 1 - DO) / DS;
+                if constexpr (n < nA) m16_set_m0(la); else m16_set_m0(lb);
+            }
+            if constexpr (j >= DO && ((j - DO) % DS) == 0 && ((j - DO) / DS) < nA + nB) {
+                constexpr int n = (j - DO) / DS;
+                if constexpr (n < nA) m16_dma_imm<1024 * (n & 3)>(a_voff[n], ga);
+                else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
+            }
+            if constexpr (HS == 0 && j == DO + 2) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
+            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { gb += b_step; asm volatile("" : "+s"(gb)); }  // even: after the last B piece -- on to B(st + 3), in the next tile if this one ends there
+            if constexpr (HS == 1 && j == DO + 4 * DS + 1) { oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oAD)); }
+            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { ga += a_step1; asm volatile("" : "+s"(ga)); } // odd: after the last A piece -- on to A(st + 3)
+            if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
+            if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }
+            if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
+            if constexpr (j == 49) { va = vbaseA[HS] + oA; asm volatile("" : "+v"(va)); }
+            if constexpr (HS == 1 && j >= 52 && j <= 55) stage_end(j - 52);
+            if constexpr (j == WG_TN_SYNC_SLOT) {
+                if constexpr (HS == 0) sync(std::integral_constant<int, 8>{});
+                else __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // m16_tile's half_step_nn (Gemm): A in four half-stage slots, a counted wait + barrier in every half-step
+    auto half_step_nn = [&](auto hs_c) {
+        constexpr int HS = decltype(hs_c)::value;
+        constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
+        static_for<64>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int t = j >> 3, u = j & 7;
+            AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            frag_slot(jc, HS ^ 1);
+            if constexpr (j == DO - 1) m16_set_m0(lds_a_wave + rD);
+            if constexpr (j == DO + 4 * DS - 4) { lb = lds_b_wave + oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(lb)); }
+            if constexpr (j == DO + 4 * DS - 1) m16_set_m0(lb);
+            if constexpr (j >= DO && ((j - DO) % DS) == 0 && (j - DO) / DS < 8) {
+                constexpr int pi = (j - DO) / DS, q = pi & 3;
+                if constexpr (pi < 4) m16_dma_imm<1024 * q>(a_voff[q], ga);
+                else m16_dma_imm<1024 * q>(b_voff[(HS == 0 ? 4 : 0) + q], gb);
+            }
+            if constexpr (j == DO + 3) { rD = (rD + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rD)); }
+            if constexpr (j == 26 && HS == 0) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
+            if constexpr (j == 27) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }
+            if constexpr (j == DO + 3 * DS + 3) { // after the last A piece: on to half-stage 2 st + 5 (even) / the first one of stage st + 3 (odd: in the next tile if this one ends there)
+                if constexpr (HS == 0) ga += a_step0; else ga += a_step1;
+                asm volatile("" : "+s"(ga));
+            }
+            if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
+            if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
+            if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
+            if constexpr (HS == 1 && j == 55) stage_end(0);
+            if constexpr (HS == 1 && j == 56) { a_step0 = rem_g >= 3u ? (uint32_t)a_full : 0u; asm volatile("" : "+s"(a_step0)); }
+            if constexpr (HS == 1 && j == 57) stage_end(1);
+            if constexpr (HS == 1 && j == 58) stage_end(2);
+            if constexpr (HS == 1 && j == WG_NN_SYNC_SLOT + 1) stage_end(3);
+            if constexpr (j == WG_NN_SYNC_SLOT) sync(std::integral_constant<int, WG_NN_KEEP>{});
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { gb += b_step; asm volatile("" : "+s"(gb)); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    // ---- prologue, first tile only (m16_tile's): what the first two half-steps read first, the rest in the order the steady state's counted waits expect ----
+    auto pro_a = [&](int h) { // GemmTr: stage h;  Gemm: half-stage h
+#pragma unroll
+        for (int q = 0; q < (TRANS_A ? 8 : 4); ++q) {
+            if ((q & 3) == 0) { m16_set_m0(lds_a_wave + (TRANS_A ? h * M16_BS_BYTES + (q >> 2) * 4096 : h * HA_BYTES)); asm volatile("s_nop 0"); }
+            m16_dma(q & 3, a_voff[q], a0 + (uint64_t)h * a_full);
+        }
+    };
+    auto pro_b = [&](int stage, int nq) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q >= nq) break;
+            if ((q & 3) == 0) { m16_set_m0(lds_b_wave + stage * M16_BS_BYTES + (q >> 2) * 4096); asm volatile("s_nop 0"); }
+            m16_dma(q & 3, b_voff[q], b0 + 128 * stage);
+        }
+    };
+    if constexpr (TRANS_A) { pro_a(0); pro_b(0, 8); pro_a(1); pro_b(1, 8); pro_b(2, 4); }
+    else { pro_a(0); pro_b(0, 8); pro_a(1); pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4); }
+    wait_dma_keep<20>();
+    __syncthreads();
+    va = vbaseA[0]; vb = vbaseB[0];
+#pragma unroll
+    for (int op = 0; op < kOps; ++op) frag(op, 0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    vb = vbaseB[1]; gb = b0 + 256; // stage 2
+    if constexpr (TRANS_A) { va = vbaseA[1]; ga = a0 + 256; }
+    else { va = vbaseA[0] + rR; ga = a0 + 4u * a_full; }
+    a_step0 = rem_g >= 3u ? (uint32_t)a_full : 0u;
+    a_step1 = rem_g >= 4u ? a_full : 0u; b_step = rem_g >= 4u ? 128u : 0u; // (S >= 4: no tile ends within its first stage)
+    asm volatile("" : "+s"(a_step0), "+s"(a_step1), "+s"(b_step));
+    __builtin_amdgcn_sched_barrier(0);
+
+    const uint32_t row_w = 128u * wm + 8u * kg; // this lane's first row within a tile
+    while (true) {
+        // the steps from this tile's "stage S" to the next tile's stage 0 (if this workgroup has a next tile)
+        const uint32_t next = tile + gridDim.x;
+        const char *na0 = a0, *nb0 = b0;
+        uint32_t nm0 = m0, nn0 = n0;
+        if (next < ntiles) bases(next, na0, nb0, nm0, nn0);
+        a_cross = a_full + (uint64_t)((int64_t)(na0 - a0) - (int64_t)((TRANS_A ? S : 2u * S) * a_full));
+        b_cross = 128u + (uint64_t)((int64_t)(nb0 - b0) - (int64_t)S * 128);
+        cross_st = next < ntiles ? S - 3u : ~0u;
+        asm volatile("" : "+s"(a_cross), "+s"(b_cross), "+s"(cross_st));
+        static_for<64>([&](auto ic) { AccQuad<decltype(ic)::value>::zero(); });
+        asm volatile("s_nop 4" ::: "memory"); // (hand-written register traffic: the compiler inserts no wait states around it)
+        while (st < S) {
+            if constexpr (TRANS_A) { half_step_tn(c0{}); half_step_tn(c1{}); }
+            else { half_step_nn(c0{}); half_step_nn(c1{}); } // ++st inside
+        }
+        // ---- epilogue of `tile`: the stores are NOT waited for; they drain under the next tile's first stage. ONE basic block (no alpha / beta / store-flavour
+        // branches: beta == 0 is the launcher's condition, x * 1.0f is x) with a scheduling fence per pack: with branches between the packs the compiler brings all
+        // 256 accumulators over to VGPRs at the loop's exit, on top of the live fragments, and spills (ISA of the first cut: 22 dwords, reloaded behind the stores).
+        _Float16 *C = g.c;
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // the last MFMA's result is out of the pipe before the first hand-written read
+        static_for<8>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const uint32_t col = n0 + 128u * wn + 16u * u + i16;
+            _Float16 *cc = C + (uint64_t)col * ldc + m0 + row_w;
+            static_for<4>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                float r[8];
+                AccQuad<8 * (2 * p) + u>::read(r[0], r[1], r[2], r[3]);
+                AccQuad<8 * (2 * p + 1) + u>::read(r[4], r[5], r[6], r[7]);
+                half8_t v;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    r[q] *= alpha;
+                    asm volatile("" : "+v"(r[q])); // the f32 product, THEN one rounding to f16, as m16_tile's epilogue does it (in one expression the two
+                                                   // become v_fma_mix*_f16, whose f16 results differ in the denormal range: 477 of 2^25 elements, alpha = -0.375)
+                    v[q] = (_Float16)r[q];
+                }
+                _Float16 *dst = cc + 32 * p;
+                if constexpr (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        if (next >= ntiles) break;
+        tile = next; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0;
+        st = 0;
+        after_store = TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
+        asm volatile("" : "+s"(st), "+s"(after_store));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing (parked pieces, stores) is in flight when the workgroup ends
+}
+
+template <bool TRANS_A, bool STREAM>
+__global__ __launch_bounds__(256, 1) void gemm_f16_m16c_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
+    m16_cont<TRANS_A, STREAM>(g, smem);
 }
 
 #ifndef WG_F16_PERSIST
@@ -1159,9 +1526,20 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // co-resident 256 x 128 tiles per CU 6.1 + 0.0263 K (Gemm) / 5.7 + 0.0298 K (GemmTr: its k-contiguous A arrives as 64-byte row pieces, twice the L2
         // requests), a last partial round of at most one tile per CU 0.6 of that. Crossover K ~ 1300 (Gemm) / ~ 650 (GemmTr): 8192 x 8192 x 256 71 -> 51 us
         // (vendor 55), x 512 92 -> 78 (83), 6144 x 6144 x 512 76 -> 50 (52). Only from one round of 256 x 256 tiles on (fewer: the 128 x 128 logic below).
+        // Round 5: where the product can take the continuous walk the big kernel's side of the comparison is that walk's model (it is ahead of the pairs on whole
+        // rounds at every K: GemmTr 8192^2 x 256 54 -> 50 us, x 512 86 -> 71; the pairs keep ragged tile counts such as 6144^2 x 512).
         bool t256x128 = ctx->tuning[WG_TUNE_F16_TILE] == 256128;
+        // (whether launch_tiles below would put the product on the continuous walk by its default rule: whole tiles and stages, more than one round)
+        const bool cont_shape = nmats == 1 && !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && tiles > (uint64_t)cus && g.beta == 0.f &&
+                                ctx->tuning[WG_TUNE_F16_CONT] != 0 && ctx->tuning[WG_TUNE_F16_SCHED] < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
         if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
-            const double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
+            double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
+            if (cont_shape) { // the continuous walk (launch_tiles below): 5 us + 5.7 + 0.0211 K per full round; a last partial round costs a whole one, or -- up to half a
+                              // round of tiles, from 6 stages on -- the cut-up tail's two extra launches (8192^2 x 256 49.6 us, x 512 71.4, x 1024 114.5; 6144^2 x 512 67.2)
+                const double per = 5.7 + 0.0211 * K;
+                const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
+                t_big = 5.0 + (double)(tiles / (uint64_t)cus) * per + (r == 0 ? 0.0 : (2u * r <= (uint32_t)cus && K >= 384u ? 25.0 + 0.0107 * K : per));
+            }
             const double r2 = (double)((uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats) / (2.0 * cus), fl = floor(r2), fr = r2 - fl;
             const double pair = trans ? 5.7 + 0.0298 * K : 6.1 + 0.0263 * K;
             t256x128 = fl * pair + (fr > 0.0 ? (fr <= 0.5 ? 0.6 : 1.0) * pair : 0.0) < 0.95 * t_big;
@@ -1262,6 +1640,30 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             auto launch_tiles = [&](GemmArgs gm, uint32_t ntiles) -> int {
                 uint32_t nwg = ntiles;
                 const int sched_env = ctx->tuning[WG_TUNE_F16_SCHED]; // 0 / 1 force (tests), default: by size
+                // The continuous tile walk (m16_cont): whole 256 x 256 tiles, whole stages, more than one round of tiles (one round: nothing to continue into).
+                // One workgroup per CU; a tile's prologue, re-dispatch and store drain (~5 us) go under its neighbours' multiplies. GemmTr 8192 x 8192 x 256
+                // 71 -> 50 us, x 640 104 -> 83, x 1024 131 -> 114 (vendor 112-114), x 2048 216 -> 200, x 4096 386 -> 369, 16384^2 x 1024 531 -> 447, 16384^2 x 4096
+                // 1511 -> 1484; Gemm 8192^2 x 256 66 -> 47, x 1024 126 -> 111 (vendor 128), x 2048 210 -> 197, x 4096 383 -> 372, 16384^2 x 1024 518 -> 437.
+                // 8192^3 717 -> 722 and 725 -> 717 (two boxes: nothing), 16384^2 x 8192 3090 -> 3145, 12288^3 2496 -> 2516: from K ~ 8192 on the XCDs' uneven speeds
+                // (tile scheduler, calibrated shares) weigh more than the tile boundaries. A cut-up tail (below) follows the full rounds as before.
+                // WG_TUNE_F16_CONT: 0 never, 1 wherever it applies, -1 (default) K <= 4096 and neither the tile scheduler nor the calibrated shares forced on.
+                {
+                    const int cont = ctx->tuning[WG_TUNE_F16_CONT];
+                    const bool applies = gm.nsplit == 1 && nmats == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
+                                         krem == 0 && K >= 256u && ntiles > (uint32_t)cus && gm.beta == 0.f;
+                    if (cont != 0 && applies && (cont == 1 || (K <= 4096u && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1))) {
+                        gm.sched = nullptr; gm.sched_tiles = ntiles;
+                        const dim3 grid((uint32_t)cus), block(256);
+                        if (trans) {
+                            if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, true>), grid, block, 0, ctx->stream, gm);
+                            else hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, false>), grid, block, 0, ctx->stream, gm);
+                        } else {
+                            if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<false, true>), grid, block, 0, ctx->stream, gm);
+                            else hipLaunchKernelGGL((gemm_f16_m16c_kernel<false, false>), grid, block, 0, ctx->stream, gm);
+                        }
+                        return WG_OK;
+                    }
+                }
                 // (a stream whose missing CUs all come from one XCD: that XCD cannot keep up with an eighth of the tiles -- the others take them from 2 rounds on)
                 const bool dyn = gm.nsplit == 1 && nmats == 1 && (sched_env >= 0 ? sched_env != 0 : ntiles >= (uint32_t)((ctx->uneven_xcds ? 2 : WG_F16_SCHED_ROUNDS) * cus));
                 if (dyn) {

@@ -149,7 +149,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
     static const struct { const char *env; wg_tuning key; } knobs[] = {
         { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
         { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID }, { "WG_F32_MID_SPLIT", WG_TUNE_F32_MID_SPLIT },
-        { "WG_GEMVT_LDS", WG_TUNE_GEMVT_LDS } };
+        { "WG_GEMVT_LDS", WG_TUNE_GEMVT_LDS }, { "WG_F16_CONT", WG_TUNE_F16_CONT } };
     for (const auto &k : knobs)
         if (const char *v = getenv(k.env)) {
             // the same validation as wg_ctx_set_tuning: a value the knob does not take is ignored (with a note), never silently reinterpreted

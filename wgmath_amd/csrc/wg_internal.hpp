@@ -60,7 +60,7 @@ struct wg_ctx {
         void *scratch = nullptr;            // raw f32 accumulator tiles of the prefix units (grow-only)
         size_t scratch_bytes = 0;
     } bal;
-    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0, 0 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0, 0, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
     bool debug_clock_open = false;
     uint32_t lds_attr_bits = 0;          // likewise for gemv_t_lds_kernel's instantiations (3 right-hand-side tiles x 5 workgroup shapes)
