@@ -614,6 +614,8 @@ WORKLOADS = {
     # short K on many tiles: the per-tile prologue / pipeline drain / epilogue weigh most here (A/B shapes of tools/ab2.sh)
     "gemm_f16_8192x8192x512": lambda: GemmWorkload("gemm_f16_8192x8192x512", 8192, 8192, 512, "f16"),
     "gemm_f16_8192x8192x2048": lambda: GemmWorkload("gemm_f16_8192x8192x2048", 8192, 8192, 2048, "f16"),
+    "gemm_f16_8192x8192x1024": lambda: GemmWorkload("gemm_f16_8192x8192x1024", 8192, 8192, 1024, "f16"),  # (the continuous tile walk's shapes: round 5)
+    "gemmtr_f16_8192x8192x1024": lambda: GemmWorkload("gemmtr_f16_8192x8192x1024", 8192, 8192, 1024, "f16", trans=True),
     # 16 and 12 rounds of 256 tiles: where the dynamic tile scheduler starts to pay (WG_F16_SCHED=0|1 forces)
     "gemm_f16_16384x16384x8192": lambda: GemmWorkload("gemm_f16_16384x16384x8192", 16384, 16384, 8192, "f16"),
     "gemm_f16_16384x12288x8192": lambda: GemmWorkload("gemm_f16_16384x12288x8192", 16384, 12288, 8192, "f16"),
@@ -631,7 +633,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_8192x8192x1024", "gemmtr_f16_8192x8192x1024", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
@@ -1388,6 +1390,8 @@ def main():
         put("c4_reduce", by.get("reduce_f32_4096x65536"), "gbs")
         put("op_assign", by.get("op_assign_f32_256M"), "gbs", brief=True)
         put("gemm_f16_2048", by.get("gemm_f16_2048"), "tflops", brief=True)
+        put("gemm_f16_8192sq_k1024", by.get("gemm_f16_8192x8192x1024"), "tflops", brief=True)
+        put("gemmtr_f16_8192sq_k1024", by.get("gemmtr_f16_8192x8192x1024"), "tflops", brief=True)
         put("gemm_f32_2048", by.get("gemm_f32_2048"), "tflops", brief=True)
         for key, name in (("c1_gemv_1024_us", "gemv_f32_1024"), ("c1_gemv_1024_graph_us", "gemv_f32_1024_graph")):
             if name in by:

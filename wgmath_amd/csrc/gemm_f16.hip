@@ -1230,22 +1230,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16c_kernel(GemmArgs g) {
     m16_cont<TRANS_A, STREAM>(g, smem);
 }
 
-#ifndef WG_F16_PERSIST
-#define WG_F16_PERSIST 0
-#endif
-#if WG_F16_PERSIST
-// Persistent form (experiment, -DWG_F16_PERSIST=1; measured 0.5-1 % SLOWER than letting the hardware re-dispatch a workgroup per tile:
-// profiles/r02_evidence.md section 3c): one workgroup per CU walks the tiles bid, bid + grid, ... itself instead of being
-// re-dispatched per tile (hardware deals ids round-robin to the XCDs and so does this walk: tile t stays on XCD t % 8).
-template <bool TRANS_A>
-__global__ __launch_bounds__(256, 1) void gemm_f16_m16p_kernel(GemmArgs g, uint32_t ntiles) {
-    __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        m16_tile<TRANS_A>(g, t, smem);
-        __syncthreads(); // every wave is done with the LDS before the next tile's prologue DMA lands in it
-    }
-}
-#endif
+// (Round 2's persistent form -- one workgroup per CU calling m16_tile per tile, a barrier in between -- measured 0.5-1 % slower than letting the hardware re-dispatch a
+// workgroup per tile, profiles/r02_evidence.md section 3c, and is gone: what a walk gains is the overlap across the tile boundary, which is m16_cont above.)
 
 // Tail split (tile quantisation): when the tile count is a little more than a multiple of the CU count, the last round would
 // run on a nearly empty chip for a full tile time. The launcher then runs the full rounds normally and cuts the few tail tiles
@@ -1734,13 +1720,6 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 WG_HIP_TRY(hipGetLastError());
                 return WG_OK;
             }
-#if WG_F16_PERSIST
-            if (nsplit == 1 && nmats == 1 && tiles >= 2ull * (uint64_t)cus) {
-                const dim3 pg((uint32_t)cus, 1);
-                if (trans) hipLaunchKernelGGL((gemm_f16_m16p_kernel<true>), pg, dim3(256), 0, ctx->stream, g, (uint32_t)tiles);
-                else hipLaunchKernelGGL((gemm_f16_m16p_kernel<false>), pg, dim3(256), 0, ctx->stream, g, (uint32_t)tiles);
-            } else
-#endif
             if (int rc = launch_tiles(g, (uint32_t)tiles)) return rc;
 #ifdef WG_F16_TRACE
             if (trace) {
