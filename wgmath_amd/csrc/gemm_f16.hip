@@ -1516,7 +1516,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // rounds at every K: GemmTr 8192^2 x 256 54 -> 50 us, x 512 86 -> 71; the pairs keep ragged tile counts such as 6144^2 x 512).
         bool t256x128 = ctx->tuning[WG_TUNE_F16_TILE] == 256128;
         // (whether launch_tiles below would put the product on the continuous walk by its default rule: whole tiles and stages, more than one round)
-        const bool cont_shape = nmats == 1 && !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && tiles > (uint64_t)cus && g.beta == 0.f &&
+        const bool cont_shape = nmats == 1 && !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && // (the pairs are a short-K choice: K <= 1536) tiles > (uint64_t)cus && g.beta == 0.f &&
                                 ctx->tuning[WG_TUNE_F16_CONT] != 0 && ctx->tuning[WG_TUNE_F16_SCHED] < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
         if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
             double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
@@ -1632,12 +1632,14 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 // 1511 -> 1484; Gemm 8192^2 x 256 66 -> 47, x 1024 126 -> 111 (vendor 128), x 2048 210 -> 197, x 4096 383 -> 372, 16384^2 x 1024 518 -> 437.
                 // 8192^3 717 -> 722 and 725 -> 717 (two boxes: nothing), 16384^2 x 8192 3090 -> 3145, 12288^3 2496 -> 2516: from K ~ 8192 on the XCDs' uneven speeds
                 // (tile scheduler, calibrated shares) weigh more than the tile boundaries. A cut-up tail (below) follows the full rounds as before.
-                // WG_TUNE_F16_CONT: 0 never, 1 wherever it applies, -1 (default) K <= 4096 and neither the tile scheduler nor the calibrated shares forced on.
+                // Up to four rounds of tiles the walk still gains 1-3 % at K = 5120 ... 8192 (5120^3 214 -> 205, 8192^2 x 6144 563 -> 549, 8192^3 737 -> 728, Gemm 760 -> 754).
+                // WG_TUNE_F16_CONT: 0 never, 1 wherever it applies, -1 (default) K <= 4096, or K <= 8192 on at most four rounds of tiles, and neither the tile scheduler nor
+                // the calibrated shares forced on.
                 {
                     const int cont = ctx->tuning[WG_TUNE_F16_CONT];
                     const bool applies = gm.nsplit == 1 && nmats == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
                                          krem == 0 && K >= 256u && ntiles > (uint32_t)cus && gm.beta == 0.f;
-                    if (cont != 0 && applies && (cont == 1 || (K <= 4096u && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1))) {
+                    if (cont != 0 && applies && (cont == 1 || ((K <= 4096u || (K <= 8192u && ntiles <= 4u * (uint32_t)cus)) && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1))) {
                         gm.sched = nullptr; gm.sched_tiles = ntiles;
                         const dim3 grid((uint32_t)cus), block(256);
                         if (trans) {
