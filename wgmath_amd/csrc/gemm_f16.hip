@@ -918,17 +918,17 @@ WG_ACC_QUADS(WG_ACC_QUAD_DEF)
 // Restrictions (launcher): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, beta == 0, one matrix, no split, no panels.
 // ===============================================================================================================
 template <bool TRANS_A, bool STREAM>
-__device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem) {
+__device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, const uint32_t walk_first, const int32_t walk_stride, const uint32_t walk_count) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int i16 = lane & 15, kg = lane >> 4;
     const int aq = i16 >> 2, bb = i16 & 3;
     const int gq = (4 - aq) & 3; // G(aq)
-    const uint32_t ntiles = g.sched_tiles;                           // tile ids 0 .. ntiles - 1 (the full rounds when a cut-up tail follows: the launcher)
     const uint32_t S = g.K / 64u;                                   // stages per tile (>= 4)
-    uint32_t tile = blockIdx.x;                                      // this workgroup's current tile
-    uint32_t rem_g = ((ntiles - 1u - tile) / gridDim.x + 1u) * S;    // stages this workgroup still has to multiply (all of its tiles)
+    uint32_t tile = walk_first;                                      // this workgroup's current tile; its walk: walk_count tiles, walk_stride ids apart
+    uint32_t tiles_left = walk_count;                                // ... counting the current one
+    uint32_t rem_g = walk_count * S;                                 // stages this workgroup still has to multiply (all of its tiles)
     float alpha = g.alpha;
     uint32_t ldc = g.ldc;
     asm volatile("" : "+s"(alpha), "+s"(ldc));
@@ -1173,13 +1173,14 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem) {
     const uint32_t row_w = 128u * wm + 8u * kg; // this lane's first row within a tile
     while (true) {
         // the steps from this tile's "stage S" to the next tile's stage 0 (if this workgroup has a next tile)
-        const uint32_t next = tile + gridDim.x;
+        const uint32_t next = tile + (uint32_t)walk_stride;
+        const bool has_next = tiles_left > 1u;
         const char *na0 = a0, *nb0 = b0;
         uint32_t nm0 = m0, nn0 = n0;
-        if (next < ntiles) bases(next, na0, nb0, nm0, nn0);
+        if (has_next) bases(next, na0, nb0, nm0, nn0);
         a_cross = a_full + (uint64_t)((int64_t)(na0 - a0) - (int64_t)((TRANS_A ? S : 2u * S) * a_full));
         b_cross = 128u + (uint64_t)((int64_t)(nb0 - b0) - (int64_t)S * 128);
-        cross_st = next < ntiles ? S - 3u : ~0u;
+        cross_st = has_next ? S - 3u : ~0u;
         asm volatile("" : "+s"(a_cross), "+s"(b_cross), "+s"(cross_st));
         static_for<64>([&](auto ic) { AccQuad<decltype(ic)::value>::zero(); });
         asm volatile("s_nop 4" ::: "memory"); // (hand-written register traffic: the compiler inserts no wait states around it)
@@ -1215,8 +1216,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem) {
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-        if (next >= ntiles) break;
-        tile = next; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0;
+        if (!has_next) break;
+        tile = next; --tiles_left; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0;
         st = 0;
         after_store = TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
         asm volatile("" : "+s"(st), "+s"(after_store));
@@ -1224,10 +1225,18 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing (parked pieces, stores) is in flight when the workgroup ends
 }
 
+// (Walks of four tiles taken from the per-XCD tile queues -- one workgroup per walk, dispatched by the hardware to whichever CU frees up, single tiles for a queue's last
+// four rounds -- were built for the long-K, many-round shapes the fixed walk loses on, and measured: bit-identical, and no faster than the per-tile launch with its tile
+// queues (16384^2 x 8192 3058 -> 3131 / 3081 us, Gemm 3097 -> 3096; 12288^3 2498 -> 2502; walks over CONSECUTIVE queue entries, which take the XCD's 32 CUs off one L2
+// patch, 5 % slower). A boundary inside a walk saves 3-5 us, 2 % of a K = 8192 tile, on three tiles of four of three quarters of the tiles: removed.
+// profiles/r05_f16_chunked_walk_*.txt.)
 template <bool TRANS_A, bool STREAM>
 __global__ __launch_bounds__(256, 1) void gemm_f16_m16c_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
-    m16_cont<TRANS_A, STREAM>(g, smem);
+    // the tiles the hardware's round-robin deal would have given this CU: blockIdx.x, + gridDim.x, ... below g.sched_tiles
+    const uint32_t first = blockIdx.x;
+    if (first >= g.sched_tiles) return;
+    m16_cont<TRANS_A, STREAM>(g, smem, first, (int32_t)gridDim.x, (g.sched_tiles - 1u - first) / gridDim.x + 1u);
 }
 
 // (Round 2's persistent form -- one workgroup per CU calling m16_tile per tile, a barrier in between -- measured 0.5-1 % slower than letting the hardware re-dispatch a
@@ -1639,9 +1648,10 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                     const int cont = ctx->tuning[WG_TUNE_F16_CONT];
                     const bool applies = gm.nsplit == 1 && nmats == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
                                          krem == 0 && K >= 256u && ntiles > (uint32_t)cus && gm.beta == 0.f;
-                    if (cont != 0 && applies && (cont == 1 || ((K <= 4096u || (K <= 8192u && ntiles <= 4u * (uint32_t)cus)) && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1))) {
-                        gm.sched = nullptr; gm.sched_tiles = ntiles;
+                    const bool by_rule = (K <= 4096u || (K <= 8192u && ntiles <= 4u * (uint32_t)cus)) && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
+                    if (cont != 0 && applies && (cont == 1 || by_rule)) {
                         const dim3 grid((uint32_t)cus), block(256);
+                        gm.sched = nullptr; gm.sched_tiles = ntiles;
                         if (trans) {
                             if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, true>), grid, block, 0, ctx->stream, gm);
                             else hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, false>), grid, block, 0, ctx->stream, gm);
