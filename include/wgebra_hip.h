@@ -196,7 +196,7 @@ typedef enum wg_tuning {
                                 128 outputs per CU on; two right-hand sides from 8), n >= 1 = from n outputs per CU on whatever the count of right-hand sides,
                                 vectors longer than the LDS in up to 4 chunks (tests: every workgroup shape of the kernel) */
     WG_TUNE_F16_CONT = 8,    /* f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU keeps its LDS-DMA stream going across its tiles):
-                                -1 = by shape (default: K <= 4096, or <= 8192 on at most four rounds of tiles; more than one round of whole tiles), 0 = never,
+                                -1 = by shape (default: K <= 4096, or <= 8192 below 16 rounds of tiles; more than one round of whole tiles), 0 = never,
                                 1 = whenever applicable (tests) */
     WG_TUNE_COUNT_ = 9
 } wg_tuning;

@@ -645,7 +645,7 @@ def test_gemm_f16_shapes(gpu, f16_tile, M, K, N, mats, tr):
                                              (4352, 1024, 4096, 3.0), (4096, 4160, 4352, 1.0), (16384, 256, 4352, 1.0)])
 def test_gemm_f16_continuous_walk_is_bit_identical(gpu, M, K, N, alpha, tr):
     """f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU goes from tile to tile without stopping its LDS-DMA stream; the default
-    for K <= 4096 -- K <= 8192 up to four rounds -- on more than one round of whole tiles) computes every tile exactly as the per-tile launch does: same bits -- whole rounds, a ragged last round, a cut-up
+    for K <= 4096 -- K <= 8192 below 16 rounds -- on more than one round of whole tiles) computes every tile exactly as the per-tile launch does: same bits -- whole rounds, a ragged last round, a cut-up
     tail behind the full rounds (6144^2: 64 tiles left over; 4352 x 4096: 16), 4 and 5 stages per tile (the shortest the walk takes), alpha != 1 (an f16-denormal
     result included: the f32 product is rounded once) -- and every element written exactly once (NaN pre-fill); the default rule must give those bits too."""
     wg = _wg()

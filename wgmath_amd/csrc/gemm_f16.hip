@@ -1641,14 +1641,15 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 // 1511 -> 1484; Gemm 8192^2 x 256 66 -> 47, x 1024 126 -> 111 (vendor 128), x 2048 210 -> 197, x 4096 383 -> 372, 16384^2 x 1024 518 -> 437.
                 // 8192^3 717 -> 722 and 725 -> 717 (two boxes: nothing), 16384^2 x 8192 3090 -> 3145, 12288^3 2496 -> 2516: from K ~ 8192 on the XCDs' uneven speeds
                 // (tile scheduler, calibrated shares) weigh more than the tile boundaries. A cut-up tail (below) follows the full rounds as before.
-                // Up to four rounds of tiles the walk still gains 1-3 % at K = 5120 ... 8192 (5120^3 214 -> 205, 8192^2 x 6144 563 -> 549, 8192^3 737 -> 728, Gemm 760 -> 754).
-                // WG_TUNE_F16_CONT: 0 never, 1 wherever it applies, -1 (default) K <= 4096, or K <= 8192 on at most four rounds of tiles, and neither the tile scheduler nor
+                // Below the tile scheduler's 16 rounds the walk still gains 1-3 % at K = 5120 ... 8192 (5120^3 214 -> 205, 8192^2 x 6144 563 -> 549, 8192^3 737 -> 728, Gemm
+                // 760 -> 754; 8 rounds: 8192 x 16384 x 8192 1496 -> 1474, 131072 x 1024 x 8192 1563 -> 1552; 9 rounds: 12288^2 x 6144 1300 -> 1276).
+                // WG_TUNE_F16_CONT: 0 never, 1 wherever it applies, -1 (default) K <= 4096, or K <= 8192 below 16 rounds of tiles, and neither the tile scheduler nor
                 // the calibrated shares forced on.
                 {
                     const int cont = ctx->tuning[WG_TUNE_F16_CONT];
                     const bool applies = gm.nsplit == 1 && nmats == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
                                          krem == 0 && K >= 256u && ntiles > (uint32_t)cus && gm.beta == 0.f;
-                    const bool by_rule = (K <= 4096u || (K <= 8192u && ntiles <= 4u * (uint32_t)cus)) && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
+                    const bool by_rule = (K <= 4096u || (K <= 8192u && ntiles < (uint32_t)(WG_F16_SCHED_ROUNDS * cus))) && !ctx->uneven_xcds && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
                     if (cont != 0 && applies && (cont == 1 || by_rule)) {
                         const dim3 grid((uint32_t)cus), block(256);
                         gm.sched = nullptr; gm.sched_tiles = ntiles;
