@@ -33,6 +33,7 @@ struct SkinnyArgs {
     uint32_t M, N, K;
     uint32_t nsplit, k_per_split; // k_per_split % 32 == 0
     uint32_t rot;              // GemmTr: workgroups start their sweep over K at different stages (see the kernel)
+    uint32_t a_nt;             // 1: the streamed operand's pieces carry the non-temporal hint (tr_dma_streamed)
 };
 
 __device__ __forceinline__ float comp4(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
@@ -57,6 +58,15 @@ constexpr uint32_t TR_BIAS = 3072; // see M16_BIAS in gemm_f16.hip
 template <int IMM>
 __device__ __forceinline__ void tr_dma(uint32_t voff, const void *sbase) {
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
+}
+// the streamed operand's pieces: with the non-temporal hint when the matrix is read once and is too large for the 256 MiB Infinity Cache anyway (SkinnyArgs::a_nt: the
+// launcher). Measured per shape (profiles/r05_skinny_nt_ab.txt): 32000 x 16 x 4096 0.734 -> 0.79-0.80 of HBM peak, Gemv 65536 x 4096 x 8 174 -> 152 us, f16 GemvTr 4096 x
+// 65536 x 8 90 -> 80; matrices that fit the cache and are swept repeatedly LOSE with the hint (4096 x 11008 x 4 32 -> 36 us), hence by size. `nt` alone: the scope bits
+// (sc0 / sc1) on top changed nothing.
+template <int IMM>
+__device__ __forceinline__ void tr_dma_streamed(uint32_t voff, const void *sbase, uint32_t nt) {
+    if (nt) asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2 nt" ::"v"(voff), "s"(sbase), "i"(IMM));
+    else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
 __device__ __forceinline__ void tr_set_m0(uint32_t lds_dst) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(lds_dst)); }
 
@@ -147,6 +157,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     // on stage (j + rot) mod nst; the sum over k is the same set of products in a rotated order (deterministic per workgroup). Only while m2's K range is
     // small (<= 256 KiB, the launcher's g.rot): every workgroup re-reads it from L2, and in step they all read the same lines of it -- out of step a
     // larger m2 stops being a broadcast (N = 64, K = 4096: 325 -> 423 us with the rotation; N = 8: 281 -> 228).
+    const uint32_t a_nt = g.a_nt; // (workgroup-uniform: a scalar branch around each of the four pieces)
     const uint32_t rot = (WG_SKINNY_ROT && TRANS_A && g.rot && last_chunks == 8u && nst > 1u) ? (uint32_t)(((uint64_t)blockIdx.x * 7u + blockIdx.y * 3u) % nst) : 0u; // (per workgroup: its four waves fetch the same stage of the small m2 together)
     auto issue = [&](uint32_t trip) { // trip -> ring slot trip % RING; the stage it carries: (trip + rot) mod nst
         const uint32_t dst = lds_wave + (trip % RING) * STAGE_BYTES;
@@ -155,8 +166,8 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
         const char *ga = ga0 + (uint64_t)st * a_step, *gb = gb0 + (uint64_t)st * b_step;
         const bool tail = rot == 0u && st + 1u == nst; // wave-uniform (with a rotation there is no partial stage)
         tr_set_m0(dst);
-        tr_dma<0>(tail ? a_tail[0] : a_voff[0], ga); tr_dma<1024>(tail ? a_tail[1] : a_voff[1], ga);
-        tr_dma<2048>(tail ? a_tail[2] : a_voff[2], ga); tr_dma<3072>(tail ? a_tail[3] : a_voff[3], ga);
+        tr_dma_streamed<0>(tail ? a_tail[0] : a_voff[0], ga, a_nt); tr_dma_streamed<1024>(tail ? a_tail[1] : a_voff[1], ga, a_nt);
+        tr_dma_streamed<2048>(tail ? a_tail[2] : a_voff[2], ga, a_nt); tr_dma_streamed<3072>(tail ? a_tail[3] : a_voff[3], ga, a_nt);
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
             tr_set_m0(dst + 4096u * (1 + u));
@@ -392,6 +403,7 @@ int wgk_gemm_f32_skinny(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = npanels;
     g.rot = (uint64_t)(ns > 1 ? kps : K) * (N < 32u * (N <= 32 ? 1u : 2u) ? N : 32u * (N <= 32 ? 1u : 2u)) * 4u <= (256u << 10) ? 1u : 0u;
+    g.a_nt = (npanels == 1 && (uint64_t)M * K * 4u >= (384ull << 20)) ? 1u : 0u; // read once, and no use to the 256 MiB Infinity Cache (tr_dma_streamed)
     const dim3 grid(row_blocks, ns, nmats * npanels);
     const bool w16 = WG_SKINNY_W16 && N <= 16u && npanels == 1u;
     if (m2_kmajor) { // GemmTr only (the few-row route)
@@ -439,6 +451,7 @@ int wgk_gemm_f16_skinny(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_
     g.b = (const float *)m2.ptr; g.ldb = m2.ld; g.b_batch = m2.batch;
     g.part = (float *)ws; g.M = M; g.N = N; g.K = K; g.nsplit = ns; g.k_per_split = kps; g.npanels = 1;
     g.rot = (uint64_t)(ns > 1 ? kps : K) * N * 2u <= (256u << 10) ? 1u : 0u;
+    g.a_nt = (uint64_t)M * K * 2u >= (384ull << 20) ? 1u : 0u;
     hipLaunchKernelGGL((gemm_f32_skinny_kernel<true, 1, false, true, _Float16>), dim3(row_blocks, ns, nmats), dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (ns == 1) return WG_OK;

@@ -749,6 +749,8 @@ static bool few_rhs_as_gemm(bool trans, bool f16, uint32_t rows_out, uint32_t k,
     if (trans) return f16 || (uint64_t)rows_out < 8ull * k;
     // f32 Gemv: since the few-column Gemm kernel multiplies N <= 16 on 16-wide MFMAs (round 5) it is ahead of the 8-accumulator N kernel on everything but a few
     // rows with a long contraction (11008 x 4096 x 4: 36.4 -> 33.2 us, 65536 x 4096 x 8: 187 -> 176, 8192^2 x 3: 47.7 -> 42.9; 4096 x 65536 x 8: 173 stays, Gemm 180)
+    // (With the non-temporal hint on its streamed pieces -- gemm_f32_skinny.hip tr_dma_streamed, round 5 -- the Gemm form of 4096 x 65536 x 8 takes 160 us in a replayed
+    // command buffer and 175 +- 14 us, at 1.79 GHz, as eager dispatches in bench.py, against the N kernel's steady 173 at 2.39 GHz: it stays on the N kernel.)
     return f16 || (uint64_t)k < 8ull * rows_out;
 }
 
