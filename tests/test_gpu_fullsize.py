@@ -33,6 +33,37 @@ def rnd(seed, n, dtype=np.float32):
     return (rng.random(n, dtype=np.float32) * 2 - 1).astype(dtype)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,M,N,K,tr", [(np.float32, 32000, 16, 4096, False), (np.float32, 32000, 16, 4096, True), (np.float32, 65536, 8, 4096, False),
+                                            (np.float16, 65536, 8, 4096, True)])
+def test_few_columns_on_a_matrix_past_the_infinity_cache(gpu, dtype, M, N, K, tr):
+    """The few-column kernel (gemm_f32_skinny.hip) reads a streamed operand of 384 MiB and more with the non-temporal hint on its LDS-DMA pieces (SkinnyArgs::a_nt:
+    bench workload gemm_f32_fewcols_32000x16x4096 0.73 -> 0.80 of HBM peak): those launches at full size, every element written, sampled rows against f64 with
+    the kernel's usual bound (the smaller parity shapes of test_gpu_parity.py all run without the hint)."""
+    wg = _wg()
+    rng = np.random.default_rng(M + N + K + int(tr))
+    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(dtype)
+    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(dtype)
+    assert a.nbytes >= 384 << 20
+    ta = up(gpu, (K, M) if tr else (M, K), a, dtype)
+    tb = up(gpu, (K, N), b, dtype)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    whole = up(gpu, (M, N), np.full(M * N, np.nan, dtype), dtype)
+    run(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, whole, ta, tb, variant))
+    got = whole.read(gpu.device()).reshape(M, N, order="F")
+    assert not np.isnan(got.astype(np.float32)).any()
+    A = (a.reshape(K, M, order="F").T if tr else a.reshape(M, K, order="F"))
+    B = b.reshape(K, N, order="F").astype(np.float64)
+    idx = np.unique(rng.integers(0, M, 96))
+    exact = A[idx].astype(np.float64) @ B
+    sabs = np.abs(A[idx].astype(np.float64)) @ np.abs(B)
+    if dtype == np.float32:
+        U.assert_close_f64(got[idx], exact, K, sabs, f"few columns {M}x{N}x{K} tr={tr} sampled vs f64")
+    else:
+        assert (np.abs(got[idx].astype(np.float64) - exact) <= np.abs(exact) * 2.0 ** -11 + np.sqrt(K) * 2.0 ** -23 * sabs + 2.0 ** -24).all()
+
+
 @pytest.mark.parametrize("tr", [False, True])
 def test_config2_gemm_f32_4096(gpu, tr):
     wg = _wg()
