@@ -644,16 +644,27 @@ def test_gemm_f16_shapes(gpu, f16_tile, M, K, N, mats, tr):
 @pytest.mark.parametrize("M,K,N,alpha", [(8192, 256, 8192, 1.0), (8192, 320, 8192, 1.0), (4096, 1024, 8192, -0.375), (5120, 640, 5120, 1.0), (6144, 448, 6144, 1.0),
                                              (4352, 1024, 4096, 3.0), (4096, 4160, 4352, 1.0), (16384, 256, 4352, 1.0)])
 def test_gemm_f16_continuous_walk_is_bit_identical(gpu, M, K, N, alpha, tr):
+    _continuous_walk_case(gpu, M, K, N, 1, alpha, tr)
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N,mats", [(2048, 512, 2048, 5), (1024, 1024, 1280, 17), (4096, 320, 2048, 3)])
+def test_gemm_f16_continuous_walk_through_a_batch(gpu, M, K, N, mats, tr):
+    """... and through the matrices of a batch in turn (the per-tile launch's grid.y, flattened into the walk's ids): 64 x 5, 20 x 17 and 128 x 3 tiles."""
+    _continuous_walk_case(gpu, M, K, N, mats, 1.0, tr)
+
+
+def _continuous_walk_case(gpu, M, K, N, mats, alpha, tr):
     """f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU goes from tile to tile without stopping its LDS-DMA stream; the default
     for K <= 4096 -- K <= 8192 below 16 rounds -- on more than one round of whole tiles) computes every tile exactly as the per-tile launch does: same bits -- whole rounds, a ragged last round, a cut-up
     tail behind the full rounds (6144^2: 64 tiles left over; 4352 x 4096: 16), 4 and 5 stages per tile (the shortest the walk takes), alpha != 1 (an f16-denormal
     result included: the f32 product is rounded once) -- and every element written exactly once (NaN pre-fill); the default rule must give those bits too."""
     wg = _wg()
     rng = np.random.default_rng(M + K + N)
-    a = (rng.random(M * K, dtype=np.float32) * 2 - 1).astype(np.float16)
-    b = (rng.random(K * N, dtype=np.float32) * 2 - 1).astype(np.float16)
-    m1 = upload(gpu, (K, M, 1) if tr else (M, K, 1), a, np.float16)
-    m2 = upload(gpu, (K, N, 1), b, np.float16)
+    a = (rng.random(M * K * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random(K * N * mats, dtype=np.float32) * 2 - 1).astype(np.float16)
+    m1 = upload(gpu, (K, M, mats) if tr else (M, K, mats), a, np.float16)
+    m2 = upload(gpu, (K, N, mats), b, np.float16)
     gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
     variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
     res = {}
@@ -662,7 +673,7 @@ def test_gemm_f16_continuous_walk_is_bit_identical(gpu, M, K, N, alpha, tr):
         gpu.set_tuning("f16_tile", 256)  # (the 256 x 128 pairs would take the shortest K otherwise)
         for cont in (0, 1, -1):
             gpu.set_tuning("f16_cont", cont)
-            out = upload(gpu, (M, N, 1), np.full(M * N, np.nan, np.float16), np.float16)
+            out = upload(gpu, (M, N, mats), np.full(M * N * mats, np.nan, np.float16), np.float16)
             run_pass(gpu, lambda p: gemm.dispatch_ex(gpu.device(), shapes, p, alpha, 0.0, out, m1, m2, variant))
             res[cont] = out.read(gpu.device()).view(np.uint16).copy()
     finally:
@@ -672,11 +683,13 @@ def test_gemm_f16_continuous_walk_is_bit_identical(gpu, M, K, N, alpha, tr):
     assert np.array_equal(res[1], res[0]), f"continuous walk differs from the per-tile launch in {(res[1] != res[0]).sum()} elements"
     assert np.array_equal(res[-1], res[0])
     # a sample of the output against f64 on the same f16 operands (the per-tile kernel's own parity tests cover it in full at smaller sizes)
-    B = b.reshape(N, K).astype(np.float64)   # column-major (K, N): column n of B is row n here
+    z = mats - 1  # (the last matrix of the batch)
+    az, bz = a.reshape(mats, -1)[z], b.reshape(mats, -1)[z]
+    B = bz.reshape(N, K).astype(np.float64)   # column-major (K, N): column n of B is row n here
     rows, cols = rng.integers(0, M, 64), rng.integers(0, N, 64)
-    Arows = a.reshape(M, K)[rows] if tr else a.reshape(K, M)[:, rows].T  # row m of op(A)
+    Arows = az.reshape(M, K)[rows] if tr else az.reshape(K, M)[:, rows].T  # row m of op(A)
     exact = alpha * np.einsum("ik,ik->i", Arows.astype(np.float64), B[cols])
-    got = res[1].view(np.float16).reshape(N, M)[cols, rows].astype(np.float64)
+    got = res[1].view(np.float16).reshape(mats, N, M)[z][cols, rows].astype(np.float64)
     bound = np.abs(exact) * 2.0 ** -11 + abs(alpha) * K * 2.0 ** -22 + 2.0 ** -24
     assert (np.abs(got - exact) <= bound).all()
 

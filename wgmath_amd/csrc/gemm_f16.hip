@@ -915,7 +915,7 @@ WG_ACC_QUADS(WG_ACC_QUAD_DEF)
 // one is the first that needs anything issued behind them). What it is for: short K on many tiles, where those 5 us are a fifth of a tile
 // (8192^2 x 1024: profiles/r05_evidence.md section 3). Same tiles, same k order, same accumulation chains as m16_tile: bit-identical results.
 // The half-steps are m16_tile's (half_step_nn / half_step_s, slot for slot: see there for the plan); what differs is marked.
-// Restrictions (launcher): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, beta == 0, one matrix, no split, no panels.
+// Restrictions (launcher): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, beta == 0, no split, no panels. Batches: the walk goes through the matrices' tiles in turn.
 // ===============================================================================================================
 template <bool TRANS_A, bool STREAM>
 __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, const uint32_t walk_first, const int32_t walk_stride, const uint32_t walk_count) {
@@ -974,18 +974,26 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     const uint64_t a_half = TRANS_A ? 64u : (uint64_t)BKH * g.lda * 2u;
     const uint64_t a_full = TRANS_A ? 128u : a_half;            // what a cursor step of A covers: a stage (GemmTr) / a half-stage (Gemm)
     // ---- tile -> global bases (scalar) ----
-    auto bases = [&](uint32_t t, const char *&a0, const char *&b0, uint32_t &m0, uint32_t &n0) {
+    // walk ids run through the matrices of a batch: id = matrix * tiles per matrix + tile (the per-tile launch's grid.y, flattened)
+    const uint32_t tiles_per = g.tiles_m * g.tiles_n;
+    auto sc64 = [](uint64_t v) -> uint64_t { // (64-bit products run on the vector unit: back to scalars by hand)
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    auto bases = [&](uint32_t id, const char *&a0, const char *&b0, uint32_t &m0, uint32_t &n0, uint64_t &c_off) {
+        const uint32_t z = __builtin_amdgcn_readfirstlane(id / tiles_per), t = __builtin_amdgcn_readfirstlane(id - z * tiles_per);
         uint32_t tm, tn;
         tile_of(t, g.tiles_m, g.tiles_n, tm, tn);
         tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
         m0 = tm * BM; n0 = tn * BN;
-        const uint64_t ao = TRANS_A ? (uint64_t)m0 * g.lda * 2u : (uint64_t)m0 * 2u, bo = (uint64_t)n0 * g.ldb * 2u; // (64-bit products run on the vector unit: back to scalars by hand)
-        a0 = (const char *)g.a + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ao >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ao)) - M16_BIAS;
-        b0 = (const char *)g.b + (((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(bo >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)bo)) - M16_BIAS;
+        const uint64_t ao = (TRANS_A ? (uint64_t)m0 * g.lda : (uint64_t)m0) + (uint64_t)z * g.a_batch, bo = (uint64_t)n0 * g.ldb + (uint64_t)z * g.b_batch; // elements
+        a0 = (const char *)g.a + sc64(ao * 2u) - M16_BIAS;
+        b0 = (const char *)g.b + sc64(bo * 2u) - M16_BIAS;
+        c_off = sc64((uint64_t)z * g.c_batch);
     };
     const char *a0, *b0; // stage 0 of the current tile's operands (less M16_BIAS)
     uint32_t m0, n0;
-    bases(tile, a0, b0, m0, n0);
+    uint64_t c_off;      // its matrix's offset in the output (elements)
+    bases(tile, a0, b0, m0, n0, c_off);
 
     uintx4 a_r[2][8]; // (the accumulators: AccQuad<8 t + u>, a[0:255])
     half8_t b_f[2][8];
@@ -1177,7 +1185,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         const bool has_next = tiles_left > 1u;
         const char *na0 = a0, *nb0 = b0;
         uint32_t nm0 = m0, nn0 = n0;
-        if (has_next) bases(next, na0, nb0, nm0, nn0);
+        uint64_t nc_off = c_off;
+        if (has_next) bases(next, na0, nb0, nm0, nn0, nc_off);
         a_cross = a_full + (uint64_t)((int64_t)(na0 - a0) - (int64_t)((TRANS_A ? S : 2u * S) * a_full));
         b_cross = 128u + (uint64_t)((int64_t)(nb0 - b0) - (int64_t)S * 128);
         cross_st = has_next ? S - 3u : ~0u;
@@ -1191,7 +1200,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         // ---- epilogue of `tile`: the stores are NOT waited for; they drain under the next tile's first stage. ONE basic block (no alpha / beta / store-flavour
         // branches: beta == 0 is the launcher's condition, x * 1.0f is x) with a scheduling fence per pack: with branches between the packs the compiler brings all
         // 256 accumulators over to VGPRs at the loop's exit, on top of the live fragments, and spills (ISA of the first cut: 22 dwords, reloaded behind the stores).
-        _Float16 *C = g.c;
+        _Float16 *C = g.c + c_off;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // the last MFMA's result is out of the pipe before the first hand-written read
         static_for<8>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
@@ -1217,7 +1226,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             });
         });
         if (!has_next) break;
-        tile = next; --tiles_left; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0;
+        tile = next; --tiles_left; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0; c_off = nc_off;
         st = 0;
         after_store = TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
         asm volatile("" : "+s"(st), "+s"(after_store));
@@ -1525,15 +1534,16 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // rounds at every K: GemmTr 8192^2 x 256 54 -> 50 us, x 512 86 -> 71; the pairs keep ragged tile counts such as 6144^2 x 512).
         bool t256x128 = ctx->tuning[WG_TUNE_F16_TILE] == 256128;
         // (whether launch_tiles below would put the product on the continuous walk by its default rule: whole tiles and stages, more than one round)
-        const bool cont_shape = nmats == 1 && !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && // (the pairs are a short-K choice: K <= 1536) tiles > (uint64_t)cus && g.beta == 0.f &&
+        const bool cont_shape = !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && tiles * nmats > (uint64_t)cus && g.beta == 0.f && // (K: the pairs are a short-K choice anyway)
                                 ctx->tuning[WG_TUNE_F16_CONT] != 0 && ctx->tuning[WG_TUNE_F16_SCHED] < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
         if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
             double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
             if (cont_shape) { // the continuous walk (launch_tiles below): 5 us + 5.7 + 0.0211 K per full round; a last partial round costs a whole one, or -- up to half a
                               // round of tiles, from 6 stages on -- the cut-up tail's two extra launches (8192^2 x 256 49.6 us, x 512 71.4, x 1024 114.5; 6144^2 x 512 67.2)
                 const double per = 5.7 + 0.0211 * K;
-                const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
-                t_big = 5.0 + (double)(tiles / (uint64_t)cus) * per + (r == 0 ? 0.0 : (2u * r <= (uint32_t)cus && K >= 384u ? 25.0 + 0.0107 * K : per));
+                const uint64_t all = tiles * nmats;
+                const uint32_t r = (uint32_t)(all % (uint64_t)cus);
+                t_big = 5.0 + (double)(all / (uint64_t)cus) * per + (r == 0 ? 0.0 : (2u * r <= (uint32_t)cus && K >= 384u && nmats == 1 ? 25.0 + 0.0107 * K : per));
             }
             const double r2 = (double)((uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats) / (2.0 * cus), fl = floor(r2), fr = r2 - fl;
             const double pair = trans ? 5.7 + 0.0298 * K : 6.1 + 0.0263 * K;
@@ -1647,12 +1657,13 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 // the calibrated shares forced on.
                 {
                     const int cont = ctx->tuning[WG_TUNE_F16_CONT];
-                    const bool applies = gm.nsplit == 1 && nmats == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
-                                         krem == 0 && K >= 256u && ntiles > (uint32_t)cus && gm.beta == 0.f;
-                    const bool by_rule = (K <= 4096u || (K <= 8192u && ntiles < (uint32_t)(WG_F16_SCHED_ROUNDS * cus))) && !ctx->uneven_xcds && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
+                    const uint64_t all = (uint64_t)ntiles * nmats; // a batch: the walk goes through the matrices' tiles in turn (grid.y of the per-tile launch, flattened)
+                    const bool applies = gm.nsplit == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
+                                         krem == 0 && K >= 256u && all > (uint64_t)cus && all <= 0x7fffffffull && gm.beta == 0.f;
+                    const bool by_rule = (K <= 4096u || (K <= 8192u && all < (uint64_t)(WG_F16_SCHED_ROUNDS * cus))) && !ctx->uneven_xcds && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
                     if (cont != 0 && applies && (cont == 1 || by_rule)) {
                         const dim3 grid((uint32_t)cus), block(256);
-                        gm.sched = nullptr; gm.sched_tiles = ntiles;
+                        gm.sched = nullptr; gm.sched_tiles = (uint32_t)all;
                         if (trans) {
                             if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, true>), grid, block, 0, ctx->stream, gm);
                             else hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, false>), grid, block, 0, ctx->stream, gm);
