@@ -1463,6 +1463,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     {   // the result past the caches when it would push the operands out of the Infinity Cache (see GemmArgs::c_stream); beta != 0 reads C back
         const uint64_t MiB = 1ull << 20, ab = ((uint64_t)M * K + (uint64_t)K * N) * nmats * 2u, cb = (uint64_t)M * N * nmats * 2u;
         g.c_stream = (beta == 0.f && ab <= 256u * MiB && ab + cb > 256u * MiB) ? 1u : 0u;
+        // (read by gemm_f16_t128.hip only: one column of 128-wide tiles. Gemm only: GemmTr's k-contiguous A arrives as 64-byte row pieces, two per line at different times)
+        g.a_nt = (!trans && N <= 128u && (uint64_t)M * K * 2u >= 384u * MiB) ? 1u : 0u;
     }
     g.tile_base = 0; g.tail_tiles = 0;
     g.sched = nullptr; g.sched_tiles = 0;

@@ -103,6 +103,8 @@ struct GemmArgs {
     // 1: the result is stored past the caches (`sc1 nt`): chosen by the launcher when the operands fit the 256 MiB Infinity Cache and the
     // result on top of them would not -- the result then leaves the operands alone there (8192^3: +1.2 ... 2.8 %, profiles/r03_evidence.md section 8)
     uint32_t c_stream;
+    // 1: op(A)'s LDS-DMA pieces carry the non-temporal hint (gemm_f16_t128.hip: one tile column, i.e. A is read once, and A too large for the Infinity Cache anyway)
+    uint32_t a_nt;
     // "tail split" launches of the 16x16x32 kernel: tile id = tile_base + blockIdx.x; with tail_tiles > 0 the workgroup (tile, split)
     // writes its f32 partial tile to part[(split * tail_tiles + blockIdx.x) * 65536 + col_local * 256 + row_local]
     uint32_t tile_base, tail_tiles;

@@ -59,6 +59,15 @@ __device__ __forceinline__ void t_dma(uint32_t voff, const void *sbase) {
     asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
 }
 
+// op(A)'s pieces when A is read once and cannot stay in the Infinity Cache (GemmArgs::a_nt: few columns on a tall matrix): the non-temporal hint, as in the few-column
+// f32 kernel (gemm_f32_skinny.hip tr_dma_streamed; profiles/r05_skinny_nt_ab.txt)
+template <int IMM>
+__device__ __forceinline__ void t_dma_streamed(uint32_t voff, const void *sbase, uint32_t nt) {
+    if (WG_T128_ABLATE & 2) return;
+    if (nt) asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2 nt" ::"v"(voff), "s"(sbase), "i"(IMM));
+    else asm volatile("global_load_lds_dwordx4 %0, %1 offset:%c2" ::"v"(voff), "s"(sbase), "i"(IMM));
+}
+
 template <int N, int STEP>
 __device__ __forceinline__ void t_wait_keep_pieces(int n) { // s_waitcnt's count is an immediate: a run-time count (a multiple of STEP below STEP * N) picks its instruction
     if constexpr (N > 0) {
@@ -130,13 +139,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * RB);
     const uint64_t a_step = TRANS_A ? 64u : (uint64_t)64u * g.lda; // bytes per half-stage (32 k)
     const char *ga0 = (const char *)a_base - T_BIAS - (rem ? 2u * a_step : 0u), *gb0 = (const char *)b_base - T_BIAS - (rem ? 128u : 0u);
+    const uint32_t a_nt = g.a_nt; // (workgroup-uniform)
     auto issue = [&](uint32_t H, uint32_t slot_off) { // this wave's PPW pieces of half-stage H into the slot at byte offset slot_off
         const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * 64u;
         t_set_m0(lds_wave + slot_off);
         asm volatile("s_nop 0");
-        t_dma<0>(a_voff[0], ga); t_dma<1024>(a_voff[1], ga);
+        t_dma_streamed<0>(a_voff[0], ga, a_nt); t_dma_streamed<1024>(a_voff[1], ga, a_nt);
         if constexpr (APW == 4) {
-            t_dma<2048>(a_voff[2], ga); t_dma<3072>(a_voff[3], ga);
+            t_dma_streamed<2048>(a_voff[2], ga, a_nt); t_dma_streamed<3072>(a_voff[3], ga, a_nt);
             t_set_m0(lds_wave + slot_off + 4096u);
             asm volatile("s_nop 0");
         }
