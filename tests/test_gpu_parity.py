@@ -654,6 +654,24 @@ def test_gemm_f16_continuous_walk_through_a_batch(gpu, M, K, N, mats, tr):
     _continuous_walk_case(gpu, M, K, N, mats, 1.0, tr)
 
 
+def _walk_fuzz_cases():
+    rng = np.random.default_rng(20261003)
+    cases = []
+    while len(cases) < 14:
+        tm, tn, mats = int(rng.integers(3, 40)), int(rng.integers(3, 40)), int(rng.choice([1, 1, 2, 3]))
+        if not 256 < tm * tn * mats <= 900:
+            continue
+        cases.append((256 * tm, 64 * int(rng.integers(4, 14)), 256 * tn, mats, bool(rng.integers(0, 2))))
+    return cases
+
+
+@pytest.mark.parametrize("M,K,N,mats,tr", _walk_fuzz_cases())
+def test_gemm_f16_continuous_walk_fuzz(gpu, M, K, N, mats, tr):
+    """Seeded random tile grids (more than one round of tiles, up to 3.5), 4 .. 13 stages per tile, one to three matrices, both variants: the walk's bits are the
+    per-tile launch's (a tile boundary falls on a different stage of the DMA ring, of A's half-stage slots and of the cut-up tail's plan in nearly every case)."""
+    _continuous_walk_case(gpu, M, K, N, mats, 1.0, tr)
+
+
 def _continuous_walk_case(gpu, M, K, N, mats, alpha, tr):
     """f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU goes from tile to tile without stopping its LDS-DMA stream; the default
     for K <= 4096 -- K <= 8192 below 16 rounds -- on more than one round of whole tiles) computes every tile exactly as the per-tile launch does: same bits -- whole rounds, a ragged last round, a cut-up
