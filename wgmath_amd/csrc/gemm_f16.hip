@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_m16_kernel(GemmArgs g) {
 
 // The continuous form's 64 accumulator quads live in a[0:255] BY NAME: left to the compiler, accumulators that are live across a tile's epilogue inside
 // an outer loop get copied to VGPRs wholesale at the inner loop's exit (on top of the fragments that must stay live there), spilled to scratch and shuffled
-// inside the multiply loop (three cuts, ISA read each time: profiles/r05_evidence.md section 3). So the multiply, the zeroing and the read-out are inline
+// inside the multiply loop (three cuts, ISA read each time: profiles/r05_evidence.md section 3). So the multiply (a tile's first one with C = 0) and the read-out are inline
 // asm on fixed registers, each naming what it overwrites; the compiler keeps no value of its own in an AGPR in that kernel (checked in the ISA test).
 #define WG_ACC_QUADS(X) \
     X(0, 0, 1, 2, 3) X(1, 4, 5, 6, 7) X(2, 8, 9, 10, 11) X(3, 12, 13, 14, 15) \
@@ -894,9 +894,8 @@ template <int I> struct AccQuad;
         static __device__ __forceinline__ void mfma(half8_t a, half8_t b) {                                                                             \
             asm volatile("v_mfma_f32_16x16x32_f16 a[" #R0 ":" #R3 "], %0, %1, a[" #R0 ":" #R3 "]" ::"v"(a), "v"(b) : "a" #R0, "a" #R1, "a" #R2, "a" #R3);  \
         }                                                                                                                                               \
-        static __device__ __forceinline__ void zero() {                                                                                                 \
-            asm volatile("v_accvgpr_write_b32 a" #R0 ", 0\n\tv_accvgpr_write_b32 a" #R1 ", 0\n\tv_accvgpr_write_b32 a" #R2 ", 0\n\tv_accvgpr_write_b32 a" #R3 ", 0" :: \
-                             : "a" #R0, "a" #R1, "a" #R2, "a" #R3);                                                                                     \
+        static __device__ __forceinline__ void mfma0(half8_t a, half8_t b) { /* the quad's first product of a tile: C = 0 instead of a zeroing pass */      \
+            asm volatile("v_mfma_f32_16x16x32_f16 a[" #R0 ":" #R3 "], %0, %1, 0" ::"v"(a), "v"(b) : "a" #R0, "a" #R1, "a" #R2, "a" #R3);                     \
         }                                                                                                                                               \
         static __device__ __forceinline__ void read(float &x0, float &x1, float &x2, float &x3) {                                                       \
             asm volatile("v_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2 "\n\tv_accvgpr_read_b32 %3, a" #R3 \
@@ -1070,15 +1069,17 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         __builtin_amdgcn_s_barrier();
     };
     // m16_tile's half_step_s (GemmTr): A in two full-stage slots, ONE counted wait + barrier per stage, in the even half-step
-    auto half_step_tn = [&](auto hs_c) {
+    auto half_step_tn = [&](auto hs_c, auto first_c) {
         constexpr int HS = decltype(hs_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value; // the tile's first half-step: every quad's first product, C = 0
         constexpr bool ADMA = HS == 1;
         constexpr int nA = ADMA ? 8 : 0, nB = 4;
         constexpr int DS = 4, DO = 2, LASTB = 24;
         static_for<64>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int t = j >> 3, u = j & 7;
-            AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            if constexpr (FIRST) AccQuad<8 * t + u>::mfma0(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            else AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
             frag_slot(jc, HS ^ 1);
             if constexpr (ADMA && j == DO - 2) { la = lds_a_wave + oAD; asm volatile("" : "+s"(la)); }
             if constexpr (ADMA && j == DO + 4 * DS - 2) { la += 4096u; asm volatile("" : "+s"(la)); }
@@ -1109,13 +1110,15 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         });
     };
     // m16_tile's half_step_nn (Gemm): A in four half-stage slots, a counted wait + barrier in every half-step
-    auto half_step_nn = [&](auto hs_c) {
+    auto half_step_nn = [&](auto hs_c, auto first_c) {
         constexpr int HS = decltype(hs_c)::value;
+        constexpr bool FIRST = decltype(first_c)::value;
         constexpr int DS = WG_NN_DSTRIDE, DO = WG_NN_DOFF;
         static_for<64>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             constexpr int t = j >> 3, u = j & 7;
-            AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            if constexpr (FIRST) AccQuad<8 * t + u>::mfma0(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
+            else AccQuad<8 * t + u>::mfma(__builtin_bit_cast(half8_t, a_r[HS][t]), b_f[HS][u]);
             frag_slot(jc, HS ^ 1);
             if constexpr (j == DO - 1) m16_set_m0(lds_a_wave + rD);
             if constexpr (j == DO + 4 * DS - 4) { lb = lds_b_wave + oD + (HS == 0 ? 4096u : 0u); asm volatile("" : "+s"(lb)); }
@@ -1191,11 +1194,12 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         b_cross = 128u + (uint64_t)((int64_t)(nb0 - b0) - (int64_t)S * 128);
         cross_st = has_next ? S - 3u : ~0u;
         asm volatile("" : "+s"(a_cross), "+s"(b_cross), "+s"(cross_st));
-        static_for<64>([&](auto ic) { AccQuad<decltype(ic)::value>::zero(); });
-        asm volatile("s_nop 4" ::: "memory"); // (hand-written register traffic: the compiler inserts no wait states around it)
+        // stage 0: its first half-step multiplies every quad once with C = 0 (no zeroing pass: 256 VALU writes, 0.45 us of a tile with the matrix cores idle)
+        if constexpr (TRANS_A) { half_step_tn(c0{}, std::true_type{}); half_step_tn(c1{}, std::false_type{}); }
+        else { half_step_nn(c0{}, std::true_type{}); half_step_nn(c1{}, std::false_type{}); }
         while (st < S) {
-            if constexpr (TRANS_A) { half_step_tn(c0{}); half_step_tn(c1{}); }
-            else { half_step_nn(c0{}); half_step_nn(c1{}); } // ++st inside
+            if constexpr (TRANS_A) { half_step_tn(c0{}, std::false_type{}); half_step_tn(c1{}, std::false_type{}); }
+            else { half_step_nn(c0{}, std::false_type{}); half_step_nn(c1{}, std::false_type{}); } // ++st inside
         }
         // ---- epilogue of `tile`: the stores are NOT waited for; they drain under the next tile's first stage. ONE basic block (no alpha / beta / store-flavour
         // branches: beta == 0 is the launcher's condition, x * 1.0f is x) with a scheduling fence per pack: with branches between the packs the compiler brings all
