@@ -648,7 +648,16 @@ def test_gemm_f16_continuous_walk_is_bit_identical(gpu, M, K, N, alpha, tr):
 
 
 @pytest.mark.parametrize("tr", [False, True])
-@pytest.mark.parametrize("M,K,N,mats", [(2048, 512, 2048, 5), (1024, 1024, 1280, 17), (4096, 320, 2048, 3)])
+@pytest.mark.parametrize("M,K,N", [(8200, 512, 8192), (8192, 512, 8193), (4352 + 248, 256, 4096 + 129), (5000, 1024, 5001), (4104, 320, 4488), (16384 + 8, 256, 4097)])
+def test_gemm_f16_continuous_walk_ragged_tiles(gpu, M, K, N, tr):
+    """... and with a ragged last tile row and / or column (M % 8 == 0 is the fast path's condition; N is free): the DMA offsets of an edge tile clamp the rows past the
+    end to the last valid one, from the slot where the operand's cursor enters the tile; its epilogue skips them; a wave of an edge tile may store nothing at all (N % 256
+    <= 128), which is why the stores of a ragged tile are waited out instead of being counted. Same bits as the per-tile launch, nothing written past the end."""
+    _continuous_walk_case(gpu, M, K, N, 1, 1.0, tr)
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("M,K,N,mats", [(2048, 512, 2048, 5), (1024, 1024, 1280, 17), (4096, 320, 2048, 3), (1000, 512, 1100, 23)])
 def test_gemm_f16_continuous_walk_through_a_batch(gpu, M, K, N, mats, tr):
     """... and through the matrices of a batch in turn (the per-tile launch's grid.y, flattened into the walk's ids): 64 x 5, 20 x 17 and 128 x 3 tiles."""
     _continuous_walk_case(gpu, M, K, N, mats, 1.0, tr)
@@ -657,17 +666,19 @@ def test_gemm_f16_continuous_walk_through_a_batch(gpu, M, K, N, mats, tr):
 def _walk_fuzz_cases():
     rng = np.random.default_rng(20261003)
     cases = []
-    while len(cases) < 14:
+    while len(cases) < 18:
         tm, tn, mats = int(rng.integers(3, 40)), int(rng.integers(3, 40)), int(rng.choice([1, 1, 2, 3]))
         if not 256 < tm * tn * mats <= 900:
             continue
-        cases.append((256 * tm, 64 * int(rng.integers(4, 14)), 256 * tn, mats, bool(rng.integers(0, 2))))
+        ragged_m, ragged_n = (8 * int(rng.integers(1, 32)) if rng.integers(0, 2) else 0), (int(rng.integers(1, 256)) if rng.integers(0, 2) else 0)
+        cases.append((256 * tm - ragged_m, 64 * int(rng.integers(4, 14)), 256 * tn - ragged_n, mats, bool(rng.integers(0, 2))))
     return cases
 
 
 @pytest.mark.parametrize("M,K,N,mats,tr", _walk_fuzz_cases())
 def test_gemm_f16_continuous_walk_fuzz(gpu, M, K, N, mats, tr):
-    """Seeded random tile grids (more than one round of tiles, up to 3.5), 4 .. 13 stages per tile, one to three matrices, both variants: the walk's bits are the
+    """Seeded random tile grids (more than one round of tiles, up to 3.5; half of them with a ragged last tile row and / or column), 4 .. 13 stages per tile, one to
+    three matrices, both variants: the walk's bits are the
     per-tile launch's (a tile boundary falls on a different stage of the DMA ring, of A's half-stage slots and of the cut-up tail's plan in nearly every case)."""
     _continuous_walk_case(gpu, M, K, N, mats, 1.0, tr)
 

@@ -914,7 +914,8 @@ WG_ACC_QUADS(WG_ACC_QUAD_DEF)
 // one is the first that needs anything issued behind them). What it is for: short K on many tiles, where those 5 us are a fifth of a tile
 // (8192^2 x 1024: profiles/r05_evidence.md section 3). Same tiles, same k order, same accumulation chains as m16_tile: bit-identical results.
 // The half-steps are m16_tile's (half_step_nn / half_step_s, slot for slot: see there for the plan); what differs is marked.
-// Restrictions (launcher): M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, beta == 0, no split, no panels. Batches: the walk goes through the matrices' tiles in turn.
+// Restrictions (launcher): K % 64 == 0, K >= 256, beta == 0, no split, no panels (and the fast path's M % 8 == 0). Batches: the walk goes through the matrices' tiles in
+// turn. Ragged tiles (M or N not a multiple of 256): rows past the end are clamped in the DMA offsets and skipped by the epilogue, as in m16_tile.
 // ===============================================================================================================
 template <bool TRANS_A, bool STREAM>
 __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, const uint32_t walk_first, const int32_t walk_stride, const uint32_t walk_count) {
@@ -932,29 +933,50 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     uint32_t ldc = g.ldc;
     asm volatile("" : "+s"(alpha), "+s"(ldc));
 
-    // ---- per-lane DMA offsets: the same for every (full) tile ----
-    uint32_t a_voff[TRANS_A ? 8 : 4], b_voff[8];
+    // ---- per-lane DMA offsets. a_int / b_int: a whole tile's; a_voff / b_voff: the current ones -- a ragged tile (last tile row / column of an M or N that is not a
+    // multiple of 256) clamps the rows past the end to the last valid one, as m16_tile does (their results are never stored): set_voffs_*, per tile, at the slot where
+    // the operand's cursor leaves the previous tile. ----
+    constexpr int NA = TRANS_A ? 8 : 4;
+    uint32_t a_int[NA], b_int[8], a_voff[NA], b_voff[8];
+    const uint32_t row_l = 64u * wave + (lane >> 3);                  // piece q of a k-contiguous operand: row row_l + 8 q of the tile
+    const uint32_t mp_l = 32u * (lane >> 4) + 8u * (lane & 3);        // Gemm's A: piece q starts at row 128 (q & 1) + mp_l
     if constexpr (TRANS_A) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+            const uint32_t row = row_l + 8u * q;
             const uint32_t fa = ((4u - ((row >> 3) & 3u)) & 3u) | (((row >> 1) & 1u) << 2); // A's rows are permuted: G index (row >> 3) & 3
-            a_voff[q] = (row * g.lda + 8u * ((lane & 7u) ^ fa)) * 2u + (M16_BIAS - 1024u * (q & 3));
+            a_int[q] = (row * g.lda + 8u * ((lane & 7u) ^ fa)) * 2u + (M16_BIAS - 1024u * (q & 3));
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { // blocks 4P..4P+3: kq = P>>1, mblk = 4 (P&1) + (lane>>4), k row (lane>>2)&3, 16-byte unit lane&3
             const uint32_t P = 4u * wave + q;
-            const uint32_t mpiece = 128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3);
-            a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u + (M16_BIAS - 1024u * q);
+            a_int[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + 128u * (P & 1) + mp_l) * 2u + (M16_BIAS - 1024u * q);
         }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const uint32_t row = 8u * (8u * wave + q) + (lane >> 3);
+        const uint32_t row = row_l + 8u * q;
         const uint32_t fb = ((4u - ((row >> 2) & 3u)) & 3u) | (((row >> 1) & 1u) << 2);
-        b_voff[q] = (row * g.ldb + 8u * ((lane & 7u) ^ fb)) * 2u + (M16_BIAS - 1024u * (q & 3));
+        b_int[q] = (row * g.ldb + 8u * ((lane & 7u) ^ fb)) * 2u + (M16_BIAS - 1024u * (q & 3));
     }
+    // lim: the last row the tile may read (GemmTr's A, B: M - 1 - m0, N - 1 - n0; Gemm's A, in pieces of 8 rows: M - 8 - m0); >= 255 / 248 in a whole tile: nothing moves
+    auto set_voffs_a = [&](uint32_t lim) {
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const uint32_t r = TRANS_A ? row_l + 8u * q : 128u * (q & 1) + mp_l;
+            const uint32_t over = r > lim ? r - lim : 0u;
+            a_voff[q] = a_int[q] - over * (TRANS_A ? g.lda * 2u : 2u);
+        }
+    };
+    auto set_voffs_b = [&](uint32_t lim) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t r = row_l + 8u * q;
+            const uint32_t over = r > lim ? r - lim : 0u;
+            b_voff[q] = b_int[q] - over * (g.ldb * 2u);
+        }
+    };
     const uint32_t lds_base = (uint32_t)(uintptr_t)(WG_AS3 char *)smem;
     const uint32_t lds_a_wave = __builtin_amdgcn_readfirstlane(lds_base + wave * (TRANS_A ? 8192 : 4096));
     const uint32_t lds_b_wave = __builtin_amdgcn_readfirstlane(lds_base + M16_B_BASE + wave * 8192);
@@ -993,6 +1015,9 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     uint32_t m0, n0;
     uint64_t c_off;      // its matrix's offset in the output (elements)
     bases(tile, a0, b0, m0, n0, c_off);
+    auto lim_a = [&](uint32_t m0_) { return TRANS_A ? g.M - 1u - m0_ : g.M - 8u - m0_; };
+    set_voffs_a(lim_a(m0)); set_voffs_b(g.N - 1u - n0);
+    uint32_t nlim_a = 0, nlim_b = 0; // the next tile's (set when a tile starts, used where the cursors leave it)
 
     uintx4 a_r[2][8]; // (the accumulators: AccQuad<8 t + u>, a[0:255])
     half8_t b_f[2][8];
@@ -1094,9 +1119,15 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                 else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
             }
             if constexpr (HS == 0 && j == DO + 2) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
-            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { gb += b_step; asm volatile("" : "+s"(gb)); }  // even: after the last B piece -- on to B(st + 3), in the next tile if this one ends there
+            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { // even: after the last B piece -- on to B(st + 3), in the next tile if this one ends there
+                gb += b_step; asm volatile("" : "+s"(gb));
+                if (st == cross_st) set_voffs_b(nlim_b);
+            }
             if constexpr (HS == 1 && j == DO + 4 * DS + 1) { oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oAD)); }
-            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { ga += a_step1; asm volatile("" : "+s"(ga)); } // odd: after the last A piece -- on to A(st + 3)
+            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { // odd: after the last A piece -- on to A(st + 3)
+                ga += a_step1; asm volatile("" : "+s"(ga));
+                if (st == cross_st) set_voffs_a(nlim_a);
+            }
             if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
             if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }
             if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
@@ -1134,6 +1165,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if constexpr (j == DO + 3 * DS + 3) { // after the last A piece: on to half-stage 2 st + 5 (even) / the first one of stage st + 3 (odd: in the next tile if this one ends there)
                 if constexpr (HS == 0) ga += a_step0; else ga += a_step1;
                 asm volatile("" : "+s"(ga));
+                if constexpr (HS == 1) { if (st == cross_st) set_voffs_a(nlim_a); }
             }
             if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
             if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
@@ -1144,7 +1176,10 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if constexpr (HS == 1 && j == 58) stage_end(2);
             if constexpr (HS == 1 && j == WG_NN_SYNC_SLOT + 1) stage_end(3);
             if constexpr (j == WG_NN_SYNC_SLOT) sync(std::integral_constant<int, WG_NN_KEEP>{});
-            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { gb += b_step; asm volatile("" : "+s"(gb)); }
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) {
+                gb += b_step; asm volatile("" : "+s"(gb));
+                if (st == cross_st) set_voffs_b(nlim_b);
+            }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -1193,7 +1228,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         a_cross = a_full + (uint64_t)((int64_t)(na0 - a0) - (int64_t)((TRANS_A ? S : 2u * S) * a_full));
         b_cross = 128u + (uint64_t)((int64_t)(nb0 - b0) - (int64_t)S * 128);
         cross_st = has_next ? S - 3u : ~0u;
-        asm volatile("" : "+s"(a_cross), "+s"(b_cross), "+s"(cross_st));
+        nlim_a = lim_a(nm0); nlim_b = g.N - 1u - nn0;
+        asm volatile("" : "+s"(a_cross), "+s"(b_cross), "+s"(cross_st), "+s"(nlim_a), "+s"(nlim_b));
         // stage 0: its first half-step multiplies every quad once with C = 0 (no zeroing pass: 256 VALU writes, 0.45 us of a tile with the matrix cores idle)
         if constexpr (TRANS_A) { half_step_tn(c0{}, std::true_type{}); half_step_tn(c1{}, std::false_type{}); }
         else { half_step_nn(c0{}, std::true_type{}); half_step_nn(c1{}, std::false_type{}); }
@@ -1206,12 +1242,15 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         // 256 accumulators over to VGPRs at the loop's exit, on top of the live fragments, and spills (ISA of the first cut: 22 dwords, reloaded behind the stores).
         _Float16 *C = g.c + c_off;
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); // the last MFMA's result is out of the pipe before the first hand-written read
+        const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N; // workgroup-uniform
         static_for<8>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const uint32_t col = n0 + 128u * wn + 16u * u + i16;
-            _Float16 *cc = C + (uint64_t)col * ldc + m0 + row_w;
+            const bool col_ok = full_tile || col < g.N;
+            _Float16 *cc = C + (uint64_t)(col_ok ? col : n0) * ldc + m0 + row_w;
             static_for<4>([&](auto pc) {
                 constexpr int p = decltype(pc)::value;
+                const bool ok = col_ok && (full_tile || m0 + row_w + 32u * p < g.M); // 8 consecutive rows, all in or all out (M % 8 == 0)
                 float r[8];
                 AccQuad<8 * (2 * p) + u>::read(r[0], r[1], r[2], r[3]);
                 AccQuad<8 * (2 * p + 1) + u>::read(r[4], r[5], r[6], r[7]);
@@ -1224,8 +1263,10 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                     v[q] = (_Float16)r[q];
                 }
                 _Float16 *dst = cc + 32 * p;
-                if constexpr (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-                else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                if (ok) { // (a wave with no row or column inside the matrix skips the instruction: see the wait behind a ragged tile below)
+                    if constexpr (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
@@ -1233,6 +1274,11 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         tile = next; --tiles_left; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0; c_off = nc_off;
         st = 0;
         after_store = TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
+        if (!full_tile) { // a ragged tile: a wave whose rows or columns lie past the end issued fewer than 32 stores (none, if all of them do), and a counted wait that
+                          // allowed for 32 would let that many pieces fly instead: wait the stores out here (edge tiles only: one tile row / column of the output)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            after_store = 0u;
+        }
         asm volatile("" : "+s"(st), "+s"(after_store));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing (parked pieces, stores) is in flight when the workgroup ends
@@ -1540,7 +1586,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // rounds at every K: GemmTr 8192^2 x 256 54 -> 50 us, x 512 86 -> 71; the pairs keep ragged tile counts such as 6144^2 x 512).
         bool t256x128 = ctx->tuning[WG_TUNE_F16_TILE] == 256128;
         // (whether launch_tiles below would put the product on the continuous walk by its default rule: whole tiles and stages, more than one round)
-        const bool cont_shape = !panels && M % 256u == 0 && N % 256u == 0 && krem == 0 && K >= 256u && K <= 4096u && tiles * nmats > (uint64_t)cus && g.beta == 0.f && // (K: the pairs are a short-K choice anyway)
+        const bool cont_shape = !panels && krem == 0 && K >= 256u && K <= 4096u && tiles * nmats > (uint64_t)cus && g.beta == 0.f && // (K: the pairs are a short-K choice anyway)
                                 ctx->tuning[WG_TUNE_F16_CONT] != 0 && ctx->tuning[WG_TUNE_F16_SCHED] < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
         if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
             double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
@@ -1664,7 +1710,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 {
                     const int cont = ctx->tuning[WG_TUNE_F16_CONT];
                     const uint64_t all = (uint64_t)ntiles * nmats; // a batch: the walk goes through the matrices' tiles in turn (grid.y of the per-tile launch, flattened)
-                    const bool applies = gm.nsplit == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 && M % 256u == 0 && N % 256u == 0 &&
+                    const bool applies = gm.nsplit == 1 && gm.panel.cols == 0 && gm.tail_tiles == 0 && gm.tile_base == 0 &&
                                          krem == 0 && K >= 256u && all > (uint64_t)cus && all <= 0x7fffffffull && gm.beta == 0.f;
                     const bool by_rule = (K <= 4096u || (K <= 8192u && all < (uint64_t)(WG_F16_SCHED_ROUNDS * cus))) && !ctx->uneven_xcds && sched_env < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
                     if (cont != 0 && applies && (cont == 1 || by_rule)) {
