@@ -1119,15 +1119,11 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                 else m16_dma_imm<1024 * ((n - nA) & 3)>(b_voff[(HS == 0 ? 4 : 0) + (n - nA)], gb);
             }
             if constexpr (HS == 0 && j == DO + 2) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
-            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { // even: after the last B piece -- on to B(st + 3), in the next tile if this one ends there
-                gb += b_step; asm volatile("" : "+s"(gb));
-                if (st == cross_st) set_voffs_b(nlim_b);
-            }
+            if constexpr (HS == 0 && j == DO + DS * 3 + 1) { gb += b_step; asm volatile("" : "+s"(gb)); }  // even: after the last B piece -- on to B(st + 3), in the next tile if this one ends there
+            if constexpr (HS == 0 && j == DO + DS * 3 + 2) { if (st == cross_st) set_voffs_b(nlim_b); }     // (a slot of its own: the compare and branch are two fillers)
             if constexpr (HS == 1 && j == DO + 4 * DS + 1) { oAD ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oAD)); }
-            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { // odd: after the last A piece -- on to A(st + 3)
-                ga += a_step1; asm volatile("" : "+s"(ga));
-                if (st == cross_st) set_voffs_a(nlim_a);
-            }
+            if constexpr (HS == 1 && j == DO + DS * 7 + 1) { ga += a_step1; asm volatile("" : "+s"(ga)); } // odd: after the last A piece -- on to A(st + 3)
+            if constexpr (HS == 1 && j == DO + DS * 7 + 2) { if (st == cross_st) set_voffs_a(nlim_a); }
             if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
             if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }
             if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
@@ -1165,8 +1161,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if constexpr (j == DO + 3 * DS + 3) { // after the last A piece: on to half-stage 2 st + 5 (even) / the first one of stage st + 3 (odd: in the next tile if this one ends there)
                 if constexpr (HS == 0) ga += a_step0; else ga += a_step1;
                 asm volatile("" : "+s"(ga));
-                if constexpr (HS == 1) { if (st == cross_st) set_voffs_a(nlim_a); }
             }
+            if constexpr (HS == 1 && j == DO + 3 * DS + 4) { if (st == cross_st) set_voffs_a(nlim_a); } // (a slot of its own, no fragment op, no piece)
             if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
             if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
             if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
@@ -1176,10 +1172,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if constexpr (HS == 1 && j == 58) stage_end(2);
             if constexpr (HS == 1 && j == WG_NN_SYNC_SLOT + 1) stage_end(3);
             if constexpr (j == WG_NN_SYNC_SLOT) sync(std::integral_constant<int, WG_NN_KEEP>{});
-            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) {
-                gb += b_step; asm volatile("" : "+s"(gb));
-                if (st == cross_st) set_voffs_b(nlim_b);
-            }
+            if constexpr (j == WG_NN_SYNC_SLOT + 1 && HS == 0) { gb += b_step; asm volatile("" : "+s"(gb)); }
+            if constexpr (j == WG_NN_SYNC_SLOT + 2 && HS == 0) { if (st == cross_st) set_voffs_b(nlim_b); }
             __builtin_amdgcn_sched_barrier(0);
         });
     };
