@@ -689,7 +689,15 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const int mid_knob = ctx->tuning[WG_TUNE_F32_MID];
     // Mid-size means mid-size: from ~4 tiles of 256 x 128 per CU on, this file's kernel runs at 93-96 % of the matrix cores' rate and the small
     // tiles' extra barriers and fills only cost (8192^3: 7287 us here, 7980 on 64 x 64 tiles).
-    if (mid_knob != 0 && (mid_knob >= 1 || tiles * nmats <= 4ull * (uint64_t)cus) && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
+    // Short K on a large output (round 5, tools/f32_mid_sweep.py): this file's 256 x 128 tile pays its prologue and its 128 KiB store burst once per 128 .. 512 k, and the
+    // 128 x 64 tile (two to four workgroups per CU, covering each other) is ahead at any output size -- plan -> 128 x 64 | vendor, us: Gemm 4096^2 x 128 50.5 -> 40.3 | 44.1,
+    // x 256 78.7 -> 68.0 | 71.3, x 384 106.8 -> 99.6 | 98.9, x 512 135.2 -> 128.3 | 126.3 (x 768: 192 / 189, x 1024: 249 / 248: nothing left); 8192^2 x 128 167.5 -> 148.3 |
+    // 156.6, 6144^2 x 256 185.4 -> 155.3 | 156.6, 2048^2 x 128 x 8 matrices 95.6 -> 77.3 | 80.6, 1024^2 x 64 x 64 124.0 -> 97.6 | 107.8; GemmTr (whose plan is the better
+    // one at short K) 4096^2 x 128 43.3 -> 39.5, x 256 70.7 -> 67.6, x 384 100.3 -> 99.5, 6144^2 x 256 176.9 -> 155.7, 8192^2 x 256 278.0 -> 273.7, x 512 128.4 -> 130.2 (not taken).
+    const bool short_k = (K <= 256u || (!trans && K <= 512u)) && tiles * nmats >= (uint64_t)cus;
+    int sk_bm = 0, sk_bn = 0; // the better of 128 x 64 / 64 x 128 by the model below, when short_k
+    double sk_est = 1e30;
+    if (mid_knob != 0 && (mid_knob >= 1 || tiles * nmats <= 4ull * (uint64_t)cus || short_k) && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
         const bool pow2_ld = trans && m1.ld >= 1024u && (m1.ld & (m1.ld - 1u)) == 0;
         const bool pow2_ldb = m2.ld >= 8192u && (m2.ld & (m2.ld - 1u)) == 0; // rows of m2 a large power of two apart: the small tiles' row segments share few channels
         // { bm, bn, k-split family, loop cost in per cent (2 x 2-wave tiles; k-split tiles: on top of the curve below), tenths of a us per tile }
@@ -713,14 +721,18 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             if (c[2] && pow2_ldb) loop += 0.10; // 1024 x 1024 x 32768: 536 us on 64 x 32 tiles against 486 for this file's split-K plan
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
+            if (short_k && !c[2] && !(c[0] == 128 && c[1] == 128) && est < sk_est) { sk_est = est; sk_bm = c[0]; sk_bn = c[1]; }
+            if (mid_knob <= 1 && tiles * nmats > 4ull * (uint64_t)cus) continue; // (past mid-size the family is a candidate for short K only)
             if (est < mid_est) { mid_est = est; mid_bm = c[0]; mid_bn = c[1]; mid_ns = 1; }
         }
-        if (mid_knob <= 1) { // few tiles, long K: the 64 x 64 tile with K cut across workgroups (mid_split_plan above)
+        if (mid_knob <= 1 && tiles * nmats <= 4ull * (uint64_t)cus) { // few tiles, long K: the 64 x 64 tile with K cut across workgroups (mid_split_plan above)
             double est;
             const uint32_t ns = mid_split_plan(est);
             if (ns > 1 && est < mid_est) { mid_est = est; mid_bm = 64; mid_bn = 64; mid_ns = ns; }
         }
     }
+    if (sk_bm && mid_knob < 1 && ctx->tuning[WG_TUNE_F32_PANELS] != 1 && !other_forced)
+        return wgk_gemm_f32_mid(ctx, trans, sk_bm, sk_bn, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, 1u);
     // Small outputs (few 256 x 128 tiles): 64-column panels of the few-column kernel (gemm_f32_skinny.hip) give 128 x 64 "tiles", eight
     // times as many, each streaming its rows through a wave-private ring at ~1.4 us per 32 k (+ ~2.5 us of pipeline fill per workgroup):
     // 1024^3 25 + 5 us instead of 33 + 7.
