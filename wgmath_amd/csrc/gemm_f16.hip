@@ -1595,6 +1595,14 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             const double pair = trans ? 5.7 + 0.0298 * K : 6.1 + 0.0263 * K;
             t256x128 = fl * pair + (fr > 0.0 ? (fr <= 0.5 ? 0.6 : 1.0) * pair : 0.0) < 0.95 * t_big;
         }
+        // Fewer 256 x 256 tiles than CUs, but about one 256 x 128 tile per CU (70 .. 100 % of them): that tile ALONE on its CU is ahead of both other families from K = 512
+        // to 4096 (tools/f16_tile_sweep.py, profiles/r05_f16_tile_sweep.txt; 128 x 128 | 256 x 256 | 256 x 128, us): 4096 x 2048 x 2048 41.2 | 52.9 | 37.4, GemmTr 43.4 | 51.8 |
+        // 36.5; x 4096 73.1 | 74.3 | 66.2; 3584 x 2048 x 2048 38.5 | 49.0 | 35.6; 2560^2 x 1024 GemmTr 22.2 | 35.6 | 19.6; 2048^3 x 2 matrices 42.3 | 53.3 | 38.3. At K = 8192 the
+        // big tile is back in front (4096 x 2048 x 8192 140 | 119 | 130), at K = 512 the three are level.
+        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats < (uint64_t)cus && K >= 512u && K <= 4096u) {
+            const uint64_t tt = (uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats;
+            if (tt <= (uint64_t)cus && 10u * tt >= 7u * (uint64_t)cus) t256x128 = true;
+        }
         if ((krem == 0 || K - krem >= 64u) && !panels && t256x128) {
             GemmArgs t = g;
             t.tiles_m = (M + 255u) / 256u;
