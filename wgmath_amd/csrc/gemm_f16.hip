@@ -1582,7 +1582,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // (whether launch_tiles below would put the product on the continuous walk by its default rule: whole tiles and stages, more than one round)
         const bool cont_shape = !panels && krem == 0 && K >= 256u && K <= 4096u && tiles * nmats > (uint64_t)cus && g.beta == 0.f && // (K: the pairs are a short-K choice anyway)
                                 ctx->tuning[WG_TUNE_F16_CONT] != 0 && ctx->tuning[WG_TUNE_F16_SCHED] < 0 && ctx->tuning[WG_TUNE_F16_BALANCE] != 1;
-        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= (trans ? 768u : 1536u)) {
+        // (GemmTr's cap was 768 while the big kernel's side of the comparison was the per-tile launch; against the walk's model the pairs only win ragged tile counts, at any
+        // K up to here: 4608^2 x 1024, 324 tiles: walk + cut-up tail 66.6 us, pairs 51.5; profiles/r05_f16_tile_sweep.txt)
+        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats >= (uint64_t)cus && K <= 1536u) {
             double t_big = (double)((tiles * nmats + cus - 1) / cus) * (12.3 + 0.0213 * K);
             if (cont_shape) { // the continuous walk (launch_tiles below): 5 us + 5.7 + 0.0211 K per full round; a last partial round costs a whole one, or -- up to half a
                               // round of tiles, from 6 stages on -- the cut-up tail's two extra launches (8192^2 x 256 49.6 us, x 512 71.4, x 1024 114.5; 6144^2 x 512 67.2)
@@ -1592,7 +1594,7 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 t_big = 5.0 + (double)(all / (uint64_t)cus) * per + (r == 0 ? 0.0 : (2u * r <= (uint32_t)cus && K >= 384u && nmats == 1 ? 25.0 + 0.0107 * K : per));
             }
             const double r2 = (double)((uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats) / (2.0 * cus), fl = floor(r2), fr = r2 - fl;
-            const double pair = trans ? 5.7 + 0.0298 * K : 6.1 + 0.0263 * K;
+            const double pair = trans ? 5.7 + 0.027 * K : 6.1 + 0.0263 * K; // (GemmTr's slope re-fitted in round 5 on 6144^2 x 768 / 1024 / 1536 and 4608^2 x 1024: 0.0262 .. 0.0277)
             t256x128 = fl * pair + (fr > 0.0 ? (fr <= 0.5 ? 0.6 : 1.0) * pair : 0.0) < 0.95 * t_big;
         }
         // Fewer 256 x 256 tiles than CUs, but about one 256 x 128 tile per CU (70 .. 100 % of them): that tile ALONE on its CU is ahead of both other families from K = 512
