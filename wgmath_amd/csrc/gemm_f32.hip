@@ -694,11 +694,13 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // x 256 78.7 -> 68.0 | 71.3, x 384 106.8 -> 99.6 | 98.9, x 512 135.2 -> 128.3 | 126.3 (x 768: 192 / 189, x 1024: 249 / 248: nothing left); 8192^2 x 128 167.5 -> 148.3 |
     // 156.6, 6144^2 x 256 185.4 -> 155.3 | 156.6, 2048^2 x 128 x 8 matrices 95.6 -> 77.3 | 80.6, 1024^2 x 64 x 64 124.0 -> 97.6 | 107.8; GemmTr (whose plan is the better
     // one at short K) 4096^2 x 128 43.3 -> 39.5, x 256 70.7 -> 67.6, x 384 100.3 -> 99.5, 6144^2 x 256 176.9 -> 155.7, 8192^2 x 256 278.0 -> 273.7, x 512 128.4 -> 130.2 (not taken).
-    const bool short_k = (K <= 256u || (!trans && K <= 512u)) && tiles * nmats >= (uint64_t)cus;
+    const bool short_k = (K <= 256u || (!trans && K <= 512u)) && 2u * tiles * nmats >= (uint64_t)cus; // (from half a tile per CU on: 1536 x 5120 x 384, 240 tiles, 57.8 -> 51.0 | 50.9)
     int sk_bm = 0, sk_bn = 0; // the better of 128 x 64 / 64 x 128 by the model below, when short_k
     double sk_est = 1e30;
     if (mid_knob != 0 && (mid_knob >= 1 || tiles * nmats <= 4ull * (uint64_t)cus || short_k) && wgk_gemm_f32_mid_ok(M, N, K, nmats, m1, m2)) {
-        const bool pow2_ld = trans && m1.ld >= 1024u && (m1.ld & (m1.ld - 1u)) == 0;
+        // (round 5: not only powers of two -- any multiple of 1024 floats, e.g. K = 3072: 768 x 5120 x 3072 GemmTr 217 us on 64 x 64 tiles against 181-187 on the others --
+        // and Gemm with its rows a large power of two apart, whose k-steps then hit the same channels: 16384 x 256 x 3072, lda 16384, 216 us against 186-189)
+        const bool pow2_ld = trans ? (m1.ld >= 1024u && m1.ld % 1024u == 0) : (m1.ld >= 8192u && (m1.ld & (m1.ld - 1u)) == 0);
         const bool pow2_ldb = m2.ld >= 8192u && (m2.ld & (m2.ld - 1u)) == 0; // rows of m2 a large power of two apart: the small tiles' row segments share few channels
         // { bm, bn, k-split family, loop cost in per cent (2 x 2-wave tiles; k-split tiles: on top of the curve below), tenths of a us per tile }
         static const int cand[9][5] = { { 128, 64, 0, 12, 10 }, { 64, 128, 0, 20, 10 }, { 64, 64, 1, 0, 15 }, { 96, 96, 1, 3, 20 }, { 96, 64, 1, 3, 18 }, { 64, 96, 1, 3, 18 },
@@ -714,7 +716,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             // k-split tiles: one workgroup alone on a CU leaves its barriers uncovered (+16 %: 1024^3, 1536^3); co-resident ones cover each other
             // (+5 % at 4 rounds) until the small tiles' traffic shows (+9 % at 16 rounds, +13 % at 64: 2048^3 / 4096^3 / 8192^3 on 64 x 64)
             double loop = c[2] ? (r <= 1.0 ? 1.16 : 1.03 + 0.02 * log2(r)) + 0.01 * c[3] : 1.0 + 0.01 * c[3];
-            if (c[0] == 64 && c[1] == 64 && pow2_ld && r > 1.0) loop = 1.30;
+            if (c[0] == 64 && c[1] == 64 && pow2_ld && r > 2.0) loop = 1.30; // (three rounds and more: at two the tile is the best one -- 2048 x 1024 x 5120 GemmTr 146 us against 153-169, 8192 x 256 x 4096 122 against 124-137)
             // a 64 x 32 / 32 x 64 tile alone on its CU has 8 MFMAs per wave between two barriers: with a long K that shows (256 x 256 x 4096 x 8 matrices 44.7 us measured
             // against 38.5 by the curve above; 128 x 128 x 4096 x 32 matrices 62 -- there the K cut on 64 x 64 tiles is the better plan, 42)
             if (c[2] && r <= 1.0 && (c[0] == 32 || c[1] == 32) && K >= 2048u) loop += 0.25;
