@@ -1601,7 +1601,8 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         // to 4096 (tools/f16_tile_sweep.py, profiles/r05_f16_tile_sweep.txt; 128 x 128 | 256 x 256 | 256 x 128, us): 4096 x 2048 x 2048 41.2 | 52.9 | 37.4, GemmTr 43.4 | 51.8 |
         // 36.5; x 4096 73.1 | 74.3 | 66.2; 3584 x 2048 x 2048 38.5 | 49.0 | 35.6; 2560^2 x 1024 GemmTr 22.2 | 35.6 | 19.6; 2048^3 x 2 matrices 42.3 | 53.3 | 38.3. At K = 8192 the
         // big tile is back in front (4096 x 2048 x 8192 140 | 119 | 130), at K = 512 the three are level.
-        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && tiles * nmats < (uint64_t)cus && K >= 512u && K <= 4096u) {
+        // (one or two matrices: 1024^3 x 8, the same tile counts, is 5 % faster on the 128 x 128 kernel)
+        if (ctx->tuning[WG_TUNE_F16_TILE] == 0 && !panels && nmats <= 2u && tiles * nmats < (uint64_t)cus && K >= 512u && K <= 4096u) {
             const uint64_t tt = (uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats;
             if (tt <= (uint64_t)cus && 10u * tt >= 7u * (uint64_t)cus) t256x128 = true;
         }
@@ -1640,7 +1641,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 const double est128 = (w128 <= 1.0 ? k128 * 0.00875 : w128 * k128 * 0.0108) + 6.0 + slabs(ns);
                 const uint32_t ns256 = wg_splitk_plan(tiles * nmats, (uint32_t)cus, K / BKH, 8, (uint64_t)M * N * nmats, 512ull << 20);
                 const double k256 = (double)(((K / BKH + ns256 - 1) / ns256) * BKH);
-                const double est256 = (double)((tiles * nmats * ns256 + cus - 1) / cus) * (k256 * 0.0234 + 8.0) + slabs(ns256);
+                // (x 0.8, round 5: the 0.0234 us per k is the whole chip's, power-capped; fewer than 256 workgroups clock higher -- 1280 x 7168 x 5120, 140 tiles: 128 us by the
+                // formula, 90 measured, and the 128 x 128 kernel it sent the product to takes 123; 4096 x 2048 x 2048 / 4096 / 8192 with two splits: 68 / 92 / 140 against 53 / 74 / 119)
+                const double est256 = 0.8 * ((double)((tiles * nmats * ns256 + cus - 1) / cus) * (k256 * 0.0234 + 8.0) + slabs(ns256));
                 want128 = est128 < est256;
             }
             if (want128 && tiles128 <= 0x7fffffffull) {
