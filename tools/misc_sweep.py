@@ -68,7 +68,10 @@ for dt, td in ((np.float16, torch.float16), (np.float32, torch.float32)):
 
 gemv = wg.Gemv.from_device(dev)
 for dt, td in ((np.float32, torch.float32), (np.float16, torch.float16)):
-    for (R, C, nrhs) in [(4096, 4096, 2), (4096, 4096, 4), (4096, 4096, 8), (4096, 65536, 8), (65536, 4096, 8), (4096, 11008, 4), (11008, 4096, 4), (8192, 8192, 3)]:
+    GEMV_SHAPES = [(4096, 4096, 2), (4096, 4096, 4), (4096, 4096, 8), (4096, 65536, 8), (65536, 4096, 8), (4096, 11008, 4), (11008, 4096, 4), (8192, 8192, 3)]
+    if os.environ.get("MISC_GEMV_SHAPES"):  # "RxCxNRHS ..." instead (e.g. single-vector shapes: 4096x4096x1)
+        GEMV_SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ["MISC_GEMV_SHAPES"].split()]
+    for (R, C, nrhs) in GEMV_SHAPES:
         for tr in (False, True):
             m = device_random(wg, gpu, (R, C), dt, 1)
             nin, nout = (R, C) if tr else (C, R)

@@ -286,7 +286,7 @@ __device__ __forceinline__ RowPiece<E, T> piece_cached(const T *p) {
     }
     return o;
 }
-template <typename T, int E>
+template <typename T, int E, int U = WG_GEMVT_U>
 __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
     const uint32_t col = blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
     const uint32_t p = threadIdx.x & 31u;
@@ -296,7 +296,8 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
     const uint32_t r_end = min(a.k, r_begin + a.k_per_split);
     const T *mp = a.m + z * a.m_batch + (uint64_t)col * a.ldm;
     const T *vp = a.v + z * a.v_batch;
-    constexpr int U = WG_GEMVT_U;
+    // U loads in flight per lane per trip. Columns of at most 4 chunks take the U = 4 instantiation (the launcher): half the registers, twice the half-waves per CU -- what
+    // a short column lacks in loads per half-wave it gets back in half-waves (f16 GemvTr 1024 x 65536: 55 us in the tail loop, 40 us as a partial trip of U = 8, see the bench line)
     constexpr uint32_t kChunk = 32u * E;   // rows a half-wave covers per load
     constexpr uint32_t kBlock = kChunk * U; // ... per trip
     float acc[E];
@@ -319,8 +320,27 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = fmaf(mv[u].f[e], xv[u].f[e], acc[e]);
     }
-    // what is left of the range (< one trip): 4 rows per lane, 128 per half-wave (k % 4 == 0: a lane's 4 rows are all in or all out)
-    for (uint32_t r = r_begin + nblocks * kBlock + 4u * p; r < r_end; r += 128u) {
+    // what is left of the range (< one trip): its whole chunks as ONE partial trip, all of its loads in flight together (round 5: columns shorter than a trip -- f16 with up to
+    // 2047 rows, 8 rows per lane -- ran entirely in the one-load-at-a-time loop below: f16 GemvTr 1024 x 65536 55 us = 2.4 TB/s, the f32 one of the same shape 7.2 TB/s)
+    const uint32_t rem_chunks = ((r_end - r_begin) - nblocks * kBlock) / kChunk; // < U, wave-uniform
+    if (rem_chunks) {
+        const uint32_t r = r_begin + nblocks * kBlock + E * p;
+        RowPiece<E, T> mv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if ((uint32_t)u < rem_chunks) mv[u] = piece_stream<E, T>(mp + r + kChunk * u);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if ((uint32_t)u < rem_chunks) xv[u] = piece_cached<E, T>(vp + r + kChunk * u);
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u)
+            if ((uint32_t)u < rem_chunks) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = fmaf(mv[u].f[e], xv[u].f[e], acc[e]);
+            }
+    }
+    // ... and the rows behind them (< one chunk): 4 rows per lane, 128 per half-wave (k % 4 == 0: a lane's 4 rows are all in or all out)
+    for (uint32_t r = r_begin + nblocks * kBlock + rem_chunks * kChunk + 4u * p; r < r_end; r += 128u) {
         const float4 mv = load4s(mp + r), xv = load4(vp + r);
         acc[0] = fmaf(mv.x, xv.x, acc[0]);
         acc[1] = fmaf(mv.y, xv.y, acc[1]);
@@ -621,6 +641,13 @@ inline uint32_t ceil_div(uint32_t a, uint32_t b) { return a / b + (a % b != 0); 
 // 4-columns-per-wave kernel (tools/gemvtr_sweep.py, profiles/r03_evidence.md section 10): f32 -1...-40 % time (4096^2 16.5 -> 10 us, 65536 x 4096
 // 169 -> 162), f16 -5...-45 % (65536 x 4096 95 -> 83 us = 6.5 TB/s) -- except f32 columns exactly 64 KiB apart with k <= 16384 (16384 x 2048 ...
 // x 16384: +5...+13 %; 15360 and 17408 rows are fine, f16 and longer columns at that stride are fine), which stay on the old kernel.
+// gemv_t_cols_kernel with 4 instead of 8 loads in flight per lane (half the registers, twice the half-waves per CU): columns of at most 8 chunks (a chunk: 32 lanes x 16 bytes),
+// and up to 31 chunks when the 8-deep form would end in a partial trip. Measured (tools/gemvtr_sweep.py, f16, us): 1024 x 65536 55 -> 20 (vendor 22), 1280 x 32768 25.4 -> 13.8,
+// 3072 x 65536 74.2 -> 57.0; whole trips of 8 stay (4096 x 65536 f16 75.0 against 79.0, 2048 x 65536 f32 76.5 against 79.5).
+static bool t_cols_u4(uint32_t k_per_split, uint32_t e) {
+    const uint32_t chunks = k_per_split / (32u * e);
+    return chunks <= 8u || (chunks < 32u && chunks % 8u != 0);
+}
 template <typename T>
 static bool uses_t_cols(bool trans, uint32_t nrhs, uint32_t k, uint32_t ldm) {
     if (!WG_GEMVT_COLS || !trans || nrhs != 1) return false;
@@ -714,9 +741,12 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
         if constexpr (sizeof(T) == 2)
             wide = (uintptr_t)a.m % 16 == 0 && (uintptr_t)a.v % 16 == 0 && a.ldm % 8 == 0 && a.k_per_split % 8 == 0 && (nmats == 1 || (a.m_batch % 8 == 0 && a.v_batch % 8 == 0));
         if constexpr (sizeof(T) == 2) {
-            if (wide) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8>), grid, block, 0, ctx->stream, a);
+            if (wide && t_cols_u4(a.k_per_split, 8u)) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8, 4>), grid, block, 0, ctx->stream, a);
+            else if (wide) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8>), grid, block, 0, ctx->stream, a);
+            else if (t_cols_u4(a.k_per_split, 4u)) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4, 4>), grid, block, 0, ctx->stream, a);
             else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4>), grid, block, 0, ctx->stream, a);
-        } else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4>), grid, block, 0, ctx->stream, a);
+        } else if (t_cols_u4(a.k_per_split, 4u)) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4, 4>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4>), grid, block, 0, ctx->stream, a);
     }
     else if (trans) {
         if (tile == 1) hipLaunchKernelGGL((gemv_t_kernel<1, T>), grid, block, 0, ctx->stream, a);
