@@ -1643,9 +1643,11 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                 const double k256 = (double)(((K / BKH + ns256 - 1) / ns256) * BKH);
                 // (x 0.8, round 5: the 0.0234 us per k is the whole chip's, power-capped; fewer than 256 workgroups clock higher -- 1280 x 7168 x 5120, 140 tiles: 128 us by the
                 // formula, 90 measured, and the 128 x 128 kernel it sent the product to takes 123; 4096 x 2048 x 2048 / 4096 / 8192 with two splits: 68 / 92 / 140 against 53 / 74 / 119)
-                // (unsplit only: with K cut across the chip's idle CUs the formula is, if anything, optimistic -- 256 x 256 x 8192: 25 us by it, 28 measured, and x 0.8 sent that
+                // (lightly split plans only: with K cut many ways across the chip's idle CUs the formula is, if anything, optimistic -- 256 x 256 x 8192: 25 us by it, 28 measured, and x 0.8 sent that
                 // product and 384 x 1408 x 2816 / 1024 x 1408 x 6144 to this kernel at 1.2-1.7 x the 128 x 128 kernel's time for an hour of the round)
-                const double est256 = (ns256 == 1 ? 0.8 : 1.0) * ((double)((tiles * nmats * ns256 + cus - 1) / cus) * (k256 * 0.0234 + 8.0) + slabs(ns256));
+                // (... up to four splits, where the measured / formula ratio is 0.73-0.83: 4096 x 2048 x 2048 .. 8192 with two, 512 x 1408 x 6144 x 8 matrices with two -- 107 by the
+                // formula, 88 measured, and the 128 x 128 kernel it went to without the factor takes 124 --, 2048^3 with four; from eight splits on it is 1.1-1.2)
+                const double est256 = (ns256 <= 4u ? 0.8 : 1.0) * ((double)((tiles * nmats * ns256 + cus - 1) / cus) * (k256 * 0.0234 + 8.0) + slabs(ns256));
                 want128 = est128 < est256;
             }
             if (want128 && tiles128 <= 0x7fffffffull) {
