@@ -322,6 +322,9 @@ GEMV_SHAPES = [
     (2048, 6004, 2, 1), (1024, 4096, 2, 2),
     # 2 .. 8 right-hand sides on more shapes (round 5): few outputs with a long contraction, a ragged column count with a batch, k off every tile size
     (65536, 128, 3, 1), (8192, 1028, 5, 2), (4100, 2048, 4, 1), (16384, 512, 8, 1), (6000, 3000, 2, 1),
+    # GemvTr, two right-hand sides on the half-wave-per-column kernel's 2-vector form (round 5: contractions of 2049 .. 8192 rows onto 4096 .. 16384 outputs): whole trips, a
+    # partial trip + ragged rows, a batch
+    (4096, 4100, 2, 1), (3000, 8192, 2, 2), (8192, 4096, 2, 1),
 ]
 # gemv_t_lds_kernel forced (WG_TUNE_GEMVT_LDS = 8 outputs per CU) onto shapes the launcher keeps on other kernels: every workgroup shape (8 / 16 / 32 / 64 / 128
 # columns per trip: gemv_t_lds_plan), vectors longer than the LDS in 2 - 4 chunks (8 right-hand sides x 8192 rows = 256 KiB; a ragged last chunk; a batch), a
@@ -1567,7 +1570,9 @@ def test_gemv_reduce_fused_single_launch(gpu, R, Cn):
                                            # one right-hand side: 16-byte loads where aligned (k % 8, batches), 8-byte loads otherwise, splits
                                            (12, 12, 1, 3), (1028, 36, 1, 2), (40004, 68, 1, 1), (300000, 8, 1, 1), (16392, 20, 1, 1), (2056, 4100, 1, 1),
                                            # 3 .. 8 right-hand sides past the launch-bound sizes: the f16 Gemm kernels
-                                           (8192, 4096, 3, 1), (4096, 2112, 8, 1), (4104, 6152, 5, 1)])
+                                           (8192, 4096, 3, 1), (4096, 2112, 8, 1), (4104, 6152, 5, 1),
+                                           # GemvTr with two right-hand sides from 2048 outputs on: the column kernel's 2-vector form (16-byte and 8-byte loads, ragged rows, a batch)
+                                           (4096, 4096, 2, 1), (2056, 4100, 2, 1), (1000, 2048, 2, 2), (12292, 2052, 2, 1)])
 def test_gemv_f16(gpu, tr, R, Cn, nrhs, mats):
     wg = _wg()
     rng = np.random.default_rng(R + Cn + nrhs + tr)

@@ -286,7 +286,7 @@ __device__ __forceinline__ RowPiece<E, T> piece_cached(const T *p) {
     }
     return o;
 }
-template <typename T, int E, int U = WG_GEMVT_U>
+template <typename T, int E, int U = WG_GEMVT_U, int NRHS = 1>
 __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
     const uint32_t col = blockIdx.x * (kThreads / 32) + (threadIdx.x >> 5);
     const uint32_t p = threadIdx.x & 31u;
@@ -300,9 +300,12 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
     // a short column lacks in loads per half-wave it gets back in half-waves (f16 GemvTr 1024 x 65536: 55 us in the tail loop, 40 us as a partial trip of U = 8, see the bench line)
     constexpr uint32_t kChunk = 32u * E;   // rows a half-wave covers per load
     constexpr uint32_t kBlock = kChunk * U; // ... per trip
-    float acc[E];
+    // NRHS right-hand sides (1, or 2: round 5): every piece of the matrix is multiplied with the same rows of each vector (columns of v, ldv apart; results ld_dst apart)
+    float acc[NRHS][E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int y = 0; y < NRHS; ++y)
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[y][e] = 0.f;
     const uint32_t nblocks = (r_end - r_begin) / kBlock;
     uint32_t rot = 0;
     if constexpr (WG_GEMVT_ROT) rot = nblocks ? (col * 5u) % nblocks : 0u;
@@ -310,51 +313,66 @@ __global__ __launch_bounds__(kThreads) void gemv_t_cols_kernel(GemvArgsT<T> a) {
         uint32_t j = i + rot;
         if (j >= nblocks) j -= nblocks;
         const uint32_t r = r_begin + j * kBlock + E * p;
-        RowPiece<E, T> mv[U], xv[U];
+        RowPiece<E, T> mv[U], xv[NRHS][U];
 #pragma unroll
         for (int u = 0; u < U; ++u) mv[u] = piece_stream<E, T>(mp + r + kChunk * u);
 #pragma unroll
-        for (int u = 0; u < U; ++u) xv[u] = piece_cached<E, T>(vp + r + kChunk * u);
+        for (int y = 0; y < NRHS; ++y)
+#pragma unroll
+            for (int u = 0; u < U; ++u) xv[y][u] = piece_cached<E, T>(vp + (uint64_t)y * a.ldv + r + kChunk * u);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] = fmaf(mv[u].f[e], xv[u].f[e], acc[e]);
+            for (int y = 0; y < NRHS; ++y)
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[y][e] = fmaf(mv[u].f[e], xv[y][u].f[e], acc[y][e]);
     }
     // what is left of the range (< one trip): its whole chunks as ONE partial trip, all of its loads in flight together (round 5: columns shorter than a trip -- f16 with up to
     // 2047 rows, 8 rows per lane -- ran entirely in the one-load-at-a-time loop below: f16 GemvTr 1024 x 65536 55 us = 2.4 TB/s, the f32 one of the same shape 7.2 TB/s)
     const uint32_t rem_chunks = ((r_end - r_begin) - nblocks * kBlock) / kChunk; // < U, wave-uniform
     if (rem_chunks) {
         const uint32_t r = r_begin + nblocks * kBlock + E * p;
-        RowPiece<E, T> mv[U], xv[U];
+        RowPiece<E, T> mv[U], xv[NRHS][U];
 #pragma unroll
         for (int u = 0; u < U - 1; ++u)
             if ((uint32_t)u < rem_chunks) mv[u] = piece_stream<E, T>(mp + r + kChunk * u);
 #pragma unroll
-        for (int u = 0; u < U - 1; ++u)
-            if ((uint32_t)u < rem_chunks) xv[u] = piece_cached<E, T>(vp + r + kChunk * u);
+        for (int y = 0; y < NRHS; ++y)
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u)
+                if ((uint32_t)u < rem_chunks) xv[y][u] = piece_cached<E, T>(vp + (uint64_t)y * a.ldv + r + kChunk * u);
 #pragma unroll
         for (int u = 0; u < U - 1; ++u)
             if ((uint32_t)u < rem_chunks) {
 #pragma unroll
-                for (int e = 0; e < E; ++e) acc[e] = fmaf(mv[u].f[e], xv[u].f[e], acc[e]);
+                for (int y = 0; y < NRHS; ++y)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[y][e] = fmaf(mv[u].f[e], xv[y][u].f[e], acc[y][e]);
             }
     }
     // ... and the rows behind them (< one chunk): 4 rows per lane, 128 per half-wave (k % 4 == 0: a lane's 4 rows are all in or all out)
     for (uint32_t r = r_begin + nblocks * kBlock + rem_chunks * kChunk + 4u * p; r < r_end; r += 128u) {
-        const float4 mv = load4s(mp + r), xv = load4(vp + r);
-        acc[0] = fmaf(mv.x, xv.x, acc[0]);
-        acc[1] = fmaf(mv.y, xv.y, acc[1]);
-        acc[2] = fmaf(mv.z, xv.z, acc[2]);
-        acc[3] = fmaf(mv.w, xv.w, acc[3]);
-    }
-    float s;
-    if constexpr (E == 4) s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    else s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        const float4 mv = load4s(mp + r);
 #pragma unroll
-    for (int sh = 16; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh, 64);
-    if (p == 0) {
-        const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + col;
-        if (a.part) a.part[off] = s; else a.out[off] = (T)s;
+        for (int y = 0; y < NRHS; ++y) {
+            const float4 xv = load4(vp + (uint64_t)y * a.ldv + r);
+            acc[y][0] = fmaf(mv.x, xv.x, acc[y][0]);
+            acc[y][1] = fmaf(mv.y, xv.y, acc[y][1]);
+            acc[y][2] = fmaf(mv.z, xv.z, acc[y][2]);
+            acc[y][3] = fmaf(mv.w, xv.w, acc[y][3]);
+        }
+    }
+#pragma unroll
+    for (int y = 0; y < NRHS; ++y) {
+        float s;
+        if constexpr (E == 4) s = (acc[y][0] + acc[y][1]) + (acc[y][2] + acc[y][3]);
+        else s = ((acc[y][0] + acc[y][1]) + (acc[y][2] + acc[y][3])) + ((acc[y][4] + acc[y][5]) + (acc[y][6] + acc[y][7]));
+#pragma unroll
+        for (int sh = 16; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh, 64);
+        if (p == 0) {
+            const uint64_t off = z * a.dst_batch + blockIdx.y * a.dst_split + (uint64_t)y * a.ld_dst + col;
+            if (a.part) a.part[off] = s; else a.out[off] = (T)s;
+        }
     }
 }
 
@@ -648,6 +666,21 @@ static bool t_cols_u4(uint32_t k_per_split, uint32_t e) {
     const uint32_t chunks = k_per_split / (32u * e);
     return chunks <= 8u || (chunks < 32u && chunks % 8u != 0);
 }
+// GemvTr with TWO right-hand sides on the half-wave-per-column kernel's 2-vector form (gemv_t_cols_kernel<.., 4, 2>, round 5): every piece of the matrix meets the same rows
+// of both vectors, no LDS, no barrier. Measured against what took these shapes before (tools/misc_sweep.py with MISC_GEMV_SHAPES, us, before -> after | vendor) -- f16 (the
+// 4-columns-per-wave kernel): 4096^2 14.0 -> 7.7 | 18, 4096 x 11008 24.0 -> 18.5 | 18.5, 11008 x 4096 23.4 -> 18.1 | 19, 8192^2 36.3 -> 25.0 | 22-27, 65536 x 4096 111 -> 88 | 108,
+// 16384^2 104 -> 91 | 98, but few outputs lose (32768 x 1536 28.8 -> 38.7): from 2048 outputs on. f32 (the vectors-in-LDS kernel): only where that kernel's one barrier per chunk
+// shows -- 4096 x 11008 41.8 -> 33.3 | 30, 4096^2 12.8 -> 12.0 -- and worse elsewhere (16384^2 163 -> 188, 11008 x 4096 32.3 -> 34.7): contractions of 2049 .. 8192 rows onto
+// 4096 .. 16384 outputs.
+#ifndef WG_GEMVT_COLS2
+#define WG_GEMVT_COLS2 1
+#endif
+template <typename T>
+static bool uses_t_cols2(bool trans, uint32_t nrhs, uint32_t rows_out, uint32_t k) {
+    if (!WG_GEMVT_COLS2 || !trans || nrhs != 2u) return false;
+    if (sizeof(T) == 2) return rows_out >= 2048u;
+    return k > 2048u && k <= 8192u && rows_out >= 4096u && rows_out <= 16384u;
+}
 template <typename T>
 static bool uses_t_cols(bool trans, uint32_t nrhs, uint32_t k, uint32_t ldm) {
     if (!WG_GEMVT_COLS || !trans || nrhs != 1) return false;
@@ -656,7 +689,7 @@ static bool uses_t_cols(bool trans, uint32_t nrhs, uint32_t k, uint32_t ldm) {
 }
 template <typename T>
 static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t gz, uint32_t ldm) {
-    const bool cols = uses_t_cols<T>(trans, nrhs, k, ldm);
+    const bool cols = uses_t_cols<T>(trans, nrhs, k, ldm) || uses_t_cols2<T>(trans, nrhs, rows_out, k);
     const uint32_t gx = cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     const uint32_t min_k_per_split = trans ? 2048u : 64u; // T: >= 8 row-steps per lane; N: >= 16 columns per wave
     const uint64_t blocks_xy = (uint64_t)gx * gz;
@@ -693,7 +726,7 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
     if (gz64 > 65535) return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: nmats * ceil(nrhs/8) = %llu exceeds 65535", (unsigned long long)gz64);
     const uint32_t gz = (uint32_t)gz64;
 
-    const bool t_cols = uses_t_cols<T>(trans, nrhs, k, m.ld);
+    const bool t_cols = uses_t_cols<T>(trans, nrhs, k, m.ld) || uses_t_cols2<T>(trans, nrhs, rows_out, k);
     const uint32_t gx = t_cols ? ceil_div(rows_out, 8u) : trans ? ceil_div(rows_out, 4u * kWaves) : ceil_div(rows_out, 256u);
     uint32_t nsplit = plan_nsplit<T>(cus, trans, rows_out, k, nrhs, gz, m.ld);
     uint32_t k_per_split = k == 0 ? 4u : ceil_div(ceil_div(k, nsplit), 4u) * 4u; // vec4 granularity
@@ -739,8 +772,14 @@ static int gemv_launch(wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, u
         // f16: 16-byte loads (8 rows per lane) where every column, split and batch keeps them aligned; 8-byte loads (the view contract) otherwise
         bool wide = false;
         if constexpr (sizeof(T) == 2)
-            wide = (uintptr_t)a.m % 16 == 0 && (uintptr_t)a.v % 16 == 0 && a.ldm % 8 == 0 && a.k_per_split % 8 == 0 && (nmats == 1 || (a.m_batch % 8 == 0 && a.v_batch % 8 == 0));
-        if constexpr (sizeof(T) == 2) {
+            wide = (uintptr_t)a.m % 16 == 0 && (uintptr_t)a.v % 16 == 0 && a.ldm % 8 == 0 && a.k_per_split % 8 == 0 && (nmats == 1 || (a.m_batch % 8 == 0 && a.v_batch % 8 == 0)) &&
+                   (nrhs == 1 || a.ldv % 8 == 0);
+        if (nrhs == 2) { // (uses_t_cols2)
+            if constexpr (sizeof(T) == 2) {
+                if (wide) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8, 4, 2>), grid, block, 0, ctx->stream, a);
+                else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4, 4, 2>), grid, block, 0, ctx->stream, a);
+            } else hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4, 4, 2>), grid, block, 0, ctx->stream, a);
+        } else if constexpr (sizeof(T) == 2) {
             if (wide && t_cols_u4(a.k_per_split, 8u)) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8, 4>), grid, block, 0, ctx->stream, a);
             else if (wide) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 8>), grid, block, 0, ctx->stream, a);
             else if (t_cols_u4(a.k_per_split, 4u)) hipLaunchKernelGGL((gemv_t_cols_kernel<T, 4, 4>), grid, block, 0, ctx->stream, a);
@@ -865,6 +904,7 @@ static int gemv_t_lds_launch(wg_ctx *ctx, uint32_t rows_out, uint32_t k, uint32_
 //     each half-wave's whole life is a few dependent round trips behind the staging of the vectors.
 static bool uses_t_lds(const wg_ctx *ctx, bool trans, uint32_t rows_out, uint32_t k, uint32_t nrhs, uint32_t nmats, uint32_t es) {
     if (!WG_GEMVT_LDS || !trans || es != 4u || nrhs < 2u || nrhs > 8u || nmats > 65535u) return false;
+    if (!ctx->tuning[WG_TUNE_GEMVT_LDS] && uses_t_cols2<float>(trans, nrhs, rows_out, k)) return false; // (two right-hand sides on the column kernel's 2-vector form)
     const uint32_t forced = (uint32_t)ctx->tuning[WG_TUNE_GEMVT_LDS], min_cols = forced ? forced : 128u; // (forced: tests, experiments -- wg_ctx_set_tuning)
     const uint32_t cus = (uint32_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const uint32_t tile = nrhs > 4u ? 8u : (nrhs > 2u ? 4u : 2u);
