@@ -699,7 +699,9 @@ static uint32_t plan_nsplit(int cus, bool trans, uint32_t rows_out, uint32_t k, 
     // costs 18 us with the combine pass against 10 us unsplit.
     // N: matrices of 256 MiB and more stream best with 2 workgroups per CU and four times the columns per workgroup (4096 x 32768 f32: 103 -> 83 us,
     // 16384^2: 167 -> 158, 4096 x 65536: 165.9 -> 162.5; f16 alike), smaller ones with 4 (tools/gemvtr_sweep.py with SWEEP_N=1, r03 evidence section 10)
-    const bool big_n = !trans && (uint64_t)rows_out * k * sizeof(T) >= (256ull << 20);
+    // (round 5: tall matrices from 128 MiB on as well -- 32768 x 1536 f32 39.3 -> 35.9 us, 16384 x 2048 30.4 -> 27.4; not the squarer ones: 8192 x 4096 23.1 -> 27.4, 11008 x 4096 31.2 -> 33.4)
+    const uint64_t n_bytes = (uint64_t)rows_out * k * sizeof(T);
+    const bool big_n = !trans && (n_bytes >= (256ull << 20) || (sizeof(T) == 4 && n_bytes >= (128ull << 20) && rows_out >= 16384u));
     const uint32_t per_cu = cols ? 2u : trans ? 4u : big_n ? 2u : 4u; // (the half-wave-per-column kernel: 2 / 4 / 8 per CU measured the same within 2 %; fewer splits, smaller combine)
     uint32_t want = blocks_xy >= (uint64_t)cus * per_cu ? 1u : ceil_div((uint32_t)cus * per_cu, (uint32_t)blocks_xy);
     if (!trans && blocks_xy >= (uint64_t)cus && k <= 1024u) want = 1u;
