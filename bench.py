@@ -43,6 +43,70 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# The driver keeps and parses the LAST stdout line; round 5's 25 KB line (27 workloads' full objects under "others") came back unparsed.
+# The line is therefore compact -- the contract's keys, `config` with the flat C1-C5 scalars, `roofline`, `cpu_baseline`, `checks`, `targets` --
+# and everything bulky ("others", the per-rank arrays of "ranks_detail" when they are long) goes to a sidecar file (--detail) and to stderr.
+MAX_LINE_BYTES = 8192
+DEFAULT_DETAIL = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def finite(o):
+    """`o` with every non-finite float replaced by None: the line and the sidecar are STRICT JSON (json.dumps(..., allow_nan=False))."""
+    if isinstance(o, dict):
+        return {str(k): finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [finite(v) for v in o]
+    if isinstance(o, (float, np.floating)):
+        return float(o) if np.isfinite(o) else None
+    if isinstance(o, np.integer):
+        return int(o)
+    if isinstance(o, np.bool_):
+        return bool(o)
+    return o
+
+
+def compact_line(full: dict) -> dict:
+    """The stdout line out of the full record: without "others"; "ranks_detail" only while it is short; and, should the rest still exceed
+    MAX_LINE_BYTES (it is ~4.5 KB at N = 1), without `config`'s copies of the scalars that `targets` carries anyway."""
+    line = {k: v for k, v in full.items() if k != "others"}
+    if line.get("ranks_detail") is not None and len(json.dumps(finite(line["ranks_detail"]), allow_nan=False)) > 1536:
+        line["ranks_detail"] = None
+    size = lambda: len(json.dumps(finite(line), allow_nan=False))  # noqa: E731
+    if size() > MAX_LINE_BYTES:
+        line["ranks_detail"] = None
+    if size() > MAX_LINE_BYTES and isinstance(line.get("targets"), dict):
+        line["config"] = {k: v for k, v in line["config"].items() if k not in line["targets"]}
+    if size() > MAX_LINE_BYTES:
+        for k in ("data", "checks"):
+            line[k] = None if k == "checks" else str(line[k])[:60]
+    return line
+
+
+def emit(full: dict, detail_path, to_stdout) -> str:
+    """Writes the full record (strict JSON) to `detail_path` (None/"-" = no file) and to stderr, then hands the compact line to `to_stdout`.
+    Returns the compact line's text."""
+    full = finite(full)
+    line = compact_line(full)
+    if detail_path and detail_path != "-":
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+            with open(detail_path, "w") as f:
+                f.write(json.dumps(full, allow_nan=False) + "\n")
+            line["detail"] = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+        except OSError as e:  # a read-only tree must not take the line down
+            log(f"[bench] could not write the detail sidecar {detail_path}: {e}")
+            line["detail"] = None
+    else:
+        line["detail"] = None
+    if "targets" in line:
+        line["targets"] = line.pop("targets")  # stays the LAST key (the driver's `tail` keeps the last 2000 characters of stdout)
+    log("[bench detail] " + json.dumps(full, allow_nan=False))
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) <= MAX_LINE_BYTES, f"bench line is {len(text)} bytes (> {MAX_LINE_BYTES}): move more of it to the sidecar"
+    to_stdout(text)
+    return text
+
+
 def usable_cpus() -> int:
     """Host threads this process can actually run at once: the scheduler affinity mask, capped by the cgroup's CPU quota (a container on a
     256-thread host with a quota of 8 CPUs runs 8 threads' worth however many it starts -- 256 OpenMP threads there spend their time in
@@ -633,7 +697,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_8192x8192x1024", "gemmtr_f16_8192x8192x1024", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_8192x8192x1024", "gemmtr_f16_8192x8192x1024", "gemmtr_f16_32768", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
@@ -989,7 +1053,7 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
         extra = {} if report is None else dict(report, gather_engine=chosen)
         detail, flat = ranks_detail(per_rank, pl.npanels)
         extra.update(flat)
-        print(json.dumps({"metric": "dry_run_gemm_tflops", "value": round(2.0 * M * N * K * args.steps / elapsed / 1e12, 9), "unit": "TFLOP/s",
+        emit({"metric": "dry_run_gemm_tflops", "value": round(2.0 * M * N * K * args.steps / elapsed / 1e12, 9), "unit": "TFLOP/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
                           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                           "data": "dry-run: host arithmetic over gloo, no GPU (launcher plumbing test)",
@@ -997,7 +1061,7 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
                                      "parallelism": f"m-shard x{world} + gloo all-gather (dry run)",
                                      "all_gather_bytes_per_step": (world - 1) * pl.Mg * N * 4,
                                      "comm_compute_units": ENGINE_COMM_CUS.get(chosen or args.gather, 0), "rccl_reported_ranks": 0, **extra},
-                          "ranks_detail": detail}), flush=True)
+                          "ranks_detail": detail}, args.detail, lambda text: print(text, flush=True))
     dist.destroy_process_group()
 
 
@@ -1059,7 +1123,7 @@ def main():
                     help="operand distribution of the run: pm1 = U[-1,1) (default, the headline), u01 = U[0,1) (the reference's new_random); the *_u01 "
                          "secondary workloads always use u01")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs reported under `others`")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra single-GPU configs (reported under `others` in the --detail sidecar, as scalars under `targets` in the line)")
     ap.add_argument("--skip", default="", help="comma-separated secondary workloads to skip (e.g. under rocprofv3)")
     ap.add_argument("--secondary-seconds", type=float, default=0.6, help="minimum timed duration of each secondary config")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the cpu_baseline sample")
@@ -1067,6 +1131,9 @@ def main():
                     help="exchange engine of the M-sharded Gemm with N > 1 ranks: RCCL all-gather (+ relayout) with 8 or 4 CUs left to its kernels, "
                          "staged contiguous peer copies (+ relayout), or auto = a short trial of each as a fresh child group, the timed steps on the fastest")
     ap.add_argument("--dry-run", action="store_true", help="multi-rank plumbing test without a GPU (gloo, host arithmetic)")
+    ap.add_argument("--detail", default=os.environ.get("WG_BENCH_DETAIL", DEFAULT_DETAIL),
+                    help="sidecar file for the full record (the stdout line + `others`: every secondary workload's roofline / cpu_baseline objects, and "
+                         "`ranks_detail`); '-' = none. The same text goes to stderr as `[bench detail] {...}`")
     args = ap.parse_args()
     VALUES = args.dist
     os.environ["WG_BENCH_VALUES"] = args.dist  # (self-launched ranks inherit it)
@@ -1377,6 +1444,7 @@ def main():
 
         head = {"workload": w_name, "value": value, "roofline": roof}
         put("c5_gemm_f16_32768", head if w_name == "gemm_f16_32768" else by.get("gemm_f16_32768"), "tflops")
+        put("c5_gemmtr_f16_32768", head if w_name == "gemmtr_f16_32768" else by.get("gemmtr_f16_32768"), "tflops")  # (K-contiguous A: what a rank's shard can be handed as)
         put("c3_gemm_f16_8192", head if w_name == "gemm_f16_8192" else by.get("gemm_f16_8192"), "tflops")
         put("c3_gemmtr_f16_8192", by.get("gemmtr_f16_8192"), "tflops")
         # the reference's own distribution, U[0, 1) (gemm.rs:152), beside the U[-1, 1) headline figures
@@ -1414,7 +1482,7 @@ def main():
         checks = {f"parity_max_ulp_vs_f64_{k}": round(max(v), 2) for k, v in ulps.items() if v and None not in v}
         targets.update(checks)
         checks["parity_ulp_unit"] = "f32: ulps of sum|a||b| (U[-1,1) operands cancel); f16: ulps of the result (one RNE rounding of an f32 accumulation)"
-        cfg_extra.update({k: v for k, v in targets.items() if k.startswith(("c1_", "c2_", "c3_", "c4_"))})
+        cfg_extra.update({k: v for k, v in targets.items() if k.startswith(("c1_", "c2_", "c3_", "c4_", "c5_"))})
         line = {
             "metric": w_metric, "value": round(value, 3), "unit": w_unit, "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
@@ -1426,11 +1494,15 @@ def main():
             "targets": targets,  # LAST key, scalars only: BASELINE configs 1-5 at a glance (value, fraction of the 8 TB/s / 2.5 PF / 157.3 TF peak, measured clock)
         }
         sys.stdout.flush()
-        if saved_stdout is not None:
-            os.dup2(saved_stdout, 1)
-        print(json.dumps(line), flush=True)
-        if saved_stdout is not None:
-            os.dup2(2, 1)  # whatever the libraries print while tearing down goes to stderr as well
+
+        def to_stdout(text):
+            if saved_stdout is not None:
+                os.dup2(saved_stdout, 1)
+            print(text, flush=True)
+            if saved_stdout is not None:
+                os.dup2(2, 1)  # whatever the libraries print while tearing down goes to stderr as well
+
+        emit(line, args.detail, to_stdout)
     if dist_mode:
         import torch.distributed as dist
         DIST = None

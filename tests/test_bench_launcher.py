@@ -18,12 +18,27 @@ def _run(*argv, env=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e, timeout=600)
 
 
-def test_self_launch_two_ranks_dry_run():
-    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run")
+def _strict(text):
+    """json.loads that refuses the bare NaN / Infinity tokens Python's own writer emits by default: the line must be STRICT JSON."""
+    def bad(tok):
+        raise ValueError(f"non-standard JSON constant {tok}")
+    return json.loads(text, parse_constant=bad)
+
+
+def test_self_launch_two_ranks_dry_run(tmp_path):
+    detail = tmp_path / "sub" / "detail.json"
+    r = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--detail", str(detail))
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # exactly one JSON line on stdout
-    line = json.loads(lines[0])
+    import bench
+    assert len(lines[0]) <= bench.MAX_LINE_BYTES == 8192
+    line = _strict(lines[0])
+    # the full record: in the sidecar (directory created on demand) and once more on stderr; the line says where
+    full = _strict(detail.read_text())
+    assert full["ranks_detail"] == line["ranks_detail"] and full["value"] == line["value"] and line["detail"] == str(detail)
+    copies = [ln for ln in r.stderr.splitlines() if "[bench detail] {" in ln]  # (torchrun may prefix the ranks' stderr lines)
+    assert len(copies) == 1 and _strict(copies[0][copies[0].index("{"):]) == full
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
     assert line["config"]["ranks"] == 2 and "m-shard x2" in line["config"]["parallelism"]
     assert line["config"]["all_gather_bytes_per_step"] == 64 * 96 * 4
@@ -62,6 +77,35 @@ def test_ranks_detail_tells_a_slow_link_from_a_slow_rank():
     assert c["exchange_wait_ms_last_panel_max"] == 0.5 and c["exchange_wait_ms_before_last_panel_max"] == 0.3 and c["exchange_wait_ms_per_step_max"] == 0.5
     d, c = bench.ranks_detail([{"ms_per_step": 1.0, "clock_ghz": None, "waits": []}], 1)
     assert c["rank_clock_ghz_min"] is None and d["panel_wait_ms_max_over_ranks"] == [0.0]
+
+
+def test_the_line_stays_small_whatever_rides_in_the_record(tmp_path):
+    """bench.emit on a made-up record the size of round 5's (27 secondary workloads' objects, 8 ranks x 64 panels of wait times, a non-finite
+    value): the stdout line keeps the contract's keys + roofline + cpu_baseline + targets inside MAX_LINE_BYTES as strict JSON with `targets`
+    last, the rest goes to the sidecar untouched."""
+    import bench
+    rf = {"bound": "mfma", "kernel": "k", "achieved": 1.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.5, "traffic": None, "note": "x" * 300}
+    cpu = {"value": 1.0, "unit": "TFLOP/s", "cores": 16, "kind": "port", "sample": "s" * 250}
+    others = [{"workload": f"w{i}", "metric": "gemm_tflops", "value": float(i), "roofline": rf, "cpu_baseline": cpu} for i in range(27)]
+    targets = {f"c{i}_some_workload_key_tflops": 1234.5 for i in range(70)}
+    big_ranks = {"ms_per_step": [1.0] * 8, "panel_wait_ms_max_over_ranks": [0.1234] * 512}
+    full = {"metric": "gemm_tflops", "value": 1.0, "unit": "TFLOP/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": float("nan"),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": dict({"workload": "gemm_f16_32768"}, **targets), "roofline": rf, "cpu_baseline": cpu, "checks": {"u": float("inf")},
+            "ranks_detail": big_ranks, "others": others, "targets": targets}
+    out = []
+    text = bench.emit(full, str(tmp_path / "d.json"), out.append)
+    assert out == [text] and len(text) <= bench.MAX_LINE_BYTES
+    line = _strict(text)
+    assert list(line)[-1] == "targets" and line["targets"] == targets and "others" not in line and line["ranks_detail"] is None
+    assert line["ms_per_step"] is None and line["checks"]["u"] is None  # non-finite -> null, never a bare NaN
+    assert line["roofline"] == rf and line["cpu_baseline"] == cpu and line["config"]["workload"] == "gemm_f16_32768"
+    side = _strict((tmp_path / "d.json").read_text())
+    assert len(side["others"]) == 27 and side["ranks_detail"] == big_ranks and side["config"] == full["config"]
+    # a short ranks_detail (2 ranks, 3 panels) stays in the line; no sidecar requested -> "detail": null
+    small = dict(full, others=[], ranks_detail={"ms_per_step": [1.0, 2.0]}, ms_per_step=1.0, checks={})
+    line = _strict(bench.emit(small, "-", out.append))
+    assert line["ranks_detail"] == {"ms_per_step": [1.0, 2.0]} and line["detail"] is None
 
 
 def test_rccl_engine_variants_leave_4_and_8_compute_units():

@@ -378,6 +378,41 @@ def test_bench_line_ends_with_targets_and_carries_the_measured_clock():
     assert 0 < line["checks"]["parity_max_ulp_vs_f64_f16_gemm"] <= 1.0  # one rounding of an f32 accumulation: within an f16 ulp of f64
 
 
+def test_default_bench_line_fits_the_driver_and_the_sidecar_holds_the_rest(tmp_path):
+    """The DEFAULT workload set (headline f16 32768^3 + every secondary config, cpu_baseline on): what the driver runs at round end, with short
+    timed regions only. The stdout line must stay <= 8 KB of strict JSON (round 5's 25 KB line came back unparsed) and still carry `roofline`,
+    `cpu_baseline` and the C1-C5 scalars; `others` lives in the sidecar."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    side = tmp_path / "detail.json"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--secondary-seconds", "0.05", "--cpu-budget", "2",
+                        "--detail", str(side)], capture_output=True, text=True, env=e, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) <= 8192, (len(lines), len(lines[0]))
+
+    def bad(tok):
+        raise ValueError(f"non-standard JSON constant {tok}")
+    line = json.loads(lines[0], parse_constant=bad)
+    assert "others" not in line and list(line)[-1] == "targets"
+    assert line["config"]["workload"] == "gemm_f16_32768" and line["dtype"] == "f16" and line["n_gpus"] == 1 and line["steps"] == 3
+    assert line["roofline"]["bound"] == "mfma" and 0.2 < line["roofline"]["frac"] < 1.0 and line["roofline"]["peak"] == 2500.0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    t = line["targets"]
+    for k in ("c5_gemm_f16_32768_tflops", "c5_gemmtr_f16_32768_tflops", "c3_gemm_f16_8192_tflops", "c3_gemmtr_f16_8192_tflops", "c2_gemm_f32_4096_tflops",
+              "c4_gemv_gbs", "c4_gemvtr_gbs", "c4_reduce_gbs", "c1_gemv_1024_us", "c1_gemv_1024_graph_us"):
+        assert t[k] > 0 and line["config"][k] == t[k], k
+    full = json.loads(side.read_text(), parse_constant=bad)
+    errs = [o for o in full["others"] if "error" in o]
+    assert not errs, errs
+    assert len(full["others"]) >= 24 and all("roofline" in o for o in full["others"]) and full["targets"] == t
+
+
 def test_bench_communicator_path_reports_rccl_rank_count_and_cu_split():
     line = _bench_line("--workload", "gemm_f16_8192", "--gather", "rccl", "--steps", "3", "--warmup", "1", "--no-secondary", "--no-cpu-baseline",
                        env={"WG_BENCH_FORCE_DIST": "1"})

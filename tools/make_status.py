@@ -25,6 +25,7 @@ ROWS = [  # (BASELINE config, workload, label, unit key)
     ("C4", "reduce_f32_4096x65536", "Reduce (Sum) 4096 vectors of 65536", "GB/s"),
     ("C4", "op_assign_f32_256M", "OpAssign (Add) 2^26 elements", "GB/s"),
     ("C5", "gemm_f16_32768", "f16 Gemm 32768^3 (1 GPU)", "TFLOP/s"),
+    ("C5", "gemmtr_f16_32768", "f16 GemmTr 32768^3 (1 GPU)", "TFLOP/s"),
     ("C5", "gemm_f16_32768_u01", "f16 Gemm 32768^3, operands U[0,1)", "TFLOP/s"),
     ("-", "gemm_f16_8192x8192x1024", "f16 Gemm 8192 x 8192 x 1024 (short K: the continuous tile walk)", "TFLOP/s"),
     ("-", "gemmtr_f16_8192x8192x1024", "f16 GemmTr 8192 x 8192 x 1024", "TFLOP/s"),
@@ -34,6 +35,22 @@ ROWS = [  # (BASELINE config, workload, label, unit key)
     ("-", "gemm_f32_ts_65536x512x4096", "f32 Gemm 65536 x 512 x 4096 (tall-skinny)", "TFLOP/s"),
     ("-", "gemm_f32_fewcols_32000x16x4096", "f32 Gemm 32000 x 16 x 4096 (few columns, HBM-bound)", "GB/s"),
 ]
+
+
+def load_record(path):
+    """A bench record: the FULL one -- bench.py's --detail sidecar (or its `[bench detail] {...}` stderr copy) -- carries "others"; a file holding only
+    the compact stdout line is completed from the sidecar next to it (`<name>_detail.json`) when there is one."""
+    with open(path) as fh:
+        txt = [ln for ln in fh.read().strip().splitlines() if ln.strip()]
+    last = txt[-1]
+    if "[bench detail] {" in last:
+        last = last[last.index("{"):]
+    rec = json.loads(last)
+    if "others" not in rec:
+        side = os.path.splitext(path)[0] + "_detail.json"
+        if os.path.exists(side):
+            rec = json.loads(open(side).read().strip().splitlines()[-1])
+    return rec
 
 
 def by_workload(line):
@@ -67,9 +84,7 @@ def main():
         args = [a for a in args if a != vendor_file]
     lines = []
     for f in args:
-        with open(f) as fh:
-            txt = fh.read().strip().splitlines()
-        lines.append((os.path.relpath(f), json.loads(txt[-1])))
+        lines.append((os.path.relpath(f), load_record(f)))
     vendor = {}
     if vendor_file and os.path.exists(vendor_file):
         # tools/vendor_vs_ours.sh: "vendor f16 8192^3 nn: X TFLOP/s" (hipBLASLt through torch.matmul, same box, same moment) and "ours <workload>: Y"
