@@ -29,10 +29,17 @@ namespace {
 //   B: [row][64 k] = 128-byte rows; logical 16-byte chunk c (0..7) of a row sits at position c ^ (G((row>>2)&3) | ((row>>1)&1)<<2):
 //      every lane group touches 16 distinct (row&1, position) bank quads -- conflict-free;
 //   TN op(A): [row][32 k] = 64-byte rows per half-stage, chunk c at c ^ G((row>>3)&3) (A's rows are permuted as above).
-//   NN A (m-contiguous): 256-byte blocks [k/4][m/32][4 k][32 m], read with ds_read_b64_tr_b16. A 32-lane pass of that
-//      instruction holds two k-groups; reading the same tile they would hit the same banks. So one instruction reads
-//      k-group g for BOTH tiles of a pair (lane rows 0/1 take the low/high 8 bytes of the same units), the next one
-//      k-group g+1, and v_permlane16_swap puts the k-groups back on the lane rows the MFMA expects.
+//   NN A (m-contiguous): 256-byte blocks [k/4][m/32][4 k][32 m], read with ds_read_b64_tr_b16: a lane row (16 lanes) takes 4 k x 16 m of ONE k-group, lane
+//      4 krow + a the 8 bytes (4 m) of 16-byte unit a of k row krow. A 32-lane pass holds two lane rows = two k-groups; reading the SAME 8-byte half of
+//      every unit they would hit the same banks. Round 5 read the two tiles of a pair in one instruction (lane rows 0/1 the low/high halves) and put
+//      the k-groups back on their lane rows with 16 v_permlane16_swap per half-step. Now (WG_NN_NOSWAP): every instruction reads ONE tile, lane row r
+//      k-group r, and the two rows of a pass still cover all 64 banks because
+//        * the tiles of a pair interleave by unit PARITY: tile tb holds rows 8 a + 4 (tb ^ (a & 1)) + e, i.e. half tb ^ (a & 1) of unit a, and
+//        * the DMA pieces of ODD k-groups swap neighbouring units (unit a lands at position a ^ 1; a piece is one unit per lane, so that is only a
+//          different per-lane global offset): in an odd k-group's block tile tb occupies exactly the 8-byte halves it does NOT occupy in an even one.
+//      Lane (kg, i16) of the result then holds, for tile 2 p + tb, rows 32 p + 8 kg + 4 (tb ^ (kg & 1)) + r: still 8 consecutive rows per pair, the two
+//      tiles' order exchanged in odd lane rows (one select per register in the epilogue, once per tile, against 16 swaps per 32 k). Same k order in
+//      every MFMA, same accumulation chain per element: bit-identical to the swapped form and to GemmTr.
 // Pipeline (H = half-step, s = H>>1 its stage). Fragments of half-step H+1 are read during H into the other register set; a
 // half-step's synchronisation (lgkmcnt(0) + counted vmcnt + barrier) sits a few MFMA slots before its end, after its last fragment
 // read and DMA piece, so the LDS slot of A(H) / B(s) is free from the start of H / of 2s+1. NN: during H, A(H+4) -> A slot H&3 (four
@@ -242,7 +249,8 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) { // blocks 4P..4P+3: kq = P>>1, mblk = 4 (P&1) + (lane>>4), k row (lane>>2)&3, 16-byte unit lane&3
             const uint32_t P = 4u * wave + q;
-            const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * (lane & 3), g.M - 8u - m0); // M % 8 == 0
+            const uint32_t unit = WG_NN_NOSWAP ? (lane & 3u) ^ ((uint32_t)wave & 1u) : (lane & 3u); // (the piece's k-group within the half-stage is `wave`: odd ones swap neighbouring units)
+            const uint32_t mpiece = min(128u * (P & 1) + 32u * (lane >> 4) + 8u * unit, g.M - 8u - m0); // M % 8 == 0
             a_voff[q] = ((4u * (P >> 1) + ((lane >> 2) & 3)) * g.lda + mpiece) * 2u + (M16_BIAS - 1024u * q);
         }
     }
@@ -268,6 +276,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 
     // ---- per-lane LDS read addresses (bytes from the start of the LDS) for half-step parity 0 / 1 of a stage ----
     uint32_t vbaseA[2], vbaseB[2];
+    uint32_t vbaseA1 = 0; // NN without swaps: the odd tiles' base (the even tiles': vbaseA[0]); the staged pipeline's second half-stage: + HA_BYTES
 #pragma unroll
     for (int hs = 0; hs < 2; ++hs) {
         const uint32_t chunk = (uint32_t)(((kg ^ gq) | ((hs ^ (bb >> 1)) << 2)) * 16);
@@ -276,10 +285,21 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         if constexpr (TRANS_A) vbaseA[hs] = lds_base + (128u * wm + 8u * aq + bb) * 128u + chunk;
     }
     if constexpr (!TRANS_A) {
-        // lane row kg reads k-group (kg&2) + ins, 8-byte half (kg&1) of unit i16 of block (kq = 2*kgroup + h, mblk = 4 wm + p)
-        vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        if constexpr (WG_NN_NOSWAP) {
+            // lane row kg reads k-group kg (blocks kq = 2 kg + h, mblk = 4 wm + p); lane 4 krow + a: k row krow, unit a -- stored at position a ^ (kg & 1) --
+            // and of it the 8-byte half tb ^ (a & 1) for tile tb
+            const uint32_t a = (uint32_t)i16 & 3u, krow = (uint32_t)i16 >> 2;
+            const uint32_t common = lds_base + (uint32_t)kg * 4096u + (4u * wm) * 256u + krow * 64u + (a ^ ((uint32_t)kg & 1u)) * 16u;
+            vbaseA[0] = common + (a & 1u) * 8u;
+            vbaseA1 = common + ((a & 1u) ^ 1u) * 8u;
+        } else {
+            // lane row kg reads k-group (kg&2) + ins, 8-byte half (kg&1) of unit i16 of block (kq = 2*kgroup + h, mblk = 4 wm + p)
+            vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        }
         vbaseA[1] = vbaseA[0] + HA_BYTES; // the second half-stage of a full stage (staged pipeline only)
     }
+    // NN without swaps: odd lane rows hold the tiles of a pair in exchanged order (rows 32 p + 8 kg + 4 (tb ^ (kg & 1)) + r): see the epilogue
+    const bool odd_row = !TRANS_A && WG_NN_NOSWAP && (kg & 1);
 
     floatx4 acc[8][8]; // [t][u]
 #pragma unroll
@@ -294,14 +314,15 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         // compiler can see makes its wait-count pass put an `s_waitcnt vmcnt(n)` in front of the first MFMA of the LOOP (where it would
         // drain this kernel's DMA pipeline in every iteration), and 64 loads through VGPRs spill.
         const uint32_t pvoff = ((128u * wn + i16) * 256u + 128u * wm + 8u * kg) * 4u;
+        const uint32_t pv_even = pvoff + (odd_row ? 16u : 0u), pv_odd = pvoff + (odd_row ? 0u : 16u); // rows + 0..3 / + 4..7 of the 8: which tile of the pair holds them
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint32_t vo = pvoff + (uint32_t)u * 16384u;
+            const uint32_t vo0 = pv_even + (uint32_t)u * 16384u, vo1 = pv_odd + (uint32_t)u * 16384u;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 // sc0 sc1: the scratch tile is rewritten by another XCD every launch; read it past this XCD's L2 as well
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p][u]) : "v"(vo), "s"(part), "i"(p * 128));
-                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p + 1][u]) : "v"(vo), "s"(part), "i"(p * 128 + 16));
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p][u]) : "v"(vo0), "s"(part), "i"(p * 128));
+                asm volatile("global_load_dwordx4 %0, %1, %2 offset:%c3 sc0 sc1" : "=a"(acc[2 * p + 1][u]) : "v"(vo1), "s"(part), "i"(p * 128));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -333,6 +354,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // DMA pieces of the half-step are issued by then, so the counts mean what they would at the very end; the MFMAs behind it only
     // touch registers). `asm volatile("" : "+s"(x))` pins an update to its slot. tools/gap_hist.py lists the fillers per gap.
     uint32_t va, vb;                                     // VGPRs: where this half-step's A / B fragment reads start
+    uint32_t va1 = 0;                                    // NN without swaps: ... of the odd tiles' A reads (va: the even tiles')
     const char *ga, *gb, *ga2 = nullptr;                 // SGPR pairs: global bases (less M16_BIAS) of the A / B pieces issued this half-step
     uint32_t oR = 0, oD = 2u * M16_BS_BYTES;             // B ring (3 stages): byte offset of the slot read / DMA'd this half-step
     uint32_t rR = 1u << 14, rD = 0;                      // NN, 4 half-stage slots of A: offset of the slot read / DMA'd this half-step
@@ -347,7 +369,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
 
     // the fragment-producing operations of one half-step, in the order the next half-step consumes them
-    constexpr int kOps = TRANS_A ? 16 : 40;
+    constexpr int kOps = TRANS_A ? 16 : WG_NN_NOSWAP ? 24 : 40;
     auto frag = [&](int op, int set) {
         auto rb = [&](int u) { b_f[set][u] = lds_h8_at(vb + u * 2048); };
         if constexpr (TRANS_A) {
@@ -355,6 +377,21 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             if (op == 0) ra(0);
             else if (op <= 8) rb(op - 1);
             else ra(op - 8);
+        } else if constexpr (WG_NN_NOSWAP) {
+            // tr(p, i): transpose read i = 2 tb + h of pair p: the 4 k of half h (block kq = 2 kg + h) of this lane row's k-group, for tile 2 p + tb, dwords 2 h, 2 h + 1
+            auto tr = [&](int p, int i) {
+                const int tb = i >> 1, h = i & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at((tb ? va1 : va) + h * 2048 + p * 256));
+                a_r[set][2 * p + tb][2 * h] = v[0];
+                a_r[set][2 * p + tb][2 * h + 1] = v[1];
+            };
+            // in the order the next half-step's MFMAs want them: tiles 0, 1 | B 0..3 | tiles 2, 3 | B 4..7 | tiles 4..7
+            if (op < 4) tr(0, op);
+            else if (op < 8) rb(op - 4);
+            else if (op < 12) tr(1, op - 8);
+            else if (op < 16) rb(op - 8);
+            else if (op < 20) tr(2, op - 16);
+            else tr(3, op - 20);
         } else {
             // tr(p, i): transpose read i = 2 h + ins of pair p lands in tile 2p+ins, dwords 2h, 2h+1;
             // sw(p, i): lane-row swap of dword i of the pair's two tiles
@@ -452,6 +489,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             }
             if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
             if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
+            if constexpr (WG_NN_NOSWAP && j == 53) { va1 = vbaseA1 + rR; asm volatile("" : "+v"(va1)); }
             if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
             if constexpr (j == 55 && HS == 1) { ++st; asm volatile("" : "+s"(st)); }
             if constexpr (WG_F16_UNPEELED && HS == 1 && j == 56) { a_inc0 = st + 3u <= S ? a_full : 0u; asm volatile("" : "+s"(a_inc0)); } // A(2 st + 5) exists
@@ -521,6 +559,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             if constexpr (HS == 0 && j == LASTB + 1) { oR = ring3(oR); asm volatile("" : "+s"(oR)); }
             if constexpr (j == LASTB + 4) { vb = vbaseB[HS] + oR; asm volatile("" : "+v"(vb)); }                             // the next half-step reads parity HS
             if constexpr (HS == 0 && j == 47) { oA ^= (uint32_t)M16_BS_BYTES; asm volatile("" : "+s"(oA)); }
+            if constexpr (!TRANS_A && WG_NN_NOSWAP && j == 48) { va1 = vbaseA1 + (HS ? (uint32_t)HA_BYTES : 0u) + oA; asm volatile("" : "+v"(va1)); }
             if constexpr (j == 49) { va = vbaseA[HS] + oA; asm volatile("" : "+v"(va)); }
             if constexpr (HS == 1 && j == 52) { ++st; asm volatile("" : "+s"(st)); }
             if constexpr (WG_F16_UNPEELED && HS == 1 && j == 53) { a_inc1 = st + 4u <= S ? a_full : 0u; asm volatile("" : "+s"(a_inc1)); } // A(st + 3) exists
@@ -603,7 +642,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     }
     wait_dma_keep<20>();
     __syncthreads();
-    va = vbaseA[0]; vb = vbaseB[0]; // half-step 0's own fragments: first half of stage 0
+    va = vbaseA[0]; va1 = vbaseA1; vb = vbaseB[0]; // half-step 0's own fragments: first half of stage 0
 #pragma unroll
     for (int op = 0; op < kOps; ++op) frag(op, 0);
     const uint64_t calib_t0 = __builtin_amdgcn_s_memrealtime(); // per-XCD rate measurement (returns before the wait below)
@@ -613,8 +652,8 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     vb = vbaseB[1];
     gb = (const char *)b_src(2u);
     if constexpr (TRANS_A) { va = vbaseA[1]; ga = (const char *)a_src(2u); }
-    else if constexpr (STAGED) { va = vbaseA[1]; ga = (const char *)a_src(4u); ga2 = (const char *)a_src(5u); }
-    else { va = vbaseA[0] + rR; ga = (const char *)a_src(4u); }
+    else if constexpr (STAGED) { va = vbaseA[1]; va1 = vbaseA1 + (uint32_t)HA_BYTES; ga = (const char *)a_src(4u); ga2 = (const char *)a_src(5u); }
+    else { va = vbaseA[0] + rR; va1 = vbaseA1 + rR; ga = (const char *)a_src(4u); }
     __builtin_amdgcn_sched_barrier(0);
     WG_TRACE_POINT(1);
 #if defined(WG_F16_TRACE) && WG_F16_TRACE >= 2
@@ -685,7 +724,8 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         }
     }
 
-    // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 ----
+    // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 (tile 2 p: + 0..3, tile 2 p + 1: + 4..7; the other way
+    // round in odd lane rows of the swap-free Gemm) ----
     const bool full_tile = (m0 + BM <= g.M) && (n0 + BN <= g.N); // workgroup-uniform
     const uint32_t row0 = m0 + 128u * wm + 8u * kg;
     if (g.tail_tiles > 0 || unit_mode == 1) { // tail split: raw f32 partial TILE (256 x 256, dense) of this split; gemm_f16_tail_reduce finishes the job
@@ -697,8 +737,8 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
                 float4 *d = reinterpret_cast<float4 *>(pc + 32 * p);
-                d[0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
-                d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
+                d[odd_row ? 1 : 0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
+                d[odd_row ? 0 : 1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -723,8 +763,8 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             for (int p = 0; p < 4; ++p) {
                 if (!(full_tile || row0 + 32 * p < g.M)) continue;
                 float4 *d = reinterpret_cast<float4 *>(pc + 32 * p);
-                d[0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
-                d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
+                d[odd_row ? 1 : 0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
+                d[odd_row ? 0 : 1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -740,9 +780,9 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     auto pack = [&](int u, int p, bool ok, const _Float16 *cc) -> half8_t {
         float r[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            r[q] = acc[2 * p][u][q];
-            r[4 + q] = acc[2 * p + 1][u][q];
+        for (int q = 0; q < 4; ++q) { // (odd lane rows of the swap-free Gemm: the pair's tiles in exchanged order)
+            r[q] = odd_row ? acc[2 * p + 1][u][q] : acc[2 * p][u][q];
+            r[4 + q] = odd_row ? acc[2 * p][u][q] : acc[2 * p + 1][u][q];
         }
         if (alpha != 1.f) {
 #pragma unroll
@@ -939,7 +979,8 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     constexpr int NA = TRANS_A ? 8 : 4;
     uint32_t a_int[NA], b_int[8], a_voff[NA], b_voff[8];
     const uint32_t row_l = 64u * wave + (lane >> 3);                  // piece q of a k-contiguous operand: row row_l + 8 q of the tile
-    const uint32_t mp_l = 32u * (lane >> 4) + 8u * (lane & 3);        // Gemm's A: piece q starts at row 128 (q & 1) + mp_l
+    // Gemm's A: piece q starts at row 128 (q & 1) + mp_l (swap-free form: the pieces of odd k-groups -- a piece's k-group within its half-stage is `wave` -- swap neighbouring units)
+    const uint32_t mp_l = 32u * (lane >> 4) + 8u * (WG_NN_NOSWAP && !TRANS_A ? (lane & 3u) ^ ((uint32_t)wave & 1u) : (lane & 3u));
     if constexpr (TRANS_A) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -987,10 +1028,19 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         vbaseB[hs] = lds_base + M16_B_BASE + ((uint32_t)128 * wn + i16) * 128u + chunk;
         if constexpr (TRANS_A) vbaseA[hs] = lds_base + (128u * wm + 8u * aq + bb) * 128u + chunk;
     }
+    uint32_t vbaseA1 = 0; // swap-free Gemm: the odd tiles' base (m16_tile: "NN A")
     if constexpr (!TRANS_A) {
-        vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        if constexpr (WG_NN_NOSWAP) {
+            const uint32_t a = (uint32_t)i16 & 3u, krow = (uint32_t)i16 >> 2;
+            const uint32_t common = lds_base + (uint32_t)kg * 4096u + (4u * wm) * 256u + krow * 64u + (a ^ ((uint32_t)kg & 1u)) * 16u;
+            vbaseA[0] = common + (a & 1u) * 8u;
+            vbaseA1 = common + ((a & 1u) ^ 1u) * 8u;
+        } else {
+            vbaseA[0] = lds_base + (uint32_t)((kg & 2) * 2) * 2048u + (4u * wm) * 256u + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
+        }
         vbaseA[1] = vbaseA[0];
     }
+    const bool odd_row = !TRANS_A && WG_NN_NOSWAP && (kg & 1); // these lanes hold the tiles of a pair in exchanged order
     // one stage of A in global memory: 128 bytes along its k-contiguous rows (GemmTr), 64 columns (Gemm; the half-stage a_half = 32 columns is its unit there)
     const uint64_t a_half = TRANS_A ? 64u : (uint64_t)BKH * g.lda * 2u;
     const uint64_t a_full = TRANS_A ? 128u : a_half;            // what a cursor step of A covers: a stage (GemmTr) / a half-stage (Gemm)
@@ -1024,7 +1074,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     using c0 = std::integral_constant<int, 0>;
     using c1 = std::integral_constant<int, 1>;
     uint32_t st = 0;
-    uint32_t va, vb;
+    uint32_t va, vb, va1 = 0;
     const char *ga, *gb;
     uint32_t oR = 0, oD = 2u * M16_BS_BYTES, oA = 0, oAD = 0, la = 0, lb = 0; // B ring (3 stages); GemmTr: A's two full-stage slots
     uint32_t rR = 1u << 14, rD = 0;                                           // Gemm: A's four half-stage slots
@@ -1037,7 +1087,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     uint32_t cross_st = ~0u;                // the stage whose steps leave the tile: S - 3, if this workgroup has a next tile
     uint32_t after_store = 0;               // counted waits that still have to allow for the finished tile's 32 stores (in flight behind this tile's first pieces)
     auto ring3 = [](uint32_t o) -> uint32_t { o += (uint32_t)M16_BS_BYTES; return o == 3u * M16_BS_BYTES ? 0u : o; };
-    constexpr int kOps = TRANS_A ? 16 : 40;
+    constexpr int kOps = TRANS_A ? 16 : WG_NN_NOSWAP ? 24 : 40;
     auto frag = [&](int op, int set) {
         auto rb = [&](int u) { b_f[set][u] = lds_h8_at(vb + u * 2048); };
         if constexpr (TRANS_A) {
@@ -1045,6 +1095,19 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if (op == 0) ra(0);
             else if (op <= 8) rb(op - 1);
             else ra(op - 8);
+        } else if constexpr (WG_NN_NOSWAP) {
+            auto tr = [&](int p, int i) { // m16_tile's: read i = 2 tb + h of pair p -> tile 2 p + tb, dwords 2 h, 2 h + 1
+                const int tb = i >> 1, h = i & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr_at((tb ? va1 : va) + h * 2048 + p * 256));
+                a_r[set][2 * p + tb][2 * h] = v[0];
+                a_r[set][2 * p + tb][2 * h + 1] = v[1];
+            };
+            if (op < 4) tr(0, op);
+            else if (op < 8) rb(op - 4);
+            else if (op < 12) tr(1, op - 8);
+            else if (op < 16) rb(op - 8);
+            else if (op < 20) tr(2, op - 16);
+            else tr(3, op - 20);
         } else {
             auto tr = [&](int p, int i) {
                 const int h = i >> 1, ins = i & 1;
@@ -1165,6 +1228,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
             if constexpr (HS == 1 && j == DO + 3 * DS + 4) { if (st == cross_st) set_voffs_a(nlim_a); } // (a slot of its own, no fragment op, no piece)
             if constexpr (j == DO + 4 * DS + 3 && HS == 0) { oD = ring3(oD); asm volatile("" : "+s"(oD)); }
             if constexpr (j == 47) { rR = (rR + 0x4000u) & 0xffffu; asm volatile("" : "+s"(rR)); }
+            if constexpr (WG_NN_NOSWAP && j == 53) { va1 = vbaseA1 + rR; asm volatile("" : "+v"(va1)); }
             if constexpr (j == 54) { va = vbaseA[0] + rR; asm volatile("" : "+v"(va)); }
             if constexpr (HS == 1 && j == 55) stage_end(0);
             if constexpr (HS == 1 && j == 56) { a_step0 = rem_g >= 3u ? (uint32_t)a_full : 0u; asm volatile("" : "+s"(a_step0)); }
@@ -1197,14 +1261,14 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     else { pro_a(0); pro_b(0, 8); pro_a(1); pro_a(2); pro_b(1, 8); pro_a(3); pro_b(2, 4); }
     wait_dma_keep<20>();
     __syncthreads();
-    va = vbaseA[0]; vb = vbaseB[0];
+    va = vbaseA[0]; va1 = vbaseA1; vb = vbaseB[0];
 #pragma unroll
     for (int op = 0; op < kOps; ++op) frag(op, 0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     vb = vbaseB[1]; gb = b0 + 256; // stage 2
     if constexpr (TRANS_A) { va = vbaseA[1]; ga = a0 + 256; }
-    else { va = vbaseA[0] + rR; ga = a0 + 4u * a_full; }
+    else { va = vbaseA[0] + rR; va1 = vbaseA1 + rR; ga = a0 + 4u * a_full; }
     a_step0 = rem_g >= 3u ? (uint32_t)a_full : 0u;
     a_step1 = rem_g >= 4u ? a_full : 0u; b_step = rem_g >= 4u ? 128u : 0u; // (S >= 4: no tile ends within its first stage)
     asm volatile("" : "+s"(a_step0), "+s"(a_step1), "+s"(b_step));
@@ -1248,6 +1312,13 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                 float r[8];
                 AccQuad<8 * (2 * p) + u>::read(r[0], r[1], r[2], r[3]);
                 AccQuad<8 * (2 * p + 1) + u>::read(r[4], r[5], r[6], r[7]);
+                if constexpr (!TRANS_A && WG_NN_NOSWAP) { // odd lane rows hold the pair's tiles in exchanged order (rows + 4..7 in tile 2 p): one select per register
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float lo = odd_row ? r[4 + q] : r[q], hi = odd_row ? r[q] : r[4 + q];
+                        r[q] = lo; r[4 + q] = hi;
+                    }
+                }
                 half8_t v;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {

@@ -120,6 +120,10 @@ struct GemmArgs {
 #endif
 };
 
+#ifndef WG_NN_NOSWAP
+#define WG_NN_NOSWAP 1  // 1: Gemm's (column-major) A fragments without v_permlane16_swap (round 6; layout: "NN A" in gemm_f16.hip). 0: round 5's paired reads + lane-row swaps
+#endif
+
 // LDS-DMA: 16 bytes per lane from `gsrc` (per-lane) to LDS byte address `lds_dst` + 16*lane (`lds_dst` wave-uniform).
 // Issued through inline asm ON PURPOSE: hipcc cannot tell that the DMA into stage t+1 does not alias the ds_reads of
 // stage t (one LDS array, no alias scopes) and would put `s_waitcnt vmcnt(0)` in front of the first ds_read of every

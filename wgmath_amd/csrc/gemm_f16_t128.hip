@@ -13,8 +13,8 @@
 //     set, issues its 4 pieces of half-stage H+5 into the slot H-1 released, and ends with lgkmcnt(0) + vmcnt(12) + barrier;
 //   * operands arrive by LDS-DMA (global_load_lds_dwordx4) in the swizzled layouts of the big kernel at half-stage granularity
 //     (64-byte rows for k-contiguous operands, chunk c at c ^ G(.), conflict-free ds_read_b128; 256-byte [4 k][32 m] blocks +
-//     ds_read_b64_tr_b16 + v_permlane16_swap for column-major A), and the same row permutation inside a wave tile so that a
-//     lane's accumulators of a tile pair are 8 consecutive rows of C (16-byte stores);
+//     ds_read_b64_tr_b16 for column-major A -- since round 6 without v_permlane16_swap: the unit-parity interleave of gemm_f16.hip "NN A"),
+//     and the same row permutation inside a wave tile so that a lane's accumulators of a tile pair are 8 consecutive rows of C (16-byte stores);
 //   * tile order: 4-tile-row strips, contiguous ranges per XCD (tile_strips, gemm_f16_common.hpp), so an XCD's L2 sees a compact
 //     patch of the output.
 // M0 is written by the inline asm without save/restore, as in gemm_f16.hip (tests/test_abi_and_host.py checks the ISA).
@@ -125,7 +125,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         } else {
             const uint32_t kq = APW == 2 ? P : P >> 1, mh = APW == 2 ? 0u : (P & 1u);
             const uint32_t k = 4u * kq + ((lane >> 2) & 3u);
-            const uint32_t m = min(128u * mh + 32u * (lane >> 4) + 8u * (lane & 3u), g.M - 8u - m0); // M % 8 == 0
+            // (swap-free form, gemm_f16.hip "NN A": the piece's k-group within the half-stage is kq >> 1 = `wave`; odd ones swap neighbouring 16-byte units)
+            const uint32_t unit = WG_NN_NOSWAP ? (lane & 3u) ^ ((uint32_t)wave & 1u) : (lane & 3u);
+            const uint32_t m = min(128u * mh + 32u * (lane >> 4) + 8u * unit, g.M - 8u - m0); // M % 8 == 0
             a_voff[q] = (k * g.lda + m) * 2u + (T_BIAS - 1024u * q);
         }
     }
@@ -166,10 +168,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb)
             a_off[tb] = 2u * wm * (uint32_t)RB + (uint32_t)(aq >> 1) * 1024u + (uint32_t)(8 * (aq & 1) + 4 * tb + bb) * 64u + pos * 16u;
+    } else if constexpr (WG_NN_NOSWAP) {
+        // lane row kg reads k-group kg = region kg of the slot; lane 4 krow + a: k row krow, unit a (at position a ^ (kg & 1)), 8-byte half tb ^ (a & 1) for tile tb
+        const uint32_t a = (uint32_t)i16 & 3u, krow = (uint32_t)i16 >> 2;
+        const uint32_t common = (uint32_t)kg * (uint32_t)RB + (APW == 2 ? (2u * wm) * 256u : (uint32_t)wm * 1024u) + krow * 64u + (a ^ ((uint32_t)kg & 1u)) * 16u;
+        a_off[0] = common + (a & 1u) * 8u;
+        a_off[1] = common + ((a & 1u) ^ 1u) * 8u;
     } else {
         a_off[0] = (uint32_t)(2 * (kg >> 1)) * (uint32_t)RB + (APW == 2 ? (2u * wm) * 256u : (uint32_t)wm * 1024u) + (uint32_t)i16 * 16u + (uint32_t)(kg & 1) * 8u;
         a_off[1] = 0;
     }
+    const bool odd_row = !TRANS_A && WG_NN_NOSWAP && (kg & 1); // these lanes hold the tiles of a pair in exchanged order (rows + 4..7 in tile 2 p)
     constexpr auto a_pair_off = [](int p) { return APW == 2 ? p * RB : (p >> 1) * RB + (p & 1) * 2048; }; // TN: where pair p's rows start
     constexpr int NN_H = APW == 2 ? 1024 : 2048;                                                         // NN: the second k-quad of a region
 
@@ -187,12 +196,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     // TN: MT reads of A, 4 of B. NN: per pair p 4 transposing reads and, behind them, 4 lane swaps; 4 reads of B -- numbered
     // [pairs 0, 1: 8 reads | B: 4 | pairs 2, 3: 8 reads (TM = 256) | swaps: 4 per pair]
     constexpr int kReads = TRANS_A ? MT + 4 : 4 * MP + 4;
-    constexpr int kOps = TRANS_A ? kReads : kReads + 4 * MP;
+    constexpr int kOps = TRANS_A || WG_NN_NOSWAP ? kReads : kReads + 4 * MP;
     auto frag_op = [&](const char *sl, int op, int set) {
         auto rb = [&](int u) { b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * RB + (u & 1) * 1024); };
         if constexpr (TRANS_A) {
             if (op < MT) a_r[set][op] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[op & 1] + a_pair_off(op >> 1)));
             else rb(op - MT);
+        } else if constexpr (WG_NN_NOSWAP) {
+            auto tr = [&](int p, int i) { // read i = 2 tb + h of pair p: the 4 k of k-quad h of this lane row's k-group, tile 2 p + tb, dwords 2 h, 2 h + 1
+                const int tb = i >> 1, h = i & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sl + a_off[tb] + h * NN_H + p * 256));
+                a_r[set][2 * p + tb][2 * h] = v[0];
+                a_r[set][2 * p + tb][2 * h + 1] = v[1];
+            };
+            if (op < 8) tr(op >> 2, op & 3);
+            else if (op < 12) rb(op - 8);
+            else tr(2 + ((op - 12) >> 2), (op - 12) & 3);
         } else {
             auto tr = [&](int p, int i) { // lands in tile 2 p + ins, dwords 2 h, 2 h + 1
                 const int h = i >> 1, ins = i & 1;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 } else {
                     constexpr int SW0 = 4 + 2 * MP; // first swap's slot: pair p's swaps sit >= 4 slots behind its reads (TM = 128: 8; 256: 12)
                     if constexpr (j < kReads) frag_op(sl, j, SET ^ 1);                                  // transpose reads and B reads
-                    if constexpr (j >= SW0 && j < SW0 + 4 * MP) frag_op(sl, kReads + (j - SW0), SET ^ 1); // lane swaps, behind their reads
+                    if constexpr (!WG_NN_NOSWAP && j >= SW0 && j < SW0 + 4 * MP) frag_op(sl, kReads + (j - SW0), SET ^ 1); // lane swaps, behind their reads
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -335,8 +354,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
             for (int p = 0; p < MP; ++p) {
                 if (!(full_tile || row0 + 32 * p < g.M)) continue;
                 float4 *d = reinterpret_cast<float4 *>(pc + 32 * p);
-                d[0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
-                d[1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
+                d[odd_row ? 1 : 0] = make_float4(acc[2 * p][u][0], acc[2 * p][u][1], acc[2 * p][u][2], acc[2 * p][u][3]);
+                d[odd_row ? 0 : 1] = make_float4(acc[2 * p + 1][u][0], acc[2 * p + 1][u][1], acc[2 * p + 1][u][2], acc[2 * p + 1][u][3]);
             }
         }
         return;
@@ -353,9 +372,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
             if (!(full_tile || row0 + 32 * p < g.M)) continue; // 8 consecutive rows, all in or all out (M % 8 == 0)
             float r[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                r[q] = acc[2 * p][u][q];
-                r[4 + q] = acc[2 * p + 1][u][q];
+            for (int q = 0; q < 4; ++q) { // (odd lane rows of the swap-free Gemm: the pair's tiles in exchanged order)
+                r[q] = odd_row ? acc[2 * p + 1][u][q] : acc[2 * p][u][q];
+                r[4 + q] = odd_row ? acc[2 * p][u][q] : acc[2 * p + 1][u][q];
             }
             if (alpha != 1.f) {
 #pragma unroll
