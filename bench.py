@@ -314,6 +314,12 @@ class GemmWorkload(Workload):
             from wgmath_amd.sharded import tapered_panels
             self.panel_widths = tapered_panels(self.N, self.panel_cols, taper)
             self.npanels = len(self.panel_widths)
+        if world > 1:
+            # the panel plan is part of the slot layout of the staging cubes: every rank must cut N the same way (WG_BENCH_TAPER / panel planning read per rank).
+            # Nothing in the library compares plans across ranks (wgebra_hip.h, wg_gemm_sharded_panels): compared here, once, before the first step.
+            plans = self.dist["all_gather_object"](tuple(self.panel_widths or [self.panel_cols]))
+            if any(p != plans[0] for p in plans):
+                raise ValueError(f"the ranks planned different N-panels: {plans}")
         self.gather_mode = GatherMode.PEER_STAGED if mode == "staged" else GatherMode.RCCL
         if rccl and self.dtype == "f16":  # the one-launch form defers its last panel too (two cubes by step parity inside the library)
             comm.set_pipelined(os.environ.get("WG_BENCH_PIPELINED", "1") != "0")
@@ -425,6 +431,51 @@ class GemmWorkload(Workload):
                 "sample": f"oracle/wgsl_oracle.c `gemm` (f32, naive WGSL order; the reference has no f16 kernel), {min(256, Ms) * (n if cores > 1 else 1)} rows x {Ns} "
                           f"columns x K={K} of the {self.M}x{self.N}x{K} problem, {n if cores > 1 else 1} of {active_wgs} active workgroups on {cores} thread(s) "
                           f"({usable_cpus()} usable CPUs), {took * 1e3:.0f} ms"}
+
+
+class RowMajorGemmWorkload(GemmWorkload):
+    """Gemm / GemmTr on ROW-major views (the reference's `Shape` with row_major_shader_defs(), shape.rs:13-15, shape.wgsl:49-57): wg_gemm_rm. Single GPU only.
+    GemmTr: m1 is K x M, m2 K x N, out M x N, all row-major -- in column-major terms a product with BOTH operands contiguous along their output dimension, which
+    gemm_f16_nt.hip takes as it lies (f16; f32 transposes m1 into scratch first)."""
+
+    def __init__(self, name, M, N, K, dtype, trans=False):
+        super().__init__(name, M, N, K, dtype, trans=trans)
+        if dtype == "f16" and trans:
+            self.kernel = "gemm_f16_nt_kernel"
+
+    def setup(self, wg, gpu, rank, world):
+        if world != 1 or (DIST is not None and DIST.get("comm") is not None):
+            raise ValueError("the row-major workloads are single-GPU")
+        super().setup(wg, gpu, rank, world)
+        self.gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+
+        def rm(t, rows, cols):  # a row-major view over the tensor's buffer: index = i * cols + j
+            return wg.GpuTensorView(wg.ViewShape([rows, cols, 1], cols, rows * cols, 0), t, 3)
+        self.vA = rm(self.A, self.K, self.M) if self.trans else rm(self.A, self.M, self.K)
+        self.vB, self.vC = rm(self.B, self.K, self.N), rm(self.C, self.M, self.N)
+
+    def step(self):
+        self.gemm.dispatch_generic(self.gpu.device(), self.shapes, self.pass_, self.vC, self.vA, self.vB, self.variant)
+
+    def check(self):
+        gpu, rng, item = self.gpu, np.random.default_rng(1), np.dtype(self.np_dtype).itemsize
+        from wgmath_amd._lib import check, lib
+
+        def read_range(t, start, n):
+            out = np.empty(n, self.np_dtype)
+            check(lib.wg_buf_read(gpu._ctx.handle, t._h, start * item, out.ctypes.data, n * item))
+            return out
+        rows, cols = np.unique(rng.integers(0, self.M, 6)), np.unique(rng.integers(0, self.N, 24))
+        B = self.B.read(gpu.device()).reshape(self.K, self.N)[:, cols].astype(np.float64)
+        A = self.A.read(gpu.device())
+        A = (A.reshape(self.K, self.M)[:, rows].T if self.trans else A.reshape(self.M, self.K)[rows]).astype(np.float64)
+        got = np.stack([read_range(self.C, int(r) * self.N, self.N)[cols] for r in rows]).astype(np.float64)
+        truth, sabs = A @ B, np.abs(A) @ np.abs(B)
+        tol = 2 * np.sqrt(self.K) * 2.0 ** -24 * sabs + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if self.dtype == "f16" else 0)
+        err = np.abs(got - truth)
+        assert (err <= tol).all(), f"bench sanity check failed (row-major): worst err/tol {(err / tol).max():.3g}"
+        scale = sabs if self.dtype == "f32" else np.abs(truth)
+        self.max_ulp_vs_f64 = float((err / np.spacing(scale.astype(self.np_dtype)).astype(np.float64)).max())
 
 
 class FewColumnsGemmWorkload(GemmWorkload):
@@ -684,6 +735,10 @@ WORKLOADS = {
     "gemm_f16_16384x16384x8192": lambda: GemmWorkload("gemm_f16_16384x16384x8192", 16384, 16384, 8192, "f16"),
     "gemm_f16_16384x12288x8192": lambda: GemmWorkload("gemm_f16_16384x12288x8192", 16384, 12288, 8192, "f16"),
     "gemmtr_f32_4096": lambda: GemmWorkload("gemmtr_f32_4096", 4096, 4096, 4096, "f32", trans=True),
+    # the ROW-major operator surface (wg_gemm_rm): GemmTr is the product with both operands contiguous along their output dimension (gemm_f16_nt.hip)
+    "gemmtr_rm_f16_8192": lambda: RowMajorGemmWorkload("gemmtr_rm_f16_8192", 8192, 8192, 8192, "f16", trans=True),
+    "gemm_rm_f16_8192": lambda: RowMajorGemmWorkload("gemm_rm_f16_8192", 8192, 8192, 8192, "f16"),
+    "gemmtr_rm_f32_4096": lambda: RowMajorGemmWorkload("gemmtr_rm_f32_4096", 4096, 4096, 4096, "f32", trans=True),
     "gemv_f32_4096x65536": lambda: GemvWorkload("gemv_f32_4096x65536", 4096, 65536, False),
     "gemvtr_f32_65536x4096": lambda: GemvWorkload("gemvtr_f32_65536x4096", 65536, 4096, True),
     "gemv_f32_4096x65536_rhs8": lambda: GemvWorkload("gemv_f32_4096x65536_rhs8", 4096, 65536, False, nrhs=8),
@@ -697,7 +752,7 @@ WORKLOADS = {
 # Headline: the north-star's M-sharded f16 GEMM (BASELINE configs[4]); the SAME problem at every --gpus N ("strong"), so the
 # driver's per-N values are comparable. It fits one GPU (3 x 2 GiB), which makes it the N = 1 workload as well.
 DEFAULT_WORKLOAD = "gemm_f16_32768"
-SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_8192x8192x1024", "gemmtr_f16_8192x8192x1024", "gemmtr_f16_32768", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
+SECONDARY = ["gemm_f16_8192", "gemmtr_f16_8192", "gemm_f16_8192x8192x1024", "gemmtr_f16_8192x8192x1024", "gemmtr_f16_32768", "gemm_f16_32768_u01", "gemm_f16_8192_u01", "gemmtr_f16_8192_u01", "gemm_f32_4096", "gemm_f32_4096_u01", "gemm_f16_2048", "gemm_f32_2048", "gemm_f16_ts_131072x1024x8192", "gemm_f32_ts_65536x512x4096", "gemm_f32_fewcols_32000x16x4096", "gemmtr_rm_f16_8192", "gemv_f32_4096x65536", "gemvtr_f32_65536x4096", "gemv_f32_4096x65536_rhs8", "gemv_f16_4096x65536", "gemvtr_f16_65536x4096", "reduce_f32_4096x65536",
              "op_assign_f32_256M", "gemv_f32_1024", "gemv_f32_1024_graph"]
 
 
@@ -1043,7 +1098,7 @@ def dry_run(args, rank, world, trials=None, trial_mode=None) -> None:
     if not ok:
         raise SystemExit("dry-run: gathered product is wrong")
     if trial_mode:
-        print(json.dumps({"trial": trial_mode, "ms_per_step": round(float(el.item()) / args.steps * 1e3, 5)}), flush=True)
+        print(json.dumps({"trial": trial_mode, "ms_per_step": round(float(el.item()) / args.steps * 1e3, 5)}, allow_nan=False), flush=True)
         dist.destroy_process_group()
         return
     per_rank = [None] * world
@@ -1280,7 +1335,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
-        print(json.dumps({"trial": trial_mode, "ms_per_step": round(float(t.item()) * 1e3, 4) if np.isfinite(float(t.item())) else None, "error": err}), flush=True)
+        print(json.dumps({"trial": trial_mode, "ms_per_step": round(float(t.item()) * 1e3, 4) if np.isfinite(float(t.item())) else None, "error": err}, allow_nan=False), flush=True)
         os.dup2(2, 1)
         for g, cm in engines.values():
             cm.close()
@@ -1329,15 +1384,29 @@ def main():
         if isinstance(wl, GemmWorkload) and wl.dist is not None:
             cm = wl.dist["comm"]
             barrier()
+            ok = True
             try:
                 cm.set_wait_timing(True)
-                for _ in range(3):
-                    wl.step()
-                wl.finish()
-                waits = cm.wait_times()
-                cm.set_wait_timing(False)
             except Exception as e:  # noqa: BLE001 -- a diagnostic must not take the line down
-                log(f"[bench] rank {rank}: wait timing failed: {e}")
+                ok = False
+                log(f"[bench] rank {rank}: wait timing unavailable: {e}")
+            # the stamped steps are collective: they run on every rank or on none (a rank stepping alone would leave its peers inside the step's exchange until the
+            # launch time-out, with the measured line lost), so the ranks agree first -- and once more afterwards on whether the figures mean anything
+            if agree(ok):
+                try:
+                    for _ in range(3):
+                        wl.step()
+                    wl.finish()
+                    waits = cm.wait_times()
+                except Exception as e:  # noqa: BLE001
+                    ok = False
+                    log(f"[bench] rank {rank}: wait timing failed: {e}")
+                if not agree(ok):
+                    waits = []
+            try:
+                cm.set_wait_timing(False)
+            except Exception:  # noqa: BLE001
+                pass
             barrier()  # (outside the try: every rank passes the same barriers whatever happened to its own diagnostic)
         ck = main_res["clock"]
         per_rank = DIST["all_gather_object"]({"ms_per_step": own_ms, "clock_ghz": (ck or {}).get("mean") if isinstance(ck, dict) else ck, "waits": waits})
@@ -1461,6 +1530,7 @@ def main():
         put("gemm_f16_8192sq_k1024", by.get("gemm_f16_8192x8192x1024"), "tflops", brief=True)
         put("gemmtr_f16_8192sq_k1024", by.get("gemmtr_f16_8192x8192x1024"), "tflops", brief=True)
         put("gemm_f32_2048", by.get("gemm_f32_2048"), "tflops", brief=True)
+        put("gemmtr_rm_f16_8192", by.get("gemmtr_rm_f16_8192"), "tflops", brief=True)  # row-major GemmTr (wg_gemm_rm): the NT kernel
         for key, name in (("c1_gemv_1024_us", "gemv_f32_1024"), ("c1_gemv_1024_graph_us", "gemv_f32_1024_graph")):
             if name in by:
                 targets[key] = by[name]["roofline"].get("dispatch_us")

@@ -198,7 +198,10 @@ typedef enum wg_tuning {
     WG_TUNE_F16_CONT = 8,    /* f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU keeps its LDS-DMA stream going across its tiles):
                                 -1 = by shape (default: K <= 4096, or <= 8192 below 16 rounds of tiles; more than one round of whole tiles), 0 = never,
                                 1 = whenever applicable (tests) */
-    WG_TUNE_COUNT_ = 9
+    WG_TUNE_RM_TR_NATIVE = 9, /* row-major GemmTr (wg_gemm_rm) of f16 operands on the kernel that takes the second operand contiguous along N (gemm_f16_nt.hip) instead of
+                                transposing m1 into a scratch buffer first: -1 = from half a round of 256 x 256 tiles on (default), 0 = never (the transposed copy: tests
+                                compare the two), 1 = whenever that kernel takes the shape */
+    WG_TUNE_COUNT_ = 10
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);
 /* Diagnostics / tests (no device needed): the f16 Gemm's calibrated-shares plan for `tiles` whole 256 x 256 tiles of `stages` stages (64 k
@@ -447,7 +450,10 @@ int wg_gemm_sharded(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_g
  * few narrower and narrower ones -- leaves only a narrow last panel's exchange exposed at the end of a step, and every panel's exchange still hides
  * under the next panel's Gemm as long as a panel is at least (exchange time / Gemm time) of the one before it. The one-launch forms
  * (wg_comm_set_one_launch) take lists of the shape "n equal panels of whole 256-column tiles, then 1 .. 8 other panels of whole tiles, the last one
- * whatever is left"; any other list runs panel by panel. Results are bit for bit those of wg_gemm_sharded. */
+ * whatever is left"; any other list runs panel by panel. Results are bit for bit those of wg_gemm_sharded.
+ * PRECONDITION the library cannot check: EVERY rank passes the same widths (and the same panel_cols to wg_gemm_sharded) -- the list is the slot layout of the
+ * staging cubes the peers copy into. Ranks with different lists would write each other's slots at the wrong offsets, silently; compare the plans across ranks once
+ * before the first step (bench.py does, through its control plane). */
 int wg_gemm_sharded_panels(wg_comm *comm, wg_gemm_variant variant, wg_dtype dtype, wg_gather_mode mode, const uint32_t *panel_widths, uint32_t npanels,
                            wg_buf *out, wg_view_shape out_shape,
                            const wg_buf *a_rows, wg_view_shape a_shape, const wg_buf *b, wg_view_shape b_shape);

@@ -39,15 +39,22 @@ template <typename T> static std::vector<T> rnd(size_t n, uint32_t seed) {
 // |got - truth| <= 2 sqrt(K) 2^-24 sum|a||b| (+ half an f16 ulp of the result for f16): tests/_util.py
 template <typename T>
 static void check_product(const char *what, const std::vector<T> &got, const std::vector<T> &A, bool tr, const std::vector<T> &B, uint32_t M, uint32_t N, uint32_t K) {
+    // (round 5's form -- every element converted from f16 inside the k loop, A walked with stride M -- was where this test's two and a half minutes went: 130 s of the
+    // 178 on the host. Operands to f64 once, both k-contiguous; every third column and, of the larger products, every second row -- the row phase alternating with the
+    // column, so every rank's block of every panel is still hit)
+    std::vector<double> Ad((size_t)M * K), Bd((size_t)K * N);
+    for (uint32_t i = 0; i < M; ++i)
+        for (uint32_t k = 0; k < K; ++k) Ad[(size_t)i * K + k] = tr ? (double)A[(size_t)i * K + k] : (double)A[(size_t)k * M + i];
+    for (size_t x = 0; x < Bd.size(); ++x) Bd[x] = (double)B[x];
     double worst = 0;
-    const uint32_t jstep = N > 512 ? 3 : 1; // every third column of the larger products (all rows: every rank's block of every panel is hit)
+    const uint32_t jstep = N > 512 ? 3 : 1, istep = (uint64_t)M * N > (1u << 20) ? 2 : 1;
     for (uint32_t j = 0; j < N; j += jstep)
-        for (uint32_t i = 0; i < M; ++i) {
+        for (uint32_t i = (j / jstep) % istep; i < M; i += istep) {
             double t = 0, s = 0;
+            const double *a = Ad.data() + (size_t)i * K, *b = Bd.data() + (size_t)j * K;
             for (uint32_t k = 0; k < K; ++k) {
-                const double a = tr ? (double)A[(size_t)i * K + k] : (double)A[(size_t)k * M + i], b = (double)B[(size_t)j * K + k];
-                t += a * b;
-                s += std::fabs(a * b);
+                t += a[k] * b[k];
+                s += std::fabs(a[k] * b[k]);
             }
             double tol = 2.0 * std::sqrt((double)K) * std::ldexp(1.0, -24) * s + 1e-30;
             if (sizeof(T) == 2) tol += std::ldexp(1.0, -11) * std::fabs(t) + std::ldexp(1.0, -25);
@@ -317,11 +324,23 @@ static void errors_and_export(wg_ctx *ctx) {
     wg_buf_destroy(a); wg_buf_destroy(b); wg_buf_destroy(c);
 }
 
+static double now_s() {
+    timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+static double t_start = 0;
+// a phase line per section on stderr (where this test's minutes go: the collective library's first communicator, see tests/test_cpp_facade.py)
+#define PHASE(name) std::fprintf(stderr, "[comm_tests %7.2f s] %s\n", now_s() - t_start, name)
+
 int main() {
+    t_start = now_s();
     wg_ctx *ctx = nullptr;
     if (wg_ctx_create(0, &ctx) != WG_OK) { std::printf("no device: %s\n", wg_last_error_string()); return 2; }
+    PHASE("context created");
     cube_relayout(ctx);
     errors_and_export(ctx);
+    PHASE("relayout + error paths done; creating the RCCL communicator");
 
     unsigned char id[WG_COMM_ID_BYTES];
     wg_comm *comm = nullptr;
@@ -329,6 +348,7 @@ int main() {
         std::printf("FAIL: RCCL communicator: %s\n", wg_last_error_string());
         return 1;
     }
+    PHASE("RCCL communicator created");
     EXPECT(wg_comm_has_collectives(comm) == 1 && wg_comm_size(comm) == 1 && wg_comm_rank(comm) == 0, "communicator facts");
     { // all-gather round trip with one rank: in place, the range must survive; then a barrier
         std::vector<float> v(4096);
@@ -343,6 +363,7 @@ int main() {
             wg_buf_destroy(b);
         }
     }
+    PHASE("first collective + barrier done");
     rccl_one_rank<float>(ctx, comm, false, 512, 768, 256, 256);
     rccl_one_rank<float>(ctx, comm, true, 512, 768, 256, 512); // ragged last panel
     rccl_one_rank<_Float16>(ctx, comm, false, 1024, 1280, 512, 512);
@@ -353,14 +374,18 @@ int main() {
     }
     rccl_pipelined_alternating_shapes(ctx, comm);
     rccl_one_rank_tapered(ctx, comm);
+    PHASE("RCCL engine cases done");
     wg_comm_destroy(comm);
+    PHASE("RCCL communicator destroyed");
 
     staged_two_ranks<float>(false, 512, 768, 256, 256);
     staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512);
     staged_two_ranks<_Float16>(true, 1024, 1280, 512, 768);
     staged_two_ranks<_Float16>(false, 1024, 1280, 512, 512, /*pipelined=*/true);
     staged_two_ranks<float>(true, 512, 768, 256, 256, /*pipelined=*/true);
+    PHASE("staged engine cases done");
     staged_timeout_and_retry();
+    PHASE("time-out + retry done");
     wg_ctx_destroy(ctx);
     if (failures == 0) std::printf("ALL OK\n");
     return failures ? 1 : 0;

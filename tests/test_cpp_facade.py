@@ -24,7 +24,7 @@ def build_comm():
     """tests/cpp/comm_tests.cpp: the multi-GPU entry points through the plain C ABI (clang++: _Float16 on the host)."""
     os.makedirs(os.path.dirname(COMM_EXE), exist_ok=True)
     lib_dir = os.path.join(ROOT, "wgmath_amd")
-    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                     os.path.join(ROOT, "tests", "cpp", "comm_tests.cpp"), "-o", COMM_EXE, "-L", lib_dir, "-lwgebra_hip",
                     f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"], check=True)
 

@@ -346,6 +346,31 @@ def test_two_processes_one_gpu_config5_full_size_staged():
 
 
 # --------------------------------------------------------------------------------------------------------
+# Communicators of 2, 4 and 8 emulated ranks created, used and destroyed back to back in ONE process (tools/rank_emulation.py: the staged engine's compute side
+# panel by panel and as one launch per step, then a 248-CU context with its own communicator, uniform and tapered panels, for every rank count) -- the sequence
+# a `bench.py --gpus 1,2,4,8` session walks through, and the one that once did not return for 30 minutes (profiles/r05_evidence.md section 4; not reproduced
+# since: profiles/r06_evidence.md). A fresh child under a hard limit; the tool prints where it stands should it ever stop again.
+# --------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("size", ["8192"])
+def test_communicators_of_2_4_8_emulated_ranks_back_to_back_in_one_process(size):
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", EMU_SIZE=size, EMU_TIMEOUT="100", STEPS="3")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rank_emulation.py"), "2", "4", "8", "2", "8", "4"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    assert time.time() - t0 < 120
+    out = json.loads(r.stdout)
+    assert set(out["ranks"]) == {"2", "4", "8"} and out["single_gpu_best"]["tflops"] > 100
+    for P, res in out["ranks"].items():
+        for key in ("no_exchange", "staged_compute_and_relayout_panel_launches", "staged_compute_and_relayout", "rccl_compute_side_248_cus", "rccl_compute_side_248_cus_tapered"):
+            assert res[key]["ms_per_step"] > 0, (P, key)
+
+
+# --------------------------------------------------------------------------------------------------------
 # The bench line itself (tests/test_bench_launcher.py checks the launcher on CPU; these need the GPU): the single-GPU line ends with the scalar
 # `targets` object and carries the clock measured in the run + the MFMA-only ceiling; the communicator path (WG_BENCH_FORCE_DIST=1: RCCL with
 # one rank) reports the rank count RCCL itself gives and the CU split.

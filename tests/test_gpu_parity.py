@@ -1017,6 +1017,46 @@ def test_gemm_row_major(gpu, dtype, tr, M, K, N, mats):
         assert (err <= tol).all(), f"row-major gemm tr={tr} mat {t}: worst err/tol {(err / tol).max():.3g}"
 
 
+@pytest.mark.parametrize("M,K,N,mats,pad", [(256, 256, 256, 1, 0), (264, 320, 520, 2, 8), (1024, 1024, 768, 1, 0), (2048, 512, 4096, 1, 16), (8, 256, 8, 3, 0),
+                                            (2304, 2048, 1280, 1, 0)])
+def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M, K, N, mats, pad):
+    """Row-major GemmTr of f16 operands (shape.wgsl:49-57, gemm.wgsl:115-148): the kernel that takes m1 where it lies (gemm_f16_nt.hip: both operands
+    contiguous along their output dimension, no scratch) against the transposed-copy path of round 5 -- the same k order and accumulation chains, so the
+    bits must agree -- and against f64. Strided row-major views with an offset, batches, ragged tiles (M, N not multiples of 256), the shortest K."""
+    wg = _wg()
+    rng = np.random.default_rng(M + 3 * K + 5 * N + mats)
+    sa, sb, sc = M + pad, N + pad, N + 2 * pad                     # row strides of m1 (K x M), m2 (K x N), out (M x N)
+    off = 8 * pad                                                  # (multiples of 8 elements: 16-byte alignment is the kernels' fast-path condition)
+    a = (rng.random((mats, K, sa), dtype=np.float32) * 2 - 1).astype(np.float16)
+    b = (rng.random((mats, K, sb), dtype=np.float32) * 2 - 1).astype(np.float16)
+    ta = upload(gpu, (off + a.size,), np.concatenate([np.zeros(off, np.float16), a.reshape(-1)]), np.float16)
+    tb = upload(gpu, (off + b.size,), np.concatenate([np.zeros(off, np.float16), b.reshape(-1)]), np.float16)
+    gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    va = _rm_view(wg, ta, K, M, mats, stride=sa, stride_mat=K * sa, offset=off)
+    vb = _rm_view(wg, tb, K, N, mats, stride=sb, stride_mat=K * sb, offset=off)
+    res = {}
+    for native in (1, 0):
+        tc = upload(gpu, (off + mats * M * sc,), np.full(off + mats * M * sc, np.nan, np.float16), np.float16)
+        vc = _rm_view(wg, tc, M, N, mats, stride=sc, stride_mat=M * sc, offset=off)
+        old = gpu.set_tuning("rm_tr_native", native)
+        try:
+            run_pass(gpu, lambda p: gemm.dispatch_tr(gpu.device(), shapes, p, vc, va, vb))
+        finally:
+            gpu.set_tuning("rm_tr_native", old)
+        res[native] = tc.read(gpu.device())
+    U.assert_bits_equal(res[1], res[0], "row-major GemmTr: native kernel vs transposed copy")
+    full = res[1][off:].reshape(mats, M, sc)
+    assert np.isnan(full[:, :, N:]).all() and np.isnan(res[1][:off]).all(), "elements outside the output view were written"
+    got = full[:, :, :N].astype(np.float64)
+    for t in range(mats):
+        a64, b64 = a[t, :, :M].T.astype(np.float64), b[t, :, :N].astype(np.float64)
+        truth, sabs = a64 @ b64, np.abs(a64) @ np.abs(b64)
+        tol = U.f32_gate(K, sabs) + 2.0 ** -11 * np.abs(truth) + 2.0 ** -25
+        err = np.abs(got[t] - truth)
+        assert (err <= tol).all(), f"row-major GemmTr mat {t}: worst err/tol {(err / tol).max():.3g}"
+
+
 def test_gemm_row_major_strided_view_and_errors(gpu):
     """A row-major sub-view (row stride > cols, offset) of a larger buffer, and the reference's dimension panic."""
     wg = _wg()

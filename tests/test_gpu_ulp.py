@@ -48,12 +48,12 @@ def _ulps(err, scale, dtype=np.float32):
 
 
 def _record(key, **vals):
-    TABLE[key] = {k: round(float(v), 3) for k, v in vals.items()}
+    TABLE[key] = {k: (round(float(v), 3) if np.isfinite(v) else None) for k, v in vals.items()}  # strict JSON: "not applicable" is null, never a bare NaN
     root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         with open(os.path.join(root, "gpurun_out", "ulp_table.json"), "w") as f:
-            json.dump(TABLE, f, indent=1, sort_keys=True)
+            json.dump(TABLE, f, indent=1, sort_keys=True, allow_nan=False)
     except OSError:
         pass
 

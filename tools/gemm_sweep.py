@@ -1,6 +1,7 @@
 """Gemm / GemmTr over a sweep of shapes (squares, LLM-like projections, few rows / few columns, ragged), f16 and f32, against hipBLASLt / rocBLAS through
 torch.matmul on the SAME memory layout (column-major C = A B is row-major C^T = B^T A^T). GPU time per call from back-to-back launches.
-Usage (GPU box): python tools/gemm_sweep.py [f16|f32] [MxNxK[xB] ...]   (B: a batch of B matrices; torch first: one HIP runtime per process)"""
+Usage (GPU box): python tools/gemm_sweep.py [rm] [f16|f32] [MxNxK[xB] ...]   (B: a batch of B matrices; torch first: one HIP runtime per process)
+`rm`: the ROW-major operator surface instead (wg_gemm_rm on row-major views = torch's own layout: C = A @ B and C = A^T @ B on contiguous tensors)."""
 import os
 import sys
 import time
@@ -22,6 +23,10 @@ SHAPES = [(512, 512, 512), (1024, 1024, 1024), (1536, 1536, 1536), (2048, 2048, 
           (8192, 1024, 8192), (16, 4096, 4096), (64, 4096, 4096), (128, 11008, 4096), (256, 4096, 11008), (4096, 16, 4096), (4096, 64, 4096), (4096, 128, 4096),
           (4104, 4104, 4104), (8200, 8200, 8200), (1000, 1000, 1000), (32768, 1024, 1024), (1024, 32768, 1024), (1024, 1024, 32768)]
 args = sys.argv[1:]
+ROW_MAJOR = bool(args) and args[0] == "rm"
+if ROW_MAJOR:
+    args = args[1:]
+    gemm = wg.Gemm.from_device(dev, wg.row_major_shader_defs())
 dts = [np.float16, np.float32]
 if args and args[0] in ("f16", "f32"):
     dts = [np.float16 if args[0] == "f16" else np.float32]
@@ -60,6 +65,55 @@ def ours(M, N, K, dt, tr, B=1):
     return best
 
 
+def ours_rm(M, N, K, dt, tr, B=1):
+    """Row-major views over plain buffers: m1 (M x K, or K x M for GemmTr), m2 (K x N), out (M x N); index = mat * rows * cols + i * cols + j."""
+    def rm(t, rows, cols):
+        return wg.GpuTensorView(wg.ViewShape([rows, cols, B], cols, rows * cols, 0), t, 3)
+    ta, tb = device_random(wg, gpu, (M * K * B,), dt, 1), device_random(wg, gpu, (K * N * B,), dt, 2)
+    tc = wg.TensorBuilder.tensor((M * N * B,), S.STORAGE).build(dev, dt)
+    va, vb, vc = (rm(ta, K, M) if tr else rm(ta, M, K)), rm(tb, K, N), rm(tc, M, N)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+
+    def run(n):
+        enc = dev.create_command_encoder()
+        p = enc.compute_pass("t", None)
+        for _ in range(n):
+            gemm.dispatch_generic(dev, shapes, p, vc, va, vb, variant)
+        p.end()
+        gpu.queue().submit([enc.finish()])
+        gpu.sync()
+    run(3)
+    n = reps_for(M, N, K * B, dt)
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        run(n)
+        best = min(best, (time.perf_counter() - t0) / n)
+    return best
+
+
+def vendor_rm(M, N, K, dt, tr, B=1):
+    td = torch.float16 if dt == np.float16 else torch.float32
+    a = (torch.rand((B, K, M) if tr else (B, M, K), device="cuda") * 2 - 1).to(td)
+    b = (torch.rand(B, K, N, device="cuda") * 2 - 1).to(td)
+    c = torch.empty(B, M, N, device="cuda", dtype=td)
+    if B == 1:
+        a, b, c = a[0], b[0], c[0]
+    aa = a.transpose(-1, -2) if tr else a
+    for _ in range(3):
+        torch.matmul(aa, b, out=c)
+    torch.cuda.synchronize()
+    n = reps_for(M, N, K * B, dt)
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            torch.matmul(aa, b, out=c)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n)
+    return best
+
+
 def vendor(M, N, K, dt, tr, B=1):
     td = torch.float16 if dt == np.float16 else torch.float32
     bt = (torch.rand(B, N, K, device="cuda") * 2 - 1).to(td)                    # B^T row-major = B column-major (k-contiguous)
@@ -85,6 +139,6 @@ for dt in dts:
     for tr in (False, True):
         for (M, N, K, B) in SHAPES:
             f = 2.0 * M * N * K * B / 1e12
-            to, tv = ours(M, N, K, dt, tr, B), vendor(M, N, K, dt, tr, B)
+            to, tv = (ours_rm(M, N, K, dt, tr, B), vendor_rm(M, N, K, dt, tr, B)) if ROW_MAJOR else (ours(M, N, K, dt, tr, B), vendor(M, N, K, dt, tr, B))
             flag = "  <-- behind" if to > 1.10 * tv else ""
-            print(f"{np.dtype(dt).name} {'gemm_tr' if tr else 'gemm   '} {M}x{N}x{K}{'' if B == 1 else 'x' + str(B)}: ours {to*1e6:9.1f} us {f/to:7.1f} TF | vendor {tv*1e6:9.1f} us {f/tv:7.1f} TF | ours/vendor time {to/tv:5.2f}{flag}", flush=True)
+            print(f"{np.dtype(dt).name} {'rm ' if ROW_MAJOR else ''}{'gemm_tr' if tr else 'gemm   '} {M}x{N}x{K}{'' if B == 1 else 'x' + str(B)}: ours {to*1e6:9.1f} us {f/to:7.1f} TF | vendor {tv*1e6:9.1f} us {f/tv:7.1f} TF | ours/vendor time {to/tv:5.2f}{flag}", flush=True)

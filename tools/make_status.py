@@ -19,6 +19,7 @@ ROWS = [  # (BASELINE config, workload, label, unit key)
     ("C3", "gemmtr_f16_8192", "f16 GemmTr 8192^3", "TFLOP/s"),
     ("C3", "gemm_f16_8192_u01", "f16 Gemm 8192^3, operands U[0,1)", "TFLOP/s"),
     ("C3", "gemmtr_f16_8192_u01", "f16 GemmTr 8192^3, operands U[0,1)", "TFLOP/s"),
+    ("C3", "gemmtr_rm_f16_8192", "f16 GemmTr 8192^3 on ROW-major views (`wg_gemm_rm`: both operands contiguous along their output dimension)", "TFLOP/s"),
     ("C4", "gemv_f32_4096x65536", "Gemv f32 4096 x 65536", "GB/s"),
     ("C4", "gemvtr_f32_65536x4096", "GemvTr f32 65536 x 4096", "GB/s"),
     ("C4", "gemv_f32_4096x65536_rhs8", "Gemv f32 4096 x 65536, 8 right-hand sides", "GB/s"),

@@ -17,15 +17,21 @@ import bench
 import wgmath_amd as wg
 from wgmath_amd.sharded import Comm, GatherMode
 
-N = K = M = 32768
+N = K = M = int(os.environ.get("EMU_SIZE", "32768"))  # (tests run the same sequence of communicators and contexts on a smaller problem)
 Ps = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 STEPS = int(os.environ.get("STEPS", "6"))
-out = {"problem": "f16 32768^3, M-sharded; one rank emulated on one GPU", "steps": STEPS, "ranks": {}}
+out = {"problem": f"f16 {M}^3, M-sharded; one rank emulated on one GPU", "steps": STEPS, "ranks": {}}
+T0 = time.time()
+
+
 def note(*a):
-    print(*a, file=sys.stderr, flush=True)
+    print(f"[{time.time() - T0:7.2f}s]", *a, file=sys.stderr, flush=True)
 
 
+import faulthandler  # noqa: E402
 import signal  # noqa: E402
+# where a run that does not return is standing: every thread's Python stack on stderr shortly before the alarm (the C frame under it is the HIP call that never came back)
+faulthandler.dump_traceback_later(max(5, int(os.environ.get("EMU_TIMEOUT", "600")) - 15), exit=False)
 signal.alarm(int(os.environ.get("EMU_TIMEOUT", "600")))  # a stuck run ends by itself with SIGALRM (round 5: one 3-rank-count run never returned; see r05_evidence.md section 4)
 
 
@@ -37,6 +43,7 @@ for P in Ps:
     A = bench.device_random(wg, gpu, (Mg, K), np.float16, 0xA000)
     B = bench.device_random(wg, gpu, (K, N), np.float16, 0xB000)
     C = wg.TensorBuilder.matrix(M, N, S.STORAGE | S.COPY_SRC | S.COPY_DST).build(dev, np.float16)
+    note("  operands allocated; creating the communicator")
     comm = Comm(gpu, P, 0, None)
     panel = bench.plan_panel_cols(Mg, N, 256)
     res = {"rows_per_rank": Mg, "panel_cols": panel, "panels": -(-N // panel)}
@@ -89,8 +96,10 @@ for P in Ps:
             res[key] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1), "last_panel_bytes_per_peer": last,
                         "one_launch_per_step": one}
     out["ranks"][str(P)] = res
+    note("  closing the communicator")
     comm.close()
     if P > 1:  # the RCCL engine's compute side: 248 of the 256 CUs
+        note("  creating the 248-CU context")
         gpu2 = wg.GpuInstance.new(0, cu_count=248, one_xcd=os.environ.get("WG_BENCH_CU_MASK_SPREAD") != "1")  # as bench.py does for the RCCL engine
         comm2 = Comm(gpu2, P, 0, None)
         prepare_staged(gpu2, comm2)
@@ -104,10 +113,13 @@ for P in Ps:
         dt = staged_side(gpu2, comm2, A, B, C, True, widths)
         res["rccl_compute_side_248_cus_tapered"] = {"ms_per_step": round(dt * 1e3, 3), "tflops_of_this_rank": round(2.0 * Mg * N * K / dt / 1e12, 1),
                                                     "stream_compute_units": 248, "panel_widths": widths}
+        note("  closing the 248-CU communicator and context")
         comm2.close()
         gpu2.close()
     del A, B, C
+    note("  closing the context")
     gpu.close()
+note("[rank_emulation] single-GPU reference run")
 # the best single-GPU run: the plain 32768^3 Gemm (one launch, tile scheduler on) -- what every speed-up below is against
 gpu = wg.GpuInstance.new(0)
 dev, shapes, S = gpu.device(), wg.ViewShapeBuffers(), wg.BufferUsages
@@ -174,4 +186,4 @@ if t1:
                 r["expected_rccl_248_tapered"] = {"ms_per_step": round(tt, 3), "speedup_vs_1_gpu": round(t1 / tt, 3), "exposed_tail_ms": round(tail_t, 3),
                                                   "exposed_tail_ms_uniform_panels_same_timeline": round(tail_u, 3),
                                                   "assumes": "as expected_rccl_248 (plain, not pipelined); the tail from a per-panel timeline: panel p's gather starts when its Gemm and panel p-1's gather are done"}
-print(json.dumps(out, indent=1))
+print(json.dumps(bench.finite(out), indent=1, allow_nan=False))

@@ -18,7 +18,7 @@ WG_GATHER_RCCL, WG_GATHER_NONE, WG_GATHER_PEER_STAGED = 0, 2, 3  # (1 was the SD
 WG_COMM_ID_BYTES, WG_IPC_HANDLE_BYTES = 128, 96
 ABI_VERSION = 4  # == WGEBRA_HIP_ABI_VERSION (checked when the library is loaded, and against the header by tests/test_abi_and_host.py)
 WG_F32, WG_F16 = 0, 1
-WG_TUNE_F16_TILE, WG_TUNE_F16_SCHED, WG_TUNE_F32_SKINNY, WG_TUNE_F32_PANELS, WG_TUNE_F16_BALANCE, WG_TUNE_F32_MID, WG_TUNE_F32_MID_SPLIT, WG_TUNE_GEMVT_LDS, WG_TUNE_F16_CONT = range(9)
+WG_TUNE_F16_TILE, WG_TUNE_F16_SCHED, WG_TUNE_F32_SKINNY, WG_TUNE_F32_PANELS, WG_TUNE_F16_BALANCE, WG_TUNE_F32_MID, WG_TUNE_F32_MID_SPLIT, WG_TUNE_GEMVT_LDS, WG_TUNE_F16_CONT, WG_TUNE_RM_TR_NATIVE = range(10)
 
 
 class ViewShapeC(ctypes.Structure):

@@ -341,9 +341,22 @@ int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out
     if (int rc = check_bounds("Gemm", "m1", a_cm, m1, dtype)) return rc;
     const size_t es = dtype == WG_F32 ? 4 : 2;
     const uint32_t K = a.rows, M = a.cols;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    // f16, from half a round of 256 x 256 tiles on: the kernel that takes m1 where it lies (gemm_f16_nt.hip) -- out^T (N x M) = m2^T (N x K, contiguous along N)
+    // * m1 (K x M, contiguous along M); no scratch, no extra pass over m1. WG_TUNE_RM_TR_NATIVE = 0 forces the copy below (tests compare the two ways), 1 the kernel at any size.
+    if (dtype == WG_F16 && ctx->tuning[WG_TUNE_RM_TR_NATIVE] != 0) {
+        const View o_cm = mk(relabel(out_shape)), b_cm = mk(relabel(m2_shape)); // N x M and N x K column-major
+        const uint64_t tiles = (uint64_t)((o_cm.rows + 255u) / 256u) * ((o_cm.cols + 255u) / 256u) * o_cm.mats;
+        if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] == 1 || 2u * tiles >= (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256)) {
+            if (int rc = check_bounds("Gemm", "m2", b_cm, m2, dtype)) return rc;
+            if (int rc = check_bounds("Gemm", "out", o_cm, out, dtype)) return rc;
+            const wgk_mat A = { elem_ptr(m2, b_cm.offset, dtype), b_cm.stride, b_cm.stride_mat }, B = { elem_ptr(m1, a_cm.offset, dtype), a_cm.stride, a_cm.stride_mat };
+            const int rc = wgk_gemm_f16_nt(ctx, o_cm.rows, o_cm.cols, K, o_cm.mats, (__half *)elem_ptr(out, o_cm.offset, dtype), o_cm.stride, o_cm.stride_mat, A, B);
+            if (rc != WG_ERR_UNSUPPORTED) return rc;
+        }
+    }
     void *ws = nullptr;
     if (int rc = wg_ctx_tr_workspace(ctx, (size_t)K * M * a.mats * es, &ws)) return rc;
-    WG_HIP_TRY(hipSetDevice(ctx->device));
     if (int rc = wgk_transpose(ctx, dtype, M, K, a.mats, elem_ptr(m1, a_cm.offset, dtype), a_cm.stride, a_cm.stride_mat, ws, K, (uint64_t)K * M))
         return rc;
     wg_buf tmp;

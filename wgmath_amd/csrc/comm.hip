@@ -244,9 +244,12 @@ int wait_end(wg_comm *c) {
 
 int run_pending(wg_comm *c) { // the deferred last panel of the previous staged call: wait for its slots, relayout it
     if (!c->pending.on) return WG_OK;
+    const wg_comm::Pending q = c->pending; // (a copy: cleared below once nothing can fail before the wait is enqueued)
+    if (wait_begin(c, q.panel) != WG_OK) { // a diagnostic must not drop the deferred panel: timing off, the wait + relayout still run
+        c->time_waits = false;
+        c->wait_used = 0;
+    }
     c->pending.on = false;
-    const wg_comm::Pending &q = c->pending;
-    if (int rc = wait_begin(c, q.panel)) return rc;
     if (q.after) { // RCCL engine
         WG_HIP_TRY(hipStreamWaitEvent(c->ctx->stream, q.after, 0));
         if (int rc = wait_end(c)) return rc;
@@ -343,16 +346,16 @@ int wg_comm_create(wg_ctx *ctx, int nranks, int rank, const void *id, wg_comm **
 
 int wg_comm_destroy(wg_comm *c) {
     if (!c) return WG_OK;
-    for (auto &w : c->wait_stamps) {
-        if (w.before) (void)hipEventDestroy(w.before);
-        if (w.after) (void)hipEventDestroy(w.after);
-    }
-    c->wait_stamps.clear();
     (void)hipSetDevice(c->ctx->device);
     for (hipStream_t st : c->peer_stream)
         if (st) (void)hipStreamSynchronize(st);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->ctx->stream);
+    for (auto &w : c->wait_stamps) { // (after the streams they were recorded on have drained)
+        if (w.before) (void)hipEventDestroy(w.before);
+        if (w.after) (void)hipEventDestroy(w.after);
+    }
+    c->wait_stamps.clear();
     if (c->nccl) (void)rccl().CommDestroy(c->nccl);
     for (hipEvent_t e : c->ev_panel)
         if (e) (void)hipEventDestroy(e);

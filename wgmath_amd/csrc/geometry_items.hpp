@@ -179,8 +179,10 @@ WGG_FN void raw_item(int op, const float *p, float *o) {
         o[3] = rot2::is_valid(cy) ? 1.f : 0.f;
         Mat3 m3 = load_mat<3>(p + 4);
         Mat4 m4 = load_mat<4>(p + 13);
-        rot2::rotate_rows3(r, m3, (uint32_t)p[29]);
-        rot2::rotate_rows4(r, m4, (uint32_t)p[30]);
+        // the row indices come straight from caller data: only 0 .. N - 2 name two rows of the matrix (negative, NaN or larger values -- whose cast would be
+        // undefined, and whose use an out-of-bounds write on the thread-local matrix -- leave it as it is; the reference's WGSL is memory-safe there)
+        if (p[29] >= 0.f && p[29] < 2.f) rot2::rotate_rows3(r, m3, (uint32_t)p[29]);
+        if (p[30] >= 0.f && p[30] < 3.f) rot2::rotate_rows4(r, m4, (uint32_t)p[30]);
         store_mat<3>(o + 4, m3);
         store_mat<4>(o + 13, m4);
     } else if (op == OP_EIGVALS2) { // in: a 2 x 2 symmetric matrix;  out: eig2::eigenvalues

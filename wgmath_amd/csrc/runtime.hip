@@ -149,7 +149,7 @@ static int ctx_create_common(int device, hipStream_t stream, bool owns, wg_ctx *
     static const struct { const char *env; wg_tuning key; } knobs[] = {
         { "WG_F16_TILE", WG_TUNE_F16_TILE }, { "WG_F16_SCHED", WG_TUNE_F16_SCHED }, { "WG_F32_SKINNY", WG_TUNE_F32_SKINNY },
         { "WG_F32_PANELS", WG_TUNE_F32_PANELS }, { "WG_F16_BALANCE", WG_TUNE_F16_BALANCE }, { "WG_F32_MID", WG_TUNE_F32_MID }, { "WG_F32_MID_SPLIT", WG_TUNE_F32_MID_SPLIT },
-        { "WG_GEMVT_LDS", WG_TUNE_GEMVT_LDS }, { "WG_F16_CONT", WG_TUNE_F16_CONT } };
+        { "WG_GEMVT_LDS", WG_TUNE_GEMVT_LDS }, { "WG_F16_CONT", WG_TUNE_F16_CONT }, { "WG_RM_TR_NATIVE", WG_TUNE_RM_TR_NATIVE } };
     for (const auto &k : knobs)
         if (const char *v = getenv(k.env)) {
             // the same validation as wg_ctx_set_tuning: a value the knob does not take is ignored (with a note), never silently reinterpreted
@@ -512,7 +512,17 @@ int wg_queue_submit(wg_ctx *ctx, wg_cmdbuf *cmdbuf) {
 
 int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf) {
     if (!cmdbuf) return WG_OK;
-    if (wg_defer_if_capturing([cmdbuf] { (void)wg_cmdbuf_destroy(cmdbuf); })) return WG_OK;
+    if (t_capturing != 0 && t_batch) {
+        // Queued into the batch of the recording(s) open on this thread. Should this command buffer itself hold that very batch (begin A, begin B, finish A -> X,
+        // destroy X while B still records), the batch would hold the closure that destroys X and X the batch: a cycle nothing ever runs. So X's own reference moves
+        // into the closure's capture list and is released there, after the destroy it guards.
+        std::shared_ptr<wg_deferred_batch> own = std::move(cmdbuf->deferred);
+        cmdbuf->deferred.reset();
+        wg_deferred_batch *batch = t_batch.get();
+        if (own.get() == batch) own.reset(); // (the batch it is queued into: its lifetime is that of the queue itself)
+        batch->items.push_back([cmdbuf, own]() mutable { (void)wg_cmdbuf_destroy(cmdbuf); own.reset(); });
+        return WG_OK;
+    }
     (void)hipSetDevice(cmdbuf->ctx->device);
     (void)hipStreamSynchronize(cmdbuf->ctx->stream);
     if (cmdbuf->exec) (void)hipGraphExecDestroy(cmdbuf->exec);

@@ -60,7 +60,7 @@ struct wg_ctx {
         void *scratch = nullptr;            // raw f32 accumulator tiles of the prefix units (grow-only)
         size_t scratch_bytes = 0;
     } bal;
-    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0, 0, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
+    int tuning[WG_TUNE_COUNT_] = { 0, -1, -1, -1, 0, -1, 0, 0, -1, -1 }; // wg_ctx_set_tuning; defaults read from the environment once, at creation
     void *debug_stamps = nullptr;        // pinned: the two stamp arrays of wg_debug_clock_begin / _end (debug.hip)
     bool debug_clock_open = false;
     uint32_t lds_attr_bits = 0;          // likewise for gemv_t_lds_kernel's instantiations (3 right-hand-side tiles x 5 workgroup shapes)
@@ -193,6 +193,10 @@ static inline uint32_t wgk_panel_goal(uint32_t M, uint32_t np) { return 4u * ((M
 int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
                  __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat m1, wgk_mat m2, float alpha = 1.f, float beta = 0.f,
                  const wgk_panels *panels = nullptr);
+// gemm_f16_nt.hip: out (M x N, column-major) = a (M x K, m-contiguous: ld between k) * b (K x N, N-CONTIGUOUS: element (k, n) at n + k * ld) -- the row-major GemmTr in
+// column-major terms. WG_ERR_UNSUPPORTED without a message: not a product that kernel takes (the caller transposes `b` and calls wgk_gemm_f16).
+int wgk_gemm_f16_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat a_mcontig, wgk_mat b_ncontig,
+                    float alpha = 1.f, float beta = 0.f);
 
 // The f16 product out_rows (M x N) = op(m1) m2 as ONE launch over N-panels with completion flags (api.hip; the operator front-end's checks
 // on m1 / m2, then wgk_gemm_f16 with `panels`). WG_ERR_UNSUPPORTED without a message: not that kind of product, launch panel by panel.

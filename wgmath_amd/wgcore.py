@@ -333,7 +333,7 @@ class GpuInstance:
         self._ctx.close()
 
     _TUNING = {"f16_tile": _lib.WG_TUNE_F16_TILE, "f16_sched": _lib.WG_TUNE_F16_SCHED, "f32_skinny": _lib.WG_TUNE_F32_SKINNY,
-               "f32_panels": _lib.WG_TUNE_F32_PANELS, "f16_balance": _lib.WG_TUNE_F16_BALANCE, "f32_mid": _lib.WG_TUNE_F32_MID, "f32_mid_split": _lib.WG_TUNE_F32_MID_SPLIT, "gemvt_lds": _lib.WG_TUNE_GEMVT_LDS, "f16_cont": _lib.WG_TUNE_F16_CONT}
+               "f32_panels": _lib.WG_TUNE_F32_PANELS, "f16_balance": _lib.WG_TUNE_F16_BALANCE, "f32_mid": _lib.WG_TUNE_F32_MID, "f32_mid_split": _lib.WG_TUNE_F32_MID_SPLIT, "gemvt_lds": _lib.WG_TUNE_GEMVT_LDS, "f16_cont": _lib.WG_TUNE_F16_CONT, "rm_tr_native": _lib.WG_TUNE_RM_TR_NATIVE}
 
     def set_tuning(self, knob: str, value: int) -> int:
         """wg_ctx_set_tuning: force a kernel-family choice for later calls on this context (tests / experiments); returns the old value."""
