@@ -43,6 +43,35 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def box_facts() -> dict:
+    """What tells one box of the pool from another WITHOUT touching the GPU: the first GPU node of the KFD topology (firmware / SDMA firmware versions, the chip's
+    unique id, its maximum engine clock) and the kernel driver's version. The replayed config-1 figure falls into two populations across boxes (2.6 vs 3.5 us,
+    STATUS.md): these are the fields to hold it against."""
+    out = {}
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for n in sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30):
+            props = {}
+            with open(os.path.join(base, n, "properties")) as f:
+                for ln in f:
+                    k, _, v = ln.strip().partition(" ")
+                    props[k] = v
+            if int(props.get("simd_count", "0")) > 0:  # a GPU node
+                for k in ("fw_version", "sdma_fw_version", "unique_id", "max_engine_clk_fcompute", "gfx_target_version", "num_xcc"):
+                    if k in props:
+                        out["kfd_" + k] = int(props[k]) if props[k].lstrip("-").isdigit() else props[k]
+                break
+    except (OSError, ValueError):
+        pass
+    for path, key in (("/sys/module/amdgpu/version", "amdgpu_version"), ("/proc/sys/kernel/osrelease", "kernel")):
+        try:
+            with open(path) as f:
+                out[key] = f.read().strip()
+        except OSError:
+            pass
+    return out
+
+
 # The driver keeps and parses the LAST stdout line; round 5's 25 KB line (27 workloads' full objects under "others") came back unparsed.
 # The line is therefore compact -- the contract's keys, `config` with the flat C1-C5 scalars, `roofline`, `cpu_baseline`, `checks`, `targets` --
 # and everything bulky ("others", the per-rank arrays of "ranks_detail" when they are long) goes to a sidecar file (--detail) and to stderr.
@@ -1559,7 +1588,7 @@ def main():
             "scaling": "strong" if w_is_gemm else "weak", "vs_baseline": None, "dtype": w_dtype,
             "data": f"synthetic (seeded {'U[0,1)' if VALUES == 'u01' else 'zeros' if VALUES == 'zero' else 'U[-1,1)'}: one 16 Mi-element random block tiled over each operand, resident in HBM "
                     "before the timed region; *_u01 workloads: U[0,1), the reference's new_random)",
-            "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra),
+            "config": dict({"workload": w_name, "device": info["name"], "compute_units": info["compute_units"], "parallelism": par}, **cfg_extra, **box_facts()),
             "roofline": roof, "cpu_baseline": main_cpu, "checks": checks, "ranks_detail": rank_detail, "others": others,
             "targets": targets,  # LAST key, scalars only: BASELINE configs 1-5 at a glance (value, fraction of the 8 TB/s / 2.5 PF / 157.3 TF peak, measured clock)
         }

@@ -19,6 +19,9 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4v __attribute__((ext_vector_type(4)));
+#ifndef WG_SKINNY_SWZ
+#define WG_SKINNY_SWZ 1 // Gemm (column-major A): the [32 k][32 m] stage image with its 16-byte chunks permuted so that the MFMA operand reads are bank-conflict-free (round 6; 0: A/B builds)
+#endif
 #ifndef WG_SKINNY_W16
 #define WG_SKINNY_W16 1 // N <= 16 on v_mfma_f32_16x16x4_f32 (two 16-row sub-tiles per wave) instead of 32x32x2 with half of its columns padding (0: A/B builds)
 #endif
@@ -123,9 +126,15 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             a_voff[q] = rel + 16u * chunk + (TR_BIAS - 1024u * q);
             a_tail[q] = rel + ES * min(CK * chunk, kmax) + (TR_BIAS - 1024u * q);
         } else { // column-major A: piece q = k rows 8 q .. 8 q + 7 of the stage, the wave's 32 rows = one 128-byte line each: image [32 k][32 m]
-            const uint32_t m = min(r0 + 4u * (lane & 7u), g.M - 4u) - min(r0, g.M - 4u); // M % 4 == 0
-            a_voff[q] = (rl * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
-            a_tail[q] = (min(rl, kmax + 3u) * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
+            // Bank conflicts (round 5's counters: 4.1 M per launch at 32000 x 16 x 4096): an operand read takes ONE float per lane at k = 4 c + s, and rows 4 (or 8, 12) k
+            // apart start on the same bank -- the four lane groups of the 16-wide form met on 16 banks (4-way), the two half-waves of the 32-wide form on 32 (2-way).
+            // A DMA lane may fetch any 16-byte chunk, so the image is permuted instead: logical (k, chunk c = m / 4) sits at row (k & 7) ^ ((k >> 2) & 1) of its piece,
+            // chunk position c ^ 4 ((k >> 3) & 1) -- rows 4 apart land on opposite bank halves, rows 8 apart on opposite halves of the row (the reads: `compute`).
+            const uint32_t kr = WG_SKINNY_SWZ ? 8u * q + ((lane >> 3) ^ ((lane >> 5) & 1u)) : rl;
+            const uint32_t ch = WG_SKINNY_SWZ ? (lane & 7u) ^ (4u * ((uint32_t)q & 1u)) : (lane & 7u);
+            const uint32_t m = min(r0 + 4u * ch, g.M - 4u) - min(r0, g.M - 4u); // M % 4 == 0
+            a_voff[q] = (kr * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
+            a_tail[q] = (min(kr, kmax + 3u) * g.lda + m) * 4u + (TR_BIAS - 1024u * q);
         }
     }
 #pragma unroll
@@ -223,7 +232,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
                 for (int t = 0; t < 2; ++t) {
                     const uint32_t row = 16u * t + (uint32_t)i16;
                     if constexpr (TRANS_A) af[t] = *reinterpret_cast<const float4 *>(sl + row * 128u + ((c ^ ((row >> 1) & 7u)) * 16u));
-                    else {
+                    else if constexpr (WG_SKINNY_SWZ) { // k = 4 c + s sits at row 4 c + (s ^ (c & 1)), m at m ^ 16 ((c >> 1) & 1): (c & 1, (c >> 1) & 1) = (kq & 1, kq >> 1), per lane
+                        const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + (row ^ (16u * (((uint32_t)kq >> 1) & 1u)));
+                        const float r0_ = ak[0], r1_ = ak[32], r2_ = ak[64], r3_ = ak[96];
+                        const bool odd = (kq & 1) != 0;
+                        af[t] = make_float4(odd ? r1_ : r0_, odd ? r0_ : r1_, odd ? r3_ : r2_, odd ? r2_ : r3_);
+                    } else {
                         const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + row;
                         af[t] = make_float4(ak[0], ak[32], ak[64], ak[96]);
                     }
@@ -254,7 +268,12 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             const uint32_t c = 2u * ks + h;
             float4 af;
             if constexpr (TRANS_A) af = *reinterpret_cast<const float4 *>(sl + rd + ((c ^ sw) * 16u));
-            else { // [k][32 m]: k = 4 c + s, one float per MFMA (lanes i consecutive: conflict-free)
+            else if constexpr (WG_SKINNY_SWZ) { // [k][32 m], permuted (see the DMA offsets): c = 2 ks + h, so row 4 c + (s ^ h) and m ^ 16 (ks & 1)
+                const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + ((uint32_t)i ^ (16u * ((uint32_t)ks & 1u)));
+                const float r0_ = ak[0], r1_ = ak[32], r2_ = ak[64], r3_ = ak[96];
+                const bool odd = h != 0;
+                af = make_float4(odd ? r1_ : r0_, odd ? r0_ : r1_, odd ? r3_ : r2_, odd ? r2_ : r3_);
+            } else { // [k][32 m]: k = 4 c + s, one float per MFMA
                 const float *ak = reinterpret_cast<const float *>(sl + (4u * c) * 128u) + i;
                 af = make_float4(ak[0], ak[32], ak[64], ak[96]);
             }
