@@ -20,7 +20,10 @@ namespace {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4v __attribute__((ext_vector_type(4)));
 #ifndef WG_SKINNY_SWZ
-#define WG_SKINNY_SWZ 1 // Gemm (column-major A): the [32 k][32 m] stage image with its 16-byte chunks permuted so that the MFMA operand reads are bank-conflict-free (round 6; 0: A/B builds)
+#define WG_SKINNY_SWZ 0 // 1: Gemm (column-major A): the [32 k][32 m] stage image with its 16-byte chunks permuted so that the MFMA operand reads are bank-conflict-free.
+                        // Built and measured in round 6 (profiles/r06_skinny_swz_ab.txt): correct, the conflicts are gone -- and the kernel is SLOWER (32000 x 16 x 4096
+                        // 6430 -> 6350 GB/s, 16384 x 32 x 4096 51 -> 61 us): this kernel is bound by the HBM stream, its LDS has time to spare for a 4-way conflict, and
+                        // the per-lane selects that undo the row swap make every MFMA wait for all four reads of its operand. Off; kept as the A/B build.
 #endif
 #ifndef WG_SKINNY_W16
 #define WG_SKINNY_W16 1 // N <= 16 on v_mfma_f32_16x16x4_f32 (two 16-row sub-tiles per wave) instead of 32x32x2 with half of its columns padding (0: A/B builds)
