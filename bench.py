@@ -791,11 +791,11 @@ DIST_SECONDARY = [("gemv_f32_4096x65536", 2000), ("gemvtr_f32_65536x4096", 2000)
 
 
 def _pmc_row(workload: str):
-    """The workload's row of the tracked counter summary: profiles/r05_pmc.csv (tools/pmc.sh: ONE rocprofv3 run per workload, separate
+    """The workload's row of the tracked counter summary: profiles/r06_pmc.csv (tools/pmc.sh: ONE rocprofv3 run per workload, separate
     --pmc passes, --kernel-trace only), else the previous round's. Static, measured on the builder's box -- every field taken from it
     carries `_profiled` in its name (or says so in `traffic_source`)."""
     import csv
-    for fn in ("r05_pmc.csv", "r04_pmc.csv", "r03_pmc.csv", "r02_pmc.csv"):
+    for fn in ("r06_pmc.csv", "r05_pmc.csv", "r04_pmc.csv", "r03_pmc.csv", "r02_pmc.csv"):
         path = os.path.join(ROOT, "profiles", fn)
         try:
             with open(path) as f:

@@ -2,7 +2,7 @@
 # The round's judged artefacts in one GPU job: kernel-trace stats of the default bench + the plain bench line (tools/make_profiles.sh),
 # the per-workload counter passes (tools/pmc.sh), the rank emulation. Copy gpurun_out/profiles_new/*, gpurun_out/pmc_$R/${R}_pmc.csv and
 # gpurun_out/${R}_rank_emulation.json into profiles/ afterwards.
-export R=${R:-r05}
+export R=${R:-r06}
 cd $GRAFT_REPO_ROOT
 bash tools/make_profiles.sh > gpurun_out/make_profiles.log 2>&1
 timeout 1800 bash tools/pmc.sh > gpurun_out/pmc_$R.log 2>&1

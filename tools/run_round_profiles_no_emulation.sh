@@ -1,4 +1,4 @@
-export R=r05
+export R=${R:-r06}
 cd $GRAFT_REPO_ROOT
 bash tools/make_profiles.sh > gpurun_out/make_profiles.log 2>&1
 timeout 2400 bash tools/pmc.sh > gpurun_out/pmc_$R.log 2>&1
