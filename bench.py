@@ -44,31 +44,32 @@ def log(*a):
 
 
 def box_facts() -> dict:
-    """What tells one box of the pool from another WITHOUT touching the GPU: the first GPU node of the KFD topology (firmware / SDMA firmware versions, the chip's
-    unique id, its maximum engine clock) and the kernel driver's version. The replayed config-1 figure falls into two populations across boxes (2.6 vs 3.5 us,
+    """What tells one box of the pool from another WITHOUT touching the GPU: the first amdgpu card in sysfs that reports a chip id (its unique id, VBIOS, and the
+    MEC / SDMA / SMC / RLC firmware versions) and the kernel's release. The replayed config-1 figure falls into two populations across boxes (2.6 vs 3.5 us,
     STATUS.md): these are the fields to hold it against."""
     out = {}
     try:
-        base = "/sys/class/kfd/kfd/topology/nodes"
-        for n in sorted(os.listdir(base), key=lambda x: int(x) if x.isdigit() else 1 << 30):
-            props = {}
-            with open(os.path.join(base, n, "properties")) as f:
-                for ln in f:
-                    k, _, v = ln.strip().partition(" ")
-                    props[k] = v
-            if int(props.get("simd_count", "0")) > 0:  # a GPU node
-                for k in ("fw_version", "sdma_fw_version", "unique_id", "max_engine_clk_fcompute", "gfx_target_version", "num_xcc"):
-                    if k in props:
-                        out["kfd_" + k] = int(props[k]) if props[k].lstrip("-").isdigit() else props[k]
-                break
-    except (OSError, ValueError):
+        base = "/sys/class/drm"
+        cards = sorted((c for c in os.listdir(base) if c.startswith("card") and c[4:].isdigit()), key=lambda c: int(c[4:]))
+        for c in cards:
+            dev = os.path.join(base, c, "device")
+            if not os.path.exists(os.path.join(dev, "unique_id")):
+                continue
+            for name, key in (("unique_id", "chip_id"), ("vbios_version", "vbios"), ("fw_version/mec_fw_version", "fw_mec"), ("fw_version/sdma_fw_version", "fw_sdma"),
+                              ("fw_version/smc_fw_version", "fw_smc"), ("fw_version/rlc_fw_version", "fw_rlc")):
+                try:
+                    with open(os.path.join(dev, name)) as f:
+                        out[key] = f.read().strip()
+                except OSError:
+                    pass
+            break
+    except OSError:
         pass
-    for path, key in (("/sys/module/amdgpu/version", "amdgpu_version"), ("/proc/sys/kernel/osrelease", "kernel")):
-        try:
-            with open(path) as f:
-                out[key] = f.read().strip()
-        except OSError:
-            pass
+    try:
+        with open("/proc/sys/kernel/osrelease") as f:
+            out["kernel"] = f.read().strip()
+    except OSError:
+        pass
     return out
 
 

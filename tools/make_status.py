@@ -109,8 +109,8 @@ def main():
         ceil = ln["targets"].get("mfma_only_ceiling_tflops")
         print(f"* `{f}`: {c.get('device', '?')}, {c.get('compute_units', '?')} CUs; MFMA-only ceiling {ceil} TFLOP/s at "
               f"{ln['targets'].get('mfma_only_ceiling_ghz')} GHz; headline `{c['workload']}` {ln['value']:.1f} {ln['unit']}"
-              + (f"; box: firmware {c.get('kfd_fw_version')}, SDMA firmware {c.get('kfd_sdma_fw_version')}, chip id {c.get('kfd_unique_id')}, driver {c.get('amdgpu_version', c.get('kernel'))}"
-                 if "kfd_fw_version" in c else ""))
+              + (f"; box: chip id {c.get('chip_id')}, VBIOS {c.get('vbios')}, firmware MEC {c.get('fw_mec')} / SDMA {c.get('fw_sdma')} / SMC {c.get('fw_smc')}, kernel {c.get('kernel')}"
+                 if "chip_id" in c else ""))
     legend = [("before_w16", "before the few-column f32 kernel got its 16-wide MFMA form (few-column row 0.69-0.70 there)"),
               ("before_walk", "before the continuous tile walk (f16 8192^3 and the K = 1024 rows on the per-tile launch there)"),
               ("before_nt", "before the non-temporal hint on the few-column kernel's streamed pieces (few-column row 0.73-0.74 there)")]
