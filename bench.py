@@ -472,6 +472,8 @@ class RowMajorGemmWorkload(GemmWorkload):
         super().__init__(name, M, N, K, dtype, trans=trans)
         if dtype == "f16" and trans:
             self.kernel = "gemm_f16_nt_kernel"
+        if dtype == "f32" and trans:
+            self.kernel = "gemm_f32_kernel"  # <false, true>: the n-contiguous-B tile bodies
 
     def setup(self, wg, gpu, rank, world):
         if world != 1 or (DIST is not None and DIST.get("comm") is not None):

@@ -1017,6 +1017,51 @@ def test_gemm_row_major(gpu, dtype, tr, M, K, N, mats):
         assert (err <= tol).all(), f"row-major gemm tr={tr} mat {t}: worst err/tol {(err / tol).max():.3g}"
 
 
+@pytest.mark.parametrize("M,K,N,mats,pad", [(4096, 1024, 4096, 1, 0), (4100, 264, 4104, 1, 4), (2048, 528, 2304, 2, 8), (260, 72, 132, 3, 0)])
+def test_gemm_tr_row_major_f32_native_kernel_matches_the_transposed_copy(gpu, M, K, N, mats, pad):
+    """The same for f32 (gemm_f32.hip's B_NC tile bodies: m2 of the column-major product contiguous along N): bit-identical to the transposed copy + the 256 x 128
+    tile kernel wherever that path runs the same unsplit tiles (forced here: no mid-size family, no few-column kernel), and inside the f64 gate everywhere.
+    Ragged tiles (the register-staged edge path), a K that is not a multiple of 16 (the remainder tile), strided views with an offset, batches."""
+    wg = _wg()
+    rng = np.random.default_rng(2 * M + 3 * K + 5 * N + mats)
+    sa, sb, sc = M + pad, N + pad, N + 2 * pad
+    off = 4 * pad
+    a = rng.random((mats, K, sa), dtype=np.float32) * 2 - 1
+    b = rng.random((mats, K, sb), dtype=np.float32) * 2 - 1
+    ta = upload(gpu, (off + a.size,), np.concatenate([np.zeros(off, np.float32), a.reshape(-1)]))
+    tb = upload(gpu, (off + b.size,), np.concatenate([np.zeros(off, np.float32), b.reshape(-1)]))
+    gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+    shapes = wg.ViewShapeBuffers()
+    va = _rm_view(wg, ta, K, M, mats, stride=sa, stride_mat=K * sa, offset=off)
+    vb = _rm_view(wg, tb, K, N, mats, stride=sb, stride_mat=K * sb, offset=off)
+    res = {}
+    olds = {k: gpu.set_tuning(k, 0) for k in ("f32_mid", "f32_skinny", "f32_panels")}  # the copy path on the big tile too: the same accumulation chains
+    try:
+        for native in (1, 0):
+            tc = upload(gpu, (off + mats * M * sc,), np.full(off + mats * M * sc, np.nan, np.float32))
+            vc = _rm_view(wg, tc, M, N, mats, stride=sc, stride_mat=M * sc, offset=off)
+            old = gpu.set_tuning("rm_tr_native", native)
+            try:
+                run_pass(gpu, lambda p: gemm.dispatch_tr(gpu.device(), shapes, p, vc, va, vb))
+            finally:
+                gpu.set_tuning("rm_tr_native", old)
+            res[native] = tc.read(gpu.device())
+    finally:
+        for k, v in olds.items():
+            gpu.set_tuning(k, v)
+    full = res[1][off:].reshape(mats, M, sc)
+    assert np.isnan(full[:, :, N:]).all() and np.isnan(res[1][:off]).all(), "elements outside the output view were written"
+    got = full[:, :, :N].astype(np.float64)
+    for t in range(mats):
+        a64, b64 = a[t, :, :M].T.astype(np.float64), b[t, :, :N].astype(np.float64)
+        truth, sabs = a64 @ b64, np.abs(a64) @ np.abs(b64)
+        err = np.abs(got[t] - truth)
+        assert (err <= U.f32_gate(K, sabs)).all(), f"row-major f32 GemmTr mat {t}: worst err/tol {(err / U.f32_gate(K, sabs)).max():.3g}"
+    tiles = (M + 255) // 256 * ((N + 127) // 128) * mats  # (output^T is N x M: 256 x 128 tiles of it; the count is symmetric enough for this purpose)
+    if ((N + 255) // 256 * ((M + 127) // 128) * mats) % 256 == 0 and tiles >= 256:  # whole rounds: the copy path's launcher cuts no K either (no tail split)
+        U.assert_bits_equal(res[1], res[0], "row-major f32 GemmTr: native kernel vs transposed copy")
+
+
 @pytest.mark.parametrize("M,K,N,mats,pad", [(256, 256, 256, 1, 0), (264, 320, 520, 2, 8), (1024, 1024, 768, 1, 0), (2048, 512, 4096, 1, 16), (8, 256, 8, 3, 0),
                                             (2304, 2048, 1280, 1, 0)])
 def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M, K, N, mats, pad):

@@ -342,16 +342,22 @@ int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out
     const size_t es = dtype == WG_F32 ? 4 : 2;
     const uint32_t K = a.rows, M = a.cols;
     WG_HIP_TRY(hipSetDevice(ctx->device));
-    // f16, from half a round of 256 x 256 tiles on: the kernel that takes m1 where it lies (gemm_f16_nt.hip) -- out^T (N x M) = m2^T (N x K, contiguous along N)
-    // * m1 (K x M, contiguous along M); no scratch, no extra pass over m1. WG_TUNE_RM_TR_NATIVE = 0 forces the copy below (tests compare the two ways), 1 the kernel at any size.
-    if (dtype == WG_F16 && ctx->tuning[WG_TUNE_RM_TR_NATIVE] != 0) {
+    // From about a round of tiles on: the kernels that take m1 where it lies (gemm_f16_nt.hip; gemm_f32.hip's B_NC tile bodies) -- out^T (N x M) = m2^T (N x K,
+    // contiguous along N) * m1 (K x M, contiguous along M); no scratch, no extra pass over m1. WG_TUNE_RM_TR_NATIVE = 0 forces the copy below (tests compare the
+    // two ways), 1 the kernels at any size.
+    if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] != 0) {
         const View o_cm = mk(relabel(out_shape)), b_cm = mk(relabel(m2_shape)); // N x M and N x K column-major
-        const uint64_t tiles = (uint64_t)((o_cm.rows + 255u) / 256u) * ((o_cm.cols + 255u) / 256u) * o_cm.mats;
-        if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] == 1 || 2u * tiles >= (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256)) {
+        const uint32_t tile_n = dtype == WG_F16 ? 256u : 128u;                   // 256 x 256 (f16) / 256 x 128 (f32) tiles
+        const uint64_t tiles = (uint64_t)((o_cm.rows + 255u) / 256u) * ((o_cm.cols + tile_n - 1u) / tile_n) * o_cm.mats;
+        const uint64_t cus = (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+        // (f32: the copy path's launcher cuts K / takes small tiles below a round of big tiles, which this launch does not: only from a full round on)
+        if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] == 1 || (dtype == WG_F16 ? 2u * tiles >= cus : tiles >= cus)) {
             if (int rc = check_bounds("Gemm", "m2", b_cm, m2, dtype)) return rc;
             if (int rc = check_bounds("Gemm", "out", o_cm, out, dtype)) return rc;
             const wgk_mat A = { elem_ptr(m2, b_cm.offset, dtype), b_cm.stride, b_cm.stride_mat }, B = { elem_ptr(m1, a_cm.offset, dtype), a_cm.stride, a_cm.stride_mat };
-            const int rc = wgk_gemm_f16_nt(ctx, o_cm.rows, o_cm.cols, K, o_cm.mats, (__half *)elem_ptr(out, o_cm.offset, dtype), o_cm.stride, o_cm.stride_mat, A, B);
+            void *o = (void *)elem_ptr(out, o_cm.offset, dtype);
+            const int rc = dtype == WG_F16 ? wgk_gemm_f16_nt(ctx, o_cm.rows, o_cm.cols, K, o_cm.mats, (__half *)o, o_cm.stride, o_cm.stride_mat, A, B)
+                                           : wgk_gemm_f32_nt(ctx, o_cm.rows, o_cm.cols, K, o_cm.mats, (float *)o, o_cm.stride, o_cm.stride_mat, A, B);
             if (rc != WG_ERR_UNSUPPORTED) return rc;
         }
     }

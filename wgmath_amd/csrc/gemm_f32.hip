@@ -101,9 +101,14 @@ __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, uint32_t
 //                                      | slots 8-13: LDS reads of tile t+1's substep-0 fragments -> set 0
 // so no LDS latency is exposed at a tile boundary and the barrier sits in the middle of a run of MFMAs.
 // EDGE = false: interior tiles, no predication (no branches in the loop).
-template <bool TRANS_A, bool EDGE>
+// B_NC (round 6, Gemm only): m2 is given contiguous along N -- element (k, n) at b + n + k * ldb -- which is what the ROW-major GemmTr is in column-major terms
+// (api.hip wg_gemm_rm; shape.wgsl:49-57). Its tile is staged as Bs[16 k][128 n], the global layout, like Gemm's A; a lane reads the float2 of columns 2 i, 2 i + 1
+// at one k, whose two components feed the two N-tiles of its wave: N-tile u holds columns {2 i + u}, undone in the epilogue's column index. The k of every MFMA is
+// the one the k-contiguous form uses, so the result is bit-identical to transposing m2 first.
+template <bool TRANS_A, bool EDGE, bool B_NC = false>
 __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, float *Bs, const float *A, const float *B, float *C,
                                               uint32_t m0, uint32_t n0) {
+    static_assert(!(B_NC && TRANS_A), "n-contiguous m2: Gemm only");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -145,6 +150,10 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, floa
                 const uint32_t m = m0 + (f >> 2), k = k0 + 4u * (f & 3);
                 ldg(ra[r], A + (uint64_t)m * g.lda + k, m < g.M && k < g.K);
             }
+        } else if constexpr (B_NC) { // B[k][n] at b + k*ldb + n : float4 along n, 32 per k row
+            const int f = tid + kThreads * (r - 4);
+            const uint32_t n = n0 + 4u * (f & 31), k = k0 + (f >> 5);
+            ldg(rb[r - 4], B + (uint64_t)k * g.ldb + n, n < g.N && k < g.K);
         } else {
             const int f = tid + kThreads * (r - 4);
             const uint32_t n = n0 + (f >> 2), k = k0 + 4u * (f & 3);
@@ -161,6 +170,9 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, floa
                 const int mm = f >> 2, ch = f & 3;
                 *reinterpret_cast<wg_f4 *>(&As[buf * A_TILE + mm * BK + 4 * (ch ^ ((mm >> 2) & 3))]) = ra[r];
             }
+        } else if constexpr (B_NC) {
+            const int f = tid + kThreads * (r - 4);
+            *reinterpret_cast<wg_f4 *>(&Bs[buf * B_TILE + (f >> 5) * BN + 4 * (f & 31)]) = rb[r - 4];
         } else {
             const int f = tid + kThreads * (r - 4);
             const int nn = f >> 2, ch = f & 3;
@@ -178,6 +190,11 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, floa
                 const int mm = wm * 128 + 32 * r + i;
                 af[set][r] = *reinterpret_cast<const float4 *>(&As[buf * A_TILE + mm * BK + 4 * (chunk ^ ((mm >> 2) & 3))]);
             }
+        } else if constexpr (B_NC) { // read r - 4 takes k = 4 chunk + 2 (r - 4) and + 1: columns 2 i, 2 i + 1 -> component s of bf[0] / bf[1]
+            const float *bk = &Bs[buf * B_TILE + (4 * chunk + 2 * (r - 4)) * BN + wn * 64 + 2 * i];
+            const float2 b0 = *reinterpret_cast<const float2 *>(bk), b1 = *reinterpret_cast<const float2 *>(bk + BN);
+            if (r == 4) { bf[set][0].x = b0.x; bf[set][1].x = b0.y; bf[set][0].y = b1.x; bf[set][1].y = b1.y; }
+            else { bf[set][0].z = b0.x; bf[set][1].z = b0.y; bf[set][0].w = b1.x; bf[set][1].w = b1.y; }
         } else {
             const int nn = wn * 64 + 32 * (r - 4) + i;
             bf[set][r - 4] = *reinterpret_cast<const float4 *>(&Bs[buf * B_TILE + nn * BK + 4 * (chunk ^ ((nn >> 2) & 3))]);
@@ -228,7 +245,7 @@ __device__ __forceinline__ void gemm_f32_tile(const GemmArgs &g, float *As, floa
     // epilogue. C/D map of the 32x32 MFMA: lane l, register e -> row (e&3) + 8*(e>>2) + 4*(l>>5), col l&31.
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const uint32_t col = n0 + wn * 64 + 32 * u + i;
+        const uint32_t col = n0 + wn * 64 + (B_NC ? 2 * i + u : 32 * u + i);
         if (EDGE && col >= g.N) continue;
         float *cc = C + (uint64_t)col * g.ldc;
 #pragma unroll
@@ -276,7 +293,7 @@ __device__ __forceinline__ void dma16(uint32_t voff, const void *sbase, uint32_t
                  : "v"(voff), "s"(sbase), "s"(lds_dst));
 }
 
-template <bool TRANS_A>
+template <bool TRANS_A, bool B_NC = false>
 __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem, const float *A, const float *B, float *C,
                                                   uint32_t m0, uint32_t n0) {
     const int tid = threadIdx.x;
@@ -295,7 +312,7 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
 
     // ---- DMA addressing: this wave stages 4 pieces of A and 2 of B per k-tile ----
     uint32_t a_voff[4], b_voff[2];
-    const float *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
+    const float *a_base, *b_base = B_NC ? B + n0 : B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -308,6 +325,10 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+        if constexpr (B_NC) { // piece P = 2*wave + q: k-rows 2P, 2P + 1 of 128 consecutive n, lane -> k row 2P + (lane>>5), n = 4*(lane&31): the slot image [16 k][128 n]
+            b_voff[q] = ((2u * (2u * wave + q) + (lane >> 5)) * g.ldb + 4u * (lane & 31)) * 4u;
+            continue;
+        }
         const uint32_t row = 16u * (2u * wave + q) + (lane >> 2);
         b_voff[q] = (row * g.ldb + 4u * ((lane & 3) ^ (lane >> 4))) * 4u;
     }
@@ -320,7 +341,8 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
             else dma16(a_voff[p], a_base + (uint64_t)k0 * g.lda, dst);
         } else {
             const uint32_t dst = __builtin_amdgcn_readfirstlane(sl + A_TILE * 4 + (2 * wave + (p - 4)) * 1024);
-            dma16(b_voff[p - 4], b_base + k0, dst);
+            if constexpr (B_NC) dma16(b_voff[p - 4], b_base + (uint64_t)k0 * g.ldb, dst);
+            else dma16(b_voff[p - 4], b_base + k0, dst);
         }
     };
 
@@ -337,6 +359,11 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
                 const int mm = wm * 128 + 32 * r + i;
                 af[set][r] = *reinterpret_cast<const float4 *>(&As[mm * BK + 4 * (chunk ^ ((mm >> 2) & 3))]);
             }
+        } else if constexpr (B_NC) { // (gemm_f32_tile's: k = 4 chunk + 2 (r - 4) and + 1, columns 2 i and 2 i + 1)
+            const float *bk = &Bs[(4 * chunk + 2 * (r - 4)) * BN + wn * 64 + 2 * i];
+            const float2 b0 = *reinterpret_cast<const float2 *>(bk), b1 = *reinterpret_cast<const float2 *>(bk + BN);
+            if (r == 4) { bf[set][0].x = b0.x; bf[set][1].x = b0.y; bf[set][0].y = b1.x; bf[set][1].y = b1.y; }
+            else { bf[set][0].z = b0.x; bf[set][1].z = b0.y; bf[set][0].w = b1.x; bf[set][1].w = b1.y; }
         } else {
             const int nn = wn * 64 + 32 * (r - 4) + i;
             bf[set][r - 4] = *reinterpret_cast<const float4 *>(&Bs[nn * BK + 4 * (chunk ^ ((nn >> 2) & 3))]);
@@ -423,6 +450,12 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int f = tid + kThreads * r;
+            if constexpr (B_NC) {
+                const uint32_t k = k0 + (f >> 5);
+                const float4 v = ldg4(B + (uint64_t)k * g.ldb + n0 + 4u * (f & 31), k < g.K);
+                *reinterpret_cast<float4 *>(&Bs[(f >> 5) * BN + 4 * (f & 31)]) = v;
+                continue;
+            }
             const int nn = f >> 2, ch = f & 3;
             const uint32_t k = k0 + 4u * ch;
             const float4 v = ldg4(B + (uint64_t)(n0 + nn) * g.ldb + k, k < g.K);
@@ -442,7 +475,7 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
     // epilogue (interior: no predication)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        float *cc = C + (uint64_t)(n0 + wn * 64 + 32 * u + i) * g.ldc;
+        float *cc = C + (uint64_t)(n0 + wn * 64 + (B_NC ? 2 * i + u : 32 * u + i)) * g.ldc;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             if constexpr (!TRANS_A) {
@@ -460,7 +493,7 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
     }
 }
 
-template <bool TRANS_A>
+template <bool TRANS_A, bool B_NC = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[NRING * SLOT_FLOATS]; // 72 KiB: 3 DMA slots, or 2 staged buffers on edge tiles
     uint32_t tm, tn;
@@ -471,7 +504,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     GemmArgs gl = g;
     gl.K = min(g.K - k_begin, g.k_per_split);
     const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
-    const float *B = g.b + z * g.b_batch + k_begin;
+    const float *B = g.b + z * g.b_batch + (B_NC ? (uint64_t)k_begin * g.ldb : (uint64_t)k_begin);
     float *C = g.c + ((uint64_t)z * g.nsplit + split) * g.c_batch;
     if (g.tail_tiles > 0) { // dense partial tile: C[n * BM + m] with (m, n) relative to the tile
         C = g.c + ((uint64_t)split * g.tail_tiles + blockIdx.x) * (uint64_t)(BM * BN) - ((uint64_t)n0 * BM + m0);
@@ -479,8 +512,8 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     }
     // workgroup-uniform: the whole tile is inside the matrices, at least one whole k-tile, and 32-bit DMA offsets suffice
     const bool interior = (m0 + BM <= gl.M) && (n0 + BN <= gl.N) && gl.K >= (uint32_t)BK && gl.dma_ok;
-    if (interior) gemm_f32_tile_dma<TRANS_A>(gl, smem, A, B, C, m0, n0);
-    else gemm_f32_tile<TRANS_A, true>(gl, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
+    if (interior) gemm_f32_tile_dma<TRANS_A, B_NC>(gl, smem, A, B, C, m0, n0);
+    else gemm_f32_tile<TRANS_A, true, B_NC>(gl, smem, smem + 2 * A_TILE, A, B, C, m0, n0);
 }
 
 // Tail split (tile quantisation): see wgk_gemm_f32. Adds a tail tile's partials in ASCENDING split order (deterministic) and writes
@@ -798,5 +831,34 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     else hipLaunchKernelGGL(gemm_f32_kernel<false>, grid, block, 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1) return wg_splitk_reduce(ctx, part, nsplit, M, N, nmats, WG_F32, out, out_ld, out_batch, alpha, beta);
+    return WG_OK;
+}
+
+// out (M x N, column-major) = a (M x K, m-contiguous) * b (K x N, N-CONTIGUOUS: element (k, n) at n + k * ld): the row-major GemmTr in column-major terms (api.hip
+// wg_gemm_rm). The 256 x 128 tile kernel with its B_NC tile bodies, whole K per workgroup (no K cut, no tail split: from one round of tiles on that is the plain
+// launch's plan anyway). WG_ERR_UNSUPPORTED without a message: not a product this launch takes -- the caller transposes `b` and calls wgk_gemm_f32.
+int wgk_gemm_f32_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat a_mcontig, wgk_mat b_ncontig,
+                    float alpha, float beta) {
+    if (M == 0 || N == 0 || nmats == 0) return WG_OK;
+    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
+    if (M % 4u || N % 4u || K % 4u || K == 0 || a_mcontig.ld % 4u || b_ncontig.ld % 4u || out_ld % 4u || !al16(a_mcontig.ptr) || !al16(b_ncontig.ptr) || !al16(out) || nmats > 65535u)
+        return WG_ERR_UNSUPPORTED;
+    if (nmats > 1 && (a_mcontig.batch % 4u || b_ncontig.batch % 4u || out_batch % 4u)) return WG_ERR_UNSUPPORTED;
+    GemmArgs g;
+    g.a = (const float *)a_mcontig.ptr; g.lda = a_mcontig.ld; g.a_batch = a_mcontig.batch;
+    g.b = (const float *)b_ncontig.ptr; g.ldb = b_ncontig.ld; g.b_batch = b_ncontig.batch;
+    g.c = out; g.ldc = out_ld; g.c_batch = out_batch;
+    g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta;
+    g.tile_base = 0; g.tail_tiles = 0; g.out_c = out; g.out_ldc = out_ld; g.out_alpha = alpha; g.out_beta = beta;
+    g.tiles_m = (M + BM - 1) / BM;
+    g.tiles_n = (N + BN - 1) / BN;
+    g.nsplit = 1; g.k_per_split = ((K + BK - 1) / BK) * BK;
+    // 32-bit DMA offsets within a k-tile: 16 k rows of either operand
+    g.dma_ok = ((uint64_t)a_mcontig.ld * 16u * 4u < (1ull << 31)) && ((uint64_t)b_ncontig.ld * 16u * 4u < (1ull << 31)) ? 1u : 0u;
+    const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
+    if (tiles > 0x7fffffffull) return WG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), dim3((uint32_t)tiles, nmats), dim3(kThreads), 0, ctx->stream, g);
+    WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

@@ -197,6 +197,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 // column-major terms. WG_ERR_UNSUPPORTED without a message: not a product that kernel takes (the caller transposes `b` and calls wgk_gemm_f16).
 int wgk_gemm_f16_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, __half *out, uint32_t out_ld, uint64_t out_batch, wgk_mat a_mcontig, wgk_mat b_ncontig,
                     float alpha = 1.f, float beta = 0.f);
+// gemm_f32.hip: the same for f32 (the 256 x 128 tile kernel with n-contiguous B tile bodies; whole K per workgroup)
+int wgk_gemm_f32_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat a_mcontig, wgk_mat b_ncontig,
+                    float alpha = 1.f, float beta = 0.f);
 
 // The f16 product out_rows (M x N) = op(m1) m2 as ONE launch over N-panels with completion flags (api.hip; the operator front-end's checks
 // on m1 / m2, then wgk_gemm_f16 with `panels`). WG_ERR_UNSUPPORTED without a message: not that kind of product, launch panel by panel.
