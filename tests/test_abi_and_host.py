@@ -215,7 +215,7 @@ def test_f16_continuous_kernel_accumulators_are_the_named_agprs():
                         "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src), "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         text = open(out).read()
     kernels = re.findall(r"^(_Z\S*gemm_f16_m16c_kernel\w*):[^\n]*\n(.*?)^\.Lfunc_end", text, flags=re.S | re.M)
-    assert len(kernels) == 4, [k for k, _ in kernels]  # Gemm / GemmTr x plain / streaming stores
+    assert len(kernels) == 8, [k for k, _ in kernels]  # Gemm / GemmTr x plain / streaming stores x alpha == 1 / any alpha
     for name, whole in kernels:
         body, desc = whole.split(".amdhsa_kernel")  # (the kernel descriptor sits between the code and .Lfunc_end)
         assert "scratch_" not in body, f"{name}: register spills"

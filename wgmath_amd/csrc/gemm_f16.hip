@@ -957,7 +957,9 @@ WG_ACC_QUADS(WG_ACC_QUAD_DEF)
 // Restrictions (launcher): K % 64 == 0, K >= 256, beta == 0, no split, no panels (and the fast path's M % 8 == 0). Batches: the walk goes through the matrices' tiles in
 // turn. Ragged tiles (M or N not a multiple of 256): rows past the end are clamped in the DMA offsets and skipped by the epilogue, as in m16_tile.
 // ===============================================================================================================
-template <bool TRANS_A, bool STREAM>
+// ALPHA1: alpha == 1 (the launcher's choice): the epilogue skips its 256 multiplies by alpha per tile (x * 1.0f is x: the same bits, a quarter fewer instructions in the
+// one stretch of a tile where no MFMA runs).
+template <bool TRANS_A, bool STREAM, bool ALPHA1>
 __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, const uint32_t walk_first, const int32_t walk_stride, const uint32_t walk_count) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1312,23 +1314,27 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                 float r[8];
                 AccQuad<8 * (2 * p) + u>::read(r[0], r[1], r[2], r[3]);
                 AccQuad<8 * (2 * p + 1) + u>::read(r[4], r[5], r[6], r[7]);
-                if constexpr (!TRANS_A && WG_NN_NOSWAP) { // odd lane rows hold the pair's tiles in exchanged order (rows + 4..7 in tile 2 p): one select per register
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float lo = odd_row ? r[4 + q] : r[q], hi = odd_row ? r[q] : r[4 + q];
-                        r[q] = lo; r[4 + q] = hi;
-                    }
-                }
                 half8_t v;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    r[q] *= alpha;
-                    asm volatile("" : "+v"(r[q])); // the f32 product, THEN one rounding to f16, as m16_tile's epilogue does it (in one expression the two
-                                                   // become v_fma_mix*_f16, whose f16 results differ in the denormal range: 477 of 2^25 elements, alpha = -0.375)
+                    if constexpr (!ALPHA1) {
+                        r[q] *= alpha;
+                        asm volatile("" : "+v"(r[q])); // the f32 product, THEN one rounding to f16, as m16_tile's epilogue does it (in one expression the two
+                                                       // become v_fma_mix*_f16, whose f16 results differ in the denormal range: 477 of 2^25 elements, alpha = -0.375)
+                    }
                     v[q] = (_Float16)r[q];
                 }
+                if constexpr (!TRANS_A && WG_NN_NOSWAP) { // odd lane rows hold the pair's tiles in exchanged order (rows + 4..7 in tile 2 p): exchanged back on the PACKED
+                                                          // halves -- two selects per tile instead of four (the epilogue is the tile boundary's cost: m16_cont's header)
+                    const uintx4 w = __builtin_bit_cast(uintx4, v);
+                    const uintx4 x = { odd_row ? w[2] : w[0], odd_row ? w[3] : w[1], odd_row ? w[0] : w[2], odd_row ? w[1] : w[3] };
+                    v = __builtin_bit_cast(half8_t, x);
+                }
                 _Float16 *dst = cc + 32 * p;
-                if (ok) { // (a wave with no row or column inside the matrix skips the instruction: see the wait behind a ragged tile below)
+#ifndef WG_CONT_ABLATE
+#define WG_CONT_ABLATE 0 // timing experiments only (results are garbage): 1 = the epilogue issues no stores; 2 = no read-out / convert either (the accumulators are simply overwritten)
+#endif
+                if (ok && !(WG_CONT_ABLATE & 1)) { // (a wave with no row or column inside the matrix skips the instruction: see the wait behind a ragged tile below)
                     if constexpr (STREAM) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
                     else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
                 }
@@ -1338,7 +1344,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         if (!has_next) break;
         tile = next; --tiles_left; a0 = na0; b0 = nb0; m0 = nm0; n0 = nn0; c_off = nc_off;
         st = 0;
-        after_store = TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
+        after_store = (WG_CONT_ABLATE & 1) ? 0u : TRANS_A ? 1u : 2u; // GemmTr: the next stage's one wait;  Gemm: its two (the third one is the first that needs a piece issued behind the stores)
         if (!full_tile) { // a ragged tile: a wave whose rows or columns lie past the end issued fewer than 32 stores (none, if all of them do), and a counted wait that
                           // allowed for 32 would let that many pieces fly instead: wait the stores out here (edge tiles only: one tile row / column of the output)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1354,13 +1360,13 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
 // queues (16384^2 x 8192 3058 -> 3131 / 3081 us, Gemm 3097 -> 3096; 12288^3 2498 -> 2502; walks over CONSECUTIVE queue entries, which take the XCD's 32 CUs off one L2
 // patch, 5 % slower). A boundary inside a walk saves 3-5 us, 2 % of a K = 8192 tile, on three tiles of four of three quarters of the tiles: removed.
 // profiles/r05_f16_chunked_walk_*.txt.)
-template <bool TRANS_A, bool STREAM>
+template <bool TRANS_A, bool STREAM, bool ALPHA1>
 __global__ __launch_bounds__(256, 1) void gemm_f16_m16c_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) char smem[160 * 1024];
     // the tiles the hardware's round-robin deal would have given this CU: blockIdx.x, + gridDim.x, ... below g.sched_tiles
     const uint32_t first = blockIdx.x;
     if (first >= g.sched_tiles) return;
-    m16_cont<TRANS_A, STREAM>(g, smem, first, (int32_t)gridDim.x, (g.sched_tiles - 1u - first) / gridDim.x + 1u);
+    m16_cont<TRANS_A, STREAM, ALPHA1>(g, smem, first, (int32_t)gridDim.x, (g.sched_tiles - 1u - first) / gridDim.x + 1u);
 }
 
 // (Round 2's persistent form -- one workgroup per CU calling m16_tile per tile, a barrier in between -- measured 0.5-1 % slower than letting the hardware re-dispatch a
@@ -1578,6 +1584,9 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     {   // the result past the caches when it would push the operands out of the Infinity Cache (see GemmArgs::c_stream); beta != 0 reads C back
         const uint64_t MiB = 1ull << 20, ab = ((uint64_t)M * K + (uint64_t)K * N) * nmats * 2u, cb = (uint64_t)M * N * nmats * 2u;
         g.c_stream = (beta == 0.f && ab <= 256u * MiB && ab + cb > 256u * MiB) ? 1u : 0u;
+#ifdef WG_FORCE_C_STREAM
+        g.c_stream = WG_FORCE_C_STREAM; // experiment builds
+#endif
         // (read by gemm_f16_t128.hip only: one column of 128-wide tiles. Gemm only: GemmTr's k-contiguous A arrives as 64-byte row pieces, two per line at different times)
         g.a_nt = (!trans && N <= 128u && (uint64_t)M * K * 2u >= 384u * MiB) ? 1u : 0u;
     }
@@ -1798,13 +1807,12 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
                     if (cont != 0 && applies && (cont == 1 || by_rule)) {
                         const dim3 grid((uint32_t)cus), block(256);
                         gm.sched = nullptr; gm.sched_tiles = (uint32_t)all;
-                        if (trans) {
-                            if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, true>), grid, block, 0, ctx->stream, gm);
-                            else hipLaunchKernelGGL((gemm_f16_m16c_kernel<true, false>), grid, block, 0, ctx->stream, gm);
-                        } else {
-                            if (gm.c_stream) hipLaunchKernelGGL((gemm_f16_m16c_kernel<false, true>), grid, block, 0, ctx->stream, gm);
-                            else hipLaunchKernelGGL((gemm_f16_m16c_kernel<false, false>), grid, block, 0, ctx->stream, gm);
-                        }
+                        auto go = [&](auto tr_c, auto st_c, auto a1_c) {
+                            hipLaunchKernelGGL((gemm_f16_m16c_kernel<decltype(tr_c)::value, decltype(st_c)::value, decltype(a1_c)::value>), grid, block, 0, ctx->stream, gm);
+                        };
+                        auto by_alpha = [&](auto tr_c, auto st_c) { if (gm.alpha == 1.f) go(tr_c, st_c, std::true_type{}); else go(tr_c, st_c, std::false_type{}); };
+                        auto by_stream = [&](auto tr_c) { if (gm.c_stream) by_alpha(tr_c, std::true_type{}); else by_alpha(tr_c, std::false_type{}); };
+                        if (trans) by_stream(std::true_type{}); else by_stream(std::false_type{});
                         return WG_OK;
                     }
                 }
