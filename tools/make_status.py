@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Writes STATUS.md -- ONE page of current numbers, nothing historical -- from the bench lines of the current round.
 
-    python tools/make_status.py profiles/r05_bench*.json [--vendor profiles/r05_vendor_vs_ours.txt] > STATUS.md
+    python tools/make_status.py profiles/r06_bench*_detail.json [--vendor profiles/r06_vendor_vs_ours.txt] > STATUS.md
 
 Every figure comes out of a file named in the page itself: a bench line is the JSON `python bench.py` printed on one box (one file = one box's
 run), the vendor column out of tools/vendor_vs_ours.sh's text (lines `<workload> ... ours <x> TF ... vendor <y> TF`). Re-run after every bench run."""
@@ -146,11 +146,12 @@ def main():
     if vendor:
         print(f"\nVendor column: `{vendor_file}` (`tools/vendor_vs_ours.sh`: hipBLASLt through `torch.matmul` on this repo's layouts -- nn = both operands as the Gemm takes them,")
         print("nt = its best layout, what GemmTr computes; the vendor's 32768^3 does not fit its workspace here, 16384^3 stands in). Shape sweeps against the vendor library:")
-        print("`profiles/r05_gemm_sweep_full_final.txt` (116 Gemm / GemmTr cases on the last code: 2 more than 10 % behind -- f32 GemmTr 64 x 4096 x 4096 and 4096 x 64 x 4096, 1.14 / 1.11 x, 1.06 x on the")
-        print("box of `r05_gemm_sweep_full_continuous.txt`), `profiles/r05_misc_sweep_final.txt` (50 batched / multi-RHS cases: 6 behind by 12-22 %).")
+        print("`profiles/r06_gemm_sweep_full.txt` (116 Gemm / GemmTr cases on the round's code: 1 more than 10 % behind -- f32 GemmTr 4096 x 64 x 4096, 1.15 x), `profiles/r06_gemm_sweep_row_major.txt`")
+        print("(the row-major surface, 26 cases: f16 GemmTr 0.66-0.97 x the vendor's time; behind: f16 GemmTr 2048^3 1.19 x and f32 GemmTr 2048^3 1.14 x, both on the transposed-copy path below a round of tiles),")
+        print("`profiles/r06_misc_sweep.txt` (50 batched / multi-RHS cases: 7 behind by 10-17 %).")
     print("\nNorth-star targets: f16 Gemm 8192^3 >= 0.80 of MFMA peak -- NOT met (see the C3 rows; the matrix cores alone, on random operands, sustain the")
     print("`MFMA-only ceiling` above at the package power cap); Gemv >= 0.70 of HBM peak -- met (C4); >= 3.5x at 4 GPUs -- not measured on hardware")
-    print("(one GPU per box here; `profiles/r05_rank_emulation.json` holds the one-rank emulation the projection in DESIGN.md section 6 rests on).")
+    print("(one GPU per box here; `profiles/r06_rank_emulation.json` holds the one-rank emulation the projection in DESIGN.md section 6 rests on).")
 
 
 if __name__ == "__main__":
