@@ -5,6 +5,7 @@
 //   pattern 2:  4 columns x 256 bytes
 //   pattern 3:  2 columns x 512 bytes (a whole tile column per 32 lanes)
 //   pattern 4:  8 columns x 128 bytes like 1, but each line's pieces on lanes 16 apart (see below)
+//   pattern 5: 16 columns x 64 bytes like 0, but a column's four pieces on four consecutive lanes
 // flavour 0: plain, 1: nt, 2: sc1 nt, 3: sc0 sc1 (write-through)
 // build: hipcc --offload-arch=gfx950 -O2 tools/cpp/store_probe.hip -o tools/cpp/_bin/store_probe
 #include <hip/hip_runtime.h>
@@ -44,6 +45,9 @@ __global__ __launch_bounds__(256) void probe(char *C, uint32_t ldc_bytes, uint32
         if constexpr (PAT == 3) { col = 64 * wave + 2 * i + (lane >> 5); rowb = (8 * (lane & 31)) * 2; }
         // pattern 4: the same bytes per instruction as pattern 1, but a line's 8 pieces on lanes kg * 16 + half * 8 + j (what a DPP row_ror:8 exchange of the MFMA layout gives)
         if constexpr (PAT == 4) { const int u = i >> 1, pp = i & 1; col = 128 * wn + 16 * (u >> 1) + 8 * (u & 1) + (lane & 7); rowb = (128 * wm + 64 * pp + 32 * ((lane >> 3) & 1) + 8 * (lane >> 4)) * 2; }
+        // pattern 5 (round 6): the SAME bytes per instruction as pattern 0 (16 columns x 64 bytes), but a column's four pieces on four CONSECUTIVE lanes (lane = 4 c + piece):
+        // what one ds_bpermute_b32 per dword of the MFMA layout would give
+        if constexpr (PAT == 5) { const int u = i >> 2, p = i & 3; col = 128 * wn + 16 * u + (lane >> 2); rowb = (128 * wm + 32 * p + 8 * (lane & 3)) * 2; }
         v.x += i;
         st<FL>(tile + (uint64_t)col * ldc_bytes + rowb, v);
     }
@@ -80,7 +84,7 @@ int main() {
     std::vector<uint64_t> out_h(1024 * 4 * 2);
     for (int wgs : { 32, 256, 1024 }) {
 #define R(P, F) if (run<P, F>(C, n, wgs, out_d, out_h)) return 1;
-        R(0, 0) R(1, 0) R(4, 0) R(2, 0) R(3, 0)
+        R(0, 0) R(5, 0) R(1, 0) R(4, 0) R(2, 0) R(3, 0)
         R(0, 2) R(1, 2) R(2, 2) R(3, 2)
         R(0, 1) R(1, 1) R(0, 3) R(1, 3)
     }
