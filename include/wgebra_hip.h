@@ -198,9 +198,9 @@ typedef enum wg_tuning {
     WG_TUNE_F16_CONT = 8,    /* f16 Gemm / GemmTr on the continuous tile walk (gemm_f16.hip m16_cont: one workgroup per CU keeps its LDS-DMA stream going across its tiles):
                                 -1 = by shape (default: K <= 4096, or <= 8192 below 16 rounds of tiles; more than one round of whole tiles), 0 = never,
                                 1 = whenever applicable (tests) */
-    WG_TUNE_RM_TR_NATIVE = 9, /* row-major GemmTr (wg_gemm_rm) of f16 operands on the kernel that takes the second operand contiguous along N (gemm_f16_nt.hip) instead of
-                                transposing m1 into a scratch buffer first: -1 = from half a round of 256 x 256 tiles on (default), 0 = never (the transposed copy: tests
-                                compare the two), 1 = whenever that kernel takes the shape */
+    WG_TUNE_RM_TR_NATIVE = 9, /* row-major GemmTr (wg_gemm_rm) on the kernels that take the second operand contiguous along N (gemm_f16_nt.hip, the B_NC instances of gemm_f16_t128.hip / gemm_f32.hip) instead of
+                                transposing m1 into a scratch buffer first: -1 = from about half a round of tiles on (default: f16 128 x 128 tiles, f32 one round of 256 x 128 tiles), 0 = never
+                                (the transposed copy: tests compare the two), 1 = whenever those kernels take the shape */
     WG_TUNE_COUNT_ = 10
 } wg_tuning;
 int wg_ctx_set_tuning(wg_ctx *ctx, wg_tuning key, int value);

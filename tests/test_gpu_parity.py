@@ -1062,9 +1062,10 @@ def test_gemm_tr_row_major_f32_native_kernel_matches_the_transposed_copy(gpu, M,
         U.assert_bits_equal(res[1], res[0], "row-major f32 GemmTr: native kernel vs transposed copy")
 
 
+@pytest.mark.parametrize("tile", [0, 128, 256128, 256])  # the launcher's own choice, then every tile family forced (gemm_f16_t128.hip's B_NC instances / gemm_f16_nt.hip)
 @pytest.mark.parametrize("M,K,N,mats,pad", [(256, 256, 256, 1, 0), (264, 320, 520, 2, 8), (1024, 1024, 768, 1, 0), (2048, 512, 4096, 1, 16), (8, 256, 8, 3, 0),
                                             (2304, 2048, 1280, 1, 0)])
-def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M, K, N, mats, pad):
+def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M, K, N, mats, pad, tile):
     """Row-major GemmTr of f16 operands (shape.wgsl:49-57, gemm.wgsl:115-148): the kernel that takes m1 where it lies (gemm_f16_nt.hip: both operands
     contiguous along their output dimension, no scratch) against the transposed-copy path of round 5 -- the same k order and accumulation chains, so the
     bits must agree -- and against f64. Strided row-major views with an offset, batches, ragged tiles (M, N not multiples of 256), the shortest K."""
@@ -1084,13 +1085,17 @@ def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M,
     for native in (1, 0):
         tc = upload(gpu, (off + mats * M * sc,), np.full(off + mats * M * sc, np.nan, np.float16), np.float16)
         vc = _rm_view(wg, tc, M, N, mats, stride=sc, stride_mat=M * sc, offset=off)
-        old = gpu.set_tuning("rm_tr_native", native)
+        old, old_tile = gpu.set_tuning("rm_tr_native", native), gpu.set_tuning("f16_tile", tile)
         try:
             run_pass(gpu, lambda p: gemm.dispatch_tr(gpu.device(), shapes, p, vc, va, vb))
         finally:
             gpu.set_tuning("rm_tr_native", old)
+            gpu.set_tuning("f16_tile", old_tile)
         res[native] = tc.read(gpu.device())
-    U.assert_bits_equal(res[1], res[0], "row-major GemmTr: native kernel vs transposed copy")
+    # (the 256 x 256 family forced on an output of fewer tiles than CUs: the copy path's launcher cuts K over the idle CUs there -- other partial sums, other bits; the
+    # native kernel never cuts K. Everywhere else the two ways run the same accumulation chains.)
+    if not (tile == 256 and -(-M // 256) * -(-N // 256) * mats < 256):
+        U.assert_bits_equal(res[1], res[0], "row-major GemmTr: native kernel vs transposed copy")
     full = res[1][off:].reshape(mats, M, sc)
     assert np.isnan(full[:, :, N:]).all() and np.isnan(res[1][:off]).all(), "elements outside the output view were written"
     got = full[:, :, :N].astype(np.float64)

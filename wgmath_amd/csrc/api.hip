@@ -350,8 +350,11 @@ int wg_gemm_rm(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, wg_buf *out
         const uint32_t tile_n = dtype == WG_F16 ? 256u : 128u;                   // 256 x 256 (f16) / 256 x 128 (f32) tiles
         const uint64_t tiles = (uint64_t)((o_cm.rows + 255u) / 256u) * ((o_cm.cols + tile_n - 1u) / tile_n) * o_cm.mats;
         const uint64_t cus = (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
-        // (f32: the copy path's launcher cuts K / takes small tiles below a round of big tiles, which this launch does not: only from a full round on)
-        if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] == 1 || (dtype == WG_F16 ? 2u * tiles >= cus : tiles >= cus)) {
+        // (f32: the copy path's launcher cuts K / takes small tiles below a round of big tiles, which this launch does not: only from a full round on.
+        //  f16: the native launcher has the mid-size tiles too (gemm_f16_t128.hip's B_NC instances): from half a round of 128 x 128 tiles on -- below that the copy
+        //  path's launcher would cut K over the idle CUs, which the native kernels do not)
+        const uint64_t tiles128 = (uint64_t)((o_cm.rows + 127u) / 128u) * ((o_cm.cols + 127u) / 128u) * o_cm.mats;
+        if (ctx->tuning[WG_TUNE_RM_TR_NATIVE] == 1 || (dtype == WG_F16 ? 2u * tiles128 >= cus : tiles >= cus)) {
             if (int rc = check_bounds("Gemm", "m2", b_cm, m2, dtype)) return rc;
             if (int rc = check_bounds("Gemm", "out", o_cm, out, dtype)) return rc;
             const wgk_mat A = { elem_ptr(m2, b_cm.offset, dtype), b_cm.stride, b_cm.stride_mat }, B = { elem_ptr(m1, a_cm.offset, dtype), a_cm.stride, a_cm.stride_mat };

@@ -200,5 +200,7 @@ static __device__ __forceinline__ void tile_of(uint32_t bid, uint32_t tiles_m, u
 int generic_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g);
 // gemm_f16_t128.hip: tm x 128 tiles, tm = 128 or 256 (g.tiles_m / g.tiles_n count those), grid = (tiles, nmats * nsplit); K per split % 64 == 0
 int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g, int tm = 128);
+// ... with m2 contiguous along N (the row-major GemmTr): Gemm only, K % 64 == 0, one split
+int t128_launch_nt(wg_ctx *ctx, dim3 grid, const GemmArgs &g, int tm = 128);
 
 } // namespace wgf16

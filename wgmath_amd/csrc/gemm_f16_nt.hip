@@ -239,6 +239,21 @@ static int nt_launch(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t n
     g.nsplit = 1; g.k_per_split = K;
     const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffull) return WG_ERR_UNSUPPORTED;
+    // Fewer 256 x 256 tiles than CUs: the mid-size tiles of gemm_f16_t128.hip in their n-contiguous-B form (two workgroups per CU) -- 256 x 128 from about half a tile
+    // per CU on (one per CU fills the chip; K <= 4096: the column-major launcher's rule for that tile), 128 x 128 below or for longer K. WG_TUNE_F16_TILE forces a family.
+    const uint64_t cus = (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
+    const int forced = ctx->tuning[WG_TUNE_F16_TILE];
+    if ((forced == 0 && tiles * nmats < cus) || forced == 128 || forced == 256128) {
+        const uint64_t t256x128 = (uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats;
+        const bool tall = forced == 256128 || (forced == 0 && 10u * t256x128 >= 5u * cus && K <= 4096u);
+        GemmArgs t = g;
+        t.tiles_m = tall ? (M + 255u) / 256u : (M + 127u) / 128u;
+        t.tiles_n = (N + 127u) / 128u;
+        t.part = nullptr;
+        const uint64_t tt = (uint64_t)t.tiles_m * t.tiles_n;
+        if (tt > 0x7fffffffull) return WG_ERR_UNSUPPORTED;
+        return t128_launch_nt(ctx, dim3((uint32_t)tt, nmats), t, tall ? 256 : 128);
+    }
     hipLaunchKernelGGL(gemm_f16_nt_kernel, dim3((uint32_t)tiles, nmats), dim3(256), 0, ctx->stream, g);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;

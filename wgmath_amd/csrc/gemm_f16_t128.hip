@@ -76,8 +76,12 @@ __device__ __forceinline__ void t_wait_keep_pieces(int n) { // s_waitcnt's count
     }
 }
 
-template <bool TRANS_A, int TM>
+// B_NC (round 6; Gemm only, K % 64 == 0): m2 contiguous along N -- element (k, n) at b + n + k * ldb -- i.e. the row-major GemmTr in column-major terms (gemm_f16_nt.hip
+// is the 256 x 256 form). B then takes column-major A's path: pieces = k-quads of 256-byte [4 k][32 n] blocks, swap-free transposing reads, N tile 2 p' + tb of the wave
+// holding column 32 p' + 8 a + 4 (tb ^ (a & 1)) + e for lane i16 = 4 a + e (the epilogue's column index).
+template <bool TRANS_A, int TM, bool B_NC = false>
 __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
+    static_assert(!(B_NC && TRANS_A) && (!B_NC || WG_NN_NOSWAP), "n-contiguous m2: Gemm only, on the swap-free read path");
     using Cfg = TCfg<TM>;
     constexpr int APW = Cfg::APW, PPW = Cfg::PPW, RB = Cfg::RB, T_SLOT = Cfg::SLOT, T_RING = Cfg::RING, MT = Cfg::MT, MP = Cfg::MP;
     __shared__ __attribute__((aligned(16))) char smem[T_RING * T_SLOT];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     K_loc -= rem;
     const uint32_t rem_dk = K_loc; // the remainder's first k, relative to k_begin
     const _Float16 *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
-    const _Float16 *B = g.b + z * g.b_batch + k_begin;
+    const _Float16 *B = g.b + z * g.b_batch + (B_NC ? (uint64_t)k_begin * g.ldb : (uint64_t)k_begin);
 
     // ---- DMA addressing: per half-stage this wave stages pieces P = 2 wave + q (q = 0, 1) of A and of B; a piece = 1 KiB of LDS
     // (64 lanes x 16 bytes). k-contiguous operands (B; op(A) for TN): piece P = rows 16P..16P+15 of 64 bytes (32 k), lane -> row
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     // instruction offset's 4095 bytes from the region's start: a second M0 value, B_IMM0 = 0; TM = 128: one M0, B_IMM0 = 2048, as before)
     constexpr int B_IMM0 = APW == 2 ? 2048 : 0;
     uint32_t a_voff[APW], b_voff[2];
-    const _Float16 *a_base, *b_base = B + (uint64_t)n0 * g.ldb;
+    const _Float16 *a_base, *b_base = B_NC ? B + n0 : B + (uint64_t)n0 * g.ldb;
     if constexpr (TRANS_A) a_base = A + (uint64_t)m0 * g.lda; else a_base = A + m0;
 #pragma unroll
     for (int q = 0; q < APW; ++q) {
@@ -133,6 +137,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
+        if constexpr (B_NC) { // piece 2 wave + q = k-quad kq of the half-stage (its k-group: `wave`): blocks [n/32 = lane >> 4], k row (lane >> 2) & 3, unit (lane & 3) ^ (wave & 1)
+            const uint32_t k = 4u * (2u * wave + q) + ((lane >> 2) & 3u);
+            const uint32_t n = min(32u * (lane >> 4) + 8u * ((lane & 3u) ^ ((uint32_t)wave & 1u)), g.N - 8u - n0); // N % 8 == 0 (launcher)
+            b_voff[q] = (k * g.ldb + n) * 2u + (T_BIAS - (uint32_t)B_IMM0 - 1024u * q);
+            continue;
+        }
         const uint32_t row = 16u * (2u * wave + q) + (lane >> 2);
         const uint32_t rb = min(row, g.N - 1u - n0);
         b_voff[q] = (rb * g.ldb + 8u * ((lane & 3u) ^ ((4u - ((row >> 2) & 3u)) & 3u))) * 2u + (T_BIAS - (uint32_t)B_IMM0 - 1024u * q);
@@ -142,8 +152,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const uint64_t a_step = TRANS_A ? 64u : (uint64_t)64u * g.lda; // bytes per half-stage (32 k)
     const char *ga0 = (const char *)a_base - T_BIAS - (rem ? 2u * a_step : 0u), *gb0 = (const char *)b_base - T_BIAS - (rem ? 128u : 0u);
     const uint32_t a_nt = g.a_nt; // (workgroup-uniform)
+    const uint64_t b_step = B_NC ? (uint64_t)64u * g.ldb : 64u; // bytes per half-stage of B
     auto issue = [&](uint32_t H, uint32_t slot_off) { // this wave's PPW pieces of half-stage H into the slot at byte offset slot_off
-        const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * 64u;
+        const char *ga = ga0 + H * a_step, *gb = gb0 + (uint64_t)H * b_step;
         t_set_m0(lds_wave + slot_off);
         asm volatile("s_nop 0");
         t_dma_streamed<0>(a_voff[0], ga, a_nt); t_dma_streamed<1024>(a_voff[1], ga, a_nt);
@@ -179,6 +190,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         a_off[1] = 0;
     }
     const bool odd_row = !TRANS_A && WG_NN_NOSWAP && (kg & 1); // these lanes hold the tiles of a pair in exchanged order (rows + 4..7 in tile 2 p)
+    uint32_t bn_off[2] = { 0, 0 }; // B_NC: lane row kg reads k-group kg = region kg, behind the region's A pieces; blocks n/32 = 2 wn + p'; even / odd N tiles of a pair
+    if constexpr (B_NC) {
+        const uint32_t a = (uint32_t)i16 & 3u, krow = (uint32_t)i16 >> 2;
+        const uint32_t common = (uint32_t)kg * (uint32_t)RB + (uint32_t)APW * 1024u + (2u * wn) * 256u + krow * 64u + (a ^ ((uint32_t)kg & 1u)) * 16u;
+        bn_off[0] = common + (a & 1u) * 8u;
+        bn_off[1] = common + ((a & 1u) ^ 1u) * 8u;
+    }
     constexpr auto a_pair_off = [](int p) { return APW == 2 ? p * RB : (p >> 1) * RB + (p & 1) * 2048; }; // TN: where pair p's rows start
     constexpr int NN_H = APW == 2 ? 1024 : 2048;                                                         // NN: the second k-quad of a region
 
@@ -195,10 +213,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     // fragment-producing operations of one half-stage (slot pointer sl), into register set `set`.
     // TN: MT reads of A, 4 of B. NN: per pair p 4 transposing reads and, behind them, 4 lane swaps; 4 reads of B -- numbered
     // [pairs 0, 1: 8 reads | B: 4 | pairs 2, 3: 8 reads (TM = 256) | swaps: 4 per pair]
-    constexpr int kReads = TRANS_A ? MT + 4 : 4 * MP + 4;
+    constexpr int kBReads = B_NC ? 8 : 4; // B_NC: two pairs x (2 tiles x 2 k-quads) transposing reads
+    constexpr int kReads = TRANS_A ? MT + 4 : 4 * MP + kBReads;
     constexpr int kOps = TRANS_A || WG_NN_NOSWAP ? kReads : kReads + 4 * MP;
     auto frag_op = [&](const char *sl, int op, int set) {
-        auto rb = [&](int u) { b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * RB + (u & 1) * 1024); };
+        auto rb = [&](int u) {
+            if constexpr (B_NC) { // read u = 4 p' + 2 tb + h: k-quad h of this lane row's k-group for N tile 2 p' + tb, halves 4 h .. 4 h + 3
+                const int pp = u >> 2, tb = (u >> 1) & 1, h = u & 1;
+                const uintx2 v = __builtin_bit_cast(uintx2, lds_tr(sl + bn_off[tb] + h * 1024 + pp * 256));
+                uintx4 w = __builtin_bit_cast(uintx4, b_f[set][2 * pp + tb]);
+                w[2 * h] = v[0]; w[2 * h + 1] = v[1];
+                b_f[set][2 * pp + tb] = __builtin_bit_cast(half8_t, w);
+            } else b_f[set][u] = lds_h8(sl + b_off + (u >> 1) * RB + (u & 1) * 1024);
+        };
         if constexpr (TRANS_A) {
             if (op < MT) a_r[set][op] = __builtin_bit_cast(uintx4, lds_h8(sl + a_off[op & 1] + a_pair_off(op >> 1)));
             else rb(op - MT);
@@ -210,8 +237,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 a_r[set][2 * p + tb][2 * h + 1] = v[1];
             };
             if (op < 8) tr(op >> 2, op & 3);
-            else if (op < 12) rb(op - 8);
-            else tr(2 + ((op - 12) >> 2), (op - 12) & 3);
+            else if (op < 8 + kBReads) rb(op - 8);
+            else tr(2 + ((op - 8 - kBReads) >> 2), (op - 8 - kBReads) & 3);
         } else {
             auto tr = [&](int p, int i) { // lands in tile 2 p + ins, dwords 2 h, 2 h + 1
                 const int h = i >> 1, ins = i & 1;
@@ -251,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 if constexpr (TRANS_A) ka = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row_a >> 3) & 3u)) & 3u));
                 else ka = 32u * h + 4u * (APW == 2 ? PA : PA >> 1) + ((lane >> 2) & 3u); // column-major A: the piece's k row
                 put(lds_wave + (uint32_t)h * T_SLOT + 1024u * q, ra + (uint64_t)h * a_step + (a_voff[q] - (T_BIAS - 1024u * q)), ka < rem);
-                if (q < 2) {
+                if constexpr (!B_NC) if (q < 2) { // (B_NC: K % 64 == 0 by the launcher: no remainder stage)
                     const uint32_t row_b = 16u * (2u * wave + q) + (lane >> 2);
                     const uint32_t kb = 32u * h + 8u * ((lane & 3u) ^ ((4u - ((row_b >> 2) & 3u)) & 3u));
                     put(lds_wave + (uint32_t)h * T_SLOT + (uint32_t)APW * 1024u + 1024u * q, rb + (uint64_t)h * 64u + (b_voff[q] - (T_BIAS - (uint32_t)B_IMM0 - 1024u * q)), kb < rem);
@@ -340,14 +367,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
         }
     }
 
-    // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 of the wave tile ----
+    // ---- epilogue: lane holds, per (pair p, N tile u), rows 32 p + 8 kg + 0..7 of column 16 u + i16 of the wave tile (B_NC: of column 32 (u >> 1) + 8 a + 4 ((u & 1) ^ (a & 1)) + e, i16 = 4 a + e) ----
+    auto col_in_wave = [&](int u) -> uint32_t {
+        if constexpr (B_NC) { const uint32_t ca = (uint32_t)i16 >> 2; return 32u * (uint32_t)(u >> 1) + 8u * ca + 4u * ((uint32_t)(u & 1) ^ (ca & 1u)) + ((uint32_t)i16 & 3u); }
+        else return 16u * (uint32_t)u + (uint32_t)i16;
+    };
     const bool full_tile = (m0 + TM <= g.M) && (n0 + TN <= g.N);
     const uint32_t row0 = m0 + (uint32_t)(TM / 2) * wm + 8u * kg;
     if (g.nsplit > 1) { // split-K: raw f32 partial sums to this split's slab (dense, ld = M); wg_splitk_reduce finishes
         float *P = g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t col = n0 + 64u * wn + 16u * u + i16;
+            const uint32_t col = n0 + 64u * wn + col_in_wave(u);
             if (!full_tile && col >= g.N) continue;
             float *pc = P + (uint64_t)col * g.M + row0;
 #pragma unroll
@@ -364,7 +395,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     const float alpha = g.alpha, beta = g.beta;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const uint32_t col = n0 + 64u * wn + 16u * u + i16;
+        const uint32_t col = n0 + 64u * wn + col_in_wave(u);
         if (!full_tile && col >= g.N) continue;
         _Float16 *cc = C + (uint64_t)col * g.ldc + row0;
 #pragma unroll
@@ -394,6 +425,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
 }
 
 } // namespace
+
+// the B_NC instances (row-major GemmTr on mid-size outputs: gemm_f16_nt.hip's launcher). Whole K per workgroup, K % 64 == 0.
+int t128_launch_nt(wg_ctx *ctx, dim3 grid, const GemmArgs &g, int tm) {
+    if (tm == 256) hipLaunchKernelGGL((gemm_f16_t128_kernel<false, 256, true>), grid, dim3(256), 0, ctx->stream, g);
+    else hipLaunchKernelGGL((gemm_f16_t128_kernel<false, 128, true>), grid, dim3(256), 0, ctx->stream, g);
+    WG_HIP_TRY(hipGetLastError());
+    return WG_OK;
+}
 
 int t128_launch(wg_ctx *ctx, bool trans, dim3 grid, const GemmArgs &g, int tm) {
     if (tm == 256) {
