@@ -147,7 +147,7 @@ def main():
         print(f"\nVendor column: `{vendor_file}` (`tools/vendor_vs_ours.sh`: hipBLASLt through `torch.matmul` on this repo's layouts -- nn = both operands as the Gemm takes them,")
         print("nt = its best layout, what GemmTr computes; the vendor's 32768^3 does not fit its workspace here, 16384^3 stands in). Shape sweeps against the vendor library:")
         print("`profiles/r06_gemm_sweep_full.txt` (116 Gemm / GemmTr cases on the round's code: 1 more than 10 % behind -- f32 GemmTr 4096 x 64 x 4096, 1.15 x), `profiles/r06_gemm_sweep_row_major.txt`")
-        print("(the row-major surface, 26 cases: f16 GemmTr 0.66-0.97 x the vendor's time; behind: f16 GemmTr 2048^3 1.19 x and f32 GemmTr 2048^3 1.14 x, both on the transposed-copy path below a round of tiles),")
+        print("(the row-major surface, 32 cases: f16 GemmTr 0.60-1.07 x the vendor's time, Gemm 0.61-0.94 x; behind: f32 GemmTr 2048^3 1.14 x, on the transposed-copy path below a round of tiles),")
         print("`profiles/r06_misc_sweep.txt` (50 batched / multi-RHS cases: 7 behind by 10-17 %).")
     print("\nNorth-star targets: f16 Gemm 8192^3 >= 0.80 of MFMA peak -- NOT met (see the C3 rows; the matrix cores alone, on random operands, sustain the")
     print("`MFMA-only ceiling` above at the package power cap); Gemv >= 0.70 of HBM peak -- met (C4); >= 3.5x at 4 GPUs -- not measured on hardware")

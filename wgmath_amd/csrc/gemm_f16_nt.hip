@@ -239,13 +239,14 @@ static int nt_launch(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t n
     g.nsplit = 1; g.k_per_split = K;
     const uint64_t tiles = (uint64_t)g.tiles_m * g.tiles_n;
     if (tiles > 0x7fffffffull) return WG_ERR_UNSUPPORTED;
-    // Fewer 256 x 256 tiles than CUs: the mid-size tiles of gemm_f16_t128.hip in their n-contiguous-B form (two workgroups per CU) -- 256 x 128 from about half a tile
-    // per CU on (one per CU fills the chip; K <= 4096: the column-major launcher's rule for that tile), 128 x 128 below or for longer K. WG_TUNE_F16_TILE forces a family.
+    // Fewer 256 x 256 tiles than CUs: the mid-size tiles of gemm_f16_t128.hip in their n-contiguous-B form (two workgroups per CU) -- 128 x 128, or 256 x 128 where
+    // that tile alone on its CU measured ahead. WG_TUNE_F16_TILE forces a family.
     const uint64_t cus = (uint64_t)(ctx->compute_units > 0 ? ctx->compute_units : 256);
     const int forced = ctx->tuning[WG_TUNE_F16_TILE];
     if ((forced == 0 && tiles * nmats < cus) || forced == 128 || forced == 256128) {
         const uint64_t t256x128 = (uint64_t)((M + 255u) / 256u) * ((N + 127u) / 128u) * nmats;
-        const bool tall = forced == 256128 || (forced == 0 && 10u * t256x128 >= 5u * cus && K <= 4096u);
+        // (the column-major launcher's measured rule for that tile: about one 256 x 128 tile per CU -- 70 .. 100 % of them --, K = 512 .. 4096, one or two matrices)
+        const bool tall = forced == 256128 || (forced == 0 && t256x128 <= cus && 10u * t256x128 >= 7u * cus && K >= 512u && K <= 4096u && nmats <= 2u);
         GemmArgs t = g;
         t.tiles_m = tall ? (M + 255u) / 256u : (M + 127u) / 128u;
         t.tiles_n = (N + 127u) / 128u;
