@@ -149,8 +149,8 @@ def main():
         print("`profiles/r06_gemm_sweep_full.txt` (116 Gemm / GemmTr cases on the round's code: 1 more than 10 % behind -- f32 GemmTr 4096 x 64 x 4096, 1.15 x), `profiles/r06_gemm_sweep_row_major.txt`")
         print("(the row-major surface, 32 cases: f16 GemmTr 0.60-1.07 x the vendor's time, Gemm 0.61-0.94 x; behind: f32 GemmTr 2048^3 1.14 x, on the transposed-copy path below a round of tiles),")
         print("`profiles/r06_misc_sweep.txt` (50 batched / multi-RHS cases: 7 behind by 10-17 %).")
-    print("\nC1 replayed: the figure depends on what the process allocated before, not on the box -- the same chips give 2.6 us per dispatch in a fresh process that runs only that workload")
-    print("(`profiles/r06_c1_replay_populations.txt`); in the full bench it runs last, behind 26 other workloads.")
+    print("\nC1 replayed: the figure depends on what the process allocated before, not on the box -- the same chip gives 2.6 us per dispatch in a fresh process and 3.4-5.7 us behind 25 other")
+    print("workloads (`profiles/r06_c1_replay_populations.txt`). The bench therefore runs config 1 right behind the headline since `r06_bench_boxF` (2.65 us); the older files ran it last.")
     print("\nNorth-star targets: f16 Gemm 8192^3 >= 0.80 of MFMA peak -- NOT met (see the C3 rows; the matrix cores alone, on random operands, sustain the")
     print("`MFMA-only ceiling` above at the package power cap); Gemv >= 0.70 of HBM peak -- met (C4); >= 3.5x at 4 GPUs -- not measured on hardware")
     print("(one GPU per box here; `profiles/r06_rank_emulation.json` holds the one-rank emulation the projection in DESIGN.md section 6 rests on).")
