@@ -160,7 +160,7 @@ def test_reduce_eval_cpu_matches_reference_helper():
     assert wg.Reduce(None, wg.ReduceOp.Min).eval_cpu(x) == x.min()
 
 
-@pytest.mark.parametrize("source,kernel,min_dma,instances", [("gemm_f16.hip", "gemm_f16_m16_kernel", 16, 2), ("gemm_f16_t128.hip", "gemm_f16_t128_kernel", 8, 4),
+@pytest.mark.parametrize("source,kernel,min_dma,instances", [("gemm_f16.hip", "gemm_f16_m16_kernel", 16, 2), ("gemm_f16_t128.hip", "gemm_f16_t128_kernel", 8, 6),  # 128 / 256 rows x Gemm / GemmTr + the two n-contiguous-B (row-major GemmTr) instances
                                                              ("gemm_f32_skinny.hip", "gemm_f32_skinny_kernel", 8, 10),  # 6 + the 16-wide forms (3 f32, 1 f16)
                                                              ("gemm_f32_mid.hip", "gemm_f32_mid_kernel", 6, 6), ("gemm_f32_mid.hip", "gemm_f32_mid_kw_kernel", 6, 12)])
 def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):

@@ -1276,7 +1276,16 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
     asm volatile("" : "+s"(a_step0), "+s"(a_step1), "+s"(b_step));
     __builtin_amdgcn_sched_barrier(0);
 
-    const uint32_t row_w = 128u * wm + 8u * kg; // this lane's first row within a tile
+#ifndef WG_CONT_STORE_PERM
+#define WG_CONT_STORE_PERM 1 // the epilogue's packs go through one ds_bpermute_b32 per dword (128 per wave and tile) so that a column's four 16-byte pieces sit on four CONSECUTIVE
+                             // lanes (lane = 4 c + piece) instead of lanes 16 apart: the same bytes per store instruction, which an idle CU gets out in 1.1 us instead of 3.4
+                             // (tools/cpp/store_probe.hip pattern 5); in the walk's lock-step tiles -- all CUs storing at once -- worth 0.5-1.5 % at K <= 1024
+                             // (profiles/r06_cont_store_perm_ab.txt). Bits unchanged. 0: the MFMA layout's own store pattern (A/B builds)
+#endif
+    // this lane's first row within a tile / its column within an N tile, as the stores see them (permuted form: lane = 4 * column + row group)
+    const uint32_t row_w = WG_CONT_STORE_PERM ? 128u * wm + 8u * ((uint32_t)lane & 3u) : 128u * wm + 8u * kg;
+    const uint32_t col_w = WG_CONT_STORE_PERM ? (uint32_t)lane >> 2 : (uint32_t)i16;
+    const uint32_t perm_src = 4u * (16u * ((uint32_t)lane & 3u) + ((uint32_t)lane >> 2)); // ds_bpermute address: this lane takes the pack of lane 16 * row group + column
     while (true) {
         // the steps from this tile's "stage S" to the next tile's stage 0 (if this workgroup has a next tile)
         const uint32_t next = tile + (uint32_t)walk_stride;
@@ -1305,7 +1314,7 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
         const bool full_tile = m0 + BM <= g.M && n0 + BN <= g.N; // workgroup-uniform
         static_for<8>([&](auto uc) {
             constexpr int u = decltype(uc)::value;
-            const uint32_t col = n0 + 128u * wn + 16u * u + i16;
+            const uint32_t col = n0 + 128u * wn + 16u * u + col_w;
             const bool col_ok = full_tile || col < g.N;
             _Float16 *cc = C + (uint64_t)(col_ok ? col : n0) * ldc + m0 + row_w;
             static_for<4>([&](auto pc) {
@@ -1329,6 +1338,12 @@ __device__ __forceinline__ void m16_cont(const GemmArgs &g, char *const smem, co
                     const uintx4 w = __builtin_bit_cast(uintx4, v);
                     const uintx4 x = { odd_row ? w[2] : w[0], odd_row ? w[3] : w[1], odd_row ? w[0] : w[2], odd_row ? w[1] : w[3] };
                     v = __builtin_bit_cast(half8_t, x);
+                }
+                if constexpr (WG_CONT_STORE_PERM) { // (every lane is active here: the predicated store comes after)
+                    uintx4 w = __builtin_bit_cast(uintx4, v);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) w[d] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)perm_src, (int)w[d]);
+                    v = __builtin_bit_cast(half8_t, w);
                 }
                 _Float16 *dst = cc + 32 * p;
 #ifndef WG_CONT_ABLATE
