@@ -13,6 +13,7 @@
 //     lgkmcnt(0) + vmcnt(16) + barrier. The k order inside every MFMA and the accumulation chain of every element are those of the column-major kernels: the result
 //     is bit-identical to transposing B first and calling them (tests/test_gpu_parity.py).
 // Takes: M % 8 == 0, N % 8 == 0, K % 64 == 0, K >= 256, leading dimensions % 8 == 0, 16-byte aligned bases; everything else goes the transposed-copy way (api.hip).
+// Outputs of fewer 256 x 256 tiles than CUs are handed to the 128 x 128 / 256 x 128 tiles of gemm_f16_t128.hip in their B_NC instances (the launcher below).
 // Bound: MFMA (2.5 PFLOP/s dense), in practice the package power cap, as the other f16 kernels.
 #include "gemm_f16_common.hpp"
 
