@@ -1107,6 +1107,33 @@ def test_gemm_tr_row_major_f16_native_kernel_matches_the_transposed_copy(gpu, M,
         assert (err <= tol).all(), f"row-major GemmTr mat {t}: worst err/tol {(err / tol).max():.3g}"
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_gemm_tr_row_major_fuzz(gpu, seed):
+    """Random shapes through wg_gemm_rm(GemmTr), f16 and f32, whatever path the launcher takes (the 256 x 256 / mid-size n-contiguous-B kernels, the f32 B_NC tile bodies,
+    the transposed copy for what they do not take: K % 64 != 0, small outputs), against f64. Ragged M / N, batches, K from one stage to a few."""
+    wg = _wg()
+    rng = np.random.default_rng(1000 + seed)
+    for dtype in (np.float16, np.float32):
+        q = 8 if dtype == np.float16 else 4
+        M, N = int(rng.integers(1, 300)) * q, int(rng.integers(1, 300)) * q
+        K = int(rng.choice([64, 128, 256, 320, 576, 1024, 1096, 2048])) if dtype == np.float16 else int(rng.integers(1, 200)) * 4
+        mats = int(rng.choice([1, 1, 2, 3]))
+        a = (rng.random((mats, K, M), dtype=np.float32) * 2 - 1).astype(dtype)
+        b = (rng.random((mats, K, N), dtype=np.float32) * 2 - 1).astype(dtype)
+        ta, tb = upload(gpu, (a.size,), a.reshape(-1), dtype), upload(gpu, (b.size,), b.reshape(-1), dtype)
+        tc = upload(gpu, (mats * M * N,), np.full(mats * M * N, np.nan, dtype), dtype)
+        gemm = wg.Gemm.from_device(gpu.device(), wg.row_major_shader_defs())
+        shapes = wg.ViewShapeBuffers()
+        run_pass(gpu, lambda p: gemm.dispatch_tr(gpu.device(), shapes, p, _rm_view(wg, tc, M, N, mats), _rm_view(wg, ta, K, M, mats), _rm_view(wg, tb, K, N, mats)))
+        got = tc.read(gpu.device()).reshape(mats, M, N).astype(np.float64)
+        for t in range(mats):
+            a64, b64 = a[t].T.astype(np.float64), b[t].astype(np.float64)
+            truth, sabs = a64 @ b64, np.abs(a64) @ np.abs(b64)
+            tol = U.f32_gate(K, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0)
+            err = np.abs(got[t] - truth)
+            assert (err <= tol).all(), f"row-major GemmTr fuzz seed {seed} {np.dtype(dtype).name} {M}x{N}x{K}x{mats} mat {t}: worst err/tol {(err / tol).max():.3g}"
+
+
 def test_gemm_row_major_strided_view_and_errors(gpu):
     """A row-major sub-view (row stride > cols, offset) of a larger buffer, and the reference's dimension panic."""
     wg = _wg()
