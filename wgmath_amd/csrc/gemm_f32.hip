@@ -57,6 +57,9 @@ struct GemmArgs {
     // (tile, split) writes its partial tile densely to c[(split * tail_tiles + blockIdx.x) * BM * BN + col_local * BM + row_local]
     uint32_t tile_base, tail_tiles;
     float *out_c; uint32_t out_ldc; float out_alpha, out_beta; // the real output, for gemm_f32_tail_reduce
+    // Batches with the tail split (round 6): flat_tiles = tiles per matrix; the launch's ids then run through the matrices' tiles in turn (id = matrix * flat_tiles + tile,
+    // grid.y = the K split only), so that the full waves and the cut-up leftover are those of the WHOLE batch. 0: grid.y carries the matrix, as before.
+    uint32_t flat_tiles; uint64_t out_batch;
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
@@ -496,16 +499,17 @@ __device__ __forceinline__ void gemm_f32_tile_dma(const GemmArgs &g, float *smem
 template <bool TRANS_A, bool B_NC = false>
 __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float smem[NRING * SLOT_FLOATS]; // 72 KiB: 3 DMA slots, or 2 staged buffers on edge tiles
-    uint32_t tm, tn;
-    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    uint32_t tm, tn, id = blockIdx.x + g.tile_base, z, split;
+    if (g.flat_tiles) { z = id / g.flat_tiles; id -= z * g.flat_tiles; split = blockIdx.y; } // (workgroup-uniform)
+    else { z = blockIdx.y / g.nsplit; split = blockIdx.y % g.nsplit; }
+    tile_of(id, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t m0 = tm * BM, n0 = tn * BN;
-    const uint32_t z = blockIdx.y / g.nsplit, split = blockIdx.y % g.nsplit;
     const uint32_t k_begin = split * g.k_per_split; // split-K: this workgroup's K range (k_per_split is a multiple of BK)
     GemmArgs gl = g;
     gl.K = min(g.K - k_begin, g.k_per_split);
     const float *A = g.a + z * g.a_batch + (TRANS_A ? (uint64_t)k_begin : (uint64_t)k_begin * g.lda);
     const float *B = g.b + z * g.b_batch + (B_NC ? (uint64_t)k_begin * g.ldb : (uint64_t)k_begin);
-    float *C = g.c + ((uint64_t)z * g.nsplit + split) * g.c_batch;
+    float *C = g.c + ((uint64_t)z * (g.flat_tiles ? 1u : g.nsplit) + (g.flat_tiles ? 0u : split)) * g.c_batch;
     if (g.tail_tiles > 0) { // dense partial tile: C[n * BM + m] with (m, n) relative to the tile
         C = g.c + ((uint64_t)split * g.tail_tiles + blockIdx.x) * (uint64_t)(BM * BN) - ((uint64_t)n0 * BM + m0);
         gl.ldc = BM;
@@ -519,8 +523,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_kernel(GemmArgs g) {
 // Tail split (tile quantisation): see wgk_gemm_f32. Adds a tail tile's partials in ASCENDING split order (deterministic) and writes
 // it with the usual alpha / beta / edge rules. grid = (tail tiles, BN / 4): 4 columns per block, float4 (4 rows) per thread.
 __global__ __launch_bounds__(256) void gemm_f32_tail_reduce(GemmArgs g) {
-    uint32_t tm, tn;
-    tile_of(blockIdx.x + g.tile_base, g.tiles_m, g.tiles_n, tm, tn);
+    uint32_t tm, tn, id = blockIdx.x + g.tile_base, z = 0;
+    if (g.flat_tiles) { z = id / g.flat_tiles; id -= z * g.flat_tiles; }
+    tile_of(id, g.tiles_m, g.tiles_n, tm, tn);
     const uint32_t rl = 4u * (threadIdx.x & 63u), cl = blockIdx.y * 4u + (threadIdx.x >> 6);
     const uint32_t row = tm * BM + rl, col = tn * BN + cl;
     if (row >= g.M || col >= g.N) return; // M % 4 == 0: the 4 rows are all in or all out
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tail_reduce(GemmArgs g) {
         const float4 q = *reinterpret_cast<const float4 *>(p + (uint64_t)i * g.tail_tiles * (uint64_t)(BM * BN));
         s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
-    float *o = g.out_c + (uint64_t)col * g.out_ldc + row;
+    float *o = g.out_c + (uint64_t)z * g.out_batch + (uint64_t)col * g.out_ldc + row;
     if (g.out_alpha != 1.f) { s.x *= g.out_alpha; s.y *= g.out_alpha; s.z *= g.out_alpha; s.w *= g.out_alpha; }
     if (g.out_beta != 0.f) {
         const float4 c = *reinterpret_cast<const float4 *>(o);
@@ -638,6 +643,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
     g.tile_base = 0; g.tail_tiles = 0; g.out_c = out; g.out_ldc = out_ld; g.out_alpha = alpha; g.out_beta = beta;
+    g.flat_tiles = 0; g.out_batch = out_batch;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     g.dma_ok = ((uint64_t)m1.ld * 256u * 4u < (1ull << 31)) && ((uint64_t)m2.ld * 128u * 4u < (1ull << 31)) ? 1u : 0u;
@@ -665,6 +671,9 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 #ifndef WG_F32_TAIL_SPLIT
 #define WG_F32_TAIL_SPLIT 1
 #endif
+#ifndef WG_F32_FLAT_BATCH
+#define WG_F32_FLAT_BATCH 1 // 0: batches keep grid.y = matrix and never get the tail split (round 5; A/B builds)
+#endif
     // More than one full wave of resident workgroups (2 per CU): the launch runs in waves of 2 x CUs tiles, K x 0.23 us each -- and the LAST
     // wave costs that much however few tiles it holds: completion times have drifted apart by then, a CU that finishes its pair is handed two
     // new workgroups at once, and the leftover r tiles end up two to a CU on r / 2 CUs (measured, K = 4096: 1024 tiles 1931 us, 1280 tiles
@@ -672,9 +681,13 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     // cut along K into sp parts that run as their own launch (spread one per CU up to CUs workgroups: 0.136 us per k then, 0.23 per wave of
     // 2 x CUs beyond), with the split count that minimises wave time + the partial tiles' write and ordered reduce.
     bool tail_done = false;
-    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > 2ull * (uint64_t)cus) {
+    // (round 6: a batch is planned as a whole -- `all` = every matrix's tiles; its launches then number the tiles through the batch, GemmArgs::flat_tiles. Before, only a
+    // single matrix got the tail split and a batch paid for its last, nearly empty wave: 4096 x 7168 x 2048 x 3 matrices 131 TFLOP/s against 143 for one)
+    const uint64_t all = tiles * nmats;
+    const bool flat_ok = all <= 0x7fffffffull && (nmats == 1 || WG_F32_FLAT_BATCH);
+    if (WG_F32_TAIL_SPLIT && flat_ok && all > 2ull * (uint64_t)cus) {
         const uint64_t cap = 2ull * (uint64_t)cus;
-        const uint32_t r = (uint32_t)(tiles % cap);
+        const uint32_t r = (uint32_t)(all % cap);
         if (r > 0 && nsplit == 1) {
             const double pair = 2.0 * us_per_k, lone = 0.136;
             double best_t = (double)K * pair * 0.97; // the leftover wave as it is (a split must pay for itself by a margin)
@@ -691,17 +704,17 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             if (best_sp > 1) { tail_r = r; tail_sp = best_sp; }
             tail_done = true;
             // what this plan takes: the full waves of 2 x CUs tiles, then the leftover wave -- as it is, or cut along K
-            best = (double)(tiles / cap) * K * pair + (best_sp > 1 ? best_t : (double)K * pair);
+            best = (double)(all / cap) * K * pair + (best_sp > 1 ? best_t : (double)K * pair);
         }
     }
-    if (WG_F32_TAIL_SPLIT && nmats == 1 && tiles > (uint64_t)cus && !tail_done) {
-        const uint32_t r = (uint32_t)(tiles % (uint64_t)cus);
+    if (WG_F32_TAIL_SPLIT && flat_ok && all > (uint64_t)cus && !tail_done) {
+        const uint32_t r = (uint32_t)(all % (uint64_t)cus);
         uint32_t sp = r ? (uint32_t)cus / r : 0;
         if (sp > ktiles / 8u) sp = ktiles / 8u; // >= 8 k-tiles (128 k) per split
         if (r > 0 && r * 2u <= (uint32_t)cus && sp >= 2 && (size_t)sp * r * BM * BN * sizeof(float) <= (512ull << 20)) {
             const uint32_t kps = ((ktiles + sp - 1) / sp) * BK;
             const double part_bytes = (double)sp * r * BM * BN * 4.0;
-            const double t = (double)((tiles - r) / (uint64_t)cus) * K * us_per_k + rounds((uint64_t)r * sp) * kps * us_per_k +
+            const double t = (double)((all - r) / (uint64_t)cus) * K * us_per_k + rounds((uint64_t)r * sp) * kps * us_per_k +
                              (part_bytes / 3.5e6 + 3.0) + (4.0 + part_bytes / 7.0e6);
             if (t < best) { best = t; nsplit = 1; tail_r = r; tail_sp = sp; }
         }
@@ -815,7 +828,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         const uint32_t kps = ((ktiles + sp - 1) / sp) * BK, n = (K + kps - 1) / kps;
         void *ws = nullptr;
         if (int rc = wg_ctx_workspace(ctx, (size_t)n * r * BM * BN * sizeof(float), &ws)) return rc;
-        const uint32_t full = (uint32_t)tiles - r;
+        const uint32_t full = (uint32_t)(tiles * nmats) - r;
+        if (nmats > 1) g.flat_tiles = (uint32_t)tiles; // the ids run through the batch
         if (trans) hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(full, 1), block, 0, ctx->stream, g);
         else hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(full, 1), block, 0, ctx->stream, g);
         GemmArgs gt = g;
@@ -851,6 +865,7 @@ int wgk_gemm_f32_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nm
     g.M = M; g.N = N; g.K = K;
     g.alpha = alpha; g.beta = beta;
     g.tile_base = 0; g.tail_tiles = 0; g.out_c = out; g.out_ldc = out_ld; g.out_alpha = alpha; g.out_beta = beta;
+    g.flat_tiles = 0; g.out_batch = out_batch;
     g.tiles_m = (M + BM - 1) / BM;
     g.tiles_n = (N + BN - 1) / BN;
     g.nsplit = 1; g.k_per_split = ((K + BK - 1) / BK) * BK;
