@@ -250,8 +250,10 @@ int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
  *   Views that are not vec4-aligned (rows / stride / stride_mat / offset of a view, or M, N, K, not a multiple of 4 -- what
  *                   GpuMatrix::slice / rows / column hand out for odd offsets and lengths, tensor.rs:574-626): the reference's
  *                   kernels bind array<vec4<f32>> and address the wrong elements there (shape.wgsl:64-66). Here they compute
- *                   op(m1) m2 like any other view, on dense zero-padded staged copies (three HBM-bound passes in a context scratch
- *                   that cannot grow inside a recording: WG_ERR_WORKSPACE). Only a view that exceeds its buffer is an error.
+ *                   op(m1) m2 like any other view: the operands that need it -- and only those -- are staged into dense zero-padded copies
+ *                   (HBM-bound passes in a context scratch that cannot grow inside a recording: WG_ERR_WORKSPACE); 1 .. 7 columns
+ *                   on otherwise aligned views run as a Gemv with that many right-hand sides, without any copy. Only a view that
+ *                   exceeds its buffer is an error.
  *   *_FAST        : the reference requires K % 256 == 0 and reads out of bounds otherwise (gemm.wgsl:40,162);
  *                   here every K % 4 == 0 is accepted and all four variants run the same tuned kernel.
  * dtype WG_F16 (extension): f16 operands, f32 accumulation, result rounded once (RNE) to f16.

@@ -272,6 +272,95 @@ def test_gemm_unaligned_views(gpu, dtype, tr):
     assert (np.abs(got2 - want) <= tol2).all()
 
 
+# One thing off at a time: only the operands that need a staged copy get one (api.hip gemm_staged / gemv_staged), so every combination of
+# "as it lies" and "copied" operands must give the product -- and leave everything outside the output view alone.
+GEMM_ONE_OFF = [
+    # M, K, N, offsets (a, b, out), what is off
+    (64, 32, 1, (0, 0, 0)), (64, 32, 2, (0, 0, 0)), (64, 32, 19, (0, 0, 0)),  # N only: m2 and out copied, m1 as it lies
+    (64, 30, 16, (0, 0, 0)),                                                   # K only: m1 and m2 copied
+    (61, 32, 16, (0, 0, 0)),                                                   # M only: m1 and out copied
+    (64, 32, 16, (1, 0, 0)), (64, 32, 16, (0, 2, 0)), (64, 32, 16, (0, 0, 3)),  # one view at an odd offset
+    (64, 32, 16, (0, 1, 1)), (516, 260, 3, (0, 0, 0)),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("case", GEMM_ONE_OFF)
+def test_gemm_one_operand_unaligned(gpu, dtype, tr, case):
+    wg, wo = _wg(), _wo()
+    (M, K, N, (oa, ob, oo)) = case
+    rng = np.random.default_rng(M * 131 + K * 17 + N + oa + 2 * ob + 4 * oo + int(tr))
+    ar, ac = (K, M) if tr else (M, K)
+    lda, ldb, ldc = ar + 4, K + 8, M + 4  # (vec4-aligned leading dimensions: the offsets and sizes are what is off)
+    pa = (rng.random(8 + lda * ac, dtype=np.float32) - 0.5).astype(dtype)
+    pb = (rng.random(8 + ldb * N, dtype=np.float32) - 0.5).astype(dtype)
+    po0 = rng.random(8 + ldc * N, dtype=np.float32).astype(dtype)
+    ta, tb, to = upload(gpu, (pa.size,), pa, dtype), upload(gpu, (pb.size,), pb, dtype), upload(gpu, (po0.size,), po0, dtype)
+    a_view = wg.GpuTensorView(wg.ViewShape((ar, ac, 1), lda, lda * ac, oa), ta, 2)
+    b_view = wg.GpuTensorView(wg.ViewShape((K, N, 1), ldb, ldb * N, ob), tb, 2)
+    o_view = wg.GpuTensorView(wg.ViewShape((M, N, 1), ldc, ldc * N, oo), to, 2)
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, o_view, a_view, b_view, variant))
+    got = to.read(gpu.device())
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    A, B = wo.view(pa, sh(a_view))[:, :, 0].astype(np.float64), wo.view(pb, sh(b_view))[:, :, 0].astype(np.float64)
+    A = A.T if tr else A
+    truth, sabs = A @ B, np.abs(A) @ np.abs(B)
+    G = wo.view(got, sh(o_view))[:, :, 0].astype(np.float64)
+    tol = U.f32_gate(K, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0.0)
+    assert (np.abs(G - truth) <= tol).all(), f"gemm {case}: worst err/tol {(np.abs(G - truth) / tol).max():.3g}"
+    mask = np.ones(po0.size, bool)
+    mask[(oo + np.arange(M)[:, None] + np.arange(N)[None, :] * ldc).ravel()] = False
+    assert np.array_equal(got[mask], po0[mask]), "wrote outside the output view"
+    # beta on an output that is used where it lies / copied: out = A B + out
+    from wgmath_amd import _lib
+    to2 = upload(gpu, (po0.size,), po0, dtype)
+    _lib.check(_lib.lib.wg_gemm_ex(gpu._ctx.handle, int(variant), wg.wgcore.wg_dtype(dtype), 1.0, 1.0, to2._h, o_view.shape().to_c(), ta._h, a_view.shape().to_c(),
+                                   tb._h, b_view.shape().to_c()))
+    got2 = wo.view(to2.read(gpu.device()), sh(o_view))[:, :, 0].astype(np.float64)
+    C0 = wo.view(po0, sh(o_view))[:, :, 0].astype(np.float64)
+    tol2 = tol + 4 * 2.0 ** (-11 if dtype == np.float16 else -24) * (np.abs(truth + C0) + np.abs(C0)) + 1e-6
+    assert (np.abs(got2 - (truth + C0)) <= tol2).all()
+
+
+GEMV_ONE_OFF = [
+    # R, C, nrhs, offsets (m, v, out)
+    (64, 32, 1, (0, 1, 0)), (64, 32, 1, (0, 0, 2)), (64, 32, 3, (1, 0, 0)), (61, 32, 1, (0, 0, 0)), (64, 30, 2, (0, 0, 0)), (516, 260, 1, (0, 3, 3)),
+]
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("case", GEMV_ONE_OFF)
+def test_gemv_one_operand_unaligned(gpu, tr, case):
+    wg, wo = _wg(), _wo()
+    (R, C, n, (om, ov, oo)) = case
+    rng = np.random.default_rng(R * 7 + C * 3 + n + om + 2 * ov + 4 * oo + int(tr))
+    ldm = R + 4
+    vlen, olen = (R, C) if tr else (C, R)
+    ldv, ldo = vlen + 4 - vlen % 4, olen + 4 - olen % 4
+    pm = (rng.random(8 + ldm * C, dtype=np.float32) - 0.5).astype(np.float32)
+    pv = (rng.random(8 + ldv * n, dtype=np.float32) - 0.5).astype(np.float32)
+    po = rng.random(8 + ldo * n, dtype=np.float32)
+    tm, tv, to = upload(gpu, (pm.size,), pm), upload(gpu, (pv.size,), pv), upload(gpu, (po.size,), po)
+    m_view = wg.GpuTensorView(wg.ViewShape((R, C, 1), ldm, ldm * C, om), tm, 2)
+    v_view = wg.GpuTensorView(wg.ViewShape((vlen, n, 1), ldv, ldv * n, ov), tv, 2)
+    o_view = wg.GpuTensorView(wg.ViewShape((olen, n, 1), ldo, ldo * n, oo), to, 2)
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, o_view, m_view, v_view, variant))
+    got = to.read(gpu.device())
+    sh = lambda v: wo.Shape(v.shape().size[0], v.shape().size[1], v.shape().size[2], v.shape().stride, v.shape().stride_mat, v.shape().offset)
+    A, X = wo.view(pm, sh(m_view))[:, :, 0], wo.view(pv, sh(v_view))[:, :, 0]
+    A = A.T if tr else A
+    truth, sabs = wo.gemm_f64(A, X)
+    U.assert_close_f64(wo.view(got, sh(o_view))[:, :, 0], truth, vlen, sabs, f"gemv {case} vs f64")
+    mask = np.ones(po.size, bool)
+    mask[(oo + np.arange(olen)[:, None] + np.arange(n)[None, :] * ldo).ravel()] = False
+    assert np.array_equal(got[mask], po[mask]), "wrote outside the output view"
+
+
 @pytest.mark.parametrize("tr", [False, True])
 def test_gemv_unaligned_views(gpu, tr):
     """Gemv on a matrix view at an odd row / with odd lengths and vectors at odd offsets (GpuVector::rows(1, n), tensor.rs:669-680), 3

@@ -55,39 +55,70 @@ inline uint32_t up8(uint32_t x) { return (x + 7u) & ~7u; }
 int gemm_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, float alpha, float beta, wg_buf *out, const View &o, const wg_buf *m1, const View &a, const wg_buf *m2,
                 const View &b, uint32_t M, uint32_t N, uint32_t K) {
     const size_t es = wg_dtype_size(dtype);
-    const uint32_t Mp = up8(M), Np = up8(N), Kp = up8(K), mats = o.mats;
-    const uint64_t ae = (uint64_t)Mp * Kp, be = (uint64_t)Kp * Np, ce = (uint64_t)Mp * Np;
+    // Only the operands that need it are copied (round 6: a 16384 x 16384 matrix times ONE column -- N % 4 != 0, nothing else -- paid 800 us for the copy
+    // of the matrix, 177 us now): a dimension that is not a multiple of 4 is rounded up to 8 in the two operands that carry it, an operand
+    // whose own view is not vec4-aligned is copied at the (possibly padded) sizes, the others are used where they lie.
+    const uint32_t Mp = M % 4 ? up8(M) : M, Np = N % 4 ? up8(N) : N, Kp = K % 4 ? up8(K) : K, mats = o.mats;
+    const bool sa = !vec4_ok(a) || Mp != M || Kp != K, sb = !vec4_ok(b) || Kp != K || Np != N, sc = !vec4_ok(o) || Mp != M || Np != N;
+    const uint64_t ae = sa ? (uint64_t)Mp * Kp : 0, be = sb ? (uint64_t)Kp * Np : 0, ce = sc ? (uint64_t)Mp * Np : 0;
     if (ae * mats >= (1ull << 32) || be * mats >= (1ull << 32) || ce * mats >= (1ull << 32))
         return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: operands too large for the staging path of views that are not vec4-aligned");
     void *ws = nullptr;
     if (int rc = wg_ctx_stage_workspace(ctx, (size_t)((ae + be + ce) * mats * es), &ws)) return rc;
     char *ap = (char *)ws, *bp = ap + ae * mats * es, *cp = bp + be * mats * es;
     const uint32_t a_ld = tr ? Kp : Mp;
-    if (int rc = wgk_stage_copy(ctx, dtype, ap, a_ld, ae, tr ? Kp : Mp, tr ? Mp : Kp, elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat, a.rows, a.cols, mats)) return rc;
-    if (int rc = wgk_stage_copy(ctx, dtype, bp, Kp, be, Kp, Np, elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat, b.rows, b.cols, mats)) return rc;
-    if (beta != 0.f)
-        if (int rc = wgk_stage_copy(ctx, dtype, cp, Mp, ce, Mp, Np, elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, N, mats)) return rc;
-    const wgk_mat A = { ap, a_ld, ae }, B = { bp, Kp, be };
-    if (int rc = dtype == WG_F32 ? wgk_gemm_f32(ctx, tr, Mp, Np, Kp, mats, (float *)cp, Mp, ce, A, B, alpha, beta)
-                                 : wgk_gemm_f16(ctx, tr, Mp, Np, Kp, mats, (__half *)cp, Mp, ce, A, B, alpha, beta))
+    wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat }, B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };
+    void *C = (void *)elem_ptr(out, o.offset, dtype);
+    uint32_t ldc = o.stride;
+    uint64_t c_batch = o.stride_mat;
+    if (sa) {
+        if (int rc = wgk_stage_copy(ctx, dtype, ap, a_ld, ae, tr ? Kp : Mp, tr ? Mp : Kp, A.ptr, a.stride, a.stride_mat, a.rows, a.cols, mats)) return rc;
+        A = wgk_mat{ ap, a_ld, ae };
+    }
+    if (sb) {
+        if (int rc = wgk_stage_copy(ctx, dtype, bp, Kp, be, Kp, Np, B.ptr, b.stride, b.stride_mat, b.rows, b.cols, mats)) return rc;
+        B = wgk_mat{ bp, Kp, be };
+    }
+    if (sc) {
+        if (beta != 0.f)
+            if (int rc = wgk_stage_copy(ctx, dtype, cp, Mp, ce, Mp, Np, C, o.stride, o.stride_mat, M, N, mats)) return rc;
+        C = cp; ldc = Mp; c_batch = ce;
+    }
+    if (int rc = dtype == WG_F32 ? wgk_gemm_f32(ctx, tr, Mp, Np, Kp, mats, (float *)C, ldc, c_batch, A, B, alpha, beta)
+                                 : wgk_gemm_f16(ctx, tr, Mp, Np, Kp, mats, (__half *)C, ldc, c_batch, A, B, alpha, beta))
         return rc;
+    if (!sc) return WG_OK;
     return wgk_stage_copy(ctx, dtype, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, M, N, cp, Mp, ce, Mp, Np, mats);
 }
 
 int gemv_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, wg_buf *out, const View &o, const wg_buf *m, const View &mm, const wg_buf *v, const View &vv,
                 uint32_t rows_out, uint32_t k) {
     const size_t es = wg_dtype_size(dtype);
-    const uint32_t Rp = up8(mm.rows), Cp = up8(mm.cols), Op = up8(rows_out), Kp = up8(k), nrhs = o.cols, mats = o.mats;
-    const uint64_t me = (uint64_t)Rp * Cp, ve = (uint64_t)Kp * nrhs, oe = (uint64_t)Op * nrhs;
+    // (as gemm_staged: only what needs it is copied -- a vector at an odd offset no longer costs a copy of the matrix)
+    const uint32_t Op = rows_out % 4 ? up8(rows_out) : rows_out, Kp = k % 4 ? up8(k) : k, nrhs = o.cols, mats = o.mats;
+    const uint32_t Rp = tr ? Kp : Op, Cp = tr ? Op : Kp;
+    const bool sm = !vec4_ok(mm) || Op != rows_out || Kp != k, sv = !vec4_ok(vv) || Kp != k, so = !vec4_ok(o) || Op != rows_out;
+    const uint64_t me = sm ? (uint64_t)Rp * Cp : 0, ve = sv ? (uint64_t)Kp * nrhs : 0, oe = so ? (uint64_t)Op * nrhs : 0;
     if (me * mats >= (1ull << 32) || ve * mats >= (1ull << 32) || oe * mats >= (1ull << 32))
         return wg_set_error(WG_ERR_UNSUPPORTED, "Gemv: operands too large for the staging path of views that are not vec4-aligned");
     void *ws = nullptr;
     if (int rc = wg_ctx_stage_workspace(ctx, (size_t)((me + ve + oe) * mats * es), &ws)) return rc;
     char *mp = (char *)ws, *vp = mp + me * mats * es, *op = vp + ve * mats * es;
-    if (int rc = wgk_stage_copy(ctx, dtype, mp, Rp, me, Rp, Cp, elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat, mm.rows, mm.cols, mats)) return rc;
-    if (int rc = wgk_stage_copy(ctx, dtype, vp, Kp, ve, Kp, nrhs, elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat, k, nrhs, mats)) return rc;
-    const wgk_mat Mx = { mp, Rp, me }, Vx = { vp, Kp, ve };
-    if (int rc = wgk_gemv(ctx, tr, dtype, Op, Kp, nrhs, mats, op, Op, oe, Mx, Vx)) return rc;
+    wgk_mat Mx = { elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat }, Vx = { elem_ptr(v, vv.offset, dtype), vv.stride, vv.stride_mat };
+    void *O = (void *)elem_ptr(out, o.offset, dtype);
+    uint32_t ldo = o.stride;
+    uint64_t o_batch = o.stride_mat;
+    if (sm) {
+        if (int rc = wgk_stage_copy(ctx, dtype, mp, Rp, me, Rp, Cp, Mx.ptr, mm.stride, mm.stride_mat, mm.rows, mm.cols, mats)) return rc;
+        Mx = wgk_mat{ mp, Rp, me };
+    }
+    if (sv) {
+        if (int rc = wgk_stage_copy(ctx, dtype, vp, Kp, ve, Kp, nrhs, Vx.ptr, vv.stride, vv.stride_mat, k, nrhs, mats)) return rc;
+        Vx = wgk_mat{ vp, Kp, ve };
+    }
+    if (so) { O = op; ldo = Op; o_batch = oe; }
+    if (int rc = wgk_gemv(ctx, tr, dtype, Op, Kp, nrhs, mats, O, ldo, o_batch, Mx, Vx)) return rc;
+    if (!so) return WG_OK;
     return wgk_stage_copy(ctx, dtype, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat, rows_out, nrhs, op, Op, oe, Op, nrhs, mats);
 }
 
@@ -137,6 +168,10 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
 
     WG_HIP_TRY(hipSetDevice(ctx->device));
     // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemm.wgsl:87,94: 4 x 4 blocks): dense staged copies
+    // (1 .. 7 columns that are not a multiple of 4 on otherwise aligned views: exactly a Gemv with that many right-hand sides -- no copy of anything)
+    if (vec4_ok(o) && vec4_ok(a) && vec4_ok(b) && m_cols % 4 == 0 && m_rows % 4 == 0 && o.cols % 4 && o.cols < 8 && alpha == 1.f && beta == 0.f)
+        return wgk_gemv(ctx, tr, dtype, m_rows, m_cols, o.cols, o.mats, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat,
+                        wgk_mat{ elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat }, wgk_mat{ elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat });
     if (!vec4_ok(o) || !vec4_ok(a) || !vec4_ok(b) || o.cols % 4 || m_cols % 4 || m_rows % 4)
         return gemm_staged(ctx, tr, dtype, alpha, beta, out, o, m1, a, m2, b, m_rows, o.cols, m_cols);
     wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
