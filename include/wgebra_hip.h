@@ -360,6 +360,15 @@ int wg_op_assign(wg_ctx *ctx, wg_op_assign_variant op, wg_dtype dtype,
  */
 int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y_shape, const wg_buf *x, wg_view_shape x_shape);
 
+/*
+ * Extension (strided / offset views): dst view = src view where the source has elements, 0 where it has none
+ * (dst.size[0] x dst.size[1] per matrix; rows / columns of `src` beyond dst's are dropped). Any offset, stride and length on either side --
+ * 16-byte accesses with a byte shift whatever the alignment (transpose.hip). It is the pass wg_gemm* / wg_gemv* run for operands that are
+ * not vec4-aligned; a caller that multiplies the same odd view many times makes the aligned copy ONCE with this and passes that instead.
+ * DIM_MISMATCH: dst.size[2] != src.size[2]. Zero-sized views: skipped. The views must not overlap.
+ */
+int wg_copy_view(wg_ctx *ctx, wg_dtype dtype, wg_buf *dst, wg_view_shape dst_shape, const wg_buf *src, wg_view_shape src_shape);
+
 /* ------------------------------------------------------------------------------------------------ */
 /* multi-GPU: the M-sharded Gemm of the north star. The reference has one wgpu::Device + Queue       */
 /* (wgcore gpu.rs:7-12) and nothing to replace here; what is kept is its tensor model: every rank's   */

@@ -272,6 +272,40 @@ def test_gemm_unaligned_views(gpu, dtype, tr):
     assert (np.abs(got2 - want) <= tol2).all()
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_copy_view_every_alignment_on_both_sides(gpu, dtype):
+    """wg_copy_view (the staging pass of the unaligned Gemm / Gemv paths, transpose.hip copy2d_kernel): every combination of source and destination
+    offset mod 16 bytes, odd leading dimensions (a different shift in every column), narrow and wide columns, a source smaller than the
+    destination (zero fill), a batch -- the destination view holds exactly the source or 0, nothing outside it is touched."""
+    wg = _wg()
+    from wgmath_amd import _lib
+    rng = np.random.default_rng(2025)
+    per = 16 // np.dtype(dtype).itemsize
+    cases = []
+    for so in range(per):
+        for do in range(per):
+            cases.append((37, 5, 37, 5, 41, 43, so, do, 1))          # narrow columns, odd leading dimensions
+    cases += [(1000, 3, 1003, 4, 1001, 1005 + d, s, d, 1) for s in (0, 1, 3) for d in (0, 2, per - 1)]  # wide columns, zero fill on both axes
+    cases += [(300, 2, 300, 2, 304, 304, 0, 0, 3), (300, 2, 290, 2, 301, 299, 5, 3, 2), (64, 7, 64, 9, 64, 64, 0, 4 % per, 1), (5, 3, 8, 3, 5, 8, 1, 0, 1)]
+    for (rs, cs, rd, cd, lds, ldd, so, do, mats) in cases:
+        src = (rng.random(so + lds * max(cs, 1) * mats + 16, dtype=np.float32) - 0.5).astype(dtype)
+        dst0 = (rng.random(do + ldd * cd * mats + 16, dtype=np.float32) + 1.0).astype(dtype)
+        ts, td = upload(gpu, (src.size,), src, dtype), upload(gpu, (dst0.size,), dst0, dtype)
+        sv = wg.ViewShape((rs, cs, mats), lds, lds * cs, so)
+        dv = wg.ViewShape((rd, cd, mats), ldd, ldd * cd, do)
+        _lib.check(_lib.lib.wg_copy_view(gpu._ctx.handle, wg.wgcore.wg_dtype(dtype), td._h, dv.to_c(), ts._h, sv.to_c()))
+        got = td.read(gpu.device())
+        want = dst0.copy()
+        for z in range(mats):
+            for j in range(cd):
+                col = np.zeros(rd, dtype)
+                if j < cs:
+                    n = min(rs, rd)
+                    col[:n] = src[so + z * lds * cs + j * lds: so + z * lds * cs + j * lds + n]
+                want[do + z * ldd * cd + j * ldd: do + z * ldd * cd + j * ldd + rd] = col
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (rs, cs, rd, cd, lds, ldd, so, do, mats)
+
+
 # One thing off at a time: only the operands that need a staged copy get one (api.hip gemm_staged / gemv_staged), so every combination of
 # "as it lies" and "copied" operands must give the product -- and leave everything outside the output view alone.
 GEMM_ONE_OFF = [

@@ -113,6 +113,7 @@ def _load() -> ctypes.CDLL:
         "wg_reduce_batched": (ci, [vp, ci, ci, vp, S, vp]),
         "wg_op_assign": (ci, [vp, ci, ci, vp, S, vp, S]),
         "wg_axpy": (ci, [vp, ctypes.c_float, ci, vp, S, vp, S]),
+        "wg_copy_view": (ci, [vp, ci, vp, S, vp, S]),
         "wg_debug_clock_begin": (ci, [vp]),
         "wg_debug_clock_end": (ci, [vp, pd, pd, pd, pd]),
         "wg_debug_mfma_ceiling": (ci, [vp, ctypes.c_double, pd, pd]),

@@ -339,6 +339,21 @@ int wg_axpy(wg_ctx *ctx, float alpha, wg_dtype dtype, wg_buf *y, wg_view_shape y
     return wgk_op_assign(ctx, 5 /* axpy */, dtype, (void *)elem_ptr(y, vy.offset, dtype), elem_ptr(x, vx.offset, dtype), n, alpha);
 }
 
+int wg_copy_view(wg_ctx *ctx, wg_dtype dtype, wg_buf *dst, wg_view_shape dst_shape, const wg_buf *src, wg_view_shape src_shape) {
+    const wg_buf *bufs[2] = { dst, src };
+    if (int rc = check_common("CopyView", ctx, dtype, bufs, 2)) return rc;
+    const View d = mk(dst_shape), s = mk(src_shape);
+    if (d.mats != s.mats) return wg_set_error(WG_ERR_DIM_MISMATCH, "CopyView: dimension mismatch. (dst has %u matrices, src has %u)", d.mats, s.mats);
+    if (dst->bytes == 0 || d.rows == 0 || d.cols == 0 || d.mats == 0) return WG_OK;
+    if (int rc = check_bounds("CopyView", "dst", d, dst, dtype)) return rc;
+    const bool empty_src = src->bytes == 0 || s.rows == 0 || s.cols == 0;
+    if (!empty_src)
+        if (int rc = check_bounds("CopyView", "src", s, src, dtype)) return rc;
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    return wgk_stage_copy(ctx, dtype, (void *)elem_ptr(dst, d.offset, dtype), d.stride, d.stride_mat, d.rows, d.cols, empty_src ? dst->ptr : elem_ptr(src, s.offset, dtype),
+                          s.stride, s.stride_mat, empty_src ? 0u : s.rows, empty_src ? 0u : s.cols, d.mats);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // ROW_MAJOR operator surface. The reference's `Shape` is row-major when its shaders are composed with
 // `row_major_shader_defs()` (shape.rs:11-15; shape.wgsl:49-57: index = t*stride_mat + offset + i*stride + j). A row-major

@@ -1414,30 +1414,6 @@ __global__ __launch_bounds__(256) void gemm_f16_tail_reduce(GemmArgs g) {
     *reinterpret_cast<h4 *>(o) = r;
 }
 
-// Copy of a column-major block with zero fill: dst (rd x cd, ld_dst) = src (rs x cs, ld_src) where it exists, 0 elsewhere. Used to stage
-// operands whose shape or alignment the MFMA kernels do not take (K % 32, M or N % 8, odd leading dimensions, unaligned views) into
-// dense zero-padded scratch copies -- zeros add nothing to a dot product, so the padded product is the product -- and to copy a padded
-// result back: HBM-bound passes over operands the GEMM reads many times.
-__global__ __launch_bounds__(256) void pad_copy_f16(_Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd,
-                                                    const _Float16 *src, uint32_t ld_src, uint64_t src_batch, uint32_t rs, uint32_t cs) {
-    // a thread moves 8 consecutive rows of a column: one 16-byte load / store each where both sides are 16-byte aligned and whole (the
-    // usual case: only K is off), element by element otherwise (unaligned views, the zero-padded edge)
-    const uint32_t i0 = (blockIdx.x * 256u + threadIdx.x) * 8u, z = blockIdx.z;
-    if (i0 >= rd) return;
-    const bool base_ok = (((uintptr_t)(dst + z * dst_batch) | (uintptr_t)(src + z * src_batch)) & 15u) == 0;
-    for (uint32_t j = blockIdx.y; j < cd; j += gridDim.y) {
-        _Float16 *d = dst + z * dst_batch + (uint64_t)j * ld_dst + i0;
-        const _Float16 *sp = src + z * src_batch + (uint64_t)j * ld_src + i0;
-        const bool in = j < cs;
-        if (base_ok && i0 + 8u <= rd && ((((uint64_t)j * ld_dst) | ((uint64_t)j * ld_src)) & 7u) == 0 && (!in || i0 + 8u <= rs || i0 >= rs)) {
-            half8_t v = {};
-            if (in && i0 < rs) v = *reinterpret_cast<const half8_t *>(sp);
-            *reinterpret_cast<half8_t *>(d) = v;
-        } else {
-            for (uint32_t e = 0; e < 8u && i0 + e < rd; ++e) d[e] = (in && i0 + e < rs) ? sp[e] : (_Float16)0.f;
-        }
-    }
-}
 
 } // namespace
 } // namespace wgf16
@@ -1578,11 +1554,8 @@ uint32_t bal_plan(const double rel[8], uint32_t tiles, uint32_t S, bool forced, 
 thread_local bool g_padding = false; // set while wgk_gemm_f16 runs on padded copies (see the staging branch)
 int pad_copy(wg_ctx *ctx, _Float16 *dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd, const _Float16 *src, uint32_t ld_src,
              uint64_t src_batch, uint32_t rs, uint32_t cs, uint32_t nmats) {
-    if (rd == 0 || cd == 0) return WG_OK;
-    const dim3 grid((rd + 2047u) / 2048u, cd < 65535u ? cd : 65535u, nmats);
-    hipLaunchKernelGGL(wgf16::pad_copy_f16, grid, dim3(256), 0, ctx->stream, dst, ld_dst, dst_batch, rd, cd, src, ld_src, src_batch, rs, cs);
-    WG_HIP_TRY(hipGetLastError());
-    return WG_OK;
+    // zero-padded copy of a column-major block, any alignment on either side (transpose.hip: 16-byte accesses with a byte shift)
+    return wgk_stage_copy(ctx, WG_F16, dst, ld_dst, dst_batch, rd, cd, src, ld_src, src_batch, rs, cs, nmats);
 }
 } // namespace
 
