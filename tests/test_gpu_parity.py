@@ -306,6 +306,61 @@ def test_copy_view_every_alignment_on_both_sides(gpu, dtype):
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (rs, cs, rd, cd, lds, ldd, so, do, mats)
 
 
+F16_ANY_ALIGN = [
+    # M, N, K, matrices -- one shape per f16 kernel family / launch plan (gemm_f16.hip launcher): 128 x 128 tiles; one 256 x 128 tile per CU; the continuous walk;
+    # per-tile launches with a K % 64 remainder; split-K slabs + reduce; full rounds + a K-cut tail; a batch; few columns
+    (512, 512, 512, 1), (4096, 2048, 1024, 1), (4096, 4096, 512, 1), (2048, 2304, 328, 1), (256, 256, 8192, 1), (4352, 4096, 1024, 1), (1024, 768, 256, 3), (8192, 16, 1024, 1),
+]
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("case", F16_ANY_ALIGN)
+def test_gemm_f16_any_offset_and_leading_dimension_is_the_aligned_product_bit_for_bit(gpu, tr, case):
+    """f16 operands at odd element offsets with odd leading dimensions and batch strides go straight into the MFMA kernels (LDS-DMA and 16-byte stores at
+    element-aligned addresses; no padded copies since round 6): the same kernels on the same numbers, so the result must be the aligned call's, bit for bit --
+    and nothing outside the output view may change."""
+    wg = _wg()
+    (M, N, K, mats) = case
+    rng = np.random.default_rng(M + 3 * N + 7 * K + mats + int(tr))
+    ar, ac = (K, M) if tr else (M, K)
+    A = (rng.random((mats, ac, ar), dtype=np.float32) - 0.5).astype(np.float16)   # [matrix][column][row]
+    B = (rng.random((mats, N, K), dtype=np.float32) - 0.5).astype(np.float16)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+
+    def run(pads, offs, bpads):
+        (pa, pb, pc), (oa, ob, oc), (ba, bb, bc) = pads, offs, bpads
+        lda, ldb, ldc = ar + pa, K + pb, M + pc
+        sa, sb, sc = lda * ac + ba, ldb * N + bb, ldc * N + bc  # batch strides
+        fa = np.zeros(oa + sa * mats + 8, np.float16); fb = np.zeros(ob + sb * mats + 8, np.float16)
+        fc = rng.random(oc + sc * mats + 8, dtype=np.float32).astype(np.float16)
+        for z in range(mats):
+            fa[oa + z * sa: oa + z * sa + lda * ac].reshape(ac, lda)[:, :ar] = A[z]
+            fb[ob + z * sb: ob + z * sb + ldb * N].reshape(N, ldb)[:, :K] = B[z]
+        ta, tb, tc = upload(gpu, (fa.size,), fa, np.float16), upload(gpu, (fb.size,), fb, np.float16), upload(gpu, (fc.size,), fc, np.float16)
+        av = wg.GpuTensorView(wg.ViewShape((ar, ac, mats), lda, sa, oa), ta, 2)
+        bv = wg.GpuTensorView(wg.ViewShape((K, N, mats), ldb, sb, ob), tb, 2)
+        cv = wg.GpuTensorView(wg.ViewShape((M, N, mats), ldc, sc, oc), tc, 2)
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, cv, av, bv, variant))
+        got = tc.read(gpu.device())
+        out = np.stack([got[oc + z * sc: oc + z * sc + ldc * N].reshape(N, ldc)[:, :M] for z in range(mats)])
+        mask = np.ones(fc.size, bool)
+        for z in range(mats):
+            mask[(oc + z * sc + np.arange(M)[None, :] + np.arange(N)[:, None] * ldc).ravel()] = False
+        assert np.array_equal(got[mask].view(np.uint16), fc[mask].view(np.uint16)), "wrote outside the output view"
+        return out
+
+    want = run((0, 0, 0), (0, 0, 0), (0, 0, 0))
+    ref = np.stack([(A[z].astype(np.float64).T if not tr else A[z].astype(np.float64)) @ B[z].astype(np.float64).T for z in range(mats)])  # [z][M][N]
+    assert np.abs(want.transpose(0, 2, 1).astype(np.float64) - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max()) + K * 2.0 ** -22
+    for pads, offs, bpads in [((1, 3, 5), (1, 3, 5), (1, 1, 1)), ((4, 0, 0), (0, 4, 0), (0, 0, 4)), ((0, 0, 7), (2, 0, 1), (0, 3, 0)), ((8, 8, 8), (7, 6, 5), (2, 2, 2))]:
+        got = run(pads, offs, bpads)
+        if tr and N <= 16:  # the few-column streaming kernel (gemm_f32_skinny.hip, T = f16) keeps its 16-byte contract: off it, the tiled kernels -- another order of the sums
+            assert np.abs(got.transpose(0, 2, 1).astype(np.float64) - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max()) + K * 2.0 ** -22
+            continue
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (case, tr, pads, offs, bpads)
+
+
 # One thing off at a time: only the operands that need a staged copy get one (api.hip gemm_staged / gemv_staged), so every combination of
 # "as it lies" and "copied" operands must give the product -- and leave everything outside the output view alone.
 GEMM_ONE_OFF = [
@@ -393,6 +448,50 @@ def test_gemv_one_operand_unaligned(gpu, tr, case):
     mask = np.ones(po.size, bool)
     mask[(oo + np.arange(olen)[:, None] + np.arange(n)[None, :] * ldo).ravel()] = False
     assert np.array_equal(got[mask], po[mask]), "wrote outside the output view"
+
+
+GEMV_ANY = [
+    # R, C, ld, offsets (m, v, out), nrhs, mats -- matrix views the vec4 kernels cannot address: one pass where they lie (gemv_any.hip)
+    (1000, 777, 1001, (3, 1, 2), 1, 1), (4097, 300, 4099, (1, 0, 0), 2, 1), (64, 5000, 66, (2, 3, 1), 1, 2), (8193, 64, 8193, (0, 0, 0), 1, 1),
+    (5, 3, 5, (1, 0, 0), 1, 1), (513, 513, 515, (7, 5, 3), 3, 2), (20000, 16, 20002, (2, 0, 1), 1, 1), (16, 20000, 18, (1, 1, 1), 1, 1), (2048, 2048, 2048, (1, 0, 0), 1, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("case", GEMV_ANY)
+def test_gemv_any_alignment(gpu, dtype, tr, case):
+    """Against f64; an Inf in the element just past every column's end (the neighbour in the parent buffer) must not leak in; nothing outside the output view is touched."""
+    wg, wo = _wg(), _wo()
+    (R, C, ld, (om, ov, oo), n, mats) = case
+    rng = np.random.default_rng(R * 3 + C + ld + om + int(tr))
+    vlen, olen = (R, C) if tr else (C, R)
+    pm = (rng.random(om + ld * C * mats + 8, dtype=np.float32) - 0.5).astype(dtype)
+    if ld > R:  # what follows a column in memory belongs to the parent, not to the view
+        for zc in range(C * mats):
+            pm[om + zc * ld + R] = np.inf
+    pv = (rng.random(ov + (vlen + 1) * n * mats + 8, dtype=np.float32) - 0.5).astype(dtype)
+    po = rng.random(oo + (olen + 3) * n * mats + 8, dtype=np.float32).astype(dtype)
+    tm, tv, to = upload(gpu, (pm.size,), pm, dtype), upload(gpu, (pv.size,), pv, dtype), upload(gpu, (po.size,), po, dtype)
+    m_view = wg.GpuTensorView(wg.ViewShape((R, C, mats), ld, ld * C, om), tm, 2)
+    v_view = wg.GpuTensorView(wg.ViewShape((vlen, n, mats), vlen + 1, (vlen + 1) * n, ov), tv, 2)
+    o_view = wg.GpuTensorView(wg.ViewShape((olen, n, mats), olen + 3, (olen + 3) * n, oo), to, 2)
+    variant = wg.GemvVariant.GemvTr if tr else wg.GemvVariant.Gemv
+    gemv, shapes = wg.Gemv.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: gemv.dispatch_generic(gpu.device(), shapes, p, o_view, m_view, v_view, variant))
+    got = to.read(gpu.device())
+    mask = np.ones(po.size, bool)
+    for z in range(mats):
+        A = pm[om + z * ld * C: om + z * ld * C + ld * C].reshape(C, ld)[:, :R].T.astype(np.float64)
+        X = pv[ov + z * (vlen + 1) * n: ov + (z + 1) * (vlen + 1) * n].reshape(n, vlen + 1)[:, :vlen].T.astype(np.float64)
+        A = A.T if tr else A
+        truth, sabs = A @ X, np.abs(A) @ np.abs(X)
+        idx = oo + z * (olen + 3) * n + np.arange(olen)[:, None] + np.arange(n)[None, :] * (olen + 3)
+        G = got[idx].astype(np.float64)
+        tol = U.f32_gate(vlen, sabs) + (2.0 ** -11 * np.abs(truth) + 2.0 ** -25 if dtype == np.float16 else 0.0)
+        assert np.isfinite(G).all() and (np.abs(G - truth) <= tol).all(), f"gemv {case}: worst err/tol {(np.abs(G - truth) / tol).max():.3g}"
+        mask[idx.ravel()] = False
+    assert np.array_equal(got[mask].view(np.uint8), po[mask].view(np.uint8)), "wrote outside the output view"
 
 
 @pytest.mark.parametrize("tr", [False, True])

@@ -1,7 +1,7 @@
 """Looks for performance cliffs next to the tuned shapes: a base Gemm / Gemv shape against the same shape with one dimension (or one view's offset / leading
 dimension) nudged off the alignments the fast kernels want (multiples of 4 elements = the reference's vec4 contract, of 8 = 16 bytes of f16, of the tile sizes).
 Prints us per dispatch and the ratio to the base shape; anything far above 1 is a path that copies or falls to a slow kernel.
-Usage (GPU box): python tools/cliff_sweep.py [f32|f16 ...]"""
+Usage (GPU box): [CLIFF_ONLY=gemv|gemm] python tools/cliff_sweep.py [f32|f16 ...]"""
 import os
 import sys
 import time
@@ -67,7 +67,7 @@ def gemv_case(dt, tr, R, C, pad=0, off=(0, 0, 0)):
 for name in (sys.argv[1:] or ["f32", "f16"]):
     dt = np.float16 if name == "f16" else np.float32
     for tr in (False, True):
-        for (M, N, K) in ([(4096, 4096, 4096), (2048, 2048, 2048), (8192, 8192, 1024)] if dt == np.float16 else [(2048, 2048, 2048), (4096, 4096, 1024)]):
+        for (M, N, K) in ([] if os.environ.get("CLIFF_ONLY") == "gemv" else [(4096, 4096, 4096), (2048, 2048, 2048), (8192, 8192, 1024)] if dt == np.float16 else [(2048, 2048, 2048), (4096, 4096, 1024)]):
             base = gemm_case(dt, tr, M, N, K)
             print(f"{name} {'gemm_tr' if tr else 'gemm'} {M}x{N}x{K}: base {base:9.1f} us", flush=True)
             for label, kw in [("M+1", dict(dM=1)), ("M+4", dict(dM=4)), ("M+8", dict(dM=8)), ("N+1", dict(dN=1)), ("N+4", dict(dN=4)), ("N+8", dict(dN=8)), ("K+1", dict(dK=1)), ("K+4", dict(dK=4)),
@@ -75,7 +75,7 @@ for name in (sys.argv[1:] or ["f32", "f16"]):
                               ("offA 4", dict(off=(4, 0, 0))), ("offB 4", dict(off=(0, 4, 0))), ("offC 4", dict(off=(0, 0, 4))), ("offA 1", dict(off=(1, 0, 0))), ("offC 1", dict(off=(0, 0, 1)))]:
                 t = gemm_case(dt, tr, M + kw.get("dM", 0), N + kw.get("dN", 0), K + kw.get("dK", 0), kw.get("pad", (0, 0, 0)), kw.get("off", (0, 0, 0)))
                 print(f"    {label:8s} {t:9.1f} us  x{t / base:5.2f}{'   <-- cliff' if t > 1.3 * base else ''}", flush=True)
-        for (R, C) in [(8192, 8192), (4096, 16384)]:
+        for (R, C) in ([] if os.environ.get("CLIFF_ONLY") == "gemm" else [(8192, 8192), (4096, 16384), (16384, 16384)]):
             base = gemv_case(dt, tr, R, C)
             print(f"{name} {'gemv_tr' if tr else 'gemv'} {R}x{C}: base {base:9.1f} us", flush=True)
             for label, kw in [("R+1", dict(dR=1)), ("R+4", dict(dR=4)), ("C+1", dict(dC=1)), ("C+4", dict(dC=4)), ("ld+4", dict(pad=4)), ("ld+8", dict(pad=8)), ("offM 4", dict(off=(4, 0, 0))), ("offM 1", dict(off=(1, 0, 0))),

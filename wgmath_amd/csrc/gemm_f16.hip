@@ -73,6 +73,7 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef uintx4 __attribute__((aligned(2))) uintx4_u; // (in global memory at any element-aligned address: gemm_f16_common.hpp half8_u)
 
 // compile-time loop: the body sees its index as a constant expression (no reliance on the unroller's size thresholds)
 template <class F, int... I>
@@ -600,7 +601,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
         // one loop, no second accumulation chain: the remainder is simply multiplied first.
         auto put = [&](uint32_t lds_dst, const char *src, bool valid) {
             uintx4 v = { 0u, 0u, 0u, 0u };
-            if (valid) v = *reinterpret_cast<const uintx4 *>(src);
+            if (valid) v = *reinterpret_cast<const uintx4_u *>(src);
             *(WG_AS3 uintx4 *)(uintptr_t)(lds_dst + 16u * (uint32_t)lane) = v;
         };
         if constexpr (TRANS_A) {
@@ -789,7 +790,7 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
             for (int q = 0; q < 8; ++q) r[q] *= alpha;
         }
         if (beta != 0.f && ok) { // beta == 0 never reads C
-            const half8_t c = *reinterpret_cast<const half8_t *>(cc + 32 * p);
+            const half8_t c = *reinterpret_cast<const half8_u *>(cc + 32 * p);
 #pragma unroll
             for (int q = 0; q < 8; ++q) r[q] = fmaf(beta, (float)c[q], r[q]);
         }
@@ -803,15 +804,15 @@ __device__ __forceinline__ void m16_tile(const GemmArgs &g, const uint32_t bid, 
     // dword for lanes 12 .. 15 of every row -- seen in the continuous kernel, round 5)
     auto store8 = [&](_Float16 *dst, half8_t v) {
         if (paneled) { // write-through to memory: when the store is acknowledged a copy engine may read it
-            if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v; // (timing experiments only: NOT visible to a copy engine in time)
+            if constexpr (WG_PANEL_STORE == 0) *reinterpret_cast<half8_u *>(dst) = v; // (timing experiments only: NOT visible to a copy engine in time)
             else if constexpr (WG_PANEL_STORE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         } else if (!(WG_ABLATE & 32)) {
             if constexpr (WG_EPI_STORE == -1) {
                 if (c_stream) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
-                else *reinterpret_cast<half8_t *>(dst) = v;
-            } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_t *>(dst) = v;
-            else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_t *>(dst));
+                else *reinterpret_cast<half8_u *>(dst) = v;
+            } else if constexpr (WG_EPI_STORE == 0) *reinterpret_cast<half8_u *>(dst) = v;
+            else if constexpr (WG_EPI_STORE == 1) __builtin_nontemporal_store(v, reinterpret_cast<half8_u *>(dst));
             else if constexpr (WG_EPI_STORE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             else if constexpr (WG_EPI_STORE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             else asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
@@ -1403,7 +1404,7 @@ __global__ __launch_bounds__(256) void gemm_f16_tail_reduce(GemmArgs g) {
         s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     _Float16 *o = g.c + (uint64_t)col * g.ldc + row;
-    struct alignas(8) h4 { _Float16 v[4]; };
+    struct alignas(2) h4 { _Float16 v[4]; }; // (C at any element-aligned address)
     if (g.alpha != 1.f) { s.x *= g.alpha; s.y *= g.alpha; s.z *= g.alpha; s.w *= g.alpha; }
     if (g.beta != 0.f) {
         const h4 t = *reinterpret_cast<const h4 *>(o);
@@ -1592,7 +1593,6 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         out_ld % 4u == 0 && al16(m1.ptr) && al16(m2.ptr) && ((uintptr_t)out & 7) == 0 && (nmats == 1 || (m1.batch % 8u == 0 && m2.batch % 8u == 0 && out_batch % 4u == 0)) &&
         (uint64_t)M * K * 2u >= (16ull << 20) && (uint64_t)m1.ld * 32u * 2u < (1ull << 31) && (uint64_t)m2.ld * 32u * 2u < (1ull << 31))
         return wgk_gemm_f16_skinny(ctx, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta);
-    const bool batch_ok = nmats == 1 || (m1.batch % 8 == 0 && m2.batch % 8 == 0 && out_batch % 8 == 0);
     // 32-bit DMA offsets within a tile: rows * ld * 2 bytes must stay below 2^31
     const bool off_ok = (uint64_t)m1.ld * 2u * (trans ? 256u : 32u) < (1ull << 31) && (uint64_t)m2.ld * 2u * 256u < (1ull << 31);
     // (N is free: B rows are clamped per column and the epilogues skip columns >= N)
@@ -1601,8 +1601,13 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
     const uint32_t krem = K % 64u;
     const bool k_big = K % 8u == 0 && K - krem >= 192u, k_small = K % 8u == 0 && K - krem >= 64u;
     const bool a_step_fits = trans || (uint64_t)m1.ld * 64u < (1ull << 32); // NN: a half-stage of A (32 k rows) apart in 32 bits (the DMA cursors' increments are SGPRs)
-    const bool fast = (M % 8 == 0) && (k_big || k_small) && (m1.ld % 8 == 0) && (m2.ld % 8 == 0) && a_step_fits &&
-                      (out_ld % 8 == 0) && al16(m1.ptr) && al16(m2.ptr) && al16(out) && batch_ok && off_ok;
+    // (Leading dimensions, base addresses and batch strides: anything element-aligned since round 6. The operands come in by LDS-DMA and the results leave in 16-byte
+    // stores, and both take any element-aligned address on this target -- tools/cpp/unaligned_probe.hip, unaligned_dma_probe.hip: the aligned rate at 4-byte offsets, 0.9 of
+    // it at 2-byte ones. Until then such views went through padded copies: 2048^3 with one odd leading dimension 35 us instead of 25, a C at an odd offset twice the time.)
+    // (The DMA'd operands at 4-byte alignment, though: pieces that start 2 bytes off a dword cost the GemmTr of 8192^2 x 1024 146 us against 127 on a padded copy of A.)
+    auto al4 = [](const void *p) { return ((uintptr_t)p & 3) == 0; };
+    const bool a_al = al4(m1.ptr) && m1.ld % 2 == 0 && (nmats == 1 || m1.batch % 2 == 0), b_al = al4(m2.ptr) && m2.ld % 2 == 0 && (nmats == 1 || m2.batch % 2 == 0);
+    const bool fast = (M % 8 == 0) && (k_big || k_small) && a_step_fits && off_ok && a_al && b_al;
     auto panels_ok = [&]() -> bool { // n_main panels of `cols`, then 1 .. 8 tail panels (<= 255 tile columns each) that end exactly at N
         if (!panels->cols || panels->cols % 256u || panels->n_tail < 1 || panels->n_tail > (uint32_t)kPanelTail || panels->n_main + panels->n_tail < 2) return false;
         uint64_t c0 = (uint64_t)panels->n_main * panels->cols;
@@ -1891,17 +1896,17 @@ int wgk_gemm_f16(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         return WG_OK;
     } else if (!g_padding && (uint64_t)M * N * K >= (1ull << 24) && K > 0 && nmats <= 65535u) {
         struct Guard { Guard() { g_padding = true; } ~Guard() { g_padding = false; } } guard; // the padded call must not pad again
-        // Shapes / alignments the MFMA kernels do not take as they are (K % 32, M or N % 8, leading dimensions % 8, unaligned views): at
+        // Shapes the MFMA kernels do not take as they are (K % 8, fewer than one whole stage, M % 8; an op(A) or B that starts or steps 2 bytes off a dword): at
         // ~40 TFLOP/s the generic kernel below is 20x slower (4096 x 4096 x 4104: 3.2 ms against 0.14 ms). Stage zero-padded dense copies
         // of the operands (and, if the output does not qualify either, a padded output that is copied back) in the context's padding
         // scratch and run the same call on those: HBM-bound passes over a few MB against a GEMM that re-reads them hundreds of times.
-        // Only what does not qualify is copied: op(A) when K, M, its leading dimension or its alignment is off, B when K or its leading
-        // dimension / alignment is, the output when M or its leading dimension / alignment is (N is free: columns are independent).
+        // Only what does not qualify is copied: op(A) when K or M is off, B when K is, the output when M is (N is free: columns are independent;
+        // leading dimensions and alignments are free since round 6).
         const bool k_ok = k_big || k_small; // (else: zero-padded to whole stages -- at least one, which the 128 x 128 kernel takes)
         const uint32_t Mp = (M + 7u) & ~7u, Kp = k_ok ? K : ((K + 63u) & ~63u);
-        const bool a_ok = k_ok && M == Mp && m1.ld % 8 == 0 && al16(m1.ptr) && (nmats == 1 || m1.batch % 8 == 0);
-        const bool b_ok = k_ok && m2.ld % 8 == 0 && al16(m2.ptr) && (nmats == 1 || m2.batch % 8 == 0);
-        const bool c_ok = M == Mp && out_ld % 8 == 0 && al16(out) && (nmats == 1 || out_batch % 8 == 0);
+        const bool a_ok = k_ok && M == Mp && a_al;
+        const bool b_ok = k_ok && b_al;
+        const bool c_ok = M == Mp;
         const uint64_t a_elems = a_ok ? 0 : (uint64_t)Mp * Kp, b_elems = b_ok ? 0 : (uint64_t)Kp * N, c_elems = c_ok ? 0 : (uint64_t)Mp * N;
         // every region starts 16-byte aligned: element counts rounded up to 8
         const uint64_t a_sz = ((a_elems + 7u) & ~7ull), b_sz = ((b_elems + 7u) & ~7ull), c_sz = ((c_elems + 7u) & ~7ull);

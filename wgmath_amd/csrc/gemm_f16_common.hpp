@@ -17,6 +17,10 @@ namespace wgf16 {
 #endif
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+// The same 16 bytes at an address in GLOBAL memory that is only element-aligned (an operand view at an odd offset or with an odd leading dimension):
+// the target runs the memory pipeline in unaligned-access mode -- one global_load / global_store_dwordx4 either way, at the aligned rate for 4-byte offsets and
+// 0.9 of it for 2-byte ones (tools/cpp/unaligned_probe.hip, unaligned_dma_probe.hip; profiles/r06_unaligned_probe.txt) -- and the type says what is really known.
+typedef half8_t __attribute__((aligned(2))) half8_u;
 typedef short short4_t __attribute__((ext_vector_type(4)));
 typedef short short8_t __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));

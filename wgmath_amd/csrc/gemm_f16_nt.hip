@@ -12,7 +12,7 @@
 //   * per half-step and wave: 64 MFMAs, 32 transposing reads (16 A + 16 B), 8 DMA pieces (4 A, then 4 B, of half-stage H + 4 into the slot H released), one
 //     lgkmcnt(0) + vmcnt(16) + barrier. The k order inside every MFMA and the accumulation chain of every element are those of the column-major kernels: the result
 //     is bit-identical to transposing B first and calling them (tests/test_gpu_parity.py).
-// Takes: M % 8 == 0, N % 8 == 0, K % 64 == 0, K >= 256, leading dimensions % 8 == 0, 16-byte aligned bases; everything else goes the transposed-copy way (api.hip).
+// Takes: M % 8 == 0, N % 8 == 0, K % 64 == 0, K >= 256 (any leading dimension and offset since round 6); everything else goes the transposed-copy way (api.hip).
 // Outputs of fewer 256 x 256 tiles than CUs are handed to the 128 x 128 / 256 x 128 tiles of gemm_f16_t128.hip in their B_NC instances (the launcher below).
 // Bound: MFMA (2.5 PFLOP/s dense), in practice the package power cap, as the other f16 kernels.
 #include "gemm_f16_common.hpp"
@@ -207,14 +207,14 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_nt_kernel(GemmArgs g) {
                 for (int q = 0; q < 8; ++q) r[q] *= alpha;
             }
             if (beta != 0.f) { // beta == 0 never reads C
-                const half8_t c = *reinterpret_cast<const half8_t *>(cc + 32 * p);
+                const half8_t c = *reinterpret_cast<const half8_u *>(cc + 32 * p);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) r[q] = fmaf(beta, (float)c[q], r[q]);
             }
             half8_t v;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-            *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+            *reinterpret_cast<half8_u *>(cc + 32 * p) = v;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing (parked pieces, stores) is in flight when the workgroup ends
@@ -225,10 +225,9 @@ __global__ __launch_bounds__(256, 1) void gemm_f16_nt_kernel(GemmArgs g) {
 // WG_ERR_UNSUPPORTED (no message): not a product this kernel takes -- the caller goes the transposed-copy way.
 static int nt_launch(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, _Float16 *out, uint32_t out_ld, uint64_t out_batch, const _Float16 *a, uint32_t lda,
               uint64_t a_batch, const _Float16 *b, uint32_t ldb, uint64_t b_batch, float alpha, float beta) {
-    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
-    if (M % 8u || N % 8u || K % 64u || K < 256u || lda % 8u || ldb % 8u || out_ld % 8u || !al16(a) || !al16(b) || !al16(out) || nmats > 65535u) return WG_ERR_UNSUPPORTED;
-    if (nmats > 1 && (a_batch % 8u || b_batch % 8u || out_batch % 8u)) return WG_ERR_UNSUPPORTED;
+    // (any leading dimension, offset and batch stride: the LDS-DMA and the 16-byte stores take element-aligned addresses -- gemm_f16_common.hpp half8_u)
+    if (M % 8u || N % 8u || K % 64u || K < 256u || nmats > 65535u) return WG_ERR_UNSUPPORTED;
     if ((uint64_t)lda * 64u >= (1ull << 31) || (uint64_t)ldb * 64u >= (1ull << 31)) return WG_ERR_UNSUPPORTED; // 32-bit offsets within a half-stage, 32-bit cursor steps
     GemmArgs g{};
     g.a = a; g.lda = lda; g.a_batch = a_batch;

@@ -35,6 +35,7 @@ namespace {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+typedef uintx4 __attribute__((aligned(2))) uintx4_u;
 
 template <class F, int... I>
 __device__ __forceinline__ void t_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
     if (rem) {
         auto put = [&](uint32_t dst, const char *src, bool valid) {
             uintx4 v = { 0u, 0u, 0u, 0u };
-            if (valid) v = *reinterpret_cast<const uintx4 *>(src);
+            if (valid) v = *reinterpret_cast<const uintx4_u *>(src);
             *(WG_AS3 uintx4 *)(uintptr_t)(dst + 16u * (uint32_t)lane) = v;
         };
         const char *ra = TRANS_A ? (const char *)(a_base + rem_dk) : (const char *)(a_base + (uint64_t)rem_dk * g.lda);
@@ -412,14 +413,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_t128_kernel(GemmArgs g) {
                 for (int q = 0; q < 8; ++q) r[q] *= alpha;
             }
             if (beta != 0.f) { // beta == 0 never reads C
-                const half8_t c = *reinterpret_cast<const half8_t *>(cc + 32 * p);
+                const half8_t c = *reinterpret_cast<const half8_u *>(cc + 32 * p);
 #pragma unroll
                 for (int q = 0; q < 8; ++q) r[q] = fmaf(beta, (float)c[q], r[q]);
             }
             half8_t v;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (_Float16)r[q];
-            *reinterpret_cast<half8_t *>(cc + 32 * p) = v;
+            *reinterpret_cast<half8_u *>(cc + 32 * p) = v;
         }
     }
 }

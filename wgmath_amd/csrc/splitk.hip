@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
         s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
     OUT *o = out + z * c_batch + (uint64_t)col * ldc + 4u * m4;
-    struct alignas(8) h4 { _Float16 v[4]; };
+    struct alignas(2) h4 { _Float16 v[4]; }; // (an f16 result at any element-aligned address: gemm_f16_common.hpp half8_u)
     if (alpha != 1.f) { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
     if (beta != 0.f) { // out = alpha * sum + beta * out (wg_gemm_ex); beta == 0 never reads `out`
         float4 c;

@@ -4,6 +4,7 @@
 // pre-pass, 2 * sizeof(T) * rows * cols bytes. 64 x 64 tiles through a padded LDS tile: reads walk rows of src (coalesced),
 // writes walk rows of dst (coalesced).
 #include "wg_internal.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -46,72 +47,47 @@ int wgk_transpose(wg_ctx *ctx, wg_dtype dtype, uint32_t rows, uint32_t cols, uin
 }
 
 // Copy of a column-major block with zero fill: dst (rd x cd, ld_dst) = src (rs x cs, ld_src) where it exists, 0 elsewhere -- any alignment, any
-// stride, either side. The operator front-end (api.hip) stages views that are not vec4-aligned -- the ones GpuMatrix::slice / rows / column
-// hand out for odd offsets and lengths (tensor.rs:574-626) -- into dense zero-padded copies with it and copies the result back, and the f16
-// launcher pads operands the MFMA kernels do not take as they are (gemm_f16.hip): HBM-bound passes over operands the kernels then read at full width.
+// stride, either side. The operator front-end (api.hip) stages operands whose LENGTHS the kernels do not take into zero-padded copies with it and copies
+// padded results back, the f16 launcher pads operands the MFMA kernels do not take as they are (gemm_f16.hip), and wg_copy_view exposes it.
 //
-// Round 6: 16-byte accesses whatever the alignment (the element-by-element kernel ran at ~1.3 TB/s; the f16 one fell back to it whenever
-// one side was only 8-byte aligned). A thread owns one 16-byte-aligned chunk of a destination column; the source bytes that belong there start
-// `m` bytes into an aligned 16-byte chunk of the source column (m is the same for the whole column), so it loads that chunk and the next one and
-// shifts (v_alignbyte_b32). Aligned chunks that hold at least one byte of the source column are the only ones read: such a chunk lies in the
-// same page as that byte. The ragged ends of a column (a first / last chunk that is only partly inside it) are masked and stored element by element.
+// Round 6: 16-byte accesses whatever the alignment (the element-by-element kernel ran at ~1.3 TB/s; the f16 one fell back to it whenever one side was only
+// 8-byte aligned). global_load_dwordx4 / global_store_dwordx4 take any element-aligned address on this target (tools/cpp/unaligned_probe.hip,
+// profiles/r06_unaligned_probe.txt: within 2 % of the aligned rate at 4-byte offsets, 0.88 of it at 2-byte offsets), so a thread moves 16 bytes of a column
+// -- E = 4 f32 / 8 f16 elements counted from the column's first -- with one load and one store wherever the two sides lie. Only a chunk that is not whole on
+// a side (the last rows of a length that is not a multiple of E; the edge of the zero padding) goes element by element there: a 16-byte access
+// could run off the end of a buffer.
 namespace {
-__device__ __forceinline__ uint4 shift_chunks(uint4 lo, uint4 hi, uint32_t m) { // bytes [m, m + 16) of lo:hi
-    const uint32_t w[8] = { lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w };
-    const uint32_t b = m & 3u;
-    uint4 r;
-    switch (m >> 2) { // (uniform over the wave)
-    case 0: r = make_uint4(__builtin_amdgcn_alignbyte(w[1], w[0], b), __builtin_amdgcn_alignbyte(w[2], w[1], b), __builtin_amdgcn_alignbyte(w[3], w[2], b), __builtin_amdgcn_alignbyte(w[4], w[3], b)); break;
-    case 1: r = make_uint4(__builtin_amdgcn_alignbyte(w[2], w[1], b), __builtin_amdgcn_alignbyte(w[3], w[2], b), __builtin_amdgcn_alignbyte(w[4], w[3], b), __builtin_amdgcn_alignbyte(w[5], w[4], b)); break;
-    case 2: r = make_uint4(__builtin_amdgcn_alignbyte(w[3], w[2], b), __builtin_amdgcn_alignbyte(w[4], w[3], b), __builtin_amdgcn_alignbyte(w[5], w[4], b), __builtin_amdgcn_alignbyte(w[6], w[5], b)); break;
-    default: r = make_uint4(__builtin_amdgcn_alignbyte(w[4], w[3], b), __builtin_amdgcn_alignbyte(w[5], w[4], b), __builtin_amdgcn_alignbyte(w[6], w[5], b), __builtin_amdgcn_alignbyte(w[7], w[6], b)); break;
-    }
-    return r;
-}
-
+typedef uint32_t wg_u32x4 __attribute__((ext_vector_type(4)));
 // ES: bytes per element (2 or 4). CPB: columns per workgroup (1: 256 chunks of one column; 4: a wave per column, for short columns).
 template <int ES, int CPB>
 __global__ __launch_bounds__(256) void copy2d_kernel(char *__restrict__ dst, uint32_t ld_dst, uint64_t dst_batch, uint32_t rd, uint32_t cd,
                                                      const char *__restrict__ src, uint32_t ld_src, uint64_t src_batch, uint32_t rs, uint32_t cs) {
-    constexpr uint32_t TX = 256u / CPB;
+    constexpr uint32_t TX = 256u / CPB, E = 16u / ES;
+    using elem_t = std::conditional_t<ES == 4, uint32_t, uint16_t>;
+    using gvec = const __attribute__((address_space(1), aligned(ES))) wg_u32x4;
+    using gvec_w = __attribute__((address_space(1), aligned(ES))) wg_u32x4;
     const uint32_t z = blockIdx.z;
-    const int64_t q = (int64_t)blockIdx.x * TX + (threadIdx.x % TX);
-    const int64_t nb = (int64_t)rd * ES;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * TX + (threadIdx.x % TX)) * E;
+    if (i0 >= rd) return;
     for (uint32_t j = blockIdx.y * CPB + threadIdx.x / TX; j < cd; j += gridDim.y * CPB) {
-        const uintptr_t D = (uintptr_t)dst + (z * dst_batch + (uint64_t)j * ld_dst) * ES;
-        const int64_t o = 16 * q - (int64_t)(D & 15u); // this chunk's first byte, as an offset into the column (< 0: the chunk starts ahead of it)
-        if (o >= nb) continue;
-        const uintptr_t S = (uintptr_t)src + (z * src_batch + (uint64_t)j * ld_src) * ES;
-        const int64_t vb = j < cs ? (int64_t)rs * ES : 0; // bytes of the source column
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (o + 16 > 0 && o < vb) {
-            const uintptr_t sa = S + o;
-            const uint32_t m = (uint32_t)(sa & 15u);
-            const int64_t ol = o - (int64_t)m; // column offset of the aligned source chunk `lo`
-            uint4 lo = make_uint4(0u, 0u, 0u, 0u), hi = lo;
-            if (ol + 16 > 0 && ol < vb) lo = *reinterpret_cast<const uint4 *>(sa - m);
-            if (m && ol + 32 > 0 && ol + 16 < vb) hi = *reinterpret_cast<const uint4 *>(sa - m + 16);
-            v = shift_chunks(lo, hi, m);
-            if (o < 0 || o + 16 > vb) { // an end of the source column: what lies outside it is zero, whatever the chunks held
-                uint32_t w[4] = { v.x, v.y, v.z, v.w };
+        const uintptr_t D = (uintptr_t)dst + (z * dst_batch + (uint64_t)j * ld_dst + i0) * ES;
+        const uintptr_t S = (uintptr_t)src + (z * src_batch + (uint64_t)j * ld_src + i0) * ES;
+        const uint32_t have = j < cs && i0 < rs ? (uint32_t)min((uint64_t)E, rs - i0) : 0u; // source elements of this chunk
+        wg_u32x4 v = { 0u, 0u, 0u, 0u };
+        if (have == E) v = *reinterpret_cast<gvec *>(S);
+        else if (have) {
+            elem_t e[E];
 #pragma unroll
-                for (int e = 0; e < 16 / ES; ++e) {
-                    const int64_t at = o + e * ES;
-                    if (at < 0 || at >= vb) w[(e * ES) >> 2] &= ES == 4 ? 0u : (e & 1 ? 0x0000ffffu : 0xffff0000u);
-                }
-                v = make_uint4(w[0], w[1], w[2], w[3]);
-            }
+            for (uint32_t k = 0; k < E; ++k) e[k] = k < have ? reinterpret_cast<const __attribute__((address_space(1))) elem_t *>(S)[k] : (elem_t)0;
+            if constexpr (ES == 4) v = wg_u32x4{ e[0], e[1], e[2], e[3] };
+            else v = wg_u32x4{ e[0] | (uint32_t)e[1] << 16, e[2] | (uint32_t)e[3] << 16, e[4] | (uint32_t)e[5] << 16, e[6] | (uint32_t)e[7] << 16 };
         }
-        if (o >= 0 && o + 16 <= nb) *reinterpret_cast<uint4 *>(D + o) = v;
+        if (i0 + E <= rd) *reinterpret_cast<gvec_w *>(D) = v;
         else {
             const uint32_t w[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-            for (int e = 0; e < 16 / ES; ++e) {
-                const int64_t at = o + e * ES;
-                if (at < 0 || at >= nb) continue;
-                if (ES == 4) *reinterpret_cast<uint32_t *>(D + at) = w[e];
-                else *reinterpret_cast<uint16_t *>(D + at) = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-            }
+            for (uint32_t k = 0; k < E; ++k)
+                if (i0 + k < rd) reinterpret_cast<__attribute__((address_space(1))) elem_t *>(D)[k] = ES == 4 ? (elem_t)w[k] : (elem_t)(w[k >> 1] >> (16u * (k & 1u)));
         }
     }
 }
@@ -122,7 +98,7 @@ int wgk_stage_copy(wg_ctx *ctx, wg_dtype dtype, void *dst, uint32_t ld_dst, uint
     if (rd == 0 || cd == 0 || nmats == 0) return WG_OK;
     if (nmats > 65535u) return wg_set_error(WG_ERR_UNSUPPORTED, "staging copy: more than 65535 matrices");
     const uint32_t es = dtype == WG_F32 ? 4u : 2u;
-    const uint64_t chunks = ((uint64_t)rd * es + 15u) / 16u + 1u; // (+ 1: a column that starts inside a chunk ends in one more)
+    const uint64_t chunks = ((uint64_t)rd * es + 15u) / 16u;
     const bool narrow = chunks <= 64u;
     const uint32_t tx = narrow ? 64u : 256u, cpb = narrow ? 4u : 1u, gy = (cd + cpb - 1u) / cpb;
     const dim3 grid((uint32_t)((chunks + tx - 1u) / tx), gy < 65535u ? gy : 65535u, nmats), block(256);

@@ -159,6 +159,9 @@ int wgk_gemv(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t rows_out, uint32_
 
 // out (M x N) = op(m1) (M x K) * m2 (K x N); trans: m1 stored K x M
 // fused Gemv + Reduce (one launch) for launch-bound sizes; WG_ERR_UNSUPPORTED (no error message) = not that shape family
+// Gemv / GemvTr on a matrix view of any alignment (gemv_any.hip): m is the R x C view as stored, v / out hold nrhs columns
+int wgk_gemv_any(wg_ctx *ctx, bool trans, wg_dtype dtype, uint32_t R, uint32_t C, uint32_t nrhs, uint32_t nmats, void *out, uint32_t out_ld, uint64_t out_batch,
+                 wgk_mat m, wgk_mat v);
 int wgk_gemv_small_reduce(wg_ctx *ctx, int op, uint32_t rows_out, uint32_t k, float *y, wgk_mat m, wgk_mat v, unsigned *counter, float *result);
 
 int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats,
