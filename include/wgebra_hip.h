@@ -250,10 +250,11 @@ int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
  *   Views that are not vec4-aligned (rows / stride / stride_mat / offset of a view, or M, N, K, not a multiple of 4 -- what
  *                   GpuMatrix::slice / rows / column hand out for odd offsets and lengths, tensor.rs:574-626): the reference's
  *                   kernels bind array<vec4<f32>> and address the wrong elements there (shape.wgsl:64-66). Here they compute
- *                   op(m1) m2 like any other view: the operands that need it -- and only those -- are staged into dense zero-padded copies
- *                   (HBM-bound passes in a context scratch that cannot grow inside a recording: WG_ERR_WORKSPACE); 1 .. 7 columns
- *                   on otherwise aligned views run as a Gemv with that many right-hand sides, without any copy. Only a view that
- *                   exceeds its buffer is an error.
+ *                   op(m1) m2 like any other view. f16: any offset / stride runs on the tuned kernels as it is (16-byte accesses and LDS-DMA take
+ *                   element-aligned addresses on this target); lengths that are not multiples of 4 -- and, for f32, views at odd offsets / strides --
+ *                   are staged into dense zero-padded copies of the operands that need one (HBM-bound passes in a context scratch that cannot grow
+ *                   inside a recording: WG_ERR_WORKSPACE); 1 .. 7 columns on otherwise aligned views run as a Gemv with that many right-hand
+ *                   sides, without any copy. Only a view that exceeds its buffer is an error.
  *   *_FAST        : the reference requires K % 256 == 0 and reads out of bounds otherwise (gemm.wgsl:40,162);
  *                   here every K % 4 == 0 is accepted and all four variants run the same tuned kernel.
  * dtype WG_F16 (extension): f16 operands, f32 accumulation, result rounded once (RNE) to f16.
@@ -278,7 +279,7 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
  * column y < out.size[1] and matrix z < out.size[2]; `out` is overwritten.
  *   DIM_MISMATCH  : gemv.rs:89-90 (only m_cols == v_rows and m_rows == out_rows are checked there too).
  *   PRECONDITION  : WG_GEMV_FAST / WG_GEMV_TR_FAST with out rows % 4 != 0 (assert_eq! gemv.rs:122). Views that are not
- *                   vec4-aligned run on staged copies, as for wg_gemm.
+ *                   vec4-aligned run in ONE pass on the matrix where it lies (gemv_any.hip: 16-byte loads at element-aligned addresses).
  *   WG_GEMV_TR_FAST with m rows % 128 != 0 silently runs as WG_GEMV_TR (gemv.rs:99-104) -- same kernel here.
  * dtype WG_F16 (extension): f16 elements, f32 accumulation, one rounding at the store -- the same HBM-bound kernels.
  * Several right-hand sides: one pass over the matrix for all of them; from 9 on -- and from 3 on when the matrix is past the launch-bound

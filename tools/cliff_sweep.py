@@ -1,7 +1,7 @@
 """Looks for performance cliffs next to the tuned shapes: a base Gemm / Gemv shape against the same shape with one dimension (or one view's offset / leading
 dimension) nudged off the alignments the fast kernels want (multiples of 4 elements = the reference's vec4 contract, of 8 = 16 bytes of f16, of the tile sizes).
 Prints us per dispatch and the ratio to the base shape; anything far above 1 is a path that copies or falls to a slow kernel.
-Usage (GPU box): [CLIFF_ONLY=gemv|gemm] python tools/cliff_sweep.py [f32|f16 ...]"""
+Usage (GPU box): [CLIFF_ONLY=gemv|gemm|vec] python tools/cliff_sweep.py [f32|f16 ...]"""
 import os
 import sys
 import time
@@ -64,8 +64,40 @@ def gemv_case(dt, tr, R, C, pad=0, off=(0, 0, 0)):
     return timed(lambda p: gemv.dispatch_generic(dev, shapes, p, ov, mv, vv, variant), 100)
 
 
+def vec_case(dt, what, n, offs):
+    a = device_random(wg, gpu, (n + 8,), dt, 1)
+    b = device_random(wg, gpu, (n + 8,), dt, 2)
+    res = wg.TensorBuilder.vector(4, S.STORAGE).build(dev, dt)
+    av = wg.GpuTensorView(wg.ViewShape((n, 1, 1), n, n, offs[0]), a, 1)
+    bv = wg.GpuTensorView(wg.ViewShape((n, 1, 1), n, n, offs[1]), b, 1)
+    if what == "add":
+        op = wg.OpAssign.new(dev, wg.OpAssignVariant.Add)
+        return timed(lambda p: op.dispatch(dev, shapes, p, av, bv), 50)
+    if what == "copy":
+        op = wg.OpAssign.new(dev, wg.OpAssignVariant.Copy)
+        return timed(lambda p: op.dispatch(dev, shapes, p, av, bv), 50)
+    if what == "axpy":
+        op = wg.Axpy.from_device(dev)
+        return timed(lambda p: op.dispatch(dev, shapes, p, 0.5, av, bv), 50)
+    red = wg.Reduce.new(dev, wg.ReduceOp.Sum)
+    if what == "reduce_fast":
+        return timed(lambda p: red.dispatch_fast(dev, shapes, p, av, res), 50)
+    return timed(lambda p: red.dispatch(dev, shapes, p, av, res), 20)
+
+
 for name in (sys.argv[1:] or ["f32", "f16"]):
     dt = np.float16 if name == "f16" else np.float32
+    if os.environ.get("CLIFF_ONLY") in (None, "vec"):
+        for what, n in [("add", 1 << 26), ("copy", 1 << 26), ("axpy", 1 << 26), ("reduce_fast", 1 << 26), ("reduce", 1 << 22)]:
+            base = vec_case(dt, what, n, (0, 0))
+            print(f"{name} {what} {n}: base {base:9.1f} us", flush=True)
+            for label, offs in [("a+1", (1, 0)), ("b+1", (0, 1)), ("both+1", (1, 1)), ("a+4", (4, 0)), ("b+2", (0, 2))]:
+                if what.startswith("reduce") and offs[0] == 0:
+                    continue
+                t = vec_case(dt, what, n, offs)
+                print(f"    {label:8s} {t:9.1f} us  x{t / base:5.2f}{'   <-- cliff' if t > 1.3 * base else ''}", flush=True)
+    if os.environ.get("CLIFF_ONLY") == "vec":
+        continue
     for tr in (False, True):
         for (M, N, K) in ([] if os.environ.get("CLIFF_ONLY") == "gemv" else [(4096, 4096, 4096), (2048, 2048, 2048), (8192, 8192, 1024)] if dt == np.float16 else [(2048, 2048, 2048), (4096, 4096, 1024)]):
             base = gemm_case(dt, tr, M, N, K)

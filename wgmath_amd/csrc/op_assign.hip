@@ -56,7 +56,9 @@ __device__ __forceinline__ void st4(float4 *p, float4 v) {
 
 // `a`/`b` point at the first element; [head, head + 4*n4) is the 16-byte aligned body, the <= 3 elements before
 // and after it are done by the first lanes of block 0.
-template <int OP>
+// BU: `b` is not 16-byte aligned where `a` is (different offsets into their buffers): its float4 are loaded from element-aligned addresses (round 6; such pairs took
+// the element-wise kernel before: Copy of 2^26 floats 116 us against 81)
+template <int OP, bool BU>
 __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const float *b0, uint32_t head, uint32_t n4, uint32_t n, float alpha) {
     if (blockIdx.x == 0) {
         const uint32_t body_end = head + 4u * n4;
@@ -69,7 +71,11 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
         }
     }
     float4 *a = reinterpret_cast<float4 *>(a0 + head);
-    const float4 *b = reinterpret_cast<const float4 *>(b0 + head);
+    const float *bs = b0 + head;
+    auto ldb = [&](uint64_t i) -> float4 {
+        if constexpr (BU) return OPA_NT >= 1 ? wg_ld_nt_u(bs + 4u * i) : wg_ld_u(bs + 4u * i);
+        else return ld4(reinterpret_cast<const float4 *>(bs) + i);
+    };
     if (OPA_MODE == 2) {
         const uint64_t base = (uint64_t)blockIdx.x * (kUnroll * kThreads) + threadIdx.x;
         float4 va[kUnroll], vb[kUnroll];
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
         for (int u = 0; u < kUnroll; ++u) {
             const uint64_t i = base + (uint64_t)u * kThreads;
             if (i < n4) {
-                vb[u] = ld4(&b[i]);
+                vb[u] = ldb(i);
                 if constexpr (OP != OP_COPY) va[u] = ld4(&a[i]);
             }
         }
@@ -95,27 +101,16 @@ __global__ __launch_bounds__(kThreads) void op_assign_f32_vec(float *a0, const f
         float4 va[kUnroll], vb[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            vb[u] = ld4(&b[i + u * stride]);
+            vb[u] = ldb(i + u * stride);
             if constexpr (OP != OP_COPY) va[u] = ld4(&a[i + u * stride]);
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) st4(&a[i + u * stride], apply4<OP>(va[u], vb[u], alpha));
     }
     for (; i < n4; i += stride) {
-        float4 vb = b[i], va = vb;
+        float4 vb = ldb(i), va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
         a[i] = apply4<OP>(va, vb, alpha);
-    }
-}
-
-// any alignment; also the head/tail of the vector path
-template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f32_scalar(float *a, const float *b, uint32_t n, float alpha) {
-    const uint32_t stride = gridDim.x * kThreads;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        float vb = b[i], va = vb;
-        if constexpr (OP != OP_COPY) va = a[i];
-        a[i] = apply<OP>(va, vb, alpha);
     }
 }
 
@@ -134,8 +129,9 @@ __device__ __forceinline__ __half apply_h(__half a, __half b, float alpha) {
 }
 
 struct alignas(16) half8 { __half h[8]; };
+struct alignas(2) half8_u { __half h[8]; }; // (the same 16 bytes at an element-aligned address)
 
-template <int OP>
+template <int OP, bool BU>
 __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const __half *b0, uint32_t head, uint32_t n8, uint32_t n, float alpha) {
     if (blockIdx.x == 0) {
         const uint32_t body_end = head + 8u * n8;
@@ -148,10 +144,12 @@ __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const 
         }
     }
     half8 *a = reinterpret_cast<half8 *>(a0 + head);
-    const half8 *b = reinterpret_cast<const half8 *>(b0 + head);
     const uint32_t stride = gridDim.x * kThreads; // flat grid: at most one trip
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n8; i += stride) {
-        half8 vb = b[i], va = vb;
+        half8 vb, va;
+        if constexpr (BU) { const half8_u t = reinterpret_cast<const half8_u *>(b0 + head)[i]; __builtin_memcpy(&vb, &t, 16); }
+        else vb = reinterpret_cast<const half8 *>(b0 + head)[i];
+        va = vb;
         if constexpr (OP != OP_COPY) va = a[i];
         half8 r;
 #pragma unroll
@@ -159,16 +157,6 @@ __global__ __launch_bounds__(kThreads) void op_assign_f16_vec(__half *a0, const 
         a[i] = r;
     }
 }
-template <int OP>
-__global__ __launch_bounds__(kThreads) void op_assign_f16_scalar(__half *a, const __half *b, uint32_t n, float alpha) {
-    const uint32_t stride = gridDim.x * kThreads;
-    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += stride) {
-        __half vb = b[i], va = vb;
-        if constexpr (OP != OP_COPY) va = a[i];
-        a[i] = apply_h<OP>(va, vb, alpha);
-    }
-}
-
 inline uint32_t grid_for(uint64_t work_items, int cus) {
     uint64_t blocks = (work_items + kThreads - 1) / kThreads;
     uint64_t cap = (uint64_t)(cus > 0 ? cus : 256) * OPA_WG_PER_CU; // workgroups of 4 waves per CU, grid-stride beyond
@@ -180,16 +168,13 @@ inline uint32_t grid_for(uint64_t work_items, int cus) {
 template <int OP>
 int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n, float alpha) {
     const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
-    if ((pa & 15) == (pb & 15)) {
-        // scalar head up to the 16-byte boundary, vector body, scalar tail
-        uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 4);
-        if (head > n) head = n;
-        uint32_t n4 = (n - head) / 4;
-        const uint32_t blocks = OPA_MODE == 2 ? (uint32_t)(((uint64_t)n4 + kUnroll * kThreads - 1) / (kUnroll * kThreads)) : grid_for(n4, ctx->compute_units);
-        hipLaunchKernelGGL(op_assign_f32_vec<OP>, dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n4, n, alpha);
-    } else {
-        hipLaunchKernelGGL(op_assign_f32_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
-    }
+    // scalar head up to `a`'s 16-byte boundary, vector body, scalar tail; `b` at whatever alignment that leaves it
+    uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 4);
+    if (head > n) head = n;
+    uint32_t n4 = (n - head) / 4;
+    const uint32_t blocks = OPA_MODE == 2 ? (uint32_t)(((uint64_t)n4 + kUnroll * kThreads - 1) / (kUnroll * kThreads)) : grid_for(n4, ctx->compute_units);
+    if ((pa & 15) == (pb & 15)) hipLaunchKernelGGL((op_assign_f32_vec<OP, false>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n4, n, alpha);
+    else hipLaunchKernelGGL((op_assign_f32_vec<OP, true>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n4, n, alpha);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
@@ -197,15 +182,12 @@ int launch_f32(wg_ctx *ctx, float *a, const float *b, uint32_t n, float alpha) {
 template <int OP>
 int launch_f16(wg_ctx *ctx, __half *a, const __half *b, uint32_t n, float alpha) {
     const uintptr_t pa = (uintptr_t)a, pb = (uintptr_t)b;
-    if ((pa & 15) == (pb & 15) && (pa & 1) == 0) {
-        uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 2);
-        if (head > n) head = n;
-        uint32_t n8 = (n - head) / 8;
-        const uint32_t blocks = (n8 + kThreads - 1) / kThreads;
-        hipLaunchKernelGGL(op_assign_f16_vec<OP>, dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n8, n, alpha);
-    } else {
-        hipLaunchKernelGGL(op_assign_f16_scalar<OP>, dim3(grid_for(n, ctx->compute_units)), dim3(kThreads), 0, ctx->stream, a, b, n, alpha);
-    }
+    uint32_t head = (uint32_t)(((16 - (pa & 15)) & 15) / 2);
+    if (head > n) head = n;
+    uint32_t n8 = (n - head) / 8;
+    const uint32_t blocks = (n8 + kThreads - 1) / kThreads;
+    if ((pa & 15) == (pb & 15)) hipLaunchKernelGGL((op_assign_f16_vec<OP, false>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n8, n, alpha);
+    else hipLaunchKernelGGL((op_assign_f16_vec<OP, true>), dim3(blocks ? blocks : 1), dim3(kThreads), 0, ctx->stream, a, b, head, n8, n, alpha);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

@@ -12,7 +12,6 @@
 //   * the tree's cross-lane steps (strides 64..4) are wave shuffles inside each 32-lane half, strides 2 and 1
 //     are in-register; no LDS, no barrier.
 // HBM-bound: 4 bytes per element read, 4 bytes per vector written.
-// Vectors whose base is not 16-byte aligned take the scalar twin (128 lanes x 4-byte loads, same tree).
 #include "wg_internal.hpp"
 #include "reduce_ops.hpp"
 
@@ -36,14 +35,17 @@ __device__ __forceinline__ const T *vector_base(const T *base, uint32_t q, uint3
 
 // Element types: f32 (the reference's), and f16 as this build's extension -- f16 elements are converted to f32 (exact), folded in the
 // reference's order in f32, and the result is rounded once (RNE) to f16. Four consecutive elements of a row, as floats:
-__device__ __forceinline__ float4 load4(const float *p, bool nt) { return nt ? wg_ld_nt(reinterpret_cast<const float4 *>(p)) : *reinterpret_cast<const float4 *>(p); }
+// (at any element-aligned address, round 6: vectors whose base is not a multiple of 4 elements took a 128-lane element-wise twin of the kernel below before --
+// 2.6x the time on one long vector; unaligned-access mode, wg_internal.hpp wg_ld_nt_u)
+__device__ __forceinline__ float4 load4(const float *p, bool nt) { return nt ? wg_ld_nt_u(p) : wg_ld_u(p); }
 __device__ __forceinline__ float4 load4(const _Float16 *p, bool nt) {
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    const h4 v = nt ? __builtin_nontemporal_load(reinterpret_cast<const h4 *>(p)) : *reinterpret_cast<const h4 *>(p);
+    typedef _Float16 h4a __attribute__((ext_vector_type(4)));
+    typedef h4a __attribute__((aligned(2))) h4;
+    const h4a v = nt ? __builtin_nontemporal_load(reinterpret_cast<const h4 *>(p)) : *reinterpret_cast<const h4 *>(p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
-// 32 physical lanes x 4 elements per vector; requires every vector base aligned to 4 elements (16 bytes f32, 8 bytes f16).
+// 32 physical lanes x 4 elements per vector, at any element-aligned base.
 template <int OP, typename T>
 __global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ base, uint32_t n, uint32_t ncols,
                                                          uint32_t nvec, uint32_t stride, uint32_t stride_mat,
@@ -94,42 +96,6 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ b
     if (p == 0) results[q] = (T)acc[0];
 }
 
-// 128 physical lanes per vector, any alignment; 2 vectors per workgroup.
-template <int OP, typename T>
-__global__ __launch_bounds__(kThreads) void reduce_rows1(const T *__restrict__ base, uint32_t n, uint32_t ncols,
-                                                         uint32_t nvec, uint32_t stride, uint32_t stride_mat,
-                                                         T *__restrict__ results) {
-    __shared__ float upper[2][64];
-    const uint32_t half = threadIdx.x >> 7; // which vector of the workgroup
-    const uint32_t t = threadIdx.x & 127;
-    const uint32_t q = blockIdx.x * 2 + half;
-    float acc = r_init<OP>();
-    if (q < nvec) {
-        const T *x = vector_base(base, q, ncols, stride, stride_mat);
-        uint32_t i = t;
-        for (; (uint64_t)i + 128u * (kUnroll - 1) < n; i += 128u * kUnroll) {
-            float v[kUnroll];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = (float)x[i + 128u * u];
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) acc = r_ws<OP>(acc, v[u]);
-        }
-        for (; i < n; i += 128u) {
-            acc = r_ws<OP>(acc, (float)x[i]);
-            if (i + 128u < i) break;
-        }
-    }
-    // stride 64 crosses the two waves of a vector: through LDS
-    if (t >= 64) upper[half][t - 64] = acc;
-    __syncthreads();
-    if (t < 64) {
-        acc = r_red<OP>(acc, upper[half][t]);
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) acc = r_red<OP>(acc, __shfl_down(acc, s, 64));
-        if (t == 0 && q < nvec) results[q] = (T)acc;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // Long vectors, few of them (the reference's own use: ONE vector per dispatch): the per-lane chain order pins the arithmetic
 // to one half-wave, and a half-wave alone keeps only ~8 KiB of loads in flight (measured 10 GB/s from HBM). Here all 8 waves
@@ -139,34 +105,34 @@ __global__ __launch_bounds__(kThreads) void reduce_rows1(const T *__restrict__ b
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kLongThreads = 512;
 constexpr int kLongSlots = 8;
-constexpr int kLongSlotRows = 32;                       // rows of 128 floats (512 B) per slot
-constexpr int kLongSlotBytes = kLongSlotRows * 512;     // 16 KiB
+constexpr int kLongSlotBytes = 16384;                   // 32 rows of 128 floats (64 rows of 128 f16) per slot
 constexpr int kLongPieces = kLongSlotBytes / 1024 / 8;  // DMA pieces per wave per slot (= 2)
 
-__device__ __forceinline__ void red_dma16(const float *gsrc, uint32_t lds_dst) {
+__device__ __forceinline__ void red_dma16(const void *gsrc, uint32_t lds_dst) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_dst));
 }
 
-template <int OP>
-__global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restrict__ base, uint32_t n, uint32_t ncols, uint32_t nvec,
-                                                            uint32_t stride, uint32_t stride_mat, float *__restrict__ results) {
+template <int OP, typename T>
+__global__ __launch_bounds__(kLongThreads) void reduce_long(const T *__restrict__ base, uint32_t n, uint32_t ncols, uint32_t nvec,
+                                                            uint32_t stride, uint32_t stride_mat, T *__restrict__ results) {
+    constexpr int kLongSlotRows = kLongSlotBytes / (128 * (int)sizeof(T)), kPieceElems = 1024 / (int)sizeof(T), kLaneElems = 16 / (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) char ring[kLongSlots * kLongSlotBytes];
     const uint32_t q = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float *x = vector_base(base, q, ncols, stride, stride_mat);
+    const T *x = vector_base(base, q, ncols, stride, stride_mat);
     const uint32_t full_rows = n / 128u;
     const uint32_t nslots = full_rows / kLongSlotRows; // whole slots; the rest is folded straight from global memory below
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)ring;
 
     auto issue = [&](uint32_t slot) { // this wave's 2 KiB of vector slot `slot` -> ring position slot % 8
-        const float *src = x + (uint64_t)slot * (kLongSlotRows * 128u) + (uint32_t)wave * (kLongPieces * 256u) + 4u * lane;
+        const T *src = x + (uint64_t)slot * (kLongSlotRows * 128u) + (uint32_t)wave * (kLongPieces * kPieceElems) + (uint32_t)(kLaneElems * lane);
         const uint32_t dst = lds_base + (slot % kLongSlots) * kLongSlotBytes + wave * (kLongPieces * 1024);
 #pragma unroll
-        for (int p = 0; p < kLongPieces; ++p) red_dma16(src + p * 256, __builtin_amdgcn_readfirstlane(dst + p * 1024));
+        for (int p = 0; p < kLongPieces; ++p) red_dma16(src + p * kPieceElems, __builtin_amdgcn_readfirstlane(dst + p * 1024));
     };
 
     // Consumers: waves 0 and 1, ONE chain per lane (chain t = 64 wave + lane folds x[t], x[t + 128], ... ascending -- reduce.wgsl:71-74): a slot's 32
@@ -191,19 +157,19 @@ __global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restr
         __syncthreads(); // everyone's pieces of slot s are in LDS; the consumers have left slot s-1
         if (s + kLongSlots - 1 < nslots) issue(s + kLongSlots - 1); // refill the position slot s-1 occupied
         if (consumer) {
-            const float *rows = reinterpret_cast<const float *>(ring + (s % kLongSlots) * kLongSlotBytes) + t;
+            const T *rows = reinterpret_cast<const T *>(ring + (s % kLongSlots) * kLongSlotBytes) + t;
             float v[kLongSlotRows];
 #pragma unroll
-            for (int r = 0; r < kLongSlotRows; ++r) v[r] = rows[r * 128];
+            for (int r = 0; r < kLongSlotRows; ++r) v[r] = (float)rows[r * 128];
 #pragma unroll
             for (int r = 0; r < kLongSlotRows; ++r) acc = r_ws<OP>(acc, v[r]); // ascending rows
             // (reading slot s while folding slot s - 1 out of registers measured slower: 56 -> 50 GB/s)
         }
     }
     if (consumer) {
-        for (uint32_t r = nslots * kLongSlotRows; r < full_rows; ++r) acc = r_ws<OP>(acc, x[(uint64_t)r * 128u + t]); // < 32 left-over full rows
+        for (uint32_t r = nslots * kLongSlotRows; r < full_rows; ++r) acc = r_ws<OP>(acc, (float)x[(uint64_t)r * 128u + t]); // the left-over full rows, less than a slot
         const uint32_t i0 = full_rows * 128u + t;
-        if (i0 < n) acc = r_ws<OP>(acc, x[i0]); // ragged last row
+        if (i0 < n) acc = r_ws<OP>(acc, (float)x[i0]); // ragged last row
     }
     // the 64 .. 1 tree of reduce.wgsl:76-87 over the 128 chains: stride 64 crosses the two consumer waves (LDS), the rest is inside wave 0
     __shared__ float upper[64];
@@ -213,7 +179,7 @@ __global__ __launch_bounds__(kLongThreads) void reduce_long(const float *__restr
     acc = r_red<OP>(acc, upper[lane]);
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) acc = r_red<OP>(acc, __shfl_down(acc, sft, 64));
-    if (lane == 0) results[q] = acc;
+    if (lane == 0) results[q] = (T)acc;
 }
 
 template <int OP, typename T>
@@ -223,22 +189,13 @@ int launch(wg_ctx *ctx, const T *base, uint32_t n, uint32_t ncols, uint32_t nmat
     if (nvec64 == 0) return WG_OK;
     if (nvec64 > 0x7fffffffull) return wg_set_error(WG_ERR_UNSUPPORTED, "Reduce: more than 2^31 vectors in one call");
     const uint32_t nvec = (uint32_t)nvec64;
-    const bool aligned = ((uintptr_t)base % (4 * sizeof(T)) == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
-    if constexpr (sizeof(T) == 4) {
-        if (aligned && n >= 65536u && nvec <= 256u) { // long vectors, fewer than there are CUs: one 8-wave workgroup each
-            hipLaunchKernelGGL(reduce_long<OP>, dim3(nvec), dim3(kLongThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
-            WG_HIP_TRY(hipGetLastError());
-            return WG_OK;
-        }
+    if (n >= 65536u && nvec <= 256u) { // long vectors, fewer than there are CUs: one 8-wave workgroup each (f16 too since round 6: 2^22 elements 900 -> ~300 us)
+        hipLaunchKernelGGL((reduce_long<OP, T>), dim3(nvec), dim3(kLongThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
+        WG_HIP_TRY(hipGetLastError());
+        return WG_OK;
     }
-    if (aligned) {
-        const uint32_t per_block = kThreads / 32;
-        hipLaunchKernelGGL((reduce_rows4<OP, T>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n,
-                           ncols, nvec, stride, stride_mat, results);
-    } else {
-        hipLaunchKernelGGL((reduce_rows1<OP, T>), dim3((nvec + 1) / 2), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride,
-                           stride_mat, results);
-    }
+    const uint32_t per_block = kThreads / 32;
+    hipLaunchKernelGGL((reduce_rows4<OP, T>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }

@@ -135,6 +135,17 @@ __device__ __forceinline__ float4 wg_ld_nt(const float4 *p) {
     wg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wg_f4 *>(p));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+// ... at an address that is only element-aligned: the memory pipeline runs in unaligned-access mode (one global_load_dwordx4 either way, the aligned rate at
+// 4-byte offsets: tools/cpp/unaligned_probe.hip, profiles/r06_unaligned_probe.txt); the pointer type states the alignment that is really there
+typedef wg_f4 __attribute__((aligned(4))) wg_f4_u;
+__device__ __forceinline__ float4 wg_ld_nt_u(const float *p) {
+    wg_f4 v = __builtin_nontemporal_load(reinterpret_cast<const wg_f4_u *>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float4 wg_ld_u(const float *p) {
+    wg_f4 v = *reinterpret_cast<const wg_f4_u *>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 
 static inline size_t wg_dtype_size(wg_dtype d) { return d == WG_F16 ? 2 : 4; }
 
