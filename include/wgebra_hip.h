@@ -250,9 +250,9 @@ int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
  *   Views that are not vec4-aligned (rows / stride / stride_mat / offset of a view, or M, N, K, not a multiple of 4 -- what
  *                   GpuMatrix::slice / rows / column hand out for odd offsets and lengths, tensor.rs:574-626): the reference's
  *                   kernels bind array<vec4<f32>> and address the wrong elements there (shape.wgsl:64-66). Here they compute
- *                   op(m1) m2 like any other view. f16: any offset / stride runs on the tuned kernels as it is (16-byte accesses and LDS-DMA take
- *                   element-aligned addresses on this target); lengths that are not multiples of 4 -- and, for f32, views at odd offsets / strides --
- *                   are staged into dense zero-padded copies of the operands that need one (HBM-bound passes in a context scratch that cannot grow
+ *                   op(m1) m2 like any other view. Any offset / stride runs on the tuned kernels as it is (16-byte accesses and LDS-DMA take
+ *                   element-aligned addresses on this target); lengths that are not multiples of 4
+ *                   are staged into dense zero-padded copies of the operands that carry them (HBM-bound passes in a context scratch that cannot grow
  *                   inside a recording: WG_ERR_WORKSPACE); 1 .. 7 columns on otherwise aligned views run as a Gemv with that many right-hand
  *                   sides, without any copy. Only a view that exceeds its buffer is an error.
  *   *_FAST        : the reference requires K % 256 == 0 and reads out of bounds otherwise (gemm.wgsl:40,162);

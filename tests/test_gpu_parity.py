@@ -361,6 +361,55 @@ def test_gemm_f16_any_offset_and_leading_dimension_is_the_aligned_product_bit_fo
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (case, tr, pads, offs, bpads)
 
 
+F32_ANY_ALIGN = [
+    # M, N, K, matrices -- the f32 kernel families (gemm_f32.hip launcher): the 256 x 128 kernel (DMA interior + edge tiles), its tail split, the mid-size tiles, K split over the
+    # workgroup's waves, few columns / few rows (gemm_f32_skinny.hip, 16- and 32-wide), split-K slabs, a batch, the 64 < M <= 128 transposed form
+    (1536, 1280, 192, 1), (2304, 2048, 256, 1), (96, 96, 512, 1), (64, 64, 4096, 1), (2048, 16, 1024, 1), (2048, 48, 512, 1), (16, 2048, 1024, 1), (128, 128, 8192, 1),
+    (1024, 768, 256, 3), (96, 8192, 256, 1),
+]
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("case", F32_ANY_ALIGN)
+def test_gemm_f32_any_offset_and_leading_dimension(gpu, tr, case):
+    """f32 operands at odd element offsets with odd leading dimensions and batch strides run on the tuned kernels as they are (round 6: LDS-DMA and 16-byte
+    accesses at element-aligned addresses; padded copies only for lengths): against f64 with the usual bound (the launcher's tile choice looks at leading
+    dimensions, so the aligned call need not be the same kernel), and nothing outside the output view may change."""
+    wg = _wg()
+    (M, N, K, mats) = case
+    rng = np.random.default_rng(11 * M + 3 * N + 7 * K + mats + int(tr))
+    ar, ac = (K, M) if tr else (M, K)
+    A = (rng.random((mats, ac, ar), dtype=np.float32) - 0.5)
+    B = (rng.random((mats, N, K), dtype=np.float32) - 0.5)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    A64 = [(A[z].astype(np.float64).T if not tr else A[z].astype(np.float64)) for z in range(mats)]
+    ref = np.stack([A64[z] @ B[z].astype(np.float64).T for z in range(mats)])
+    sabs = np.stack([np.abs(A64[z]) @ np.abs(B[z].astype(np.float64).T) for z in range(mats)])
+    for (pa, pb, pc), (oa, ob, oc), (ba, bb, bc) in [((0, 0, 0), (0, 0, 0), (0, 0, 0)), ((1, 3, 5), (1, 3, 5), (1, 1, 1)), ((4, 0, 0), (0, 2, 0), (0, 0, 3)), ((7, 2, 1), (3, 0, 2), (0, 3, 0))]:
+        lda, ldb, ldc = ar + pa, K + pb, M + pc
+        sa, sb, sc = lda * ac + ba, ldb * N + bb, ldc * N + bc
+        fa = np.zeros(oa + sa * mats + 8, np.float32); fb = np.zeros(ob + sb * mats + 8, np.float32)
+        fc = rng.random(oc + sc * mats + 8, dtype=np.float32)
+        for z in range(mats):
+            fa[oa + z * sa: oa + z * sa + lda * ac].reshape(ac, lda)[:, :ar] = A[z]
+            fb[ob + z * sb: ob + z * sb + ldb * N].reshape(N, ldb)[:, :K] = B[z]
+        ta, tb, tc = upload(gpu, (fa.size,), fa), upload(gpu, (fb.size,), fb), upload(gpu, (fc.size,), fc)
+        av = wg.GpuTensorView(wg.ViewShape((ar, ac, mats), lda, sa, oa), ta, 2)
+        bv = wg.GpuTensorView(wg.ViewShape((K, N, mats), ldb, sb, ob), tb, 2)
+        cv = wg.GpuTensorView(wg.ViewShape((M, N, mats), ldc, sc, oc), tc, 2)
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, cv, av, bv, variant))
+        got = tc.read(gpu.device())
+        mask = np.ones(fc.size, bool)
+        for z in range(mats):
+            idx = oc + z * sc + np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+            G = got[idx].astype(np.float64)
+            tol = U.f32_gate(K, sabs[z])
+            assert (np.abs(G - ref[z]) <= tol).all(), f"{case} {tr} pads {(pa, pb, pc)} offsets {(oa, ob, oc)}: worst err/tol {(np.abs(G - ref[z]) / tol).max():.3g}"
+            mask[idx.ravel()] = False
+        assert np.array_equal(got[mask].view(np.uint32), fc[mask].view(np.uint32)), "wrote outside the output view"
+
+
 # One thing off at a time: only the operands that need a staged copy get one (api.hip gemm_staged / gemv_staged), so every combination of
 # "as it lies" and "copied" operands must give the product -- and leave everything outside the output view alone.
 GEMM_ONE_OFF = [

@@ -59,8 +59,8 @@ int gemm_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, float alpha, float beta, w
     // of the matrix, 177 us now): a dimension that is not a multiple of 4 is rounded up to 8 in the two operands that carry it, an operand
     // whose own view is not vec4-aligned is copied at the (possibly padded) sizes, the others are used where they lie.
     const uint32_t Mp = M % 4 ? up8(M) : M, Np = N % 4 ? up8(N) : N, Kp = K % 4 ? up8(K) : K, mats = o.mats;
-    const bool any_view = dtype == WG_F16; // (the f16 kernels take any offset / leading dimension: only lengths are padded)
-    const bool sa = (!any_view && !vec4_ok(a)) || Mp != M || Kp != K, sb = (!any_view && !vec4_ok(b)) || Kp != K || Np != N, sc = (!any_view && !vec4_ok(o)) || Mp != M || Np != N;
+    // (the kernels take any offset / leading dimension / batch stride -- element-aligned LDS-DMA and 16-byte accesses --: only lengths are padded)
+    const bool sa = Mp != M || Kp != K, sb = Kp != K || Np != N, sc = Mp != M || Np != N;
     const uint64_t ae = sa ? (uint64_t)Mp * Kp : 0, be = sb ? (uint64_t)Kp * Np : 0, ce = sc ? (uint64_t)Mp * Np : 0;
     if (ae * mats >= (1ull << 32) || be * mats >= (1ull << 32) || ce * mats >= (1ull << 32))
         return wg_set_error(WG_ERR_UNSUPPORTED, "Gemm: operands too large for the staging path of views that are not vec4-aligned");
@@ -176,12 +176,12 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
     WG_HIP_TRY(hipSetDevice(ctx->device));
     // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemm.wgsl:87,94: 4 x 4 blocks): dense staged copies
     // (1 .. 7 columns that are not a multiple of 4 on otherwise aligned views: exactly a Gemv with that many right-hand sides -- no copy of anything)
-    if (vec4_ok(o) && vec4_ok(a) && vec4_ok(b) && m_cols % 4 == 0 && m_rows % 4 == 0 && o.cols % 4 && o.cols < 8 && alpha == 1.f && beta == 0.f)
+    if (vec4_ok(o) && vec4_ok(a) && vec4_ok(b) && m_cols % 4 == 0 && m_rows % 4 == 0 && o.cols % 4 && o.cols < 8 && alpha == 1.f && beta == 0.f) // (the tuned Gemv kernels: aligned views)
         return wgk_gemv(ctx, tr, dtype, m_rows, m_cols, o.cols, o.mats, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat,
                         wgk_mat{ elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat }, wgk_mat{ elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat });
-    // (f16: the kernels take any offset, leading dimension and batch stride -- gemm_f16.hip -- so only the lengths count)
-    const bool views_ok = dtype == WG_F16 || (vec4_ok(o) && vec4_ok(a) && vec4_ok(b));
-    if (!views_ok || o.cols % 4 || m_cols % 4 || m_rows % 4)
+    // (the kernels take any offset, leading dimension and batch stride since round 6 -- gemm_f16.hip, gemm_f32*.hip: LDS-DMA and 16-byte accesses at element-aligned
+    // addresses -- so only the lengths count)
+    if (o.cols % 4 || m_cols % 4 || m_rows % 4)
         return gemm_staged(ctx, tr, dtype, alpha, beta, out, o, m1, a, m2, b, m_rows, o.cols, m_cols);
     wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
     wgk_mat B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };

@@ -63,16 +63,16 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float4 ldg4(const float *p, bool ok) {
-    return ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    return ok ? wg_ld_u(p) : make_float4(0.f, 0.f, 0.f, 0.f); // (any element-aligned address: wg_internal.hpp)
 }
 // epilogue element: alpha * acc (+ beta * old). (alpha, beta) = (1, 0) returns acc unchanged and never reads old.
 __device__ __forceinline__ void store_c(float *p, float4 v, float alpha, float beta) {
     if (alpha != 1.f) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
     if (beta != 0.f) {
-        const float4 c = *reinterpret_cast<const float4 *>(p);
+        const float4 c = wg_ld_u(p);
         v.x = fmaf(beta, c.x, v.x); v.y = fmaf(beta, c.y, v.y); v.z = fmaf(beta, c.z, v.z); v.w = fmaf(beta, c.w, v.w);
     }
-    *reinterpret_cast<float4 *>(p) = v;
+    wg_st_u(p, v);
 }
 __device__ __forceinline__ float comp(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
@@ -538,10 +538,10 @@ __global__ __launch_bounds__(256) void gemm_f32_tail_reduce(GemmArgs g) {
     float *o = g.out_c + (uint64_t)z * g.out_batch + (uint64_t)col * g.out_ldc + row;
     if (g.out_alpha != 1.f) { s.x *= g.out_alpha; s.y *= g.out_alpha; s.z *= g.out_alpha; s.w *= g.out_alpha; }
     if (g.out_beta != 0.f) {
-        const float4 c = *reinterpret_cast<const float4 *>(o);
+        const float4 c = wg_ld_u(o);
         s.x = fmaf(g.out_beta, c.x, s.x); s.y = fmaf(g.out_beta, c.y, s.y); s.z = fmaf(g.out_beta, c.z, s.z); s.w = fmaf(g.out_beta, c.w, s.w);
     }
-    *reinterpret_cast<float4 *>(o) = s;
+    wg_st_u(o, s);
 }
 
 } // namespace
@@ -854,10 +854,8 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
 int wgk_gemm_f32_nt(wg_ctx *ctx, uint32_t M, uint32_t N, uint32_t K, uint32_t nmats, float *out, uint32_t out_ld, uint64_t out_batch, wgk_mat a_mcontig, wgk_mat b_ncontig,
                     float alpha, float beta) {
     if (M == 0 || N == 0 || nmats == 0) return WG_OK;
-    auto al16 = [](const void *p) { return ((uintptr_t)p & 15) == 0; };
-    if (M % 4u || N % 4u || K % 4u || K == 0 || a_mcontig.ld % 4u || b_ncontig.ld % 4u || out_ld % 4u || !al16(a_mcontig.ptr) || !al16(b_ncontig.ptr) || !al16(out) || nmats > 65535u)
-        return WG_ERR_UNSUPPORTED;
-    if (nmats > 1 && (a_mcontig.batch % 4u || b_ncontig.batch % 4u || out_batch % 4u)) return WG_ERR_UNSUPPORTED;
+    // (any leading dimension, offset and batch stride: LDS-DMA and the 16-byte loads / stores take element-aligned addresses -- wg_internal.hpp wg_ld_u)
+    if (M % 4u || N % 4u || K % 4u || K == 0 || nmats > 65535u) return WG_ERR_UNSUPPORTED;
     GemmArgs g;
     g.a = (const float *)a_mcontig.ptr; g.lda = a_mcontig.ld; g.a_batch = a_mcontig.batch;
     g.b = (const float *)b_ncontig.ptr; g.ldb = b_ncontig.ld; g.b_batch = b_ncontig.batch;

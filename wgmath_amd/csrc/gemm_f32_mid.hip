@@ -48,10 +48,10 @@ struct MidArgs {
 __device__ __forceinline__ void store_c(float *p, float4 v, float alpha, float beta) {
     if (alpha != 1.f) { v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha; }
     if (beta != 0.f) {
-        const float4 c = *reinterpret_cast<const float4 *>(p);
+        const float4 c = wg_ld_u(p);
         v.x = fmaf(beta, c.x, v.x); v.y = fmaf(beta, c.y, v.y); v.z = fmaf(beta, c.z, v.z); v.w = fmaf(beta, c.w, v.w);
     }
-    *reinterpret_cast<float4 *>(p) = v;
+    wg_st_u(p, v);
 }
 __device__ __forceinline__ float comp(const float4 &v, int s) { return s == 0 ? v.x : (s == 1 ? v.y : (s == 2 ? v.z : v.w)); }
 
@@ -233,13 +233,13 @@ __global__ __launch_bounds__(kThreads, (WT_M * WT_N == 4 ? 2 : 3)) void gemm_f32
             if constexpr (!TRANS_A) { // float4 along m at k-row f / (BM / 4)
                 const uint32_t kr = (uint32_t)f / (BM / 4), m = min(4u * ((uint32_t)f % (BM / 4)), g.M - 4u - m0), k = k0 + kr;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)k * g.lda + m);
+                if (k < g.K) v = wg_ld_u(a_base + (uint64_t)k * g.lda + m);
                 *reinterpret_cast<float4 *>(&As[kr * BM + 4 * (f % (BM / 4))]) = v;
             } else { // float4 along k: row f >> 2, chunk f & 3
                 const int mm = f >> 2, ch = f & 3;
                 const uint32_t k = k0 + 4u * ch, row = min((uint32_t)mm, g.M - 1u - m0);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < g.K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)row * g.lda + k);
+                if (k < g.K) v = wg_ld_u(a_base + (uint64_t)row * g.lda + k);
                 *reinterpret_cast<float4 *>(&As[mm * BK + 4 * (ch ^ ((mm >> 2) & 3))]) = v;
             }
         }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(kThreads, (WT_M * WT_N == 4 ? 2 : 3)) void gemm_f32
             const int nn = f >> 2, ch = f & 3;
             const uint32_t k = k0 + 4u * ch, row = min((uint32_t)nn, g.N - 1u - n0);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < g.K) v = *reinterpret_cast<const float4 *>(b_base + (uint64_t)row * g.ldb + k);
+            if (k < g.K) v = wg_ld_u(b_base + (uint64_t)row * g.ldb + k);
             *reinterpret_cast<float4 *>(&Bs[nn * BK + 4 * (ch ^ ((nn >> 2) & 3))]) = v;
         }
         __syncthreads();
@@ -455,13 +455,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             if constexpr (!TRANS_A) {
                 const uint32_t kr = (uint32_t)f / (BM / 4), m = min(4u * ((uint32_t)f % (BM / 4)), g.M - 4u - m0), k = k0 + kr;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)k * g.lda + m);
+                if (k < K) v = wg_ld_u(a_base + (uint64_t)k * g.lda + m);
                 *reinterpret_cast<float4 *>(&As[kr * BM + 4 * (f % (BM / 4))]) = v;
             } else {
                 const int mm = f >> 3, ch = f & 7;
                 const uint32_t k = k0 + 4u * ch, row = min((uint32_t)mm, g.M - 1u - m0);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K) v = *reinterpret_cast<const float4 *>(a_base + (uint64_t)row * g.lda + k);
+                if (k < K) v = wg_ld_u(a_base + (uint64_t)row * g.lda + k);
                 *reinterpret_cast<float4 *>(&As[mm * BK2 + 4 * (ch ^ ((mm >> 1) & 7))]) = v;
             }
         }
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_f32_mid_kw_kernel(MidArgs g)
             const int nn = f >> 3, ch = f & 7;
             const uint32_t k = k0 + 4u * ch, row = min((uint32_t)nn, g.N - 1u - n0);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < K) v = *reinterpret_cast<const float4 *>(b_base + (uint64_t)row * g.ldb + k);
+            if (k < K) v = wg_ld_u(b_base + (uint64_t)row * g.ldb + k);
             *reinterpret_cast<float4 *>(&Bs[nn * BK2 + 4 * (ch ^ ((nn >> 1) & 7))]) = v;
         }
         __syncthreads();

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
     float *P = (direct && !F16) ? g.c + z * g.c_batch : g.part + ((uint64_t)z * g.nsplit + split) * ((uint64_t)g.M * g.N);
     const uint32_t ldp = direct ? g.ldc : g.M;
     auto put4 = [&](uint32_t col, uint32_t row, float4 v) { // rows row .. row + 3 of column col (M % 4 == 0: all in or all out)
-        float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
+        float *dst = P + (uint64_t)col * ldp + row; // (any element-aligned address: wg_internal.hpp wg_ld_u / wg_st_u)
         if (direct) {
             if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
             if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
@@ -332,11 +332,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
                 return;
             }
             if (g.beta != 0.f) {
-                const float4 o = *dst;
+                const float4 o = wg_ld_u(dst);
                 v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
             }
         }
-        *dst = v;
+        wg_st_u(dst, v);
     };
     if constexpr (W16) {
         const uint32_t col = col0 + (uint32_t)i16;
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
             const uint32_t row = r0 + 8u * gq + 4u * h;
             if (row >= g.M) continue; // M % 4 == 0
             float4 v = make_float4(acc[u][4 * gq + 0], acc[u][4 * gq + 1], acc[u][4 * gq + 2], acc[u][4 * gq + 3]);
-            float4 *dst = reinterpret_cast<float4 *>(P + (uint64_t)col * ldp + row);
+            float *dst = P + (uint64_t)col * ldp + row; // (any element-aligned address: wg_internal.hpp wg_ld_u / wg_st_u)
             if (direct) {
                 if (g.alpha != 1.f) { v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha; }
                 if (g.crs != 1u) { // transposed output (few-row products): four scalars, rows g.crs apart
@@ -379,11 +379,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f32_skinny_kernel(SkinnyArgs g) {
                     continue;
                 }
                 if (g.beta != 0.f) {
-                    const float4 o = *dst;
+                    const float4 o = wg_ld_u(dst);
                     v.x = fmaf(g.beta, o.x, v.x); v.y = fmaf(g.beta, o.y, v.y); v.z = fmaf(g.beta, o.z, v.z); v.w = fmaf(g.beta, o.w, v.w);
                 }
             }
-            *dst = v;
+            wg_st_u(dst, v);
         }
     }
 }

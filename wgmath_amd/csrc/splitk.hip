@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     if (alpha != 1.f) { s.x *= alpha; s.y *= alpha; s.z *= alpha; s.w *= alpha; }
     if (beta != 0.f) { // out = alpha * sum + beta * out (wg_gemm_ex); beta == 0 never reads `out`
         float4 c;
-        if constexpr (sizeof(OUT) == 4) c = *reinterpret_cast<const float4 *>(o);
+        if constexpr (sizeof(OUT) == 4) c = wg_ld_u(reinterpret_cast<const float *>(o));
         else { const h4 t = *reinterpret_cast<const h4 *>(o); c = make_float4((float)t.v[0], (float)t.v[1], (float)t.v[2], (float)t.v[3]); }
         s.x = fmaf(beta, c.x, s.x); s.y = fmaf(beta, c.y, s.y); s.z = fmaf(beta, c.z, s.z); s.w = fmaf(beta, c.w, s.w);
     }
     if constexpr (sizeof(OUT) == 4) {
-        *reinterpret_cast<float4 *>(o) = s;
+        wg_st_u(reinterpret_cast<float *>(o), s);
     } else {
         h4 r = { { (_Float16)s.x, (_Float16)s.y, (_Float16)s.z, (_Float16)s.w } };
         *reinterpret_cast<h4 *>(o) = r;

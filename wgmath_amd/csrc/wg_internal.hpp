@@ -146,6 +146,7 @@ __device__ __forceinline__ float4 wg_ld_u(const float *p) {
     wg_f4 v = *reinterpret_cast<const wg_f4_u *>(p);
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ void wg_st_u(float *p, float4 v) { *reinterpret_cast<wg_f4_u *>(p) = wg_f4{ v.x, v.y, v.z, v.w }; }
 
 static inline size_t wg_dtype_size(wg_dtype d) { return d == WG_F16 ? 2 : 4; }
 
