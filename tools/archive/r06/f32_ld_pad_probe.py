@@ -10,10 +10,10 @@ ns = {"__file__": os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tools/clif
 exec(compile(src, "cs", "exec"), ns)
 gpu, gemm_case = ns["gpu"], ns["gemm_case"]
 for tr in (False, True):
-    for (M, N, K) in [(2048, 2048, 2048), (1536, 1536, 1536), (3072, 3072, 1024), (4096, 4096, 1024)]:
-        for pad in [(0, 0, 0), (8, 8, 8), (4, 4, 4), (64, 64, 64)]:
+    for (M, N, K) in [(2048, 2048, 2048), (2048, 2048, 1024), (2048, 2048, 4096), (3072, 3072, 1024), (1024, 4096, 2048), (4096, 1024, 1024), (1920, 1920, 2048)]:
+        for pad in [(0, 0, 0), (8, 8, 8), (64, 64, 64), (8, 0, 0), (0, 8, 0)]:
             row = []
-            for knob in (-1, 0, 128128, 128064, 64128, 64064):
+            for knob in (-1, 128064, 64064):
                 old = gpu.set_tuning("f32_mid", knob)
                 try:
                     row.append(f"{knob}:{gemm_case(np.float32, tr, M, N, K, pad):7.1f}")

@@ -767,6 +767,10 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
             // against 38.5 by the curve above; 128 x 128 x 4096 x 32 matrices 62 -- there the K cut on 64 x 64 tiles is the better plan, 42)
             if (c[2] && r <= 1.0 && (c[0] == 32 || c[1] == 32) && K >= 2048u) loop += 0.25;
             if (c[2] && pow2_ldb) loop += 0.10; // 1024 x 1024 x 32768: 536 us on 64 x 32 tiles against 486 for this file's split-K plan
+            // (round 6, tools/archive/r06/f32_ld_pad_probe.py: the 64 x 64 tile at ONE round of four workgroups per CU -- 2048^2, 1024 x 4096 outputs -- loses to 128 x 64 whenever
+            // its rows are not fed ideally: GemmTr at any leading dimension (2048^3 172 us against 152; only ld % 1024 == 0 was penalised above, so ld = 2056 took the slow tile),
+            // Gemm with rows of m1 or m2 that are not 64-byte aligned (165-178 against 153; K = 4096: 334 against 299). At 8-9 workgroups per CU neither shows: 3072^2 x 1024 stays on it.)
+            if (c[0] == 64 && c[1] == 64 && 2u * t > 7ull * (uint64_t)cus && t <= 4ull * (uint64_t)cus && (trans || m1.ld % 16u != 0 || m2.ld % 16u != 0 || K >= 4096u)) loop += 0.15; // (K = 4096, everything aligned: 313 against 297)
             const double tile_us = 2.0 * c[0] * c[1] * (double)K / 614400.0; // one tile at a CU's full rate
             const double est = r * (tile_us * loop + 0.1 * c[4]) + 3.0;
             if (short_k && !c[2] && !(c[0] == 128 && c[1] == 128) && est < sk_est) { sk_est = est; sk_bm = c[0]; sk_bn = c[1]; }
