@@ -35,18 +35,26 @@ __device__ __forceinline__ const T *vector_base(const T *base, uint32_t q, uint3
 
 // Element types: f32 (the reference's), and f16 as this build's extension -- f16 elements are converted to f32 (exact), folded in the
 // reference's order in f32, and the result is rounded once (RNE) to f16. Four consecutive elements of a row, as floats:
-// (at any element-aligned address, round 6: vectors whose base is not a multiple of 4 elements took a 128-lane element-wise twin of the kernel below before --
-// 2.6x the time on one long vector; unaligned-access mode, wg_internal.hpp wg_ld_nt_u)
-__device__ __forceinline__ float4 load4(const float *p, bool nt) { return nt ? wg_ld_nt_u(p) : wg_ld_u(p); }
+// AL = false: at any element-aligned address (round 6: vectors whose base is not a multiple of 4 elements took a 128-lane element-wise twin of the kernel below before --
+// 2.6x the time on one long vector; unaligned-access mode, wg_internal.hpp wg_ld_u). The aligned instance keeps its own typed load: the backend drops the non-temporal
+// hint from a load whose type is under-aligned, and the hint is worth 13 % on config 4's read-once stream (6.59 -> 5.69 TB/s when it went missing for an afternoon).
+template <bool AL>
+__device__ __forceinline__ float4 load4(const float *p, bool nt) {
+    if constexpr (AL) return nt ? wg_ld_nt(reinterpret_cast<const float4 *>(p)) : *reinterpret_cast<const float4 *>(p);
+    else return wg_ld_u(p);
+}
+template <bool AL>
 __device__ __forceinline__ float4 load4(const _Float16 *p, bool nt) {
     typedef _Float16 h4a __attribute__((ext_vector_type(4)));
-    typedef h4a __attribute__((aligned(2))) h4;
-    const h4a v = nt ? __builtin_nontemporal_load(reinterpret_cast<const h4 *>(p)) : *reinterpret_cast<const h4 *>(p);
+    typedef h4a __attribute__((aligned(2))) h4u;
+    h4a v;
+    if constexpr (AL) v = nt ? __builtin_nontemporal_load(reinterpret_cast<const h4a *>(p)) : *reinterpret_cast<const h4a *>(p);
+    else v = *reinterpret_cast<const h4u *>(p);
     return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
 }
 
 // 32 physical lanes x 4 elements per vector, at any element-aligned base.
-template <int OP, typename T>
+template <int OP, typename T, bool AL>
 __global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ base, uint32_t n, uint32_t ncols,
                                                          uint32_t nvec, uint32_t stride, uint32_t stride_mat,
                                                          T *__restrict__ results) {
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ b
     for (; r + kUnroll <= full_rows; r += kUnroll) {
         float4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load4(x + ((uint64_t)(r + u) * 32u + p) * 4u, RED_NT);
+        for (int u = 0; u < kUnroll; ++u) v[u] = load4<AL>(x + ((uint64_t)(r + u) * 32u + p) * 4u, RED_NT);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) { // rows in ascending order: the per-lane chain of reduce.wgsl:71-74
             acc[0] = r_ws<OP>(acc[0], v[u].x);
@@ -71,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void reduce_rows4(const T *__restrict__ b
         }
     }
     for (; r < full_rows; ++r) {
-        float4 v = load4(x + ((uint64_t)r * 32u + p) * 4u, false);
+        float4 v = load4<AL>(x + ((uint64_t)r * 32u + p) * 4u, false);
         acc[0] = r_ws<OP>(acc[0], v.x);
         acc[1] = r_ws<OP>(acc[1], v.y);
         acc[2] = r_ws<OP>(acc[2], v.z);
@@ -195,7 +203,9 @@ int launch(wg_ctx *ctx, const T *base, uint32_t n, uint32_t ncols, uint32_t nmat
         return WG_OK;
     }
     const uint32_t per_block = kThreads / 32;
-    hipLaunchKernelGGL((reduce_rows4<OP, T>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
+    const bool aligned = ((uintptr_t)base % (4 * sizeof(T)) == 0) && (nvec == 1 || ((stride % 4 == 0) && (nmats == 1 || stride_mat % 4 == 0)));
+    if (aligned) hipLaunchKernelGGL((reduce_rows4<OP, T, true>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
+    else hipLaunchKernelGGL((reduce_rows4<OP, T, false>), dim3((nvec + per_block - 1) / per_block), dim3(kThreads), 0, ctx->stream, base, n, ncols, nvec, stride, stride_mat, results);
     WG_HIP_TRY(hipGetLastError());
     return WG_OK;
 }
@@ -237,14 +247,14 @@ __global__ __launch_bounds__(kThreads) void reduce_fast_pass1(const T *__restric
     for (; (uint64_t)i + 7u * kThreads < n4; i += 8u * kThreads) {
         float4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = load4(p4 + 4ull * (i + u * kThreads), true);
+        for (int u = 0; u < 8; ++u) v[u] = load4<true>(p4 + 4ull * (i + u * kThreads), true);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             acc = r_ws<OP>(acc, v[u].x); acc = r_ws<OP>(acc, v[u].y); acc = r_ws<OP>(acc, v[u].z); acc = r_ws<OP>(acc, v[u].w);
         }
     }
     for (; i < n4; i += kThreads) {
-        const float4 v = load4(p4 + 4ull * i, true);
+        const float4 v = load4<true>(p4 + 4ull * i, true);
         acc = r_ws<OP>(acc, v.x); acc = r_ws<OP>(acc, v.y); acc = r_ws<OP>(acc, v.z); acc = r_ws<OP>(acc, v.w);
     }
     const uint32_t tail0 = head + n4 * 4u;
