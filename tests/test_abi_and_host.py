@@ -196,7 +196,7 @@ def test_f16_gemm_kernel_owns_m0(source, kernel, min_dma, instances):
             assert "scratch_" not in loop[:loop.index("s_cbranch_scc1")], f"{name}: register spills inside the main loop"
 
 
-@pytest.mark.parametrize("source,kernel,min_nt", [("reduce.hip", r"reduce_rows4ILi\d+EfLb1E", 16), ("reduce.hip", r"reduce_fast_pass1ILi\d+EfE", 8), ("op_assign.hip", r"op_assign_f32_vecILi\d+ELb0E", 2),
+@pytest.mark.parametrize("source,kernel,min_nt", [("reduce.hip", r"reduce_rows4ILi\d+EfLb1E", 16), ("reduce.hip", r"reduce_fast_pass1ILi\d+EfE", 8), ("op_assign.hip", r"op_assign_f32_vecILi\d+ELb0E", 1),
                                                    ("gemv.hip", r"gemv_n_kernelILi1EfE", 60), ("gemv.hip", r"gemv_t_cols_kernelIfLi4ELi4ELi1E", 4)])
 def test_streaming_kernels_keep_their_non_temporal_hint(source, kernel, min_nt):
     """The HBM-bound kernels read their operand once and say so (`nt`: + 13 % on config 4's Reduce). The hint is a property of the load the backend emits, not of
