@@ -100,13 +100,13 @@ def test_reduce_batched_and_unaligned(gpu, oracle_c):
         res = upload(gpu, (96,), np.full(96, np.nan, np.float32))
         run_pass(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, mat, res))
         U.assert_bits_equal(res.read(gpu.device()), g[f"expected_batched_{int(op)}"], f"batched reduce {op!r}")
-        # unaligned vector base (offset 3, length 777): the scalar twin must give the same bits as the oracle
+        # unaligned vector base (offset 3, length 777): the kernel at an element-aligned base must give the same bits as the oracle
         res1 = upload(gpu, (), np.array([np.nan], np.float32))
         view = wg.GpuTensorView(wg.ViewShape((777, 1, 1), 1, 1, 3), mat, 1)
         run_pass(gpu, lambda p: red.dispatch(gpu.device(), shapes, p, view, res1))
         exp = oracle_c.reduce(int(op), xb, wo.Shape(777, 1, 1, 1, 1, 3))
         U.assert_bits_equal(res1.read(gpu.device()), np.array([exp], np.float32), f"unaligned reduce {op!r}")
-        # odd stride (not a multiple of 4) -> every column unaligned -> scalar twin, batched
+        # odd stride (not a multiple of 4) -> every column unaligned, batched
         v2 = wg.GpuTensorView(wg.ViewShape((333, 50, 1), 1001, 1, 2), mat, 2)
         res2 = upload(gpu, (50,), np.full(50, np.nan, np.float32))
         run_pass(gpu, lambda p: red.dispatch_batched(gpu.device(), shapes, p, v2, res2))
@@ -230,7 +230,7 @@ def test_gemm_strided_views(gpu, oracle_c):
 def test_gemm_unaligned_views(gpu, dtype, tr):
     """Views that are not vec4-aligned -- what GpuMatrix::slice((1, 0), ..), rows(1, n), columns of a parent with an odd row count and
     lengths that are not multiples of 4 produce (tensor.rs:574-626) -- which the reference's vec4 kernels cannot address
-    (shape.wgsl:64-66). They compute op(A) B on dense staged copies here: against f64 with the usual bound, nothing outside the output
+    (shape.wgsl:64-66). They compute op(A) B like any other view here (lengths off a multiple of 4: on zero-padded copies): against f64 with the usual bound, nothing outside the output
     view touched, alpha / beta honoured."""
     wg, wo = _wg(), _wo()
     rng = np.random.default_rng(321 + int(tr))
@@ -546,7 +546,7 @@ def test_gemv_any_alignment(gpu, dtype, tr, case):
 @pytest.mark.parametrize("tr", [False, True])
 def test_gemv_unaligned_views(gpu, tr):
     """Gemv on a matrix view at an odd row / with odd lengths and vectors at odd offsets (GpuVector::rows(1, n), tensor.rs:669-680), 3
-    right-hand sides: staged copies, checked against f64; nothing outside the output view touched."""
+    right-hand sides: the any-alignment kernels, checked against f64; nothing outside the output view touched."""
     wg, wo = _wg(), _wo()
     rng = np.random.default_rng(654 + int(tr))
     PR, PC = 203, 150
@@ -681,7 +681,7 @@ def test_errors_and_skips(gpu):
         wg.OpAssign.new(dev, wg.OpAssignVariant.Add).dispatch(dev, shapes, p, z(8), z(12))
     with pytest.raises(wg.PreconditionFailed):  # gemv.rs:122
         gemv.dispatch_generic(dev, shapes, p, z(6), z(6, 8), z(8), wg.GemvVariant.GemvFast)
-    gemm.dispatch(dev, shapes, p, z(6, 8), z(6, 8), z(8, 8))  # not vec4-aligned: computed on staged copies (test_gemm_unaligned_views), no error
+    gemm.dispatch(dev, shapes, p, z(6, 8), z(6, 8), z(8, 8))  # not vec4-aligned: computed all the same (test_gemm_unaligned_views), no error
     with pytest.raises(wg.WgError, match="addresses"):  # view larger than its buffer
         big = z(8, 8)
         gemm.dispatch(dev, shapes, p, wg.GpuTensorView(wg.ViewShape((16, 16, 1), 16, 256, 0), big, 2), z(16, 16), z(16, 16))

@@ -49,9 +49,10 @@ inline uint32_t up8(uint32_t x) { return (x + 7u) & ~7u; }
 // Views that are not vec4-aligned. The reference's kernels cannot address them (they bind array<vec4<f32>> and divide rows, strides
 // and offsets by 4, shape.wgsl:64-66: a slice at an odd row, a column block with an odd stride or a length that is not a multiple of
 // 4 reads the wrong elements there), yet its own constructors hand them out (GpuMatrix::slice / rows / column, tensor.rs:574-626).
-// Here they compute op(A) B exactly as the aligned call would: every operand is staged into a dense, 16-byte aligned, zero-padded
-// copy (dimensions rounded up to 8; zeros add nothing to a dot product), the usual kernels run on the copies, and the M x N result
-// is copied back into the output view -- three HBM-bound passes in a fourth context scratch (it cannot grow inside a recording).
+// Here they compute op(A) B exactly as the aligned call would. Offsets, leading dimensions and batch strides are free (the kernels' 16-byte
+// accesses and LDS-DMA take element-aligned addresses); an operand that carries a LENGTH that is not a multiple of 4 is staged into a dense
+// zero-padded copy (the length rounded up to 8; zeros add nothing to a dot product), the usual kernels run, and a padded result is copied back
+// into the output view -- HBM-bound passes in a fourth context scratch (it cannot grow inside a recording).
 int gemm_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, float alpha, float beta, wg_buf *out, const View &o, const wg_buf *m1, const View &a, const wg_buf *m2,
                 const View &b, uint32_t M, uint32_t N, uint32_t K) {
     const size_t es = wg_dtype_size(dtype);
@@ -174,7 +175,7 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
     if (int rc = check_bounds("Gemm", "m2", b, m2, dtype)) return rc;
 
     WG_HIP_TRY(hipSetDevice(ctx->device));
-    // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemm.wgsl:87,94: 4 x 4 blocks): dense staged copies
+    // lengths the kernels' 4 x 4 blocks do not take (gemm.wgsl:87,94): zero-padded copies of the operands that carry them
     // (1 .. 7 columns that are not a multiple of 4 on otherwise aligned views: exactly a Gemv with that many right-hand sides -- no copy of anything)
     if (vec4_ok(o) && vec4_ok(a) && vec4_ok(b) && m_cols % 4 == 0 && m_rows % 4 == 0 && o.cols % 4 && o.cols < 8 && alpha == 1.f && beta == 0.f) // (the tuned Gemv kernels: aligned views)
         return wgk_gemv(ctx, tr, dtype, m_rows, m_cols, o.cols, o.mats, (void *)elem_ptr(out, o.offset, dtype), o.stride, o.stride_mat,
@@ -221,7 +222,7 @@ int wg_gemv(wg_ctx *ctx, wg_gemv_variant variant, wg_dtype dtype, wg_buf *out, w
     if (int rc = check_bounds("Gemv", "v", v_eff, v, dtype)) return rc;
 
     WG_HIP_TRY(hipSetDevice(ctx->device));
-    // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemv.wgsl:73,76): dense staged copies
+    // views / sizes the vec4 kernels cannot address as they are (shape.wgsl:64-66; gemv.wgsl:73,76): the any-alignment kernels (a matrix that is off), or copies of the vectors
     if (!vec4_ok(o) || !vec4_ok(m_eff) || !vec4_ok(v_eff) || m_cols % 4 || m_rows % 4)
         return gemv_staged(ctx, tr, dtype, out, o, m, m_eff, v, v_eff, m_rows, m_cols);
     wgk_mat M = { elem_ptr(m, mm.offset, dtype), mm.stride, mm.stride_mat };
