@@ -44,10 +44,18 @@ __device__ __forceinline__ void to_floats(wg_u32x4 v, float (&f)[Elt<T>::E]) {
 }
 // 16 bytes at any element-aligned address (an integer address says nothing about the address space: without the cast the load is a flat_load; the pointer type
 // states the alignment that is really there -- the backend keeps one global_load_dwordx4, the target runs in unaligned-access mode)
+#ifndef WG_ANY_NT
+#define WG_ANY_NT 1 // the matrix is read once: the non-temporal hint, as in gemv.hip
+#endif
 template <int ES>
 __device__ __forceinline__ wg_u32x4 ld16(uintptr_t addr) {
-    if constexpr (ES == 4) return *reinterpret_cast<const __attribute__((address_space(1), aligned(4))) wg_u32x4 *>(addr);
-    else return *reinterpret_cast<const __attribute__((address_space(1), aligned(2))) wg_u32x4 *>(addr);
+    if constexpr (ES == 4) {
+        const __attribute__((address_space(1), aligned(4))) wg_u32x4 *p = reinterpret_cast<const __attribute__((address_space(1), aligned(4))) wg_u32x4 *>(addr);
+        return WG_ANY_NT ? __builtin_nontemporal_load(p) : *p;
+    } else {
+        const __attribute__((address_space(1), aligned(2))) wg_u32x4 *p = reinterpret_cast<const __attribute__((address_space(1), aligned(2))) wg_u32x4 *>(addr);
+        return WG_ANY_NT ? __builtin_nontemporal_load(p) : *p;
+    }
 }
 // the E elements from element `first` on of a run of `len` >= 1 elements at `base`, as floats; elements past the run are 0. WHOLE: the caller knows first + E <= len.
 template <typename T, bool WHOLE>
