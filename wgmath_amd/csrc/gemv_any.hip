@@ -44,24 +44,23 @@ __device__ __forceinline__ void to_floats(wg_u32x4 v, float (&f)[Elt<T>::E]) {
 }
 // 16 bytes at any element-aligned address (an integer address says nothing about the address space: without the cast the load is a flat_load; the pointer type
 // states the alignment that is really there -- the backend keeps one global_load_dwordx4, the target runs in unaligned-access mode)
-#ifndef WG_ANY_NT
-#define WG_ANY_NT 1 // the matrix is read once: the non-temporal hint, as in gemv.hip
-#endif
-template <int ES>
+// NT: the non-temporal hint for a matrix that cannot stay in the Infinity Cache anyway (the launcher: from 512 MiB on -- 16384^2 f32 207 -> 199 us; below that it costs
+// repeated products of one matrix their cache hits: 8192^2 f16 at offset 1 33.8 -> 39.3 us; profiles/r06_gemv_any_ab.txt)
+template <int ES, bool NT>
 __device__ __forceinline__ wg_u32x4 ld16(uintptr_t addr) {
     if constexpr (ES == 4) {
         const __attribute__((address_space(1), aligned(4))) wg_u32x4 *p = reinterpret_cast<const __attribute__((address_space(1), aligned(4))) wg_u32x4 *>(addr);
-        return WG_ANY_NT ? __builtin_nontemporal_load(p) : *p;
+        return NT ? __builtin_nontemporal_load(p) : *p;
     } else {
         const __attribute__((address_space(1), aligned(2))) wg_u32x4 *p = reinterpret_cast<const __attribute__((address_space(1), aligned(2))) wg_u32x4 *>(addr);
-        return WG_ANY_NT ? __builtin_nontemporal_load(p) : *p;
+        return NT ? __builtin_nontemporal_load(p) : *p;
     }
 }
 // the E elements from element `first` on of a run of `len` >= 1 elements at `base`, as floats; elements past the run are 0. WHOLE: the caller knows first + E <= len.
-template <typename T, bool WHOLE>
+template <typename T, bool WHOLE, bool NT = false>
 __device__ __forceinline__ void load_elems(uintptr_t base, uint32_t first, uint32_t len, float (&f)[Elt<T>::E]) {
     constexpr int E = Elt<T>::E, ES = Elt<T>::ES;
-    if constexpr (WHOLE) to_floats<T>(ld16<ES>(base + (uintptr_t)first * ES), f);
+    if constexpr (WHOLE) to_floats<T>(ld16<ES, NT>(base + (uintptr_t)first * ES), f);
     else { // (no branch: every lane reads E elements at clamped positions and drops what lies past the run -- a branch per chunk serialises the columns' loads, and
            // the one ragged row block of an N launch then takes longer than all the whole ones together)
         const __attribute__((address_space(1))) T *p = reinterpret_cast<const __attribute__((address_space(1))) T *>(base);
@@ -96,7 +95,7 @@ __device__ __forceinline__ void store_out(const AnyArgs &a, uint32_t z, uint32_t
 }
 
 // grid = (row blocks of 64 E, column splits, matrices * right-hand sides)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(kThreads) void gemv_any_n_kernel(AnyArgs a) {
     constexpr int E = Elt<T>::E, ES = Elt<T>::ES, U = WG_ANY_NU;
     __shared__ float part[kWaves][E][64];
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void gemv_any_n_kernel(AnyArgs a) {
                 float f[U][E];
 #pragma unroll
                 for (int u = 0; u < U; ++u) // (a slot past the end re-reads the last column; its values are dropped below, not multiplied by 0: they may be Inf / NaN)
-                    load_elems<T, WHOLE>(mb + (uint64_t)min(cb + u0 + u, w_end - 1u) * a.ldm * ES, r0, a.R, f[u]);
+                    load_elems<T, WHOLE, NT>(mb + (uint64_t)min(cb + u0 + u, w_end - 1u) * a.ldm * ES, r0, a.R, f[u]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (u0 + u < n) {
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(kThreads) void gemv_any_n_kernel(AnyArgs a) {
 }
 
 // grid = (groups of 4 * kWaves columns, row splits, matrices * right-hand sides)
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(kThreads) void gemv_any_t_kernel(AnyArgs a) {
     constexpr int E = Elt<T>::E, ES = Elt<T>::ES, CW = 4;
     const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void gemv_any_t_kernel(AnyArgs a) {
         const uint32_t r0 = rb + lane * E;
         float f[CW][E], x[E];
 #pragma unroll
-        for (int c = 0; c < CW; ++c) load_elems<T, WHOLE>(mb + (uint64_t)min(c0 + c, a.C - 1u) * a.ldm * ES, r0, r_end, f[c]);
+        for (int c = 0; c < CW; ++c) load_elems<T, WHOLE, NT>(mb + (uint64_t)min(c0 + c, a.C - 1u) * a.ldm * ES, r0, r_end, f[c]);
         load_elems<T, WHOLE>(vb, r0, r_end, x);
 #pragma unroll
         for (int c = 0; c < CW; ++c)
@@ -221,8 +220,12 @@ int launch_any(wg_ctx *ctx, bool trans, uint32_t R, uint32_t C, uint32_t nrhs, u
         a.part = (float *)ws;
     }
     const dim3 grid(gx, nsplit, (uint32_t)gz), block(kThreads);
-    if (trans) hipLaunchKernelGGL(gemv_any_t_kernel<T>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(gemv_any_n_kernel<T>, grid, block, 0, ctx->stream, a);
+    const bool nt = (uint64_t)R * C * sizeof(T) >= (512ull << 20);
+    if (trans) {
+        if (nt) hipLaunchKernelGGL((gemv_any_t_kernel<T, true>), grid, block, 0, ctx->stream, a);
+        else hipLaunchKernelGGL((gemv_any_t_kernel<T, false>), grid, block, 0, ctx->stream, a);
+    } else if (nt) hipLaunchKernelGGL((gemv_any_n_kernel<T, true>), grid, block, 0, ctx->stream, a);
+    else hipLaunchKernelGGL((gemv_any_n_kernel<T, false>), grid, block, 0, ctx->stream, a);
     WG_HIP_TRY(hipGetLastError());
     if (nsplit > 1u) {
         hipLaunchKernelGGL(gemv_any_combine_kernel<T>, dim3((out_len + kThreads - 1u) / kThreads, (uint32_t)gz), block, 0, ctx->stream, a, out_len);
