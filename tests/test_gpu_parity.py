@@ -361,6 +361,28 @@ def test_gemm_f16_any_offset_and_leading_dimension_is_the_aligned_product_bit_fo
         assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (case, tr, pads, offs, bpads)
 
 
+def test_copy_view_errors_and_skips(gpu):
+    """wg_copy_view: a batch-count mismatch is the reference's kind of panic, a view past its buffer is an error, zero-sized views are skipped, an empty source zero-fills."""
+    wg = _wg()
+    from wgmath_amd import _lib
+    a = np.arange(64, dtype=np.float32)
+    ta, tb = upload(gpu, (64,), a), upload(gpu, (64,), np.full(64, 7.0, np.float32))
+    dt = wg.wgcore.wg_dtype(np.float32)
+    call = lambda dv, sv: _lib.check(_lib.lib.wg_copy_view(gpu._ctx.handle, dt, tb._h, dv.to_c(), ta._h, sv.to_c()))
+    with pytest.raises(wg.DimensionMismatch, match="CopyView: dimension mismatch"):
+        call(wg.ViewShape((4, 4, 2), 4, 16, 0), wg.ViewShape((4, 4, 1), 4, 16, 0))
+    with pytest.raises(_lib.WgError, match="CopyView"):
+        call(wg.ViewShape((4, 4, 1), 4, 16, 60), wg.ViewShape((4, 4, 1), 4, 16, 0))   # dst view runs past its buffer
+    with pytest.raises(_lib.WgError, match="CopyView"):
+        call(wg.ViewShape((4, 4, 1), 4, 16, 0), wg.ViewShape((4, 4, 1), 4, 16, 61))   # src view runs past its buffer
+    call(wg.ViewShape((0, 4, 1), 4, 16, 0), wg.ViewShape((4, 4, 1), 4, 16, 0))        # nothing to write
+    assert np.array_equal(tb.read(gpu.device()), np.full(64, 7.0, np.float32))
+    call(wg.ViewShape((3, 2, 1), 5, 10, 1), wg.ViewShape((0, 0, 1), 1, 0, 0))         # an empty source: zeros
+    want = np.full(64, 7.0, np.float32)
+    want[1:4] = 0; want[6:9] = 0
+    assert np.array_equal(tb.read(gpu.device()), want)
+
+
 F32_ANY_ALIGN = [
     # M, N, K, matrices -- the f32 kernel families (gemm_f32.hip launcher): the 256 x 128 kernel (DMA interior + edge tiles), its tail split, the mid-size tiles, K split over the
     # workgroup's waves, few columns / few rows (gemm_f32_skinny.hip, 16- and 32-wide), split-K slabs, a batch, the 64 < M <= 128 transposed form
