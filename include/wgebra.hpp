@@ -325,4 +325,13 @@ struct Axpy {
     }
 };
 
+// extension: dst view = src view where it has elements, 0 elsewhere -- any offset, stride and length on either side (wg_copy_view: the aligned copy of an odd view, made once)
+struct CopyView {
+    static CopyView from_device(const Device &) { return {}; }
+    template <typename T>
+    void dispatch(const Device &, const ViewShapeBuffers &, ComputePass &pass, GpuTensorView<T> dst, GpuTensorView<T> src) const {
+        check(wg_copy_view(pass.ctx(), dtype_of<T>::value, dst.buffer(), dst.shape(), src.buffer(), src.shape()));
+    }
+};
+
 } // namespace wgebra

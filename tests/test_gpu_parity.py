@@ -381,6 +381,14 @@ def test_copy_view_errors_and_skips(gpu):
     want = np.full(64, 7.0, np.float32)
     want[1:4] = 0; want[6:9] = 0
     assert np.array_equal(tb.read(gpu.device()), want)
+    # the operator form of the mirror (wgmath_amd.CopyView): a 5 x 3 block at offset 3 of `a` into offset 2 of `b`
+    dst = wg.GpuTensorView(wg.ViewShape((5, 3, 1), 6, 18, 2), tb, 2)
+    src = wg.GpuTensorView(wg.ViewShape((5, 3, 1), 7, 21, 3), ta, 2)
+    cv, shapes = wg.CopyView.from_device(gpu.device()), wg.ViewShapeBuffers()
+    run_pass(gpu, lambda p: cv.dispatch(gpu.device(), shapes, p, dst, src))
+    for j in range(3):
+        want[2 + 6 * j: 2 + 6 * j + 5] = a[3 + 7 * j: 3 + 7 * j + 5]
+    assert np.array_equal(tb.read(gpu.device()), want)
 
 
 F32_ANY_ALIGN = [

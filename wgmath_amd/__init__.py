@@ -8,7 +8,7 @@ from ._lib import (LIB_PATH, DimensionMismatch, NoDevice, PreconditionFailed, Wg
 from .wgcore import (BufferUsages, CommandBuffer, CommandEncoder, ComputePass, Device, GpuCube, GpuInstance,  # noqa: F401
                      GpuBuffer, GpuMatrix, GpuScalar, GpuTensor, GpuTensorView, GpuTimestamps, GpuVector, Queue, TensorBuilder,
                      ViewShape, ViewShapeBuffers, as_view)
-from .wgebra import (Axpy, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
+from .wgebra import (Axpy, CopyView, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
                      gemv_reduce, row_major_shader_defs)
 from .sharded import Comm, GatherMode, MShardPlan, ShardedGemm, new_unique_id  # noqa: F401,E402
 from . import geometry  # noqa: F401,E402
