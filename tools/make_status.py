@@ -146,10 +146,10 @@ def main():
     if vendor:
         print(f"\nVendor column: `{vendor_file}` (`tools/vendor_vs_ours.sh`: hipBLASLt through `torch.matmul` on this repo's layouts -- nn = both operands as the Gemm takes them,")
         print("nt = its best layout, what GemmTr computes; the vendor's 32768^3 does not fit its workspace here, 16384^3 stands in). Shape sweeps against the vendor library:")
-        print("`profiles/r06_gemm_sweep_full.txt` (116 Gemm / GemmTr cases on the round's code: none more than 10 % behind), `profiles/r06_gemm_sweep_row_major.txt`")
+        print("`profiles/r06_gemm_sweep_full.txt` (116 Gemm / GemmTr cases on the final code: one 10 % behind, f32 GemmTr 64 x 4096 x 4096), `profiles/r06_gemm_sweep_row_major.txt`")
         print("(the row-major surface, 32 cases: f16 GemmTr 0.60-1.07 x the vendor's time, Gemm 0.61-0.94 x; behind: f32 GemmTr 2048^3 1.14 x, on the transposed-copy path below a round of tiles),")
-        print("`profiles/r06_misc_sweep.txt` (50 batched / multi-RHS cases: 6 behind by 12-17 %); 48 random shapes x Gemm / GemmTr (`r06_gemm_sweep_random48_*.txt`): f16 17 of 96 behind,")
-        print("f32 7 of 96 (16 before the batch-wide tail split), row-major f16 5 of 96 -- mid-size outputs, where the vendor's stream-K kernels fill the chip better.")
+        print("`profiles/r06_misc_sweep.txt` (50 batched / multi-RHS cases: 6 behind by 12-17 %); 48 random shapes x Gemm / GemmTr (`r06_gemm_sweep_random48_*.txt`, `tools/random48_shapes.txt`; f16 / f32 re-run on the final code): f16 16 of 96 behind,")
+        print("f32 5 of 96 (16 before the batch-wide tail split), row-major f16 5 of 96 -- mid-size outputs, where the vendor's stream-K kernels fill the chip better.")
     print("\nC1 replayed: the figure depends on what the process allocated before, not on the box -- the same chip gives 2.6 us per dispatch in a fresh process and 3.4-5.7 us behind 25 other")
     print("workloads (`profiles/r06_c1_replay_populations.txt`). The bench therefore runs config 1 right behind the headline since `r06_bench_boxF` (2.65 us); the older files ran it last.")
     print("\nNorth-star targets: f16 Gemm 8192^3 >= 0.80 of MFMA peak -- NOT met (see the C3 rows; the matrix cores alone, on random operands, sustain the")
