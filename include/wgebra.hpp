@@ -189,6 +189,40 @@ class GpuTensor {
         return GpuTensorView<T>(s, buffer());
     }
     operator GpuTensorView<T>() const { return as_embedded_view(); } // From<&GpuTensor> (tensor.rs:403-409)
+    GpuTensorView<T> as_view() const { return as_embedded_view(); }   // tensor.rs:282-284
+    bool is_empty() const { return len() == 0; }                       // tensor.rs:198-200
+    uint64_t bytes_len_encased() const { return bytes_len(); }         // tensor.rs:217-222: T::min_size() * len; the element types here are scalars (size == min_size)
+    void copy_from_encased(CommandEncoder &enc, const GpuTensor &src) const { copy_from(enc, src); } // tensor.rs:235-241
+    void copy_from_view(CommandEncoder &enc, GpuTensorView<T> src) const {                           // tensor.rs:244-264: `bytes_len()` bytes from the view's offset on
+        const uint32_t rows = shape_.empty() ? 1u : shape_[0];
+        if (src.shape().size[0] != rows) throw Panic(WG_ERR_DIM_MISMATCH, "assertion `left == right` failed (copy_from_view: rows)");
+        check(wg_buf_copy(enc.ctx(), src.buffer(), (uint64_t)src.shape().offset * sizeof(T), buffer(), 0, bytes_len()));
+    }
+    // tensor.rs:514-541: a view of the first prod(shape) elements with the given (default: column-major) strides
+    GpuTensorView<T> reshape(const std::vector<uint32_t> &shape, int64_t stride = -1, int64_t stride_mat = -1) const {
+        uint32_t n = 1, m = 1;
+        for (auto v : shape) n *= v; // (the reference multiplies in u32)
+        for (auto v : shape_) m *= v;
+        if (n > m) throw Panic(WG_ERR_PRECONDITION, "assertion failed: reshape to more elements than the tensor holds");
+        ViewShape s{{1, 1, 1}, 1, 1, 0};
+        for (size_t i = 0; i < shape.size() && i < 3; ++i) s.size[i] = shape[i];
+        const uint32_t s0 = shape.size() > 0 ? shape[0] : 1u, s1 = shape.size() > 1 ? shape[1] : 1u;
+        s.stride = stride < 0 ? s0 : (uint32_t)stride;
+        s.stride_mat = stride_mat < 0 ? s0 * s1 : (uint32_t)stride_mat;
+        return GpuTensorView<T>(s, buffer());
+    }
+    // GpuMatrix::slice (tensor.rs:587-594): offset = i + j * nrows with the SLICE's nrows, as the reference computes it (columns / rows give the conventional blocks)
+    GpuTensorView<T> slice(uint32_t i, uint32_t j, uint32_t nrows, uint32_t ncols) const {
+        if (shape_.size() != 2) throw Panic(WG_ERR_PRECONDITION, "GpuMatrix::slice on a tensor that is not a matrix");
+        return GpuTensorView<T>(ViewShape{{nrows, ncols, 1}, shape_[0], shape_[0] * shape_[1], i + j * nrows}, buffer());
+    }
+    // tensor.rs:277-279: gives up the tensor, keeps the allocation (shared here: the buffer lives as long as the last holder)
+    std::shared_ptr<wg_buf> into_inner() && { return std::move(buf_); }
+    // GpuMatrix / GpuVector sugar (tensor.rs:544-706)
+    static GpuTensor uninit(const Device &dev, std::vector<uint32_t> shape, uint32_t usage);
+    static GpuTensor init(const Device &dev, std::vector<uint32_t> shape, const std::vector<T> &data, uint32_t usage);
+    static GpuTensor uninit_encased(const Device &dev, std::vector<uint32_t> shape, uint32_t usage) { return uninit(dev, std::move(shape), usage); }
+    static GpuTensor encase(const Device &dev, const std::vector<T> &data, uint32_t usage) { return init(dev, { (uint32_t)data.size() }, data, usage); }
   private:
     CtxPtr ctx_;                  // declared before buf_: members are destroyed in reverse order, so the buffer goes first
     std::shared_ptr<wg_buf> buf_;
@@ -221,11 +255,26 @@ class TensorBuilder {
         check(wg_buf_create_init(dev.raw(), data.data(), sizeof(T) * len(), usage_, &b));
         return GpuTensor<T>(dev.shared(), b, shape_);
     }
+    // tensor.rs:148-173: raw bytes; items in their storage layout (the scalar element types of this path: the same bytes as build_init); uninitialised, sized by the layout
+    template <typename T> GpuTensor<T> build_bytes(const Device &dev, const void *data, size_t nbytes) const {
+        wg_buf *b = nullptr;
+        check(wg_buf_create_init(dev.raw(), data, nbytes, usage_, &b));
+        return GpuTensor<T>(dev.shared(), b, shape_);
+    }
+    template <typename T> GpuTensor<T> build_encase(const Device &dev, const std::vector<T> &data) const { return build_init<T>(dev, data); }
+    template <typename T> GpuTensor<T> build_uninit_encased(const Device &dev) const { return build<T>(dev); }
   private:
     TensorBuilder(std::vector<uint32_t> shape, uint32_t usage) : shape_(std::move(shape)), usage_(usage) {}
     std::vector<uint32_t> shape_;
     uint32_t usage_;
 };
+
+template <typename T> GpuTensor<T> GpuTensor<T>::uninit(const Device &dev, std::vector<uint32_t> shape, uint32_t usage) {
+    return TensorBuilder::tensor(std::move(shape), usage).template build<T>(dev);
+}
+template <typename T> GpuTensor<T> GpuTensor<T>::init(const Device &dev, std::vector<uint32_t> shape, const std::vector<T> &data, uint32_t usage) {
+    return TensorBuilder::tensor(std::move(shape), usage).template build_init<T>(dev, data);
+}
 
 } // namespace wgcore
 

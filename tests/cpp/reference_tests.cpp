@@ -160,6 +160,47 @@ static void handles_outlive_the_instance() {
     EXPECT(kept.first.len() == 1024, "tensor survived");
 } // both destroyed here, then the context
 
+// The rest of tensor.rs in the C++ mirror: reshape / slice / as_view, copy_from_view, build_bytes / build_encase / build_uninit_encased, uninit / init / encase,
+// into_inner -- and CopyView (wg_copy_view) on a view at an odd offset.
+static void tensor_members(const GpuInstance &gpu) {
+    const uint32_t R = 12, C = 5;
+    std::vector<float> host(R * C);
+    for (size_t i = 0; i < host.size(); ++i) host[i] = (float)i;
+    auto m = GpuTensor<float>::init(gpu.device(), { R, C }, host, BufferUsages::STORAGE | BufferUsages::COPY_SRC);
+    EXPECT(!m.is_empty() && m.bytes_len_encased() == R * C * 4, "init / is_empty / bytes_len_encased");
+    auto sl = m.slice(1, 2, 4, 3); // the reference's offset: i + j * (the SLICE's nrows) = 1 + 2 * 4
+    EXPECT(sl.shape().offset == 9 && sl.shape().stride == R && sl.shape().size[0] == 4 && sl.shape().size[1] == 3, "slice: the reference's offset arithmetic");
+    auto rs = m.reshape({ 6, 4 });
+    EXPECT(rs.shape().stride == 6 && rs.shape().stride_mat == 24 && rs.shape().offset == 0, "reshape: column-major defaults");
+    // column 2 of m into a vector, through copy_from_view
+    auto col = TensorBuilder::vector(R, BufferUsages::STORAGE | BufferUsages::COPY_SRC | BufferUsages::COPY_DST).build_uninit_encased<float>(gpu.device());
+    auto enc = gpu.create_command_encoder();
+    col.copy_from_view(enc, m.as_view().columns(2, 1));
+    gpu.queue().submit(enc.finish());
+    auto got = col.read(gpu.device());
+    bool ok = true;
+    for (uint32_t r = 0; r < R; ++r) ok &= got[r] == host[2 * R + r];
+    EXPECT(ok, "copy_from_view: a column");
+    // CopyView: rows 1 .. 9 of columns 1 .. 3 (offset 13: odd) into a dense 12 x 4 block -- zero beyond the source
+    auto dst = GpuTensor<float>::uninit(gpu.device(), { 12, 4 }, BufferUsages::STORAGE | BufferUsages::COPY_SRC);
+    auto e2 = gpu.create_command_encoder();
+    auto pass = e2.compute_pass("copy", nullptr);
+    wgebra::CopyView::from_device(gpu.device()).dispatch<float>(gpu.device(), ViewShapeBuffers::create(), pass, dst, m.as_view().columns(1, 3).rows(1, 9));
+    gpu.queue().submit(e2.finish());
+    auto d = dst.read(gpu.device());
+    ok = true;
+    for (uint32_t c = 0; c < 4; ++c)
+        for (uint32_t r = 0; r < 12; ++r) ok &= d[c * 12 + r] == ((c < 3 && r < 9) ? host[(c + 1) * R + 1 + r] : 0.f);
+    EXPECT(ok, "CopyView: an odd-offset block into a larger dense one, zero-filled");
+    auto raw = TensorBuilder::vector(4, BufferUsages::STORAGE | BufferUsages::COPY_SRC).build_bytes<float>(gpu.device(), host.data(), 16);
+    auto enc3 = TensorBuilder::vector(4, BufferUsages::STORAGE | BufferUsages::COPY_SRC).build_encase<float>(gpu.device(), host);
+    EXPECT(raw.read(gpu.device()) == enc3.read(gpu.device()), "build_bytes == build_encase for scalar items");
+    auto v = GpuTensor<float>::encase(gpu.device(), host, BufferUsages::STORAGE);
+    EXPECT(v.len() == host.size(), "GpuVector::encase");
+    auto inner = std::move(v).into_inner();
+    EXPECT(inner && wg_buf_device_ptr(inner.get()) != nullptr, "into_inner keeps the allocation");
+}
+
 int main() {
     try {
         handles_outlive_the_instance();
@@ -169,6 +210,7 @@ int main() {
         gpu_reduce(gpu);
         gpu_op_assign(gpu);
         panics(gpu);
+        tensor_members(gpu);
     } catch (const std::exception &e) {
         std::printf("FAIL: exception: %s\n", e.what());
         return 2;

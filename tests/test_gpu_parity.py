@@ -2272,6 +2272,14 @@ def test_encased_builders_and_into_inner(gpu):
     del t  # the consumed tensor no longer owns anything: dropping it must not free the allocation
     again = wg.GpuTensor.wrap(gpu.device(), inner.device_ptr(), (37 * 4,), np.uint32, keepalive=inner)
     assert again.read_bytes(gpu.device()) == host.tobytes()
+    # GpuVector::encase / uninit_encased, bytes_len_encased, copy_from_encased (tensor.rs:217-241,633-655)
+    v = wg.GpuTensor.encase(gpu.device(), host, S.STORAGE | S.COPY_SRC)
+    w = wg.GpuTensor.uninit_encased(gpu.device(), 37, S.STORAGE | S.COPY_SRC | S.COPY_DST, item_dtype=item)
+    assert v.bytes_len_encased() == w.bytes_len_encased() == 37 * 16
+    enc = gpu.device().create_command_encoder()
+    w.copy_from_encased(enc, v)
+    gpu.queue().submit([enc.finish()])
+    assert w.read_bytes(gpu.device()) == host.tobytes()
 
 
 @pytest.mark.parametrize("M,K,N", [(64, 160, 12288), (12288, 160, 64), (48, 256, 16384), (64, 132, 24576)])

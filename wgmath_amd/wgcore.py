@@ -511,6 +511,10 @@ class GpuTensor:
     def bytes_len(self) -> int:
         return self.len() * self.dtype.itemsize
 
+    def bytes_len_encased(self) -> int:
+        """tensor.rs:217-222: `T::min_size() * len` -- the item size of the storage layout, which the tensor's (possibly structured) dtype carries."""
+        return self.bytes_len()
+
     def shape(self) -> tuple:
         return self._shape
 
@@ -532,6 +536,11 @@ class GpuTensor:
     def copy_from(self, encoder: CommandEncoder, source: "GpuTensor") -> None:
         assert self.len() == source.len()
         check(lib.wg_buf_copy(encoder._ctx.handle, source._h, 0, self._h, 0, self.bytes_len()))
+
+    def copy_from_encased(self, encoder: CommandEncoder, source: "GpuTensor") -> None:
+        """tensor.rs:235-241: the same buffer-to-buffer copy, sized by the storage layout."""
+        assert self.len() == source.len()
+        check(lib.wg_buf_copy(encoder._ctx.handle, source._h, 0, self._h, 0, self.bytes_len_encased()))
 
     def copy_from_view(self, encoder: CommandEncoder, source) -> None:
         source = as_view(source, max(self.DIM, 1))
@@ -598,6 +607,18 @@ class GpuTensor:
     def init(device: Device, data, usage, dtype=None) -> "GpuTensor":
         arr = np.asarray(data)
         return TensorBuilder(arr.shape, usage).build_init(device, arr, dtype or arr.dtype)
+
+    @staticmethod
+    def uninit_encased(device: Device, *shape_and_usage, item_dtype) -> "GpuTensor":
+        """tensor.rs:553-558,650-655: `GpuMatrix / GpuVector::uninit_encased` -- items of a shader struct, `item_dtype` = the structured dtype with its storage layout."""
+        *shape, usage = shape_and_usage
+        return TensorBuilder(shape, usage).build_uninit_encased(device, item_dtype)
+
+    @staticmethod
+    def encase(device: Device, data, usage) -> "GpuTensor":
+        """tensor.rs:633-639: `GpuVector::encase` -- a vector of shader-struct items uploaded in their storage layout (the structured dtype of `data`)."""
+        arr = np.ascontiguousarray(data).reshape(-1)
+        return TensorBuilder.vector(arr.size, usage).build_encase(device, arr)
 
     def _require(self, dim: int, what: str):
         if self.DIM != dim:
