@@ -71,20 +71,93 @@ class CommandBuffer {
     std::shared_ptr<wg_cmdbuf> cb_;
 };
 
+// timestamps.rs:9-248: a pool of timestamp slots, written at compute-pass boundaries or explicitly inside a pass; events on the context's stream
+class ComputePass;
+class CommandEncoder;
+class GpuTimestamps {
+  public:
+    struct PassWrites { GpuTimestamps *query_set; uint32_t beginning_of_pass_write_index, end_of_pass_write_index; }; // wgpu::ComputePassTimestampWrites
+    GpuTimestamps(wg_ctx *ctx, CtxPtr keep, uint32_t capacity) : keep_(std::move(keep)), capacity_(capacity) {
+        wg_timestamps *t = nullptr;
+        check(wg_timestamps_create(ctx, capacity, &t));
+        ts_.reset(t, [](wg_timestamps *p) { wg_timestamps_destroy(p); });
+    }
+    bool is_empty() const { return len() == 0; }
+    uint32_t len() const { return wg_timestamps_len(ts_.get()); }
+    wg_timestamps *query_set() const { return ts_.get(); }
+    void clear() { check(wg_timestamps_clear(ts_.get())); }
+    // all or none: std::nullopt-like `false` when the slots do not fit (timestamps.rs:59-94)
+    bool next_query_indices(uint32_t count, uint32_t *first) { check(wg_timestamps_reserve(ts_.get(), count, first)); return *first != UINT32_MAX; }
+    bool next_query_index(uint32_t *index) { return next_query_indices(1, index); }
+    bool next_compute_pass_timestamp_writes(PassWrites *w) {
+        uint32_t first = 0;
+        if (!next_query_indices(2, &first)) return false;
+        *w = PassWrites{ this, first, first + 1 };
+        return true;
+    }
+    inline bool write_next_timestamp(ComputePass &pass, uint32_t *index = nullptr);
+    inline bool write_timestamp_at(ComputePass &pass, uint32_t query_index);
+    void resolve(CommandEncoder &) const {} // events need no resolve copy
+    std::vector<double> wait_for_results_ms() const {
+        std::vector<double> ms(len());
+        check(wg_timestamps_wait_for_results_ms(ts_.get(), ms.data(), (uint32_t)ms.size()));
+        return ms;
+    }
+    std::vector<uint64_t> wait_for_results() const { // raw values: nanoseconds since the first written slot (period 1)
+        std::vector<uint64_t> raw;
+        for (double m : wait_for_results_ms()) raw.push_back((uint64_t)(m * 1.0e6 + 0.5));
+        return raw;
+    }
+    static std::vector<double> timestamps_to_ms(const std::vector<uint64_t> &raw, float timestamp_period) {
+        std::vector<double> ms;
+        for (uint64_t t : raw) ms.push_back((double)t * (double)timestamp_period / 1.0e6);
+        return ms;
+    }
+  private:
+    CtxPtr keep_;
+    std::shared_ptr<wg_timestamps> ts_;
+    uint32_t capacity_;
+};
+
 class CommandEncoder;
 class ComputePass {
   public:
     explicit ComputePass(wg_ctx *c) : ctx_(c) {}
+    ComputePass(wg_ctx *c, GpuTimestamps::PassWrites w) : ctx_(c), writes_(w), timed_(true) { // beginning_of_pass_write_index
+        check(wg_timestamps_write_at(ctx_, writes_.query_set->query_set(), writes_.beginning_of_pass_write_index));
+    }
+    ComputePass(ComputePass &&o) noexcept : ctx_(o.ctx_), writes_(o.writes_), timed_(o.timed_) { o.timed_ = false; }
+    ComputePass(const ComputePass &) = delete;
+    ~ComputePass() { if (timed_) (void)wg_timestamps_write_at(ctx_, writes_.query_set->query_set(), writes_.end_of_pass_write_index); } // drop(pass): end_of_pass_write_index
     wg_ctx *ctx() const { return ctx_; }
   private:
     wg_ctx *ctx_;
+    GpuTimestamps::PassWrites writes_{};
+    bool timed_ = false;
 };
+inline bool GpuTimestamps::write_next_timestamp(ComputePass &pass, uint32_t *index) {
+    uint32_t i = 0;
+    if (!next_query_index(&i)) return false;
+    check(wg_timestamps_write_at(pass.ctx(), ts_.get(), i));
+    if (index) *index = i;
+    return true;
+}
+inline bool GpuTimestamps::write_timestamp_at(ComputePass &pass, uint32_t query_index) {
+    if (query_index >= capacity_) return false;
+    check(wg_timestamps_write_at(pass.ctx(), ts_.get(), query_index));
+    return true;
+}
 
 // wgpu::CommandEncoder + CommandEncoderExt::compute_pass (kernel.rs:15-27). record == false: work is enqueued as encoded.
 class CommandEncoder {
   public:
     CommandEncoder(CtxPtr c, bool record) : ctx_(std::move(c)), record_(record) { if (record_) check(wg_encoder_begin(ctx_.get())); }
     ComputePass compute_pass(const char * /*label*/, std::nullptr_t = nullptr) { return ComputePass(ctx_.get()); }
+    ComputePass compute_pass(const char * /*label*/, GpuTimestamps &timestamps) { // kernel.rs:15-27: the pass writes the next two slots at its beginning and its end
+        GpuTimestamps::PassWrites w{};
+        if (!timestamps.next_compute_pass_timestamp_writes(&w)) return ComputePass(ctx_.get());
+        return ComputePass(ctx_.get(), w);
+    }
     CommandBuffer finish() {
         if (!record_) return CommandBuffer();
         wg_cmdbuf *cb = nullptr;
@@ -101,6 +174,7 @@ class Queue {
   public:
     explicit Queue(wg_ctx *c) : ctx_(c) {}
     void submit(const CommandBuffer &cb) const { if (cb.raw()) check(wg_queue_submit(ctx_, cb.raw())); }
+    float get_timestamp_period() const { return 1.f; } // nanoseconds per tick of GpuTimestamps::wait_for_results' raw values
   private:
     wg_ctx *ctx_;
 };
@@ -113,8 +187,12 @@ class GpuInstance {
         check(wg_ctx_create(device_index, &c));
         return GpuInstance(c);
     }
+    static GpuInstance with_backends(unsigned /*backends*/, int device_index = 0) { return create(device_index); } // gpu.rs: one backend here
+    static GpuInstance without_gl(int device_index = 0) { return create(device_index); }
     const Device &device() const { return device_; }
+    const Device &device_arc() const { return device_; } // gpu.rs: the device behind an Arc -- the context is shared already
     const Queue &queue() const { return queue_; }
+    GpuTimestamps timestamps(uint32_t capacity) const { return GpuTimestamps(ctx_.get(), ctx_, capacity); } // GpuTimestamps::new(device, capacity)
     CommandEncoder create_command_encoder(bool record = false) const { return CommandEncoder(ctx_, record); }
     void poll_wait() const { check(wg_ctx_sync(ctx_.get())); }
   private:

@@ -487,10 +487,14 @@ int wg_cmdbuf_destroy(wg_cmdbuf *cmdbuf);
 int wg_timestamps_create(wg_ctx *ctx, uint32_t capacity, wg_timestamps **out); /* GpuTimestamps::new */
 int wg_timestamps_destroy(wg_timestamps *ts);
 int wg_timestamps_clear(wg_timestamps *ts);
-/* Record the next timestamp at the current point of the stream; *index (optional) receives its slot. */
+/* Record the next timestamp at the current point of the stream; *index (optional) receives its slot. (write_next_timestamp, timestamps.rs:98-102) */
 int wg_timestamps_write(wg_ctx *ctx, wg_timestamps *ts, uint32_t *index);
+/* next_query_indices::<COUNT> (timestamps.rs:80-94): `count` consecutive slots, all or none -- *first = UINT32_MAX when they do not fit (the reference's None; no error). */
+int wg_timestamps_reserve(wg_timestamps *ts, uint32_t count, uint32_t *first);
+/* write_timestamp_at (timestamps.rs:108-115): the timestamp of slot `index` (< capacity) at the current point of the stream. A reserved slot never written reads 0. */
+int wg_timestamps_write_at(wg_ctx *ctx, wg_timestamps *ts, uint32_t index);
 uint32_t wg_timestamps_len(const wg_timestamps *ts);
-/* wait_for_results_ms (timestamps.rs:226-230): block, then out_ms[i] = time of slot i relative to slot 0. */
+/* wait_for_results_ms (timestamps.rs:226-230): block, then out_ms[i] = time of slot i relative to the first written slot (slot 0 in the begin / end use). */
 int wg_timestamps_wait_for_results_ms(wg_timestamps *ts, double *out_ms, uint32_t capacity);
 
 #ifdef __cplusplus

@@ -201,6 +201,35 @@ static void tensor_members(const GpuInstance &gpu) {
     EXPECT(inner && wg_buf_device_ptr(inner.get()) != nullptr, "into_inner keeps the allocation");
 }
 
+// timestamps.rs in the C++ mirror: a pass timed by the next two slots, an explicit write inside it, reserved slots all-or-none, raw values and their conversion
+static void timestamps(const GpuInstance &gpu) {
+    std::vector<float> ones(1 << 20, 1.f);
+    auto a = TensorBuilder::vector(1 << 20, BufferUsages::STORAGE).build_init(gpu.device(), ones);
+    auto b = TensorBuilder::vector(1 << 20, BufferUsages::STORAGE).build_init(gpu.device(), ones);
+    auto ts = gpu.timestamps(6);
+    EXPECT(ts.is_empty(), "timestamps: empty at first");
+    auto enc = gpu.create_command_encoder();
+    uint32_t mid = 99;
+    {
+        auto pass = enc.compute_pass("timed", ts);
+        OpAssign::create(gpu.device(), OpAssignVariant::Add).dispatch<float>(gpu.device(), ViewShapeBuffers::create(), pass, a, b);
+        EXPECT(ts.write_next_timestamp(pass, &mid) && mid == 2, "timestamps: the third slot, inside the pass");
+        OpAssign::create(gpu.device(), OpAssignVariant::Add).dispatch<float>(gpu.device(), ViewShapeBuffers::create(), pass, a, b);
+        EXPECT(!ts.write_timestamp_at(pass, 6), "timestamps: a slot past the capacity is refused");
+    } // drop(pass): the end-of-pass slot
+    ts.resolve(enc);
+    gpu.queue().submit(enc.finish());
+    uint32_t first = 0;
+    EXPECT(!ts.next_query_indices(4, &first) && ts.len() == 3, "timestamps: 3 + 4 > 6: none taken");
+    EXPECT(ts.next_query_indices(3, &first) && first == 3 && ts.len() == 6, "timestamps: the last three slots");
+    auto ms = ts.wait_for_results_ms();
+    EXPECT(ms.size() == 6 && ms[0] == 0.0 && ms[2] > 0.0 && ms[1] > ms[2] && ms[1] < 1000.0 && ms[3] == 0.0, "timestamps: begin < inside < end, unwritten slots read 0");
+    auto back = GpuTimestamps::timestamps_to_ms(ts.wait_for_results(), gpu.queue().get_timestamp_period());
+    EXPECT(back.size() == 6 && std::fabs(back[1] - ms[1]) < 1e-5, "timestamps: raw values x period");
+    ts.clear();
+    EXPECT(ts.is_empty(), "timestamps: clear");
+}
+
 int main() {
     try {
         handles_outlive_the_instance();
@@ -211,6 +240,7 @@ int main() {
         gpu_op_assign(gpu);
         panics(gpu);
         tensor_members(gpu);
+        timestamps(gpu);
     } catch (const std::exception &e) {
         std::printf("FAIL: exception: %s\n", e.what());
         return 2;

@@ -757,6 +757,32 @@ def test_record_replay_and_timestamps(gpu):
     assert len(t) == 2 and t[0] == 0.0 and 0.0 < t[1] < 1000.0
     assert np.array_equal(a.slow_read(gpu), np.full(n, 20, np.float32))
 
+    # the rest of timestamps.rs: slots reserved first (next_query_indices: all or none), a pass that writes its reserved pair, explicit writes inside a pass,
+    # raw values and their conversion, the async forms, clear
+    ts.clear()
+    assert ts.is_empty() and ts.query_set() is ts
+    writes = ts.next_compute_pass_timestamp_writes()
+    assert (writes.beginning_of_pass_write_index, writes.end_of_pass_write_index) == (0, 1) and ts.len() == 2
+    enc = dev.create_command_encoder()
+    with enc.compute_pass("timed by reserved slots", writes) as p:
+        add.dispatch(dev, shapes, p, a, b)
+        assert ts.write_next_timestamp(p) == 2        # a third timestamp inside the pass
+        add.dispatch(dev, shapes, p, a, b)
+        assert ts.write_timestamp_at(p, 5) and not ts.write_timestamp_at(p, 8)  # slot 5 is below the capacity (never allocated: len stays), slot 8 is not
+    gpu.queue().submit([enc.finish()])
+    assert ts.next_query_indices(6) is None and ts.len() == 3   # 3 + 6 > 8: nothing is taken
+    assert ts.next_query_indices(5) == [3, 4, 5, 6, 7] and ts.next_query_index() is None
+    ms = ts.wait_for_results_ms(dev, gpu.queue())
+    assert len(ms) == 8 and ms[0] == 0.0 and 0.0 < ms[2] < ms[1] < 1000.0 and ms[2] <= ms[5] <= ms[1] and ms[3] == ms[4] == ms[6] == ms[7] == 0.0
+    raw = ts.wait_for_results(dev)
+    assert all(isinstance(x, int) for x in raw) and raw[1] > raw[2] > 0
+    back = wg.GpuTimestamps.timestamps_to_ms(raw, gpu.queue().get_timestamp_period())
+    assert all(abs(x - y) < 1e-5 for x, y in zip(back, ms))
+    import asyncio
+    assert asyncio.run(ts.wait_for_results_async(dev)) == raw and asyncio.run(ts.wait_for_results_ms_async(gpu.queue(), dev)) == ms
+    g2 = wg.GpuInstance.without_gl()
+    assert g2.device_arc() is g2.device() and wg.GpuInstance.with_backends("vulkan").adapter()["compute_units"] > 0
+
 
 def test_objects_dropped_during_a_recording_are_freed_after_it(gpu):
     """A tensor, a command buffer or a whole GpuInstance whose last reference goes away WHILE the thread records (Python's cyclic GC picks its

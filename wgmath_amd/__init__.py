@@ -6,7 +6,7 @@ Importing it loads the shared library and fails loudly if it is not built: there
 """
 from ._lib import (LIB_PATH, DimensionMismatch, NoDevice, PreconditionFailed, WgError, WorkspaceMustGrow)  # noqa: F401
 from .wgcore import (BufferUsages, CommandBuffer, CommandEncoder, ComputePass, Device, GpuCube, GpuInstance,  # noqa: F401
-                     GpuBuffer, GpuMatrix, GpuScalar, GpuTensor, GpuTensorView, GpuTimestamps, GpuVector, Queue, TensorBuilder,
+                     GpuBuffer, GpuMatrix, GpuScalar, GpuTensor, GpuTensorView, GpuTimestamps, ComputePassTimestampWrites, GpuVector, Queue, TensorBuilder,
                      ViewShape, ViewShapeBuffers, as_view)
 from .wgebra import (Axpy, CopyView, Gemm, GemmVariant, Gemv, GemvVariant, OpAssign, OpAssignVariant, Reduce, ReduceOp,  # noqa: F401
                      gemv_reduce, row_major_shader_defs)

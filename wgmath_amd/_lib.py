@@ -148,6 +148,8 @@ def _load() -> ctypes.CDLL:
         "wg_timestamps_destroy": (ci, [vp]),
         "wg_timestamps_clear": (ci, [vp]),
         "wg_timestamps_write": (ci, [vp, vp, ctypes.POINTER(u32)]),
+        "wg_timestamps_reserve": (ci, [vp, u32, ctypes.POINTER(u32)]),
+        "wg_timestamps_write_at": (ci, [vp, vp, u32]),
         "wg_timestamps_len": (u32, [vp]),
         "wg_timestamps_wait_for_results_ms": (ci, [vp, ctypes.POINTER(ctypes.c_double), u32]),
     }

@@ -549,6 +549,7 @@ int wg_timestamps_create(wg_ctx *ctx, uint32_t capacity, wg_timestamps **out) {
     if (!ts) return wg_set_error(WG_ERR_HIP, "out of host memory");
     ts->ctx = ctx;
     ts->events.resize(capacity, nullptr);
+    ts->written.assign(capacity, 0);
     for (uint32_t i = 0; i < capacity; ++i) {
         hipError_t e = hipEventCreate(&ts->events[i]);
         if (e != hipSuccess) {
@@ -573,6 +574,28 @@ int wg_timestamps_destroy(wg_timestamps *ts) {
 int wg_timestamps_clear(wg_timestamps *ts) {
     if (!ts) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_clear: NULL argument");
     ts->len = 0;
+    std::fill(ts->written.begin(), ts->written.end(), (uint8_t)0);
+    return WG_OK;
+}
+
+// next_query_indices::<COUNT> (timestamps.rs:80-94): `count` consecutive slots, or none at all (*first = UINT32_MAX: the reference's None -- not an error)
+int wg_timestamps_reserve(wg_timestamps *ts, uint32_t count, uint32_t *first) {
+    if (!ts || !first) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_reserve: NULL argument");
+    if (count == 0) { *first = 0; return WG_OK; }
+    if ((uint64_t)ts->len + count > ts->events.size()) { *first = UINT32_MAX; return WG_OK; }
+    *first = ts->len;
+    ts->len += count;
+    return WG_OK;
+}
+
+// write_timestamp_at (timestamps.rs:108-115): the timestamp of slot `index` (any slot below the capacity) at the current point of the stream
+int wg_timestamps_write_at(wg_ctx *ctx, wg_timestamps *ts, uint32_t index) {
+    if (!ctx || !ts) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write_at: NULL argument");
+    if (index >= ts->events.size()) return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "wg_timestamps_write_at: slot %u of %zu", index, ts->events.size());
+    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write_at: not recordable");
+    WG_HIP_TRY(hipSetDevice(ctx->device));
+    WG_HIP_TRY(hipEventRecord(ts->events[index], ctx->stream));
+    ts->written[index] = 1;
     return WG_OK;
 }
 
@@ -580,9 +603,7 @@ int wg_timestamps_write(wg_ctx *ctx, wg_timestamps *ts, uint32_t *index) {
     if (!ctx || !ts) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write: NULL argument");
     if (ts->len >= ts->events.size())
         return wg_set_error(WG_ERR_OUT_OF_BOUNDS, "wg_timestamps_write: capacity %zu exhausted", ts->events.size());
-    if (ctx->recording) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_write: not recordable");
-    WG_HIP_TRY(hipSetDevice(ctx->device));
-    WG_HIP_TRY(hipEventRecord(ts->events[ts->len], ctx->stream));
+    if (int rc = wg_timestamps_write_at(ctx, ts, ts->len)) return rc;
     if (index) *index = ts->len;
     ts->len++;
     return WG_OK;
@@ -594,11 +615,13 @@ int wg_timestamps_wait_for_results_ms(wg_timestamps *ts, double *out_ms, uint32_
     if (!ts || (capacity && !out_ms)) return wg_set_error(WG_ERR_INVALID_ARG, "wg_timestamps_wait_for_results_ms: NULL argument");
     if (ts->len == 0) return WG_OK;
     WG_HIP_TRY(hipSetDevice(ts->ctx->device));
-    WG_HIP_TRY(hipEventSynchronize(ts->events[ts->len - 1]));
-    uint32_t n = ts->len < capacity ? ts->len : capacity;
+    const uint32_t n = ts->len < capacity ? ts->len : capacity;
+    int first = -1; // times are relative to the first slot that was written (slot 0 in the usual begin / end use); a reserved slot never written reads 0
+    for (uint32_t i = 0; i < ts->len; ++i)
+        if (ts->written[i]) { WG_HIP_TRY(hipEventSynchronize(ts->events[i])); if (first < 0) first = (int)i; }
     for (uint32_t i = 0; i < n; ++i) {
         float ms = 0.f;
-        if (i > 0) WG_HIP_TRY(hipEventElapsedTime(&ms, ts->events[0], ts->events[i]));
+        if (ts->written[i] && (int)i != first) WG_HIP_TRY(hipEventElapsedTime(&ms, ts->events[first], ts->events[i]));
         out_ms[i] = (double)ms;
     }
     return WG_OK;

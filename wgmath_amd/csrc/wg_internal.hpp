@@ -103,6 +103,7 @@ struct wg_cmdbuf {
 struct wg_timestamps {
     wg_ctx *ctx = nullptr;
     std::vector<hipEvent_t> events;
+    std::vector<uint8_t> written; // slot i holds a recorded event (a slot can be reserved -- next_query_indices -- and written later, or never)
     uint32_t len = 0;
 };
 

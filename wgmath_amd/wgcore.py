@@ -142,7 +142,10 @@ class ComputePass:
         self._ts = timestamps
         self._ended = False
         if timestamps is not None:
-            timestamps._write(encoder._ctx)  # beginning_of_pass_write_index
+            if hasattr(timestamps, "beginning_of_pass_write_index"):  # ComputePassTimestampWrites: the slots were reserved by next_compute_pass_timestamp_writes
+                check(lib.wg_timestamps_write_at(encoder._ctx.handle, timestamps.query_set._h, timestamps.beginning_of_pass_write_index))
+            else:
+                timestamps._write(encoder._ctx)  # beginning_of_pass_write_index
 
     @property
     def _ctx(self) -> _Ctx:
@@ -153,7 +156,10 @@ class ComputePass:
         if not self._ended:
             self._ended = True
             if self._ts is not None:
-                self._ts._write(self.encoder._ctx)  # end_of_pass_write_index
+                if hasattr(self._ts, "end_of_pass_write_index"):
+                    check(lib.wg_timestamps_write_at(self.encoder._ctx.handle, self._ts.query_set._h, self._ts.end_of_pass_write_index))
+                else:
+                    self._ts._write(self.encoder._ctx)  # end_of_pass_write_index
 
     def __enter__(self):
         return self
@@ -233,6 +239,10 @@ class Queue:
             if cb is not None and cb._h:
                 check(lib.wg_queue_submit(self._ctx.handle, cb._h))
 
+    def get_timestamp_period(self) -> float:
+        """wgpu::Queue::get_timestamp_period: nanoseconds per tick of the raw values `GpuTimestamps.wait_for_results` returns (1: they are nanoseconds)."""
+        return 1.0
+
     def write_buffer(self, tensor: "GpuTensor", offset_bytes: int, data) -> None:
         arr = np.ascontiguousarray(data)
         check(lib.wg_buf_write(self._ctx.handle, tensor._h, offset_bytes, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
@@ -283,6 +293,20 @@ class GpuInstance:
 
     without_gl = new
     with_backends = new
+
+    @staticmethod
+    def with_backends(backends=None, device_index: int = 0) -> "GpuInstance":
+        """gpu.rs: `GpuInstance::with_backends(backends)` -- there is one backend here (HIP on gfx950); the argument is accepted and ignored."""
+        return GpuInstance.new(device_index)
+
+    @staticmethod
+    def without_gl(device_index: int = 0) -> "GpuInstance":
+        """gpu.rs: `GpuInstance::without_gl()`."""
+        return GpuInstance.new(device_index)
+
+    def device_arc(self) -> "Device":
+        """gpu.rs: the device behind an `Arc` -- Python references are that already."""
+        return self.device()
 
     @staticmethod
     def device_count() -> int:
@@ -746,12 +770,72 @@ class GpuTimestamps:
     def write(self, device: Device) -> int:
         return self._write(device._ctx)
 
+    def query_set(self) -> "GpuTimestamps":
+        """timestamps.rs:54-57: the underlying query set -- the events live in this object."""
+        return self
+
+    # slot allocation (timestamps.rs:59-94): all or nothing, `None` when the slots do not fit
+    def next_query_indices(self, count: int) -> Optional[list]:
+        first = ctypes.c_uint32()
+        check(lib.wg_timestamps_reserve(self._h, int(count), ctypes.byref(first)))
+        return None if first.value == 0xFFFFFFFF else [first.value + i for i in range(int(count))]
+
+    def next_query_index(self) -> Optional[int]:
+        ids = self.next_query_indices(1)
+        return None if ids is None else ids[0]
+
+    def next_compute_pass_timestamp_writes(self) -> Optional["ComputePassTimestampWrites"]:
+        """timestamps.rs:59-71: two slots for the beginning and the end of a compute pass: `encoder.compute_pass(label, writes)` writes them."""
+        ids = self.next_query_indices(2)
+        return None if ids is None else ComputePassTimestampWrites(self, ids[0], ids[1])
+
+    # explicit writes inside a pass (timestamps.rs:96-115)
+    def write_next_timestamp(self, compute_pass: ComputePass) -> Optional[int]:
+        idx = self.next_query_index()
+        if idx is not None:
+            check(lib.wg_timestamps_write_at(compute_pass._ctx.handle, self._h, idx))
+        return idx
+
+    def write_timestamp_at(self, compute_pass: ComputePass, query_index: int) -> bool:
+        if not 0 <= query_index < self.capacity:
+            return False
+        check(lib.wg_timestamps_write_at(compute_pass._ctx.handle, self._h, int(query_index)))
+        return True
+
     def resolve(self, encoder: CommandEncoder) -> None:
         """timestamps.rs:119-134: a no-op here (events need no resolve copy)."""
 
-    def wait_for_results_ms(self) -> list:
-        """timestamps.rs:226-230: blocks; times in ms relative to the first timestamp."""
+    TIMESTAMP_PERIOD_NS = 1.0  # `Queue::get_timestamp_period`: the raw values below are nanoseconds
+
+    def wait_for_results_ms(self, device: Optional[Device] = None, queue=None) -> list:
+        """timestamps.rs:226-230: blocks; times in ms relative to the first written timestamp."""
         n = self.len()
         out = (ctypes.c_double * max(n, 1))()
         check(lib.wg_timestamps_wait_for_results_ms(self._h, out, n))
         return [out[i] for i in range(n)]
+
+    def wait_for_results(self, device: Optional[Device] = None) -> list:
+        """timestamps.rs:205-224: the raw integer timestamps (here: nanoseconds since the first one; `timestamps_to_ms(raw, queue.get_timestamp_period())` gives ms)."""
+        return [int(round(ms * 1.0e6)) for ms in self.wait_for_results_ms()]
+
+    async def wait_for_results_async(self, device: Optional[Device] = None) -> list:
+        """timestamps.rs:146-181 (the stream is drained with a blocking wait underneath: there is no map_async here)."""
+        return self.wait_for_results(device)
+
+    async def wait_for_results_ms_async(self, queue=None, device: Optional[Device] = None) -> list:
+        """timestamps.rs:188-196."""
+        return self.wait_for_results_ms(device, queue)
+
+    @staticmethod
+    def timestamps_to_ms(timestamps, timestamp_period: float) -> list:
+        """timestamps.rs:235-240: raw * period (ns per tick) / 1e6."""
+        return [float(t) * float(timestamp_period) / 1.0e6 for t in timestamps]
+
+
+class ComputePassTimestampWrites:
+    """wgpu::ComputePassTimestampWrites as `GpuTimestamps.next_compute_pass_timestamp_writes` hands it out: the query set and the two reserved slots."""
+
+    def __init__(self, query_set: GpuTimestamps, beginning_of_pass_write_index: int, end_of_pass_write_index: int):
+        self.query_set = query_set
+        self.beginning_of_pass_write_index = beginning_of_pass_write_index
+        self.end_of_pass_write_index = end_of_pass_write_index
