@@ -533,6 +533,8 @@ GEMV_ANY = [
     # R, C, ld, offsets (m, v, out), nrhs, mats -- matrix views the vec4 kernels cannot address: one pass where they lie (gemv_any.hip)
     (1000, 777, 1001, (3, 1, 2), 1, 1), (4097, 300, 4099, (1, 0, 0), 2, 1), (64, 5000, 66, (2, 3, 1), 1, 2), (8193, 64, 8193, (0, 0, 0), 1, 1),
     (5, 3, 5, (1, 0, 0), 1, 1), (513, 513, 515, (7, 5, 3), 3, 2), (20000, 16, 20002, (2, 0, 1), 1, 1), (16, 20000, 18, (1, 1, 1), 1, 1), (2048, 2048, 2048, (1, 0, 0), 1, 1),
+    # many whole row blocks + a ragged one, column / row splits with partials, an odd leading dimension (every column its own alignment)
+    (8193, 4099, 8195, (1, 0, 1), 1, 1), (4099, 8193, 4101, (3, 2, 0), 2, 1),
 ]
 
 
