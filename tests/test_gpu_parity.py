@@ -391,6 +391,79 @@ def test_copy_view_errors_and_skips(gpu):
     assert np.array_equal(tb.read(gpu.device()), want)
 
 
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("MK", [(512, 512), (4096, 1024), (256, 8192), (8192, 256), (2048, 328), (1024, 1024)])
+def test_gemm_f16_any_number_of_columns(gpu, tr, MK):
+    """f16 Gemm / GemmTr onto N columns that are not a multiple of 4 run on the kernels as they are (no padded copies of m2 and out since round 6): every
+    kernel family the launcher picks over N = 9 .. 4097, against f64, and not one element outside the M x N view written (the output's leading dimension
+    leaves a gap after every column and the buffer goes on behind the last one)."""
+    wg = _wg()
+    M, K = MK
+    rng = np.random.default_rng(M + 7 * K + int(tr))
+    ar, ac = (K, M) if tr else (M, K)
+    A = (rng.random((ac, ar), dtype=np.float32) - 0.5).astype(np.float16)
+    ta = upload(gpu, (A.size,), A.ravel(), np.float16)
+    av = wg.GpuTensorView(wg.ViewShape((ar, ac, 1), ar, ar * ac, 0), ta, 2)
+    A64 = A.astype(np.float64).T if not tr else A.astype(np.float64)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    for N in (9, 13, 17, 31, 33, 63, 65, 127, 129, 255, 257, 1001, 4097):
+        if M * N * K > (1 << 33):
+            continue
+        B = (rng.random((N, K), dtype=np.float32) - 0.5).astype(np.float16)
+        ldc = M + 4
+        fc = rng.random(ldc * N + 64, dtype=np.float32).astype(np.float16)
+        tb, tc = upload(gpu, (B.size,), B.ravel(), np.float16), upload(gpu, (fc.size,), fc, np.float16)
+        bv = wg.GpuTensorView(wg.ViewShape((K, N, 1), K, K * N, 0), tb, 2)
+        cv = wg.GpuTensorView(wg.ViewShape((M, N, 1), ldc, ldc * N, 0), tc, 2)
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, cv, av, bv, variant))
+        got = tc.read(gpu.device())
+        ref = A64 @ B.astype(np.float64).T
+        idx = np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+        G = got[idx].astype(np.float64)
+        assert np.abs(G - ref).max() <= 2.0 ** -10 * max(1.0, np.abs(ref).max()) + K * 2.0 ** -22, (M, K, N, tr)
+        mask = np.ones(fc.size, bool)
+        mask[idx.ravel()] = False
+        assert np.array_equal(got[mask].view(np.uint16), fc[mask].view(np.uint16)), f"wrote outside the output view (M {M} K {K} N {N})"
+
+
+@pytest.mark.parametrize("tr", [False, True])
+@pytest.mark.parametrize("MK", [(512, 512), (4096, 256), (256, 8192), (64, 4096), (96, 512), (2048, 132), (1024, 1024), (16, 2048), (128, 1024)])
+def test_gemm_f32_any_number_of_columns(gpu, tr, MK):
+    """The f32 twin of the test above: N = 9 .. 4097 over the f32 launcher's families (main kernel, tail split, mid-size tiles, few rows / few columns, split-K).
+    f32 keeps the zero-padded copies of m2 and out for these N (its few-row forms assume N % 4 == 0: tried without in round 6, 5 of 18 cases wrong): the same checks."""
+    wg = _wg()
+    M, K = MK
+    rng = np.random.default_rng(3 * M + 7 * K + int(tr))
+    ar, ac = (K, M) if tr else (M, K)
+    A = (rng.random((ac, ar), dtype=np.float32) - 0.5)
+    ta = upload(gpu, (A.size,), A.ravel())
+    av = wg.GpuTensorView(wg.ViewShape((ar, ac, 1), ar, ar * ac, 0), ta, 2)
+    A64 = A.astype(np.float64).T if not tr else A.astype(np.float64)
+    variant = wg.GemmVariant.GemmTr if tr else wg.GemmVariant.Gemm
+    gemm, shapes = wg.Gemm.from_device(gpu.device()), wg.ViewShapeBuffers()
+    for N in (9, 13, 17, 31, 33, 63, 65, 127, 129, 255, 257, 1001, 4097):
+        if M * N * K > (1 << 32):
+            continue
+        B = (rng.random((N, K), dtype=np.float32) - 0.5)
+        ldc = M + 4
+        fc = rng.random(ldc * N + 64, dtype=np.float32)
+        tb, tc = upload(gpu, (B.size,), B.ravel()), upload(gpu, (fc.size,), fc)
+        bv = wg.GpuTensorView(wg.ViewShape((K, N, 1), K, K * N, 0), tb, 2)
+        cv = wg.GpuTensorView(wg.ViewShape((M, N, 1), ldc, ldc * N, 0), tc, 2)
+        run_pass(gpu, lambda p: gemm.dispatch_generic(gpu.device(), shapes, p, cv, av, bv, variant))
+        got = tc.read(gpu.device())
+        B64 = B.astype(np.float64).T
+        ref, sabs = A64 @ B64, np.abs(A64) @ np.abs(B64)
+        idx = np.arange(M)[:, None] + np.arange(N)[None, :] * ldc
+        G = got[idx].astype(np.float64)
+        tol = U.f32_gate(K, sabs)
+        assert (np.abs(G - ref) <= tol).all(), f"M {M} K {K} N {N} tr {tr}: worst err/tol {(np.abs(G - ref) / tol).max():.3g}"
+        mask = np.ones(fc.size, bool)
+        mask[idx.ravel()] = False
+        assert np.array_equal(got[mask].view(np.uint32), fc[mask].view(np.uint32)), f"wrote outside the output view (M {M} K {K} N {N})"
+
+
 F32_ANY_ALIGN = [
     # M, N, K, matrices -- the f32 kernel families (gemm_f32.hip launcher): the 256 x 128 kernel (DMA interior + edge tiles), its tail split, the mid-size tiles, K split over the
     # workgroup's waves, few columns / few rows (gemm_f32_skinny.hip, 16- and 32-wide), split-K slabs, a batch, the 64 < M <= 128 transposed form
