@@ -251,7 +251,7 @@ int wg_buf_fill_zero(wg_ctx *ctx, wg_buf *buf);
  *                   GpuMatrix::slice / rows / column hand out for odd offsets and lengths, tensor.rs:574-626): the reference's
  *                   kernels bind array<vec4<f32>> and address the wrong elements there (shape.wgsl:64-66). Here they compute
  *                   op(m1) m2 like any other view. Any offset / stride runs on the tuned kernels as it is (16-byte accesses and LDS-DMA take
- *                   element-aligned addresses on this target); lengths that are not multiples of 4 (f16: of M and K only -- any N runs as it is)
+ *                   element-aligned addresses on this target); lengths that are not multiples of 4 (of M and K; N too for f32 products with up to 128 rows -- otherwise any N runs as it is)
  *                   are staged into dense zero-padded copies of the operands that carry them (HBM-bound passes in a context scratch that cannot grow
  *                   inside a recording: WG_ERR_WORKSPACE); 1 .. 7 columns on otherwise aligned views run as a Gemv with that many right-hand
  *                   sides, without any copy. Only a view that exceeds its buffer is an error.

@@ -428,10 +428,11 @@ def test_gemm_f16_any_number_of_columns(gpu, tr, MK):
 
 
 @pytest.mark.parametrize("tr", [False, True])
-@pytest.mark.parametrize("MK", [(512, 512), (4096, 256), (256, 8192), (64, 4096), (96, 512), (2048, 132), (1024, 1024), (16, 2048), (128, 1024)])
+@pytest.mark.parametrize("MK", [(512, 512), (4096, 256), (256, 8192), (64, 4096), (96, 512), (2048, 132), (1024, 1024), (16, 2048), (128, 1024), (132, 1024), (1536, 192), (192, 4096)])
 def test_gemm_f32_any_number_of_columns(gpu, tr, MK):
     """The f32 twin of the test above: N = 9 .. 4097 over the f32 launcher's families (main kernel, tail split, mid-size tiles, few rows / few columns, split-K).
-    f32 keeps the zero-padded copies of m2 and out for these N (its few-row forms assume N % 4 == 0: tried without in round 6, 5 of 18 cases wrong): the same checks."""
+    From 129 rows on f32 takes these N as they are too; up to 128 rows it keeps the zero-padded copies of m2 and out (the few-row forms compute the transposed
+    product, whose row count N then is: without the copies 5 of 18 cases here were wrong)."""
     wg = _wg()
     M, K = MK
     rng = np.random.default_rng(3 * M + 7 * K + int(tr))

@@ -59,7 +59,7 @@ int gemm_staged(wg_ctx *ctx, bool tr, wg_dtype dtype, float alpha, float beta, w
     // Only the operands that need it are copied (round 6: a 16384 x 16384 matrix times ONE column -- N % 4 != 0, nothing else -- paid 800 us for the copy
     // of the matrix, 177 us now): a dimension that is not a multiple of 4 is rounded up to 8 in the two operands that carry it, an operand
     // whose own view is not vec4-aligned is copied at the (possibly padded) sizes, the others are used where they lie.
-    const uint32_t Mp = M % 4 ? up8(M) : M, Np = N % 4 && dtype != WG_F16 ? up8(N) : N, Kp = K % 4 ? up8(K) : K, mats = o.mats; // (f16: any N as it is)
+    const uint32_t Mp = M % 4 ? up8(M) : M, Np = N % 4 && !(dtype == WG_F16 || M > 128u) ? up8(N) : N, Kp = K % 4 ? up8(K) : K, mats = o.mats; // (f16: any N as it is)
     // (the kernels take any offset / leading dimension / batch stride -- element-aligned LDS-DMA and 16-byte accesses --: only lengths are padded)
     const bool sa = Mp != M || Kp != K, sb = Kp != K || Np != N, sc = Mp != M || Np != N;
     const uint64_t ae = sa ? (uint64_t)Mp * Kp : 0, be = sb ? (uint64_t)Kp * Np : 0, ce = sc ? (uint64_t)Mp * Np : 0;
@@ -183,8 +183,10 @@ int wg_gemm_ex(wg_ctx *ctx, wg_gemm_variant variant, wg_dtype dtype, float alpha
     // (the kernels take any offset, leading dimension and batch stride since round 6 -- gemm_f16.hip, gemm_f32*.hip: LDS-DMA and 16-byte accesses at element-aligned
     // addresses -- so only the lengths count)
     // (f16: the kernels take any number of columns -- they clamp their loads of m2 per column and skip the stores past N --, so N is as free as the offsets;
-    //  f32: the few-row forms of its launcher assume N % 4 == 0 -- tests/test_gpu_parity.py::test_gemm_f32_any_number_of_columns fails without the copies)
-    if ((o.cols % 4 && dtype != WG_F16) || m_cols % 4 || m_rows % 4)
+    //  f32: likewise from 129 rows on; the few-row forms of its launcher compute the transposed product and need N % 4 == 0 --
+    //  tests/test_gpu_parity.py::test_gemm_f32_any_number_of_columns fails on them without the copies)
+    const bool n_free = dtype == WG_F16 || m_rows > 128u; // (f32 with up to 128 rows: the few-row forms compute the transposed product, where N is the length that must be a multiple of 4)
+    if ((o.cols % 4 && !n_free) || m_cols % 4 || m_rows % 4)
         return gemm_staged(ctx, tr, dtype, alpha, beta, out, o, m1, a, m2, b, m_rows, o.cols, m_cols);
     wgk_mat A = { elem_ptr(m1, a.offset, dtype), a.stride, a.stride_mat };
     wgk_mat B = { elem_ptr(m2, b.offset, dtype), b.stride, b.stride_mat };

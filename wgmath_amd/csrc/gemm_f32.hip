@@ -598,7 +598,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         }
         if (est < 1e29) return wgk_gemm_f32_mid(ctx, trans, 64, 64, M, N, K, nmats, out, out_ld, out_batch, m1, m2, alpha, beta, ns);
     }
-    if (!mid_forced && M > 64 && M <= 128 && N > 4096 && K >= 128 && beta == 0.f) {
+    if (!mid_forced && M > 64 && M <= 128 && N > 4096 && N % 4u == 0 && K >= 128 && beta == 0.f) { // (N % 4: it is the transposed product's row count)
         const uint64_t at_elems = trans ? 0 : (uint64_t)K * M, ct_elems = (uint64_t)N * M;
         void *ws = nullptr;
         if (int rc = wg_ctx_pad_workspace(ctx, (size_t)((at_elems + ct_elems) * nmats * sizeof(float)), &ws)) return rc;
@@ -611,7 +611,7 @@ int wgk_gemm_f32(wg_ctx *ctx, bool trans, uint32_t M, uint32_t N, uint32_t K, ui
         if (int rc = wgk_gemm_f32(ctx, true, N, M, K, nmats, ct, N, ct_elems, m2, a2, alpha, 0.f)) return rc;
         return wgk_transpose(ctx, WG_F32, N, M, nmats, ct, N, ct_elems, out, out_ld, out_batch);
     }
-    if (!mid_forced && M <= 64 && N >= 512 && K >= 128 && beta == 0.f) {
+    if (!mid_forced && M <= 64 && N >= 512 && N % 4u == 0 && K >= 128 && beta == 0.f) {
         // the few-column GemmTr kernel takes m2' = op(A)^T either k-contiguous (GemmTr: m1 as it is) or with its columns contiguous (Gemm:
         // m1 as it is, "k-major"), and writes -- or its split-K reduce does -- straight into the transposed position: "row" n of C^T is
         // column n of C (out_ld apart), "column" m is row m (adjacent). No copy of anything.
